@@ -1,0 +1,131 @@
+/*
+ * mm_rng.h -- the engine's counter-based random stream (host + device, one definition).
+ *
+ * Replaces, for the GPU path, the per-chain `SmallRng` + ziggurat stack of the reference
+ * (metropolis_hastings.rs:109,190,310; distributions.rs:347,364-372; nuts.rs:388,554-563,579,660,910;
+ * hmc.rs:309-313,359-363 use burn's global RNG).  A lane cannot carry the reference's sequential
+ * generator state across launches or GPUs without serialising, so every draw is a pure function
+ *
+ *        philox4x32-10( key = seed, counter = (chain, iteration, block) )
+ *
+ * which makes results independent of launch partitioning, iterations-per-launch and GPU count.
+ *
+ * Draw schedule (normative; oracle/philox_stream.c restates it independently in plain C):
+ *   counter = { chain & 0xffffffff, chain >> 32, iteration, block },  key = { seed & 0xffffffff, seed >> 32 }
+ *   u24(w)       = (float)((w >> 8) + 1) * 2^-24                      in (0,1]
+ *   u53(hi, lo)  = (double)((((u64)hi << 21) | (lo >> 11)) + 1) * 2^-53   in (0,1]
+ *   f32 block b: words w0..w3
+ *       normals z[4b+0], z[4b+1] = box_muller(u24(w0), u24(w1));  z[4b+2], z[4b+3] = box_muller(u24(w2), u24(w3))
+ *       spare uniform           = u24-style from the low bytes: s = (w0&255) | (w1&255)<<8 | (w2&255)<<16,
+ *                                 (float)(s + 1) * 2^-24
+ *   f64 block b: z[2b+0], z[2b+1] = box_muller(u53(w0,w1), u53(w2,w3))
+ *   box_muller(u1, u2) = ( r cos(2 pi u2), r sin(2 pi u2) ),  r = sqrt(-2 ln u1)
+ *   MH / HMC iteration t of a chain:
+ *       noise z[0..D) from blocks 0..;   accept uniform: f32 -> spare of block 0;  f64 -> u53(w0,w1) of block AUX
+ *   NUTS iteration: momentum z[0..D) as above; auxiliary draw k (k = 0: Exp(1) = -ln u, then the uniforms in
+ *       program order) = u53 of words (2(k&1), 2(k&1)+1) of block AUX + (k >> 1)  -- always 53-bit.
+ */
+#ifndef MM_RNG_H
+#define MM_RNG_H
+
+#include "mm_math.h"
+
+#define MM_AUX_BLOCK 0x40000000u
+
+typedef struct {
+    uint32_t w[4];
+} mm_u32x4;
+
+MM_HD void mm_mulhilo32(uint32_t a, uint32_t b, uint32_t *hi, uint32_t *lo)
+{
+    uint64_t p = (uint64_t)a * (uint64_t)b;
+    *lo = (uint32_t)p;
+    *hi = (uint32_t)(p >> 32);
+}
+
+/* Philox4x32-10 (Salmon et al., SC'11). */
+MM_HD mm_u32x4 mm_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0, lo0, hi1, lo1;
+        mm_mulhilo32(0xD2511F53u, c0, &hi0, &lo0);
+        mm_mulhilo32(0xCD9E8D57u, c2, &hi1, &lo1);
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    mm_u32x4 o;
+    o.w[0] = c0;
+    o.w[1] = c1;
+    o.w[2] = c2;
+    o.w[3] = c3;
+    return o;
+}
+
+MM_HD mm_u32x4 mm_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t block)
+{
+    return mm_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), iteration, block, (uint32_t)seed,
+                            (uint32_t)(seed >> 32));
+}
+
+MM_HD float mm_u24(uint32_t w) { return (float)((w >> 8) + 1u) * 0x1.0p-24f; }
+
+MM_HD float mm_spare_u24(mm_u32x4 b)
+{
+    uint32_t s = (b.w[0] & 255u) | ((b.w[1] & 255u) << 8) | ((b.w[2] & 255u) << 16);
+    return (float)(s + 1u) * 0x1.0p-24f;
+}
+
+MM_HD double mm_u53(uint32_t hi, uint32_t lo)
+{
+    uint64_t m = ((uint64_t)hi << 21) | (uint64_t)(lo >> 11);
+    return (double)(m + 1ull) * 0x1.0p-53;
+}
+
+MM_HD void mm_box_muller_f32(float u1, float u2, float *z0, float *z1)
+{
+    float r = sqrtf(-2.0f * mm_logf(u1));
+    float s, c;
+    mm_sincos2pif(u2, &s, &c);
+    *z0 = r * c;
+    *z1 = r * s;
+}
+
+MM_HD void mm_box_muller_f64(double u1, double u2, double *z0, double *z1)
+{
+    double r = sqrt(-2.0 * mm_log(u1));
+    double s, c;
+    mm_sincos2pi(u2, &s, &c);
+    *z0 = r * c;
+    *z1 = r * s;
+}
+
+/* four f32 normals of one block */
+MM_HD void mm_normals4_f32(mm_u32x4 b, float z[4])
+{
+    mm_box_muller_f32(mm_u24(b.w[0]), mm_u24(b.w[1]), &z[0], &z[1]);
+    mm_box_muller_f32(mm_u24(b.w[2]), mm_u24(b.w[3]), &z[2], &z[3]);
+}
+
+/* two f64 normals of one block */
+MM_HD void mm_normals2_f64(mm_u32x4 b, double z[2])
+{
+    mm_box_muller_f64(mm_u53(b.w[0], b.w[1]), mm_u53(b.w[2], b.w[3]), &z[0], &z[1]);
+}
+
+/* auxiliary 53-bit uniform k of an iteration (NUTS; f64 accept uniform uses k = 0) */
+MM_HD double mm_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t k)
+{
+    mm_u32x4 b = mm_block(seed, chain, iteration, MM_AUX_BLOCK + (k >> 1));
+    return (k & 1u) ? mm_u53(b.w[2], b.w[3]) : mm_u53(b.w[0], b.w[1]);
+}
+
+#endif /* MM_RNG_H */

@@ -1,0 +1,171 @@
+/*
+ * oracle/orng.c -- TEST INFRASTRUCTURE ONLY. Random-stream backends for the oracle samplers (see orng.h).
+ *
+ * Backend (b), the engine stream, is an INDEPENDENT plain-C statement of the Philox4x32-10 generator
+ * (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; pinned in
+ * tests/test_oracle_rng.py by the Random123 known-answer vectors) and of the draw schedule written
+ * down in DESIGN.md / mini_mcmc_amd/csrc/mm_rng.h.  It shares only the elementary functions
+ * (mm_logf, mm_sincos2pif, ...) with the product, because those DEFINE the engine's log/sin/cos.
+ */
+#include "orng.h"
+
+#include "../mini_mcmc_amd/csrc/mm_math.h"
+
+#include <math.h>
+
+/* ---------------- backend (a): the reference's stream ---------------- */
+
+static double rcb_normal(o_rng *r) { return rc_standard_normal(&r->rc); }
+static double rcb_exp1(o_rng *r) { return rc_exp1(&r->rc); }
+static double rcb_uniform_f64(o_rng *r) { return rc_uniform_f64(&r->rc); }
+static float rcb_uniform_f32(o_rng *r) { return rc_uniform_f32(&r->rc); }
+static void rcb_begin_iter(o_rng *r, uint64_t it)
+{
+    (void)r;
+    (void)it;
+}
+static double rcb_accept_uniform(o_rng *r)
+{
+    return r->is_f32 ? (double)rc_uniform_f32(&r->rc) : rc_uniform_f64(&r->rc);
+}
+
+void o_rng_init_rand_compat(o_rng *r, uint64_t seed)
+{
+    int is_f32 = r->is_f32;
+    memset(r, 0, sizeof *r);
+    r->is_f32 = is_f32;
+    r->normal_f64 = rcb_normal;
+    r->exp1_f64 = rcb_exp1;
+    r->uniform_f64 = rcb_uniform_f64;
+    r->uniform_f32 = rcb_uniform_f32;
+    r->accept_uniform = rcb_accept_uniform;
+    r->begin_iter = rcb_begin_iter;
+    rc_seed_from_u64(&r->rc, seed);
+}
+
+/* ---------------- backend (b): the engine's counter-based stream ---------------- */
+
+static void philox_round(uint32_t c[4], uint32_t k[2])
+{
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n[4];
+    n[0] = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    n[1] = (uint32_t)p1;
+    n[2] = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    n[3] = (uint32_t)p0;
+    c[0] = n[0];
+    c[1] = n[1];
+    c[2] = n[2];
+    c[3] = n[3];
+}
+
+void o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    uint32_t k[2] = {key[0], key[1]};
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0];
+    out[1] = c[1];
+    out[2] = c[2];
+    out[3] = c[3];
+}
+
+void o_engine_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t block, uint32_t out[4])
+{
+    uint32_t ctr[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), iteration, block};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    o_philox4x32_10(ctr, key, out);
+}
+
+static float u24(uint32_t w) { return (float)((w >> 8) + 1u) * 0x1.0p-24f; }
+static double u53(uint32_t hi, uint32_t lo)
+{
+    uint64_t m = ((uint64_t)hi << 21) | (uint64_t)(lo >> 11);
+    return (double)(m + 1ull) * 0x1.0p-53;
+}
+
+/* normal #i of (chain, iteration) in the f32 schedule */
+float o_engine_normal_f32(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i)
+{
+    uint32_t w[4];
+    o_engine_block(seed, chain, iteration, i / 4, w);
+    uint32_t pair = (i % 4) / 2;
+    float u1 = u24(w[2 * pair]), u2 = u24(w[2 * pair + 1]);
+    float r = sqrtf(-2.0f * mm_logf(u1));
+    float s, c;
+    mm_sincos2pif(u2, &s, &c);
+    return (i % 2) ? r * s : r * c;
+}
+
+double o_engine_normal_f64(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i)
+{
+    uint32_t w[4];
+    o_engine_block(seed, chain, iteration, i / 2, w);
+    double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+    double r = sqrt(-2.0 * mm_log(u1));
+    double s, c;
+    mm_sincos2pi(u2, &s, &c);
+    return (i % 2) ? r * s : r * c;
+}
+
+/* MH / HMC accept uniform of (chain, iteration) */
+float o_engine_accept_f32(uint64_t seed, uint64_t chain, uint32_t iteration)
+{
+    uint32_t w[4];
+    o_engine_block(seed, chain, iteration, 0, w);
+    uint32_t s = (w[0] & 255u) | ((w[1] & 255u) << 8) | ((w[2] & 255u) << 16);
+    return (float)(s + 1u) * 0x1.0p-24f;
+}
+
+double o_engine_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t k)
+{
+    uint32_t w[4];
+    o_engine_block(seed, chain, iteration, 0x40000000u + (k >> 1), w);
+    return (k & 1u) ? u53(w[2], w[3]) : u53(w[0], w[1]);
+}
+
+static double eng_normal(o_rng *r)
+{
+    uint32_t i = r->n_normal++;
+    return r->is_f32 ? (double)o_engine_normal_f32(r->seed, r->chain, (uint32_t)r->iteration, i)
+                     : o_engine_normal_f64(r->seed, r->chain, (uint32_t)r->iteration, i);
+}
+static double eng_aux(o_rng *r) { return o_engine_aux_u53(r->seed, r->chain, (uint32_t)r->iteration, r->draw++); }
+static double eng_exp1(o_rng *r)
+{
+    double u = eng_aux(r);
+    return -mm_log(u);
+}
+static double eng_uniform_f64(o_rng *r) { return eng_aux(r); }
+static float eng_uniform_f32(o_rng *r) { return (float)eng_aux(r); }
+static double eng_accept_uniform(o_rng *r)
+{
+    return r->is_f32 ? (double)o_engine_accept_f32(r->seed, r->chain, (uint32_t)r->iteration)
+                     : o_engine_aux_u53(r->seed, r->chain, (uint32_t)r->iteration, 0);
+}
+static void eng_begin_iter(o_rng *r, uint64_t it)
+{
+    r->iteration = it;
+    r->draw = 0;
+    r->n_normal = 0;
+}
+
+void o_rng_init_engine_stream(o_rng *r, uint64_t seed, uint64_t chain)
+{
+    int is_f32 = r->is_f32;
+    memset(r, 0, sizeof *r);
+    r->is_f32 = is_f32;
+    r->normal_f64 = eng_normal;
+    r->exp1_f64 = eng_exp1;
+    r->uniform_f64 = eng_uniform_f64;
+    r->uniform_f32 = eng_uniform_f32;
+    r->accept_uniform = eng_accept_uniform;
+    r->begin_iter = eng_begin_iter;
+    r->seed = seed;
+    r->chain = chain;
+}

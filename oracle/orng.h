@@ -1,0 +1,51 @@
+/*
+ * oracle/orng.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * The oracle samplers draw their randomness through this small vtable so the same restated sampler
+ * code can run on
+ *   (a) the reference's own stream (rand_compat: xoshiro256++ + ziggurat), which is what the
+ *       reference's seeded known-answer tests pin, and
+ *   (b) the GPU engine's counter-based stream (an independent plain-C statement of the Philox4x32-10
+ *       draw schedule in DESIGN.md), so GPU results can be compared against the reference-ordered
+ *       arithmetic on identical noise.
+ */
+#ifndef ORACLE_ORNG_H
+#define ORACLE_ORNG_H
+
+#include "rand_compat.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct o_rng o_rng;
+struct o_rng {
+    double (*normal_f64)(o_rng *);     /* rand_distr::StandardNormal -> f64 (f32 callers cast) */
+    double (*exp1_f64)(o_rng *);       /* rand_distr::Exp1 -> f64 */
+    double (*uniform_f64)(o_rng *);    /* StandardUniform f64 */
+    float (*uniform_f32)(o_rng *);     /* StandardUniform f32 */
+    double (*accept_uniform)(o_rng *); /* the MH / HMC accept draw `rng.random::<T>()`, T per is_f32 */
+    void (*begin_iter)(o_rng *, uint64_t iteration); /* counter-based streams re-key here; no-op for (a) */
+    int is_f32;                                       /* element type the sampler runs in */
+    rc_rng rc;                                        /* state of backend (a) */
+    uint64_t seed, chain, iteration;                  /* state of backend (b) */
+    uint32_t draw, n_normal;                          /* running indices within the iteration, (b) */
+};
+
+/* (a): SmallRng::seed_from_u64(seed).  Keeps r->is_f32. */
+void o_rng_init_rand_compat(o_rng *r, uint64_t seed);
+/* (b): engine stream of global chain id `chain` under `seed`.  Keeps r->is_f32. */
+void o_rng_init_engine_stream(o_rng *r, uint64_t seed, uint64_t chain);
+
+/* raw pieces of (b), exported for the known-answer tests and for noise injection */
+void o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void o_engine_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t block, uint32_t out[4]);
+float o_engine_normal_f32(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
+double o_engine_normal_f64(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
+float o_engine_accept_f32(uint64_t seed, uint64_t chain, uint32_t iteration);
+double o_engine_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

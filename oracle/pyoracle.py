@@ -1,0 +1,510 @@
+"""ctypes bindings of oracle/_build/liboracle.so -- TEST INFRASTRUCTURE ONLY (see oracle/oracle.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+# target kinds (oracle/targets.h)
+GAUSSIAN2D, DIFFABLE_GAUSSIAN2D, ISOTROPIC_GAUSSIAN, ROSENBROCK2D, ROSENBROCK_ND, STANDARD_NORMAL, GAUSSIAN_ND = range(7)
+
+
+class OTarget(C.Structure):
+    _fields_ = [("kind", C.c_int), ("dim", C.c_int), ("p", C.c_double * 8), ("mat", C.POINTER(C.c_double))]
+
+
+class ORng(C.Structure):
+    _fields_ = [
+        ("normal_f64", C.c_void_p),
+        ("exp1_f64", C.c_void_p),
+        ("uniform_f64", C.c_void_p),
+        ("uniform_f32", C.c_void_p),
+        ("accept_uniform", C.c_void_p),
+        ("begin_iter", C.c_void_p),
+        ("is_f32", C.c_int),
+        ("rc", C.c_uint64 * 4),
+        ("seed", C.c_uint64),
+        ("chain", C.c_uint64),
+        ("iteration", C.c_uint64),
+        ("draw", C.c_uint32),
+        ("n_normal", C.c_uint32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
+    if force or not os.path.exists(_LIB_PATH) or _stale():
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+def _stale() -> bool:
+    try:
+        t = os.path.getmtime(_LIB_PATH)
+        deps = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+        deps.append(os.path.join(_HERE, "..", "mini_mcmc_amd", "csrc", "mm_math.h"))
+        return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    except OSError:
+        return True
+
+
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    tp = C.POINTER(OTarget)
+    sig = {
+        "rc_seed_from_u64": (None, [_u64p, C.c_uint64]),
+        "rc_next_u64": (C.c_uint64, [_u64p]),
+        "rc_next_u32": (C.c_uint32, [_u64p]),
+        "rc_uniform_f64": (C.c_double, [_u64p]),
+        "rc_uniform_f32": (C.c_float, [_u64p]),
+        "rc_open01_f64": (C.c_double, [_u64p]),
+        "rc_standard_normal": (C.c_double, [_u64p]),
+        "rc_exp1": (C.c_double, [_u64p]),
+        "rc_zig_norm_x": (_dp, []),
+        "rc_zig_norm_f": (_dp, []),
+        "rc_zig_exp_x": (_dp, []),
+        "rc_zig_exp_f": (_dp, []),
+        "o_philox4x32_10": (None, [_u32p, _u32p, _u32p]),
+        "o_engine_block": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _u32p]),
+        "o_engine_normal_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+        "o_engine_normal_f64": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+        "o_engine_accept_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32]),
+        "o_engine_aux_u53": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+        "ot_logp_f32": (C.c_float, [tp, _fp]),
+        "ot_logp_f64": (C.c_double, [tp, _dp]),
+        "ot_logp_grad_f32": (C.c_float, [tp, _fp, _fp]),
+        "ot_logp_grad_f64": (C.c_double, [tp, _dp, _dp]),
+        "ot_make_diffable_gaussian2d": (None, [tp, _dp, _dp, C.c_int]),
+        "o_init_with_seed": (None, [C.c_size_t, C.c_size_t, C.c_uint64, _dp]),
+        "o_mh_create": (C.c_void_p, [tp, C.c_double, _dp, C.c_int, C.c_int]),
+        "o_mh_destroy": (None, [C.c_void_p]),
+        "o_mh_proposal_seed": (None, [C.c_void_p, C.c_uint64]),
+        "o_mh_seed": (None, [C.c_void_p, C.c_uint64]),
+        "o_mh_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_mh_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, _dp, _u64p]),
+        "o_mh_state": (None, [C.c_void_p, _dp]),
+        "o_hmc_create": (C.c_void_p, [tp, _dp, C.c_int, C.c_double, C.c_int, C.c_int]),
+        "o_hmc_destroy": (None, [C.c_void_p]),
+        "o_hmc_seed_global": (None, [C.c_void_p, C.c_uint64]),
+        "o_hmc_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_hmc_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, _dp, _u64p]),
+        "o_hmc_state": (None, [C.c_void_p, _dp]),
+        "o_nuts_create": (C.c_void_p, [tp, _dp, C.c_int, C.c_double, C.c_int]),
+        "o_nuts_destroy": (None, [C.c_void_p]),
+        "o_nuts_set_chain_seed": (None, [C.c_void_p, C.c_int, C.c_uint64]),
+        "o_nuts_set_seed": (None, [C.c_void_p, C.c_uint64]),
+        "o_nuts_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_nuts_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp]),
+        "o_nuts_chain_state": (None, [C.c_void_p, C.c_int, _dp]),
+        "o_nuts_find_reasonable_epsilon": (C.c_double, [tp, _dp, _dp, C.c_int]),
+        "o_nuts_build_tree": (
+            None,
+            [tp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_int, _dp, _dp],
+        ),
+        "o_split_rhat_mean_ess": (None, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
+        "o_autocov_bf": (None, [_fp, C.c_size_t, C.c_size_t, _fp]),
+        "o_autocov_fft": (None, [_fp, C.c_size_t, C.c_size_t, _fp]),
+        "o_basic_stats": (None, [_fp, C.c_size_t, _fp]),
+        "o_multichain_tracker": (None, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
+        "o_chain_trackers_rhat": (None, [_fp, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def default_threads() -> int:
+    return os.cpu_count() or 1
+
+
+# ---------------------------------------------------------------- RNG
+
+
+class SmallRng:
+    """rand 0.9 SmallRng (xoshiro256++) + rand_distr 0.5 StandardNormal/Exp1 -- see oracle/rand_compat.c."""
+
+    def __init__(self, seed: int):
+        self._s = (C.c_uint64 * 4)()
+        lib().rc_seed_from_u64(self._s, seed)
+
+    @property
+    def state(self):
+        return [int(x) for x in self._s]
+
+    def next_u64(self):
+        return int(lib().rc_next_u64(self._s))
+
+    def next_u32(self):
+        return int(lib().rc_next_u32(self._s))
+
+    def f64(self):
+        return float(lib().rc_uniform_f64(self._s))
+
+    def f32(self):
+        return np.float32(lib().rc_uniform_f32(self._s))
+
+    def normal(self):
+        return float(lib().rc_standard_normal(self._s))
+
+    def exp1(self):
+        return float(lib().rc_exp1(self._s))
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().o_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def engine_normals_f32(seed, chain, iteration, n):
+    L = lib()
+    return np.array([L.o_engine_normal_f32(seed, chain, iteration, i) for i in range(n)], dtype=np.float32)
+
+
+def engine_normals_f64(seed, chain, iteration, n):
+    L = lib()
+    return np.array([L.o_engine_normal_f64(seed, chain, iteration, i) for i in range(n)], dtype=np.float64)
+
+
+def engine_accept_f32(seed, chain, iteration):
+    return np.float32(lib().o_engine_accept_f32(seed, chain, iteration))
+
+
+def engine_aux_u53(seed, chain, iteration, k):
+    return float(lib().o_engine_aux_u53(seed, chain, iteration, k))
+
+
+# ---------------------------------------------------------------- targets
+
+
+class Target:
+    """POD target descriptor (oracle/targets.h)."""
+
+    def __init__(self, kind, dim, params=(), mat=None):
+        self.t = OTarget()
+        self.t.kind = kind
+        self.t.dim = dim
+        for i, v in enumerate(params):
+            self.t.p[i] = float(v)
+        self._mat = None
+        if mat is not None:
+            self._mat = np.ascontiguousarray(mat, dtype=np.float64)
+            assert self._mat.shape == (dim, dim)
+            self.t.mat = _d(self._mat)
+        self.kind, self.dim = kind, dim
+
+    @property
+    def ref(self):
+        return C.byref(self.t)
+
+    def logp(self, x, dtype=np.float64):
+        x = np.ascontiguousarray(x, dtype=dtype)
+        if dtype == np.float32:
+            return np.float32(lib().ot_logp_f32(self.ref, _f(x)))
+        return float(lib().ot_logp_f64(self.ref, _d(x)))
+
+    def logp_grad(self, x, dtype=np.float64):
+        x = np.ascontiguousarray(x, dtype=dtype)
+        g = np.zeros_like(x)
+        if dtype == np.float32:
+            lp = np.float32(lib().ot_logp_grad_f32(self.ref, _f(x), _f(g)))
+        else:
+            lp = float(lib().ot_logp_grad_f64(self.ref, _d(x), _d(g)))
+        return lp, g
+
+
+def gaussian2d(mean, cov):
+    cov = np.asarray(cov, dtype=np.float64).reshape(4)
+    return Target(GAUSSIAN2D, 2, [mean[0], mean[1], cov[0], cov[1], cov[2], cov[3]])
+
+
+def diffable_gaussian2d(mean, cov, t_is_f32=False):
+    t = Target(DIFFABLE_GAUSSIAN2D, 2)
+    m = np.asarray(mean, dtype=np.float64)
+    c = np.asarray(cov, dtype=np.float64).reshape(4)
+    lib().ot_make_diffable_gaussian2d(t.ref, _d(m), _d(c), int(t_is_f32))
+    return t
+
+
+def isotropic_gaussian(std, dim):
+    return Target(ISOTROPIC_GAUSSIAN, dim, [std])
+
+
+def rosenbrock2d(a, b):
+    return Target(ROSENBROCK2D, 2, [a, b])
+
+
+def rosenbrock_nd(dim):
+    return Target(ROSENBROCK_ND, dim)
+
+
+def standard_normal(dim):
+    return Target(STANDARD_NORMAL, dim)
+
+
+def gaussian_nd(precision):
+    a = np.asarray(precision, dtype=np.float64)
+    return Target(GAUSSIAN_ND, a.shape[0], mat=a)
+
+
+# ---------------------------------------------------------------- init
+
+
+def init_with_seed(n, d, seed, dtype=np.float64):
+    """core.rs:413-435. init_det(n, d) = init_with_seed(n, d, 42)."""
+    out = np.zeros((n, d), dtype=np.float64)
+    lib().o_init_with_seed(n, d, seed, _d(out))
+    return out.astype(dtype)
+
+
+def init_det(n, d, dtype=np.float64):
+    return init_with_seed(n, d, 42, dtype)
+
+
+# ---------------------------------------------------------------- samplers
+
+
+class MetropolisHastings:
+    """metropolis_hastings.rs:149-193 + core.rs:176-186 with IsotropicGaussian proposal."""
+
+    def __init__(self, target: Target, proposal_std, init, dtype=np.float64, proposal_seed=None):
+        init = np.ascontiguousarray(init, dtype=np.float64)
+        self.n_chains, self.dim = init.shape
+        self.dtype = dtype
+        self._target = target
+        self._h = lib().o_mh_create(target.ref, float(proposal_std), _d(init), self.n_chains, int(dtype == np.float32))
+        if not self._h:
+            raise ValueError("o_mh_create failed")
+        if proposal_seed is not None:
+            lib().o_mh_proposal_seed(self._h, proposal_seed)
+
+    def seed(self, seed):
+        lib().o_mh_seed(self._h, seed)
+        return self
+
+    def use_engine_stream(self, seed, chain_offset=0):
+        lib().o_mh_use_engine_stream(self._h, seed, chain_offset)
+        return self
+
+    def run(self, n_collect, n_discard, n_threads=None, want_out=True):
+        out = np.zeros((self.n_chains, n_collect, self.dim), dtype=np.float64) if want_out else None
+        acc = np.zeros(self.n_chains, dtype=np.uint64)
+        lib().o_mh_run(
+            self._h, n_collect, n_discard, n_threads or default_threads(), _d(out) if want_out else None,
+            acc.ctypes.data_as(_u64p)
+        )
+        self.accept_counts = acc
+        return out.astype(self.dtype) if want_out else None
+
+    def state(self):
+        out = np.zeros((self.n_chains, self.dim))
+        lib().o_mh_state(self._h, _d(out))
+        return out.astype(self.dtype)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().o_mh_destroy(self._h)
+            self._h = None
+
+
+class HMC:
+    """hmc.rs:87-158, 304-431."""
+
+    def __init__(self, target: Target, init, step_size, n_leapfrog, dtype=np.float32):
+        init = np.ascontiguousarray(init, dtype=np.float64)
+        self.n_chains, self.dim = init.shape
+        self.dtype = dtype
+        self._target = target
+        self._h = lib().o_hmc_create(
+            target.ref, _d(init), self.n_chains, float(step_size), int(n_leapfrog), int(dtype == np.float32)
+        )
+        if not self._h:
+            raise ValueError("o_hmc_create failed")
+
+    def seed_global(self, seed):
+        lib().o_hmc_seed_global(self._h, seed)
+        return self
+
+    def use_engine_stream(self, seed, chain_offset=0):
+        lib().o_hmc_use_engine_stream(self._h, seed, chain_offset)
+        return self
+
+    def run(self, n_collect, n_discard, n_threads=None, want_out=True):
+        out = np.zeros((self.n_chains, n_collect, self.dim), dtype=np.float64) if want_out else None
+        acc = np.zeros(self.n_chains, dtype=np.uint64)
+        lib().o_hmc_run(
+            self._h, n_collect, n_discard, n_threads or default_threads(), _d(out) if want_out else None,
+            acc.ctypes.data_as(_u64p)
+        )
+        self.accept_counts = acc
+        return out.astype(self.dtype) if want_out else None
+
+    def state(self):
+        out = np.zeros((self.n_chains, self.dim))
+        lib().o_hmc_state(self._h, _d(out))
+        return out.astype(self.dtype)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().o_hmc_destroy(self._h)
+            self._h = None
+
+
+class NUTS:
+    """nuts.rs:123-170, 347-353 (multi-chain) over NUTSChain nuts.rs:410-691.
+
+    mode 0: f32 tensors + f64 scalars (reference T=f64); 1: f32/f32 (reference T=f32); 2: f64/f64."""
+
+    def __init__(self, target: Target, init, target_accept_p, mode=0):
+        init = np.ascontiguousarray(init, dtype=np.float64)
+        if init.ndim == 1:
+            init = init[None, :]
+        self.n_chains, self.dim = init.shape
+        self.mode = mode
+        self._target = target
+        self._h = lib().o_nuts_create(target.ref, _d(init), self.n_chains, float(target_accept_p), mode)
+        if not self._h:
+            raise ValueError("o_nuts_create failed")
+
+    def set_seed(self, seed):
+        lib().o_nuts_set_seed(self._h, seed)
+        return self
+
+    def set_chain_seed(self, chain, seed):
+        lib().o_nuts_set_chain_seed(self._h, chain, seed)
+        return self
+
+    def use_engine_stream(self, seed, chain_offset=0):
+        lib().o_nuts_use_engine_stream(self._h, seed, chain_offset)
+        return self
+
+    def run(self, n_collect, n_discard, progress=False, n_threads=None):
+        out = np.zeros((self.n_chains, n_collect, self.dim), dtype=np.float64)
+        lib().o_nuts_run(self._h, n_collect, n_discard, int(progress), n_threads or default_threads(), _d(out))
+        return out
+
+    def chain_state(self, chain=0):
+        out = np.zeros(7)
+        lib().o_nuts_chain_state(self._h, chain, _d(out))
+        keys = ["epsilon", "epsilon_bar", "h_bar", "mu", "m", "last_depth", "n_leapfrog_total"]
+        return dict(zip(keys, out.tolist()))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().o_nuts_destroy(self._h)
+            self._h = None
+
+
+def find_reasonable_epsilon(target: Target, position, mom, mode=0):
+    p = np.ascontiguousarray(position, dtype=np.float64)
+    m = np.ascontiguousarray(mom, dtype=np.float64)
+    return float(lib().o_nuts_find_reasonable_epsilon(target.ref, _d(p), _d(m), mode))
+
+
+def build_tree(target: Target, position, mom, grad, logu, v, j, epsilon, joint_0, rng_seed=0, mode=0):
+    d = target.dim
+    p = np.ascontiguousarray(position, dtype=np.float64)
+    m = np.ascontiguousarray(mom, dtype=np.float64)
+    g = np.ascontiguousarray(grad, dtype=np.float64)
+    vec = np.zeros((8, d))
+    sc = np.zeros(5)
+    lib().o_nuts_build_tree(
+        target.ref, _d(p), _d(m), _d(g), float(logu), int(v), int(j), float(epsilon), float(joint_0), rng_seed, mode,
+        _d(vec), _d(sc)
+    )
+    names = ["position_minus", "mom_minus", "grad_minus", "position_plus", "mom_plus", "grad_plus", "position_prime",
+             "grad_prime"]
+    out = {k: vec[i].copy() for i, k in enumerate(names)}
+    out.update(logp_prime=sc[0], n_prime=int(sc[1]), s_prime=bool(sc[2]), alpha_prime=sc[3], n_alpha_prime=int(sc[4]))
+    return out
+
+
+# ---------------------------------------------------------------- diagnostics
+
+
+def split_rhat_mean_ess(sample):
+    """stats.rs:416-423 on [chains, n, params] -> (rhat[params], ess[params]); 'rhat' is sqrt(W/var+) (Q7)."""
+    s = np.ascontiguousarray(sample, dtype=np.float32)
+    c, n, p = s.shape
+    rhat = np.zeros(p, dtype=np.float32)
+    ess = np.zeros(p, dtype=np.float32)
+    lib().o_split_rhat_mean_ess(_f(s), c, n, p, _f(rhat), _f(ess))
+    return rhat, ess
+
+
+def autocov_bf(data):
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().o_autocov_bf(_f(x), x.shape[0], x.shape[1], _f(out))
+    return out
+
+
+def autocov_fft(data):
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().o_autocov_fft(_f(x), x.shape[0], x.shape[1], _f(out))
+    return out
+
+
+def basic_stats(data):
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    out = np.zeros(5, dtype=np.float32)
+    lib().o_basic_stats(_f(x), x.size, _f(out))
+    return dict(min=out[0], median=out[1], max=out[2], mean=out[3], std=out[4])
+
+
+def run_stats(sample):
+    """RunStats::from stats.rs:360-371."""
+    rhat, ess = split_rhat_mean_ess(sample)
+    return dict(ess=basic_stats(ess), rhat=basic_stats(rhat))
+
+
+def multichain_tracker_rhat(states):
+    """MultiChainTracker stats.rs:189-306 fed states [steps, chains, params]."""
+    s = np.ascontiguousarray(states, dtype=np.float32)
+    steps, chains, params = s.shape
+    rhat = np.zeros(params, dtype=np.float32)
+    pa = C.c_float()
+    lib().o_multichain_tracker(_f(s), steps, chains, params, _f(rhat), C.byref(pa))
+    return rhat, np.float32(pa.value)
+
+
+def chain_trackers_rhat(init, states):
+    """ChainTracker + collect_rhat (stats.rs:26-178): init [chains, params], states [chains, steps, params]."""
+    i0 = np.ascontiguousarray(init, dtype=np.float32)
+    s = np.ascontiguousarray(states, dtype=np.float32)
+    chains, steps, params = s.shape
+    rhat = np.zeros(params, dtype=np.float32)
+    pa = np.zeros(chains, dtype=np.float32)
+    lib().o_chain_trackers_rhat(_f(i0), _f(s), chains, steps, params, _f(rhat), _f(pa))
+    return rhat, pa
