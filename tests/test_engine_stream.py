@@ -1,0 +1,117 @@
+"""The engine's counter-based stream: Philox4x32-10 known answers, the draw schedule's distribution, and the
+accuracy of the shared elementary functions (mini_mcmc_amd/csrc/mm_math.h).  CPU only.
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_philox_random123_known_answers(O):
+    # Random123 kat_vectors, philox4x32-10
+    assert O.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert O.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert O.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_engine_block_is_philox_of_chain_iteration_block(O):
+    out = (C.c_uint32 * 4)()
+    chain = (7 << 32) | 123456
+    O.lib().o_engine_block(0x1122334455667788, chain, 99, 3, out)
+    assert list(out) == O.philox4x32_10([123456, 7, 99, 3], [0x55667788, 0x11223344])
+
+
+def test_engine_normals_and_uniforms_distribution(O):
+    z = np.concatenate([O.engine_normals_f32(42, c, 5, 8) for c in range(20000)]).astype(np.float64)
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1) < 0.02 and abs((z**4).mean() - 3) < 0.1
+    assert np.all(np.isfinite(z))
+    u = np.array([O.engine_accept_f32(42, c, 5) for c in range(50000)], dtype=np.float64)
+    assert u.min() > 0 and u.max() <= 1 and abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    # the spare uniform is independent of the normals made from the same block
+    z0 = np.array([O.engine_normals_f32(42, c, 5, 1)[0] for c in range(50000)], dtype=np.float64)
+    assert abs(np.corrcoef(z0, u)[0, 1]) < 0.02
+    z64 = np.concatenate([O.engine_normals_f64(42, c, 5, 4) for c in range(20000)])
+    assert abs(z64.mean()) < 0.015 and abs(z64.var() - 1) < 0.03
+    a = np.array([O.engine_aux_u53(42, 3, 5, k) for k in range(20000)])
+    assert a.min() > 0 and a.max() <= 1 and abs(a.mean() - 0.5) < 0.01
+
+
+@pytest.fixture(scope="module")
+def mmath(tmp_path_factory):
+    """Host build of mm_math.h alone (the functions that DEFINE the engine's log/exp/sincos)."""
+    d = tmp_path_factory.mktemp("mmath")
+    src = d / "w.c"
+    src.write_text(
+        '#include "mm_math.h"\n'
+        "float w_logf(float x){return mm_logf(x);} float w_expf(float x){return mm_expf(x);}\n"
+        "void w_sc(float u,float*s,float*c){mm_sincos2pif(u,s,c);}\n"
+        "double w_log(double x){return mm_log(x);} double w_exp(double x){return mm_exp(x);}\n"
+        "void w_scd(double u,double*s,double*c){mm_sincos2pi(u,s,c);}\n"
+    )
+    so = d / "w.so"
+    subprocess.run(
+        ["gcc", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-shared", "-fPIC", "-I",
+         os.path.join(ROOT, "mini_mcmc_amd", "csrc"), str(src), "-o", str(so), "-lm"], check=True)
+    L = C.CDLL(str(so))
+    L.w_logf.restype = C.c_float
+    L.w_logf.argtypes = [C.c_float]
+    L.w_expf.restype = C.c_float
+    L.w_expf.argtypes = [C.c_float]
+    L.w_sc.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.w_log.restype = C.c_double
+    L.w_log.argtypes = [C.c_double]
+    L.w_exp.restype = C.c_double
+    L.w_exp.argtypes = [C.c_double]
+    L.w_scd.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    return L
+
+
+def test_mm_math_f32_accuracy(mmath):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.random(20000), 2.0 ** rng.uniform(-24, 0, 20000), [1.0, 2.0**-24, 0.5, 0.70710678]])
+    xs = xs.astype(np.float32)
+    got = np.array([mmath.w_logf(float(x)) for x in xs], dtype=np.float64)
+    ref = np.log(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)) < 3e-7
+    assert mmath.w_logf(1.0) == 0.0
+    ys = rng.uniform(-90, 88, 20000).astype(np.float32)
+    got = np.array([mmath.w_expf(float(y)) for y in ys], dtype=np.float64)
+    ref = np.exp(ys.astype(np.float64))
+    ok = ref > 1e-37
+    assert np.max(np.abs(got[ok] - ref[ok]) / ref[ok]) < 3e-7
+    assert mmath.w_expf(0.0) == 1.0 and mmath.w_expf(-200.0) == 0.0 and math.isinf(mmath.w_expf(100.0))
+    s, c = C.c_float(), C.c_float()
+    us = np.concatenate([rng.random(20000), [0.0, 0.25, 0.5, 0.75, 1.0, 0.125, 0.375]]).astype(np.float32)
+    err = 0.0
+    for u in us:
+        mmath.w_sc(float(u), C.byref(s), C.byref(c))
+        err = max(err, abs(s.value - math.sin(2 * math.pi * float(u))), abs(c.value - math.cos(2 * math.pi * float(u))))
+    assert err < 3e-7
+    mmath.w_sc(0.25, C.byref(s), C.byref(c))
+    assert (s.value, c.value) == (1.0, 0.0)
+    mmath.w_sc(0.5, C.byref(s), C.byref(c))
+    assert (abs(s.value), c.value) == (0.0, -1.0)
+
+
+def test_mm_math_f64_accuracy(mmath):
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.random(20000), 2.0 ** rng.uniform(-53, 3, 20000), [1.0, 2.0**-53]])
+    got = np.array([mmath.w_log(float(x)) for x in xs])
+    ref = np.log(xs)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-12)) < 5e-16
+    ys = rng.uniform(-700, 700, 20000)
+    got = np.array([mmath.w_exp(float(y)) for y in ys])
+    ref = np.exp(ys)
+    assert np.max(np.abs(got - ref) / ref) < 5e-16
+    s, c = C.c_double(), C.c_double()
+    err = 0.0
+    for u in rng.random(20000):
+        mmath.w_scd(float(u), C.byref(s), C.byref(c))
+        err = max(err, abs(s.value - math.sin(2 * math.pi * u)), abs(c.value - math.cos(2 * math.pi * u)))
+    assert err < 2e-15  # the libm reference itself rounds 2*pi*u
