@@ -1,0 +1,164 @@
+/*
+ * mmcmc.h -- C ABI of libmmcmc.so: the MI355X-native many-chain engine for mini-mcmc's per-chain inner loop.
+ *
+ * This is the drop-in boundary.  The reference (mini-mcmc v0.8.3, Rust) has no FFI of its own: its boundary is
+ * the trait + constructor surface of the crate.  Each entry point below names the reference item it stands in
+ * for (file:line in the reference tree); INTEGRATION.md shows the `extern "C"` block and the safe Rust wrapper
+ * (`GpuMetropolisHastings`, `GpuHmc`, `GpuNuts`) a maintainer would add on top.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types; no exceptions cross the boundary
+ *   - every function returns an int status: MMCMC_OK (0), negative = invalid argument / unsupported,
+ *     positive = the hipError_t of the failing HIP call.  mmcmc_status_string() names them.
+ *   - sample layout is the reference's: [n_chains, n_collect, dim] row-major (core.rs:176-186, hmc.rs:157)
+ *   - a handle owns its device state (current positions, iteration counter, seed), so calling run() twice
+ *     continues the chains exactly as the Rust sampler structs do
+ *   - handles are not thread-safe; one handle = one device; `stream` arguments are hipStream_t passed as
+ *     void* (NULL = the handle's own stream); run() is asynchronous when `out` is device memory and no
+ *     host-side result (accept counts) is requested -- call mmcmc_*_sync() or synchronise the stream.
+ *   - the library has NO CPU fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef MMCMC_H
+#define MMCMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMCMC_VERSION 100 /* 0.1.0 */
+
+/* ---- status ---- */
+#define MMCMC_OK 0
+#define MMCMC_ERR_INVALID_ARG (-1)  /* NULL pointer, zero chains, negative count, ...            */
+#define MMCMC_ERR_UNSUPPORTED (-2)  /* target kind / dim / dtype combination has no kernel        */
+#define MMCMC_ERR_SHAPE (-3)        /* the analogue of ndarray::ShapeError from core.rs:184       */
+#define MMCMC_ERR_NO_DEVICE (-4)    /* no HIP device: the engine never falls back to the CPU      */
+#define MMCMC_ERR_STATE (-5)        /* handle used in the wrong state (e.g. destroyed)            */
+
+/* ---- element types ---- */
+#define MMCMC_F32 0
+#define MMCMC_F64 1
+
+/* ---- built-in targets: the closed registry standing in for `impl Target` / `impl BatchedGradientTarget`
+ *      / `impl GradientTarget` (distributions.rs:65-108).  params[] meaning per kind:
+ *   MMCMC_GAUSSIAN2D           mean0, mean1, cov00, cov01, cov10, cov11     distributions.rs:158-206
+ *   MMCMC_DIFFABLE_GAUSSIAN2D  mean0, mean1, cov00, cov01, cov10, cov11     distributions.rs:212-316
+ *   MMCMC_ISOTROPIC_GAUSSIAN   std                                          distributions.rs:344-402
+ *   MMCMC_ROSENBROCK2D         a, b                                         distributions.rs:490-524
+ *   MMCMC_ROSENBROCK_ND        (none)                                       distributions.rs:528-547
+ *   MMCMC_STANDARD_NORMAL      (none)                                       nuts.rs:1024-1037 (test target)
+ *   MMCMC_GAUSSIAN_ND          matrix = precision A, row-major dim x dim    (not in the reference; config 5) */
+#define MMCMC_GAUSSIAN2D 0
+#define MMCMC_DIFFABLE_GAUSSIAN2D 1
+#define MMCMC_ISOTROPIC_GAUSSIAN 2
+#define MMCMC_ROSENBROCK2D 3
+#define MMCMC_ROSENBROCK_ND 4
+#define MMCMC_STANDARD_NORMAL 5
+#define MMCMC_GAUSSIAN_ND 6
+
+typedef struct mmcmc_target_desc {
+    int32_t kind;
+    int32_t dim;
+    double params[8];
+    const double *matrix; /* host pointer, only for MMCMC_GAUSSIAN_ND */
+} mmcmc_target_desc;
+
+/* `impl Proposal`: only the reference's IsotropicGaussian (distributions.rs:344-392) */
+#define MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN 0
+typedef struct mmcmc_proposal_desc {
+    int32_t kind;
+    int32_t reserved;
+    double std;
+} mmcmc_proposal_desc;
+
+/* summary of one diagnostic (stats.rs:373-381 BasicStats) */
+typedef struct mmcmc_basic_stats {
+    float min, median, max, mean, std;
+} mmcmc_basic_stats;
+/* stats.rs:338-342 RunStats */
+typedef struct mmcmc_run_stats {
+    mmcmc_basic_stats ess;
+    mmcmc_basic_stats rhat;
+} mmcmc_run_stats;
+
+/* timing of the most recent run(): device time of the sampling kernel(s), measured with HIP events on the
+ * stream the kernels were launched on */
+typedef struct mmcmc_timing {
+    float kernel_ms;      /* sum over launches */
+    uint32_t n_launches;
+    uint32_t reserved;
+    uint64_t out_bytes;   /* sample bytes written by the kernels */
+    uint64_t state_bytes; /* chain state bytes loaded + stored */
+} mmcmc_timing;
+
+/* ---- library ---- */
+int mmcmc_version(void);
+const char *mmcmc_status_string(int status);
+int mmcmc_device_count(int *count);
+
+/* ---- core.rs:394-435  init_with_seed / init_det (seed 42): n*d StandardNormal draws of the reference's own
+ *      stream (rand 0.9 SmallRng = xoshiro256++, rand_distr 0.5 ziggurat), row-major, as double. Host only. */
+int mmcmc_init_with_seed(size_t n, size_t d, uint64_t seed, double *out);
+
+/* ---- Metropolis-Hastings -----------------------------------------------------------------------------
+ * MetropolisHastings::new(target, proposal, initial_states)   metropolis_hastings.rs:149-159
+ * init: host, [n_chains, dim] of `dtype` elements */
+typedef struct mmcmc_mh mmcmc_mh;
+int mmcmc_mh_create(mmcmc_mh **out, const mmcmc_target_desc *target, const mmcmc_proposal_desc *proposal,
+                    const void *init, size_t n_chains, int dtype, int device);
+/* MetropolisHastings::seed   metropolis_hastings.rs:187-193 */
+int mmcmc_mh_seed(mmcmc_mh *h, uint64_t seed);
+/* multi-GPU sharding: global id of this handle's first chain (stream key = chain_offset + local index) */
+int mmcmc_mh_set_chain_offset(mmcmc_mh *h, uint64_t chain_offset);
+/* ChainRunner::run(n_collect, n_discard) -> Array3 [n_chains, n_collect, dim]   core.rs:176-186 (+ :55-73)
+ * out: [n_chains, n_collect, dim] of dtype, device memory if out_is_device else host (may be NULL: no samples).
+ * accept_counts: host, [n_chains], accepted proposals per chain over the whole call (may be NULL). */
+int mmcmc_mh_run(mmcmc_mh *h, size_t n_collect, size_t n_discard, void *out, int out_is_device,
+                 uint64_t *accept_counts, void *stream);
+/* MarkovChain::current_state for every chain   core.rs:43-44 ; host [n_chains, dim] */
+int mmcmc_mh_state(mmcmc_mh *h, void *out);
+int mmcmc_mh_sync(mmcmc_mh *h);
+int mmcmc_mh_timing(mmcmc_mh *h, mmcmc_timing *t);
+int mmcmc_mh_destroy(mmcmc_mh *h);
+
+/* ---- HMC ---------------------------------------------------------------------------------------------
+ * HMC::new(target, initial_positions, step_size, n_leapfrog)   hmc.rs:87-109 */
+typedef struct mmcmc_hmc mmcmc_hmc;
+int mmcmc_hmc_create(mmcmc_hmc **out, const mmcmc_target_desc *target, const void *init, size_t n_chains,
+                     double step_size, int n_leapfrog, int dtype, int device);
+/* HMC::set_seed   hmc.rs:118-121 (inert in the reference, quirk Q6; here it keys the stream) */
+int mmcmc_hmc_seed(mmcmc_hmc *h, uint64_t seed);
+int mmcmc_hmc_set_chain_offset(mmcmc_hmc *h, uint64_t chain_offset);
+/* HMC::run(n_collect, n_discard) -> Tensor [n_chains, n_collect, dim]   hmc.rs:137-158 */
+int mmcmc_hmc_run(mmcmc_hmc *h, size_t n_collect, size_t n_discard, void *out, int out_is_device,
+                  uint64_t *accept_counts, void *stream);
+/* HMC::step   hmc.rs:304-377 : one transition of every chain */
+int mmcmc_hmc_step(mmcmc_hmc *h, void *stream);
+/* HMC::positions   hmc.rs:49 ; host [n_chains, dim] */
+int mmcmc_hmc_state(mmcmc_hmc *h, void *out);
+int mmcmc_hmc_sync(mmcmc_hmc *h);
+int mmcmc_hmc_timing(mmcmc_hmc *h, mmcmc_timing *t);
+int mmcmc_hmc_destroy(mmcmc_hmc *h);
+
+/* knob shared by the samplers: iterations per kernel launch (0 = the whole run in one launch, the default) */
+int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters);
+int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters);
+
+/* ---- densities, for parity tests ---------------------------------------------------------------------
+ * BatchedGradientTarget::unnorm_logp_batch (distributions.rs:65-76) / unnorm_logp_and_grad (:81-87)
+ * x: host [n, dim]; logp: host [n]; grad: host [n, dim] or NULL; all of `dtype` */
+int mmcmc_logp_grad_batch(const mmcmc_target_desc *target, int dtype, const void *x, size_t n, void *logp,
+                          void *grad, int device);
+
+/* ---- the engine's random stream, for parity tests: noise of (seed, chain, iteration) exactly as the kernels
+ *      draw it.  z: host [n_chains, dim] of dtype, u: host [n_chains] of dtype; computed on the device. */
+int mmcmc_draw_noise(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n_chains, int dim, int dtype,
+                     void *z, void *u, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMCMC_H */

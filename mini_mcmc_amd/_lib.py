@@ -1,0 +1,112 @@
+"""ctypes loader for libmmcmc.so (the C ABI declared in include/mmcmc.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C mini_mcmc_amd/csrc`.  There is NO fallback:
+if the shared object is missing or a symbol cannot be bound, importing a sampler raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmcmc.so")
+
+F32, F64 = 0, 1
+
+# target kinds (include/mmcmc.h)
+GAUSSIAN2D, DIFFABLE_GAUSSIAN2D, ISOTROPIC_GAUSSIAN, ROSENBROCK2D, ROSENBROCK_ND, STANDARD_NORMAL, GAUSSIAN_ND = range(7)
+
+OK = 0
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_SHAPE, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4, -5
+
+
+class TargetDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dim", C.c_int32), ("params", C.c_double * 8), ("matrix", C.POINTER(C.c_double))]
+
+
+class ProposalDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("std", C.c_double)]
+
+
+class BasicStats(C.Structure):
+    _fields_ = [("min", C.c_float), ("median", C.c_float), ("max", C.c_float), ("mean", C.c_float), ("std", C.c_float)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("ess", BasicStats), ("rhat", BasicStats)]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("kernel_ms", C.c_float),
+        ("n_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("out_bytes", C.c_uint64),
+        ("state_bytes", C.c_uint64),
+    ]
+
+
+class MmcmcError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        msg = lib().mmcmc_status_string(status).decode() if _lib is not None else "?"
+        super().__init__(f"{where}: status {status} ({msg})")
+
+
+_lib = None
+_vp = C.c_void_p
+_TP = C.POINTER(TargetDesc)
+_PP = C.POINTER(ProposalDesc)
+
+# name -> (restype, argtypes); every symbol include/mmcmc.h declares
+SIGNATURES = {
+    "mmcmc_version": (C.c_int, []),
+    "mmcmc_status_string": (C.c_char_p, [C.c_int]),
+    "mmcmc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mmcmc_init_with_seed": (C.c_int, [C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_double)]),
+    "mmcmc_mh_create": (C.c_int, [C.POINTER(_vp), _TP, _PP, _vp, C.c_size_t, C.c_int, C.c_int]),
+    "mmcmc_mh_seed": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_mh_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_mh_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.POINTER(C.c_uint64), _vp]),
+    "mmcmc_mh_state": (C.c_int, [_vp, _vp]),
+    "mmcmc_mh_sync": (C.c_int, [_vp]),
+    "mmcmc_mh_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
+    "mmcmc_mh_destroy": (C.c_int, [_vp]),
+    "mmcmc_mh_set_iters_per_launch": (C.c_int, [_vp, C.c_uint32]),
+    "mmcmc_hmc_create": (C.c_int, [C.POINTER(_vp), _TP, _vp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "mmcmc_hmc_seed": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_hmc_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_hmc_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.POINTER(C.c_uint64), _vp]),
+    "mmcmc_hmc_step": (C.c_int, [_vp, _vp]),
+    "mmcmc_hmc_state": (C.c_int, [_vp, _vp]),
+    "mmcmc_hmc_sync": (C.c_int, [_vp]),
+    "mmcmc_hmc_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
+    "mmcmc_hmc_destroy": (C.c_int, [_vp]),
+    "mmcmc_hmc_set_iters_per_launch": (C.c_int, [_vp, C.c_uint32]),
+    "mmcmc_logp_grad_batch": (C.c_int, [_TP, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int]),
+    "mmcmc_draw_noise": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libmmcmc.so and bind every entry point. Raises if the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mini_mcmc_amd/csrc`). mini_mcmc_amd has no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status: int, where: str) -> None:
+    if status != OK:
+        raise MmcmcError(status, where)

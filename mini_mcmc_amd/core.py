@@ -1,0 +1,111 @@
+"""Host-side mirror of the reference's `core` module (src/core.rs): initialisers and the sampler base class
+(`ChainRunner::run` is implemented by the engine: one GPU lane per chain instead of one rayon task per chain)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def init_with_seed(n: int, d: int, seed: int, dtype=np.float64) -> np.ndarray:
+    """core.rs:413-419: n starting points in d dimensions from the reference's own stream
+    (SmallRng::seed_from_u64(seed) + StandardNormal), so `init_det` gives the reference's values."""
+    out = np.empty((n, d), dtype=np.float64)
+    st = L.lib().mmcmc_init_with_seed(n, d, seed, out.ctypes.data_as(C.POINTER(C.c_double)))
+    L.check(st, "mmcmc_init_with_seed")
+    return out.astype(dtype)
+
+
+def init_det(n: int, d: int, dtype=np.float64) -> np.ndarray:
+    """core.rs:404-409: init_with_seed(n, d, 42)."""
+    return init_with_seed(n, d, 42, dtype)
+
+
+def init(n: int, d: int, dtype=np.float64) -> np.ndarray:
+    """core.rs:394-400: seeded from OS entropy."""
+    seed = int.from_bytes(__import__("os").urandom(8), "little")
+    return init_with_seed(n, d, seed, dtype)
+
+
+class _Sampler:
+    """Shared plumbing of the GPU samplers: owns one C-ABI handle."""
+
+    _prefix = ""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self.accept_counts = None
+
+    def _fn(self, name):
+        return getattr(L.lib(), f"mmcmc_{self._prefix}_{name}")
+
+    def set_chain_offset(self, first_global_chain: int):
+        """Multi-GPU sharding: this handle's chains are global chains [offset, offset + n_chains)."""
+        L.check(self._fn("set_chain_offset")(self._h, int(first_global_chain)), "set_chain_offset")
+        return self
+
+    def set_iters_per_launch(self, iters: int):
+        L.check(self._fn("set_iters_per_launch")(self._h, int(iters)), "set_iters_per_launch")
+        return self
+
+    def run(self, n_collect: int, n_discard: int = 0, to: str = "numpy", accept_counts: bool = True,
+            collect: bool = True):
+        """`run(n_collect, n_discard)` of the reference (core.rs:176-186 / hmc.rs:137-158): returns the sample
+        [n_chains, n_collect, dim].  to="numpy": host array; to="torch": a torch tensor in HBM, written by the
+        kernel on torch's current stream (no host copy)."""
+        acc = np.zeros(self.n_chains, dtype=np.uint64) if accept_counts else None
+        accp = acc.ctypes.data_as(C.POINTER(C.c_uint64)) if accept_counts else None
+        if to == "torch":
+            import torch
+
+            tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+            dev = torch.device("cuda", self.device)
+            out = torch.empty((self.n_chains, n_collect, self.dim), dtype=tdt, device=dev) if collect else None
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            st = self._fn("run")(self._h, n_collect, n_discard, out.data_ptr() if collect else None, 1, accp,
+                                 C.c_void_p(stream))
+            L.check(st, f"mmcmc_{self._prefix}_run")
+        else:
+            out = np.empty((self.n_chains, n_collect, self.dim), dtype=self.dtype) if collect else None
+            st = self._fn("run")(self._h, n_collect, n_discard, out.ctypes.data if collect else None, 0, accp, None)
+            L.check(st, f"mmcmc_{self._prefix}_run")
+            L.check(self._fn("sync")(self._h), "sync")
+        self.accept_counts = acc
+        return out
+
+    def sync(self):
+        L.check(self._fn("sync")(self._h), "sync")
+
+    def timing(self) -> dict:
+        t = L.Timing()
+        L.check(self._fn("timing")(self._h, C.byref(t)), "timing")
+        return dict(kernel_ms=t.kernel_ms, n_launches=t.n_launches, out_bytes=t.out_bytes, state_bytes=t.state_bytes)
+
+    def state(self) -> np.ndarray:
+        out = np.empty((self.n_chains, self.dim), dtype=self.dtype)
+        L.check(self._fn("state")(self._h, out.ctypes.data), "state")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._fn("destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def draw_noise(seed: int, chain_offset: int, iteration: int, n_chains: int, dim: int, dtype=np.float32, device=0):
+    """The noise the sampling kernels draw for (chain, iteration): (z[n_chains, dim], u[n_chains]); computed on
+    the GPU by the same device functions the kernels use."""
+    z = np.empty((n_chains, dim), dtype=dtype)
+    u = np.empty(n_chains, dtype=dtype)
+    st = L.lib().mmcmc_draw_noise(seed, chain_offset, iteration, n_chains, dim,
+                                  L.F32 if dtype == np.float32 else L.F64, z.ctypes.data, u.ctypes.data, device)
+    L.check(st, "mmcmc_draw_noise")
+    return z, u

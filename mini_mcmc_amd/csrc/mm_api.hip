@@ -1,0 +1,685 @@
+/*
+ * mm_api.hip -- implementation of the C ABI in include/mmcmc.h (MH, HMC, densities, init).
+ *
+ * Host logic only: handles, argument checking, kernel lookup, launches, timing.  All arithmetic of the hot path
+ * lives in mm_samplers.h / mm_targets.h / mm_rng.h and runs on the device; nothing here computes a transition
+ * on the CPU and nothing here touches oracle/.
+ */
+#include "../../include/mmcmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mm_kernels.h"
+#include "mm_host_rng.h"
+#include "mm_params.h"
+
+#define MM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return (int)_e;                                                                                       \
+    } while (0)
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+int check_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= n)
+        return MMCMC_ERR_INVALID_ARG;
+    return MMCMC_OK;
+}
+
+template <class T> const mm_kernel_entry<T> *table(int *n);
+template <> const mm_kernel_entry<float> *table<float>(int *n) { return mm_kernel_table_f32(n); }
+template <> const mm_kernel_entry<double> *table<double>(int *n) { return mm_kernel_table_f64(n); }
+template <class T> const mm_noise_entry<T> *noise_table(int *n);
+template <> const mm_noise_entry<float> *noise_table<float>(int *n) { return mm_noise_table_f32(n); }
+template <> const mm_noise_entry<double> *noise_table<double>(int *n) { return mm_noise_table_f64(n); }
+
+template <class T> const mm_kernel_entry<T> *find_kernel(int kind, int dim)
+{
+    int n = 0;
+    const mm_kernel_entry<T> *t = table<T>(&n);
+    for (int i = 0; i < n; ++i)
+        if (t[i].kind == kind && t[i].dim == dim)
+            return &t[i];
+    return nullptr;
+}
+
+int validate_target(const mmcmc_target_desc *t)
+{
+    if (!t || t->dim <= 0)
+        return MMCMC_ERR_INVALID_ARG;
+    switch (t->kind) {
+    case MMCMC_GAUSSIAN2D:
+    case MMCMC_DIFFABLE_GAUSSIAN2D:
+    case MMCMC_ROSENBROCK2D:
+        if (t->dim != 2)
+            return MMCMC_ERR_SHAPE;
+        break;
+    case MMCMC_ISOTROPIC_GAUSSIAN:
+        if (!(t->params[0] > 0.0))
+            return MMCMC_ERR_INVALID_ARG;
+        break;
+    case MMCMC_ROSENBROCK_ND:
+    case MMCMC_STANDARD_NORMAL:
+        break;
+    case MMCMC_GAUSSIAN_ND:
+        if (!t->matrix)
+            return MMCMC_ERR_INVALID_ARG;
+        break;
+    default:
+        return MMCMC_ERR_UNSUPPORTED;
+    }
+    return MMCMC_OK;
+}
+
+/* device-side parameter block in element type T (mm_params.h) + the GaussianND matrix uploaded to HBM */
+template <class T> int make_params(const mmcmc_target_desc *t, mm_tparams<T> *P, T **d_mat)
+{
+    *d_mat = nullptr;
+    if (mm_fill_params<T>(t->kind, t->params, P) != 0)
+        return MMCMC_ERR_INVALID_ARG;
+    if (t->kind == MMCMC_GAUSSIAN_ND) {
+        size_t n = (size_t)t->dim * t->dim;
+        std::vector<T> h(n);
+        for (size_t i = 0; i < n; ++i)
+            h[i] = (T)t->matrix[i];
+        MM_HIP(hipMalloc((void **)d_mat, n * sizeof(T)));
+        MM_HIP(hipMemcpy(*d_mat, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        P->mat = *d_mat;
+    }
+    return MMCMC_OK;
+}
+
+/* one sampler handle; MH and HMC differ only in the kernel entry and two scalars */
+struct Sampler {
+    int sampler = 0; /* MM_SAMPLER_MH / MM_SAMPLER_HMC */
+    int dtype = MMCMC_F32;
+    int device = 0;
+    int kind = 0, dim = 0;
+    size_t n_chains = 0;
+    double scale = 0; /* proposal std or step size */
+    int n_leapfrog = 0;
+    uint64_t seed = 0, chain_offset = 0;
+    uint64_t iter = 0;
+    uint32_t iters_per_launch = 0;
+    unsigned int block = 64;
+    void *d_state = nullptr;
+    void *d_mat = nullptr;
+    unsigned long long *d_accept = nullptr;
+    unsigned long long *d_accept_total = nullptr;
+    mm_tparams<float> Pf;
+    mm_tparams<double> Pd;
+    const mm_kernel_entry<float> *kf = nullptr;
+    const mm_kernel_entry<double> *kd = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    mmcmc_timing timing{};
+    bool alive = true;
+
+    size_t esize() const { return dtype == MMCMC_F32 ? 4 : 8; }
+};
+
+int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, double scale, int n_leapfrog,
+                   const void *init, size_t n_chains, int dtype, int device)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!init || n_chains == 0 || (dtype != MMCMC_F32 && dtype != MMCMC_F64) || !(scale > 0.0) ||
+        !std::isfinite(scale) || n_leapfrog < 0)
+        return MMCMC_ERR_INVALID_ARG;
+    int st = validate_target(target);
+    if (st != MMCMC_OK)
+        return st;
+    st = check_device(device);
+    if (st != MMCMC_OK)
+        return st;
+    Sampler *s = new (std::nothrow) Sampler();
+    if (!s)
+        return (int)hipErrorOutOfMemory;
+    s->sampler = sampler;
+    s->dtype = dtype;
+    s->device = device;
+    s->kind = target->kind;
+    s->dim = target->dim;
+    s->n_chains = n_chains;
+    s->scale = scale;
+    s->n_leapfrog = n_leapfrog;
+    if (dtype == MMCMC_F32)
+        s->kf = find_kernel<float>(s->kind, s->dim);
+    else
+        s->kd = find_kernel<double>(s->kind, s->dim);
+    if (!s->kf && !s->kd) {
+        delete s;
+        return MMCMC_ERR_UNSUPPORTED;
+    }
+    DeviceGuard g(device);
+    auto fail = [&](int code) {
+        if (s->d_state)
+            (void)hipFree(s->d_state);
+        if (s->d_mat)
+            (void)hipFree(s->d_mat);
+        if (s->d_accept)
+            (void)hipFree(s->d_accept);
+        if (s->d_accept_total)
+            (void)hipFree(s->d_accept_total);
+        if (s->stream)
+            (void)hipStreamDestroy(s->stream);
+        if (s->ev0)
+            (void)hipEventDestroy(s->ev0);
+        if (s->ev1)
+            (void)hipEventDestroy(s->ev1);
+        delete s;
+        return code;
+    };
+    if (dtype == MMCMC_F32) {
+        float *m = nullptr;
+        st = make_params<float>(target, &s->Pf, &m);
+        s->d_mat = m;
+    } else {
+        double *m = nullptr;
+        st = make_params<double>(target, &s->Pd, &m);
+        s->d_mat = m;
+    }
+    if (st != MMCMC_OK)
+        return fail(st);
+    size_t bytes = n_chains * (size_t)s->dim * s->esize();
+    hipError_t e;
+    if ((e = hipMalloc(&s->d_state, bytes)) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMemcpy(s->d_state, init, bytes, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMalloc((void **)&s->d_accept, n_chains * sizeof(unsigned long long))) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMalloc((void **)&s->d_accept_total, sizeof(unsigned long long))) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMemset(s->d_accept_total, 0, sizeof(unsigned long long))) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipEventCreate(&s->ev0)) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipEventCreate(&s->ev1)) != hipSuccess)
+        return fail((int)e);
+    *out = s;
+    return MMCMC_OK;
+}
+
+int sampler_destroy(Sampler *s)
+{
+    if (!s)
+        return MMCMC_ERR_INVALID_ARG;
+    if (!s->alive)
+        return MMCMC_ERR_STATE;
+    DeviceGuard g(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->d_state);
+    if (s->d_mat)
+        (void)hipFree(s->d_mat);
+    (void)hipFree(s->d_accept);
+    (void)hipFree(s->d_accept_total);
+    (void)hipEventDestroy(s->ev0);
+    (void)hipEventDestroy(s->ev1);
+    (void)hipStreamDestroy(s->stream);
+    s->alive = false;
+    delete s;
+    return MMCMC_OK;
+}
+
+template <class T>
+int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P, T *d_out, size_t n_total,
+                 uint32_t n_discard, uint32_t n_collect, uint32_t out_t0, hipStream_t stream)
+{
+    mm_run_args<T> a;
+    a.P = P;
+    a.scale = (T)s->scale;
+    a.n_leapfrog = s->n_leapfrog;
+    a.state = (T *)s->d_state;
+    a.out = d_out;
+    a.accept = s->d_accept;
+    a.accept_total = s->d_accept_total;
+    a.n_chains = s->n_chains;
+    a.seed = s->seed;
+    a.chain_offset = s->chain_offset;
+    a.iter0 = (unsigned int)s->iter;
+    a.n_discard = n_discard;
+    a.n_collect = n_collect;
+    a.out_t0 = out_t0;
+    a.n_total = n_total;
+    unsigned int grid = (unsigned int)((s->n_chains + s->block - 1) / s->block);
+    hipError_t e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh(a, grid, s->block, stream)
+                                                 : k->run_hmc(a, grid, s->block, stream);
+    if (e != hipSuccess)
+        return (int)e;
+    s->iter += (uint64_t)n_discard + n_collect;
+    return MMCMC_OK;
+}
+
+int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int out_is_device,
+                uint64_t *accept_counts, void *stream_v)
+{
+    if (!s)
+        return MMCMC_ERR_INVALID_ARG;
+    if (!s->alive)
+        return MMCMC_ERR_STATE;
+    if (n_collect + n_discard == 0)
+        return MMCMC_OK;
+    if ((uint64_t)n_collect * (uint64_t)s->dim >= (1ull << 32) || s->iter + n_collect + n_discard >= (1ull << 32))
+        return MMCMC_ERR_SHAPE;
+    DeviceGuard g(s->device);
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : s->stream;
+    const size_t out_bytes = s->n_chains * n_collect * (size_t)s->dim * s->esize();
+    void *d_out = nullptr;
+    bool staged = false;
+    if (out && n_collect > 0) {
+        if (out_is_device) {
+            d_out = out;
+        } else {
+            MM_HIP(hipMalloc(&d_out, out_bytes));
+            staged = true;
+        }
+    }
+    MM_HIP(hipMemsetAsync(s->d_accept, 0, s->n_chains * sizeof(unsigned long long), stream));
+
+    /* split the run into launches of at most iters_per_launch transitions (0 = one launch) */
+    uint64_t remaining_discard = n_discard, remaining_collect = n_collect, t0 = 0;
+    const uint64_t cap = s->iters_per_launch ? s->iters_per_launch : (n_discard + n_collect);
+    uint32_t launches = 0;
+    MM_HIP(hipEventRecord(s->ev0, stream));
+    while (remaining_discard + remaining_collect > 0) {
+        uint32_t nd = (uint32_t)std::min<uint64_t>(remaining_discard, cap);
+        uint32_t nc = (uint32_t)std::min<uint64_t>(remaining_collect, cap - nd);
+        int st;
+        if (s->dtype == MMCMC_F32)
+            st = launch_range<float>(s, s->kf, s->Pf, (float *)d_out, n_collect, nd, nc, (uint32_t)t0, stream);
+        else
+            st = launch_range<double>(s, s->kd, s->Pd, (double *)d_out, n_collect, nd, nc, (uint32_t)t0, stream);
+        if (st != MMCMC_OK) {
+            if (staged)
+                (void)hipFree(d_out);
+            return st;
+        }
+        remaining_discard -= nd;
+        remaining_collect -= nc;
+        t0 += nc;
+        ++launches;
+    }
+    MM_HIP(hipEventRecord(s->ev1, stream));
+    s->timed = true;
+    s->timing.n_launches = launches;
+    s->timing.out_bytes = d_out ? out_bytes : 0;
+    s->timing.state_bytes = (uint64_t)launches * 2ull * s->n_chains * s->dim * s->esize();
+    s->timing.kernel_ms = -1.0f;
+
+    if (staged) {
+        MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+        MM_HIP(hipStreamSynchronize(stream));
+        MM_HIP(hipFree(d_out));
+    }
+    if (accept_counts) {
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
+        MM_HIP(hipMemcpyAsync(accept_counts, s->d_accept, s->n_chains * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                              stream));
+        MM_HIP(hipStreamSynchronize(stream));
+    }
+    return MMCMC_OK;
+}
+
+int sampler_state(Sampler *s, void *out)
+{
+    if (!s || !out)
+        return MMCMC_ERR_INVALID_ARG;
+    if (!s->alive)
+        return MMCMC_ERR_STATE;
+    DeviceGuard g(s->device);
+    MM_HIP(hipStreamSynchronize(s->stream));
+    MM_HIP(hipDeviceSynchronize());
+    MM_HIP(hipMemcpy(out, s->d_state, s->n_chains * (size_t)s->dim * s->esize(), hipMemcpyDeviceToHost));
+    return MMCMC_OK;
+}
+
+int sampler_sync(Sampler *s)
+{
+    if (!s)
+        return MMCMC_ERR_INVALID_ARG;
+    if (!s->alive)
+        return MMCMC_ERR_STATE;
+    DeviceGuard g(s->device);
+    if (s->timed)
+        MM_HIP(hipEventSynchronize(s->ev1));
+    MM_HIP(hipStreamSynchronize(s->stream));
+    return MMCMC_OK;
+}
+
+int sampler_timing(Sampler *s, mmcmc_timing *t)
+{
+    if (!s || !t)
+        return MMCMC_ERR_INVALID_ARG;
+    if (!s->alive || !s->timed)
+        return MMCMC_ERR_STATE;
+    DeviceGuard g(s->device);
+    MM_HIP(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    MM_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    s->timing.kernel_ms = ms;
+    *t = s->timing;
+    return MMCMC_OK;
+}
+
+template <class T>
+int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, void *logp, void *grad)
+{
+    const mm_kernel_entry<T> *k = find_kernel<T>(target->kind, target->dim);
+    if (!k)
+        return MMCMC_ERR_UNSUPPORTED;
+    mm_tparams<T> P;
+    T *d_mat = nullptr;
+    int st = make_params<T>(target, &P, &d_mat);
+    if (st != MMCMC_OK)
+        return st;
+    size_t d = (size_t)target->dim;
+    T *dx = nullptr, *dl = nullptr, *dg = nullptr;
+    int rc = MMCMC_OK;
+    hipError_t e;
+    do {
+        if ((e = hipMalloc((void **)&dx, n * d * sizeof(T))) != hipSuccess)
+            break;
+        if ((e = hipMalloc((void **)&dl, n * sizeof(T))) != hipSuccess)
+            break;
+        if (grad && (e = hipMalloc((void **)&dg, n * d * sizeof(T))) != hipSuccess)
+            break;
+        if ((e = hipMemcpy(dx, x, n * d * sizeof(T), hipMemcpyHostToDevice)) != hipSuccess)
+            break;
+        if ((e = k->logp_grad(P, dx, dl, dg, (unsigned long long)n, nullptr)) != hipSuccess)
+            break;
+        if ((e = hipDeviceSynchronize()) != hipSuccess)
+            break;
+        if ((e = hipMemcpy(logp, dl, n * sizeof(T), hipMemcpyDeviceToHost)) != hipSuccess)
+            break;
+        if (grad && (e = hipMemcpy(grad, dg, n * d * sizeof(T), hipMemcpyDeviceToHost)) != hipSuccess)
+            break;
+    } while (0);
+    if (e != hipSuccess)
+        rc = (int)e;
+    (void)hipFree(dx);
+    (void)hipFree(dl);
+    if (dg)
+        (void)hipFree(dg);
+    if (d_mat)
+        (void)hipFree(d_mat);
+    return rc;
+}
+
+template <class T>
+int draw_noise_t(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n, int dim, void *z, void *u)
+{
+    int nn = 0;
+    const mm_noise_entry<T> *t = noise_table<T>(&nn);
+    const mm_noise_entry<T> *k = nullptr;
+    for (int i = 0; i < nn; ++i)
+        if (t[i].dim == dim)
+            k = &t[i];
+    if (!k)
+        return MMCMC_ERR_UNSUPPORTED;
+    T *dz = nullptr, *du = nullptr;
+    hipError_t e;
+    do {
+        if ((e = hipMalloc((void **)&dz, n * (size_t)dim * sizeof(T))) != hipSuccess)
+            break;
+        if ((e = hipMalloc((void **)&du, n * sizeof(T))) != hipSuccess)
+            break;
+        if ((e = k->noise(seed, chain_offset, iteration, (unsigned long long)n, dz, du, nullptr)) != hipSuccess)
+            break;
+        if ((e = hipDeviceSynchronize()) != hipSuccess)
+            break;
+        if ((e = hipMemcpy(z, dz, n * (size_t)dim * sizeof(T), hipMemcpyDeviceToHost)) != hipSuccess)
+            break;
+        if ((e = hipMemcpy(u, du, n * sizeof(T), hipMemcpyDeviceToHost)) != hipSuccess)
+            break;
+    } while (0);
+    (void)hipFree(dz);
+    (void)hipFree(du);
+    return e == hipSuccess ? MMCMC_OK : (int)e;
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------ C ABI */
+
+struct mmcmc_mh {
+    Sampler *s;
+};
+struct mmcmc_hmc {
+    Sampler *s;
+};
+
+extern "C" {
+
+int mmcmc_version(void) { return MMCMC_VERSION; }
+
+const char *mmcmc_status_string(int status)
+{
+    switch (status) {
+    case MMCMC_OK:
+        return "ok";
+    case MMCMC_ERR_INVALID_ARG:
+        return "invalid argument";
+    case MMCMC_ERR_UNSUPPORTED:
+        return "unsupported target kind / dimension / element type";
+    case MMCMC_ERR_SHAPE:
+        return "shape error";
+    case MMCMC_ERR_NO_DEVICE:
+        return "no HIP device (the engine has no CPU fallback)";
+    case MMCMC_ERR_STATE:
+        return "handle in the wrong state";
+    default:
+        return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
+    }
+}
+
+int mmcmc_device_count(int *count)
+{
+    if (!count)
+        return MMCMC_ERR_INVALID_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        *count = 0;
+        return MMCMC_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return MMCMC_OK;
+}
+
+int mmcmc_init_with_seed(size_t n, size_t d, uint64_t seed, double *out)
+{
+    if (!out && n * d > 0)
+        return MMCMC_ERR_INVALID_ARG;
+    mm_host::SmallRng rng(seed);
+    for (size_t i = 0; i < n * d; ++i)
+        out[i] = rng.standard_normal();
+    return MMCMC_OK;
+}
+
+/* ---- MH ---- */
+int mmcmc_mh_create(mmcmc_mh **out, const mmcmc_target_desc *target, const mmcmc_proposal_desc *proposal,
+                    const void *init, size_t n_chains, int dtype, int device)
+{
+    if (!out || !proposal)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (proposal->kind != MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN)
+        return MMCMC_ERR_UNSUPPORTED;
+    Sampler *s = nullptr;
+    int st = sampler_create(&s, MM_SAMPLER_MH, target, proposal->std, 0, init, n_chains, dtype, device);
+    if (st != MMCMC_OK)
+        return st;
+    mmcmc_mh *h = new (std::nothrow) mmcmc_mh{s};
+    if (!h) {
+        sampler_destroy(s);
+        return (int)hipErrorOutOfMemory;
+    }
+    *out = h;
+    return MMCMC_OK;
+}
+int mmcmc_mh_seed(mmcmc_mh *h, uint64_t seed)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->seed = seed;
+    return MMCMC_OK;
+}
+int mmcmc_mh_set_chain_offset(mmcmc_mh *h, uint64_t off)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->chain_offset = off;
+    return MMCMC_OK;
+}
+int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->iters_per_launch = iters;
+    return MMCMC_OK;
+}
+int mmcmc_mh_run(mmcmc_mh *h, size_t n_collect, size_t n_discard, void *out, int out_is_device,
+                 uint64_t *accept_counts, void *stream)
+{
+    return h ? sampler_run(h->s, n_collect, n_discard, out, out_is_device, accept_counts, stream)
+             : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_mh_state(mmcmc_mh *h, void *out) { return h ? sampler_state(h->s, out) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_mh_sync(mmcmc_mh *h) { return h ? sampler_sync(h->s) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_mh_timing(mmcmc_mh *h, mmcmc_timing *t) { return h ? sampler_timing(h->s, t) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_mh_destroy(mmcmc_mh *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    int st = sampler_destroy(h->s);
+    delete h;
+    return st;
+}
+
+/* ---- HMC ---- */
+int mmcmc_hmc_create(mmcmc_hmc **out, const mmcmc_target_desc *target, const void *init, size_t n_chains,
+                     double step_size, int n_leapfrog, int dtype, int device)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    Sampler *s = nullptr;
+    int st = sampler_create(&s, MM_SAMPLER_HMC, target, step_size, n_leapfrog, init, n_chains, dtype, device);
+    if (st != MMCMC_OK)
+        return st;
+    mmcmc_hmc *h = new (std::nothrow) mmcmc_hmc{s};
+    if (!h) {
+        sampler_destroy(s);
+        return (int)hipErrorOutOfMemory;
+    }
+    *out = h;
+    return MMCMC_OK;
+}
+int mmcmc_hmc_seed(mmcmc_hmc *h, uint64_t seed)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->seed = seed;
+    return MMCMC_OK;
+}
+int mmcmc_hmc_set_chain_offset(mmcmc_hmc *h, uint64_t off)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->chain_offset = off;
+    return MMCMC_OK;
+}
+int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->iters_per_launch = iters;
+    return MMCMC_OK;
+}
+int mmcmc_hmc_run(mmcmc_hmc *h, size_t n_collect, size_t n_discard, void *out, int out_is_device,
+                  uint64_t *accept_counts, void *stream)
+{
+    return h ? sampler_run(h->s, n_collect, n_discard, out, out_is_device, accept_counts, stream)
+             : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_step(mmcmc_hmc *h, void *stream)
+{
+    return h ? sampler_run(h->s, 0, 1, nullptr, 1, nullptr, stream) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_state(mmcmc_hmc *h, void *out) { return h ? sampler_state(h->s, out) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_hmc_sync(mmcmc_hmc *h) { return h ? sampler_sync(h->s) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_hmc_timing(mmcmc_hmc *h, mmcmc_timing *t) { return h ? sampler_timing(h->s, t) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_hmc_destroy(mmcmc_hmc *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    int st = sampler_destroy(h->s);
+    delete h;
+    return st;
+}
+
+/* ---- densities / noise (parity tests) ---- */
+int mmcmc_logp_grad_batch(const mmcmc_target_desc *target, int dtype, const void *x, size_t n, void *logp,
+                          void *grad, int device)
+{
+    if (!x || !logp || n == 0 || (dtype != MMCMC_F32 && dtype != MMCMC_F64))
+        return MMCMC_ERR_INVALID_ARG;
+    int st = validate_target(target);
+    if (st != MMCMC_OK)
+        return st;
+    st = check_device(device);
+    if (st != MMCMC_OK)
+        return st;
+    DeviceGuard g(device);
+    return dtype == MMCMC_F32 ? logp_grad_batch_t<float>(target, x, n, logp, grad)
+                              : logp_grad_batch_t<double>(target, x, n, logp, grad);
+}
+
+int mmcmc_draw_noise(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n_chains, int dim, int dtype,
+                     void *z, void *u, int device)
+{
+    if (!z || !u || n_chains == 0 || dim <= 0 || (dtype != MMCMC_F32 && dtype != MMCMC_F64))
+        return MMCMC_ERR_INVALID_ARG;
+    int st = check_device(device);
+    if (st != MMCMC_OK)
+        return st;
+    DeviceGuard g(device);
+    return dtype == MMCMC_F32 ? draw_noise_t<float>(seed, chain_offset, iteration, n_chains, dim, z, u)
+                              : draw_noise_t<double>(seed, chain_offset, iteration, n_chains, dim, z, u);
+}
+
+} /* extern "C" */

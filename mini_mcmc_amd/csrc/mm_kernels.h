@@ -1,0 +1,238 @@
+/*
+ * mm_kernels.h -- the many-chain sampling kernel for gfx950 (MH and HMC share one skeleton).
+ *
+ * Replaces the reference's chain drivers:
+ *   run_chain core.rs:55-73 + ChainRunner::run core.rs:176-186 (rayon task per chain, then ndarray::stack)
+ *   HMC::run hmc.rs:137-158 (one batched burn tensor op per arithmetic step, slice_assign per iteration)
+ *
+ * Mapping onto CDNA4
+ *   - one chain per lane; a wave owns 64 consecutive chains; position (and for HMC gradient, momentum) live in
+ *     VGPRs for the whole launch; the target's parameters are kernel arguments (SGPRs / scalar cache)
+ *   - the whole run (burn-in + collection) is ONE launch by default: state is read once and written once
+ *   - the output contract is chain-major [C, n_collect, D]; a lane-per-chain store would put every lane in its
+ *     own cache line, so each wave stages TILE_T iterations in LDS (row per chain, odd stride => conflict free
+ *     on the lane-strided writes AND on the chain-linear reads) and then writes, for each of its 64 chains,
+ *     one contiguous run of TILE_T*D elements with whole-wave coalesced stores
+ *   - no inter-wave communication at all: a wave only synchronises with itself (wave-scope fences), so blocks
+ *     are one wave (64 threads) and 65 536 chains give 1024 independent workgroups = 4 per CU, one per SIMD
+ *   - accept decisions are tallied per lane and, through a wave ballot + popcount, per wave
+ */
+#ifndef MM_KERNELS_H
+#define MM_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "mm_samplers.h"
+
+#define MM_SAMPLER_MH 0
+#define MM_SAMPLER_HMC 1
+
+template <class T> struct mm_run_args {
+    mm_tparams<T> P;
+    T scale;        /* MH: proposal std ; HMC: step size */
+    int n_leapfrog; /* HMC */
+    T *state;       /* [n_chains, D] current positions, row-major (the reference's layout) */
+    T *out;         /* [n_chains, n_total, D] or NULL */
+    unsigned long long *accept;      /* [n_chains] running per-chain accept counts, or NULL */
+    unsigned long long *accept_total; /* single counter fed by the wave ballots, or NULL */
+    unsigned long long n_chains;
+    unsigned long long seed, chain_offset;
+    unsigned int iter0;     /* iteration index of the first transition of this launch */
+    unsigned int n_discard; /* transitions without output */
+    unsigned int n_collect; /* transitions with output, written to rows out_t0 .. out_t0 + n_collect */
+    unsigned int out_t0;
+    unsigned long long n_total; /* row count of `out` per chain (n_collect of the whole run) */
+};
+
+/* iterations staged per flush: about 96 f32 (48 f64) elements per chain => 24.8 KB of LDS per wave */
+template <class T, int D> struct mm_tile {
+    static constexpr int target = (sizeof(T) == 4) ? 96 : 48;
+    static constexpr int tile_t = (target / D) > 0 ? (target / D) : 1;
+    static constexpr int run = tile_t * D;
+    static constexpr int stride = run | 1; /* odd => bank-conflict-free both ways */
+    static constexpr size_t lds_bytes_per_wave = (size_t)64 * stride * sizeof(T);
+};
+
+template <class T, class Tgt, int SAMPLER>
+__global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
+{
+    constexpr int D = Tgt::dim;
+    using Tile = mm_tile<T, D>;
+    constexpr int TILE_T = Tile::tile_t, RUN = Tile::run, STRIDE = Tile::stride;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    T *lds = reinterpret_cast<T *>(mm_lds_raw);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    T *tile = lds + (size_t)wave * 64 * STRIDE;
+    const unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long wave_c0 = c - lane;
+    const bool active = c < a.n_chains;
+    const unsigned long long chain = a.chain_offset + c;
+
+    T x[D], g[D], lp;
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        x[i] = active ? a.state[c * D + i] : T(0);
+    if (SAMPLER == MM_SAMPLER_HMC)
+        lp = Tgt::logp_grad(a.P, x, g);
+    else
+        lp = Tgt::logp(a.P, x);
+
+    unsigned int it = a.iter0;
+    unsigned long long n_acc = 0, wave_acc = 0;
+
+    auto step = [&]() {
+        int acc;
+        if (SAMPLER == MM_SAMPLER_HMC)
+            acc = mm_hmc_step<T, Tgt>(a.P, a.scale, a.n_leapfrog, x, &lp, g, a.seed, chain, it);
+        else
+            acc = mm_mh_step<T, Tgt>(a.P, a.scale, x, &lp, a.seed, chain, it);
+        acc = acc && active;
+        n_acc += (unsigned long long)acc;
+        wave_acc += (unsigned long long)__popcll(__ballot(acc)); /* wave-uniform: scalar add */
+        ++it;
+    };
+
+    for (unsigned int i = 0; i < a.n_discard; ++i)
+        step();
+
+    for (unsigned int t0 = 0; t0 < a.n_collect; t0 += TILE_T) {
+        const unsigned int nt = min((unsigned int)TILE_T, a.n_collect - t0);
+        for (unsigned int tt = 0; tt < nt; ++tt) {
+            step();
+            if (a.out) {
+                MM_UNROLL
+                for (int i = 0; i < D; ++i)
+                    tile[lane * STRIDE + tt * D + i] = x[i];
+            }
+        }
+        if (a.out) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            /* wave-uniform base of this tile in `out`; a chain's rows are chain_stride elements apart
+             * (host guarantees n_total * D < 2^32, so j * chain_stride is one v_mad_u64_u32) */
+            const unsigned int chain_stride = (unsigned int)(a.n_total * D);
+            T *const wbase = a.out + (wave_c0 * a.n_total + a.out_t0 + t0) * D;
+            const unsigned int n_valid = (unsigned int)min(64ull, a.n_chains > wave_c0 ? a.n_chains - wave_c0 : 0ull);
+            if (nt == (unsigned int)TILE_T) {
+                /* full tile: RUN whole-wave stores, each 64 consecutive elements of the chain-linear image */
+#pragma unroll 4
+                for (int k = 0; k < RUN; ++k) {
+                    const int idx = k * 64 + lane;
+                    const int j = idx / RUN; /* compile-time divisor */
+                    const int e = idx - j * RUN;
+                    if ((unsigned int)j < n_valid)
+                        wbase[(unsigned long long)j * chain_stride + e] = tile[j * STRIDE + e];
+                }
+            } else {
+                const int runv = (int)nt * D;
+                for (unsigned int j = 0; j < n_valid; ++j)
+                    for (int e = lane; e < runv; e += 64)
+                        wbase[(unsigned long long)j * chain_stride + e] = tile[j * STRIDE + e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    if (active) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            a.state[c * D + i] = x[i];
+        if (a.accept)
+            a.accept[c] += n_acc;
+    }
+    if (a.accept_total && lane == 0 && wave_acc)
+        atomicAdd(a.accept_total, wave_acc);
+}
+
+/* BatchedGradientTarget::unnorm_logp_batch / unnorm_logp_and_grad for n rows (parity tests) */
+template <class T, class Tgt>
+__global__ void mm_logp_grad_kernel(const mm_tparams<T> P, const T *x, T *logp, T *grad, unsigned long long n)
+{
+    constexpr int D = Tgt::dim;
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    T xv[D], gv[D];
+    MM_UNROLL
+    for (int k = 0; k < D; ++k)
+        xv[k] = x[i * D + k];
+    if (grad) {
+        logp[i] = Tgt::logp_grad(P, xv, gv);
+        MM_UNROLL
+        for (int k = 0; k < D; ++k)
+            grad[i * D + k] = gv[k];
+    } else {
+        logp[i] = Tgt::logp(P, xv);
+    }
+}
+
+/* the noise the sampling kernels draw for (chain, iteration) (parity tests) */
+template <class T, int D>
+__global__ void mm_noise_kernel(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration,
+                                unsigned long long n, T *z, T *u)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    T zz[D], uu;
+    mm_draw_noise<D>(seed, chain_offset + i, iteration, zz, &uu);
+    MM_UNROLL
+    for (int k = 0; k < D; ++k)
+        z[i * D + k] = zz[k];
+    u[i] = uu;
+}
+
+/* host-side launchers + dispatch record for one (sampler, dtype, kind, dim) instance */
+template <class T, class Tgt, int SAMPLER>
+hipError_t mm_launch_run(const mm_run_args<T> &a, unsigned int grid, unsigned int block, hipStream_t stream)
+{
+    const size_t lds = (size_t)(block / 64) * mm_tile<T, Tgt::dim>::lds_bytes_per_wave;
+    hipLaunchKernelGGL((mm_run_kernel<T, Tgt, SAMPLER>), dim3(grid), dim3(block), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <class T, class Tgt>
+hipError_t mm_launch_logp_grad(const mm_tparams<T> &P, const T *x, T *logp, T *grad, unsigned long long n,
+                               hipStream_t stream)
+{
+    const unsigned int block = 256;
+    const unsigned int grid = (unsigned int)((n + block - 1) / block);
+    hipLaunchKernelGGL((mm_logp_grad_kernel<T, Tgt>), dim3(grid), dim3(block), 0, stream, P, x, logp, grad, n);
+    return hipGetLastError();
+}
+
+template <class T, int D>
+hipError_t mm_launch_noise(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration,
+                           unsigned long long n, T *z, T *u, hipStream_t stream)
+{
+    const unsigned int block = 256;
+    const unsigned int grid = (unsigned int)((n + block - 1) / block);
+    hipLaunchKernelGGL((mm_noise_kernel<T, D>), dim3(grid), dim3(block), 0, stream, seed, chain_offset, iteration, n,
+                       z, u);
+    return hipGetLastError();
+}
+
+template <class T> struct mm_kernel_entry {
+    int kind, dim;
+    hipError_t (*run_mh)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);
+    hipError_t (*run_hmc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);
+    hipError_t (*logp_grad)(const mm_tparams<T> &, const T *, T *, T *, unsigned long long, hipStream_t);
+    size_t lds_bytes_per_wave;
+};
+
+template <class T> struct mm_noise_entry {
+    int dim;
+    hipError_t (*noise)(unsigned long long, unsigned long long, unsigned int, unsigned long long, T *, T *,
+                        hipStream_t);
+};
+
+/* defined in mm_inst_f32.hip / mm_inst_f64.hip */
+const mm_kernel_entry<float> *mm_kernel_table_f32(int *n);
+const mm_kernel_entry<double> *mm_kernel_table_f64(int *n);
+const mm_noise_entry<float> *mm_noise_table_f32(int *n);
+const mm_noise_entry<double> *mm_noise_table_f64(int *n);
+
+#endif /* MM_KERNELS_H */

@@ -24,6 +24,12 @@
 #define MM_HD static inline
 #endif
 
+#if defined(__clang__)
+#define MM_UNROLL _Pragma("unroll")
+#else
+#define MM_UNROLL
+#endif
+
 MM_HD uint32_t mm_f2u(float f)
 {
     uint32_t u;

@@ -1,0 +1,133 @@
+/*
+ * mm_samplers.h -- one transition of one chain (host + device, one definition).
+ *
+ *   mm_mh_step   <->  MHMarkovChain::step             metropolis_hastings.rs:303-315
+ *                     IsotropicGaussian::sample       distributions.rs:364-372
+ *   mm_hmc_step  <->  HMC::step + HMC::leapfrog        hmc.rs:304-377, 397-431   (one row of the batch)
+ *
+ * What is kept from the reference: the accept rules (MH strict `>`, HMC `>=`, NaN rejects), the leapfrog
+ * with two separate half-kicks per step, H = -logp + 1/2 |p|^2, positions updated only on accept.
+ * What is consciously different: the random stream (mm_rng.h instead of rand/burn:
+ * Q1, Q2, Q6), log-density of the current state carried instead of recomputed (Q3: same value), the
+ * symmetric proposal's q-terms dropped from the MH ratio (Q4: they cancel), Sigma^-1 precomputed (Q5),
+ * gradients analytic, and a*b+c written as ONE fused operation where noted -- so values agree with the
+ * reference-ordered oracle to rounding, not bit for bit; tests/test_step_parity.py bounds the difference.
+ */
+#ifndef MM_SAMPLERS_H
+#define MM_SAMPLERS_H
+
+#include "mm_rng.h"
+#include "mm_targets.h"
+
+MM_HD float mm_logT(float x) { return mm_logf(x); }
+MM_HD double mm_logT(double x) { return mm_log(x); }
+MM_HD float mm_expT(float x) { return mm_expf(x); }
+MM_HD double mm_expT(double x) { return mm_exp(x); }
+
+/* noise of (chain, iteration): z[0..D) ~ N(0,1) and the accept uniform u in (0,1]  (schedule: mm_rng.h) */
+template <int D> MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, float *z, float *u)
+{
+    MM_UNROLL
+    for (int b = 0; b < (D + 3) / 4; ++b) {
+        mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
+        if (b == 0)
+            *u = mm_spare_u24(blk);
+        float z0, z1;
+        mm_box_muller_f32(mm_u24(blk.w[0]), mm_u24(blk.w[1]), &z0, &z1);
+        z[4 * b] = z0;
+        if (4 * b + 1 < D)
+            z[4 * b + 1] = z1;
+        if (4 * b + 2 < D) {
+            mm_box_muller_f32(mm_u24(blk.w[2]), mm_u24(blk.w[3]), &z0, &z1);
+            z[4 * b + 2] = z0;
+            if (4 * b + 3 < D)
+                z[4 * b + 3] = z1;
+        }
+    }
+}
+
+template <int D> MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z, double *u)
+{
+    MM_UNROLL
+    for (int b = 0; b < (D + 1) / 2; ++b) {
+        mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
+        double z0, z1;
+        mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
+        z[2 * b] = z0;
+        if (2 * b + 1 < D)
+            z[2 * b + 1] = z1;
+    }
+    *u = mm_aux_u53(seed, chain, iter, 0);
+}
+
+/* One Metropolis-Hastings transition with the isotropic Gaussian random-walk proposal.
+ * x[D], lp = logp(x) are updated in place; returns 1 if the proposal was accepted. */
+template <class T, class Tgt>
+MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t seed, uint64_t chain, uint32_t iter)
+{
+    constexpr int D = Tgt::dim;
+    T z[D], prop[D], u;
+    mm_draw_noise<D>(seed, chain, iter, z, &u);
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        prop[i] = mm_fma(prop_std, z[i], x[i]);
+    T lpp = Tgt::logp(P, prop);
+    T log_accept_ratio = lpp - *lp;
+    int acc = log_accept_ratio > mm_logT(u);
+    if (acc) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            x[i] = prop[i];
+        *lp = lpp;
+    }
+    return acc;
+}
+
+/* One HMC transition: x[D], lp = logp(x), g = grad logp(x) updated in place; returns 1 on accept. */
+template <class T, class Tgt>
+MM_HD int mm_hmc_step(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, uint64_t seed,
+                      uint64_t chain, uint32_t iter)
+{
+    constexpr int D = Tgt::dim;
+    T p[D], xn[D], gn[D], u;
+    mm_draw_noise<D>(seed, chain, iter, p, &u);
+    const T h = eps * T(0.5);
+    T ke = 0;
+    MM_UNROLL
+    for (int i = 0; i < D; ++i) {
+        ke = mm_fma(p[i], p[i], ke);
+        xn[i] = x[i];
+        gn[i] = g[i];
+    }
+    T h_current = ke * T(0.5) - *lp;
+    T lpn = *lp;
+    for (int l = 0; l < n_leapfrog; ++l) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            p[i] = mm_fma(h, gn[i], p[i]);   /* half kick with the gradient of the previous position */
+            xn[i] = mm_fma(eps, p[i], xn[i]); /* drift */
+        }
+        lpn = Tgt::logp_grad(P, xn, gn);
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            p[i] = mm_fma(h, gn[i], p[i]); /* half kick with the new gradient */
+    }
+    T kp = 0;
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        kp = mm_fma(p[i], p[i], kp);
+    T h_proposed = kp * T(0.5) - lpn;
+    T accept_logp = h_current - h_proposed;
+    int acc = accept_logp >= mm_logT(u);
+    if (acc) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            x[i] = xn[i];
+            g[i] = gn[i];
+        }
+        *lp = lpn;
+    }
+    return acc;
+}
+
+#endif /* MM_SAMPLERS_H */

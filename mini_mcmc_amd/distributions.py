@@ -1,0 +1,134 @@
+"""Built-in targets and the proposal -- host-side mirror of the reference's `distributions` module.
+
+Each class is a plain descriptor handed to the C ABI (mmcmc_target_desc / mmcmc_proposal_desc); the densities
+themselves are evaluated on the GPU (csrc/mm_targets.h).  Reference: src/distributions.rs
+  Gaussian2D :158-206   DiffableGaussian2D :212-316   IsotropicGaussian :344-402
+  Rosenbrock2D :490-524   RosenbrockND :528-547   (StandardNormal: nuts.rs:1024-1037, test target)
+GaussianND (dense precision matrix) is not in the reference; BASELINE.json config 5 needs it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Target:
+    kind: int = -1
+
+    def __init__(self, dim: int, params=(), matrix=None):
+        self.dim = int(dim)
+        self.params = [float(p) for p in params]
+        self._matrix = None if matrix is None else np.ascontiguousarray(matrix, dtype=np.float64)
+
+    def desc(self) -> L.TargetDesc:
+        d = L.TargetDesc()
+        d.kind = self.kind
+        d.dim = self.dim
+        for i, p in enumerate(self.params):
+            d.params[i] = p
+        if self._matrix is not None:
+            d.matrix = self._matrix.ctypes.data_as(C.POINTER(C.c_double))
+        return d
+
+    def unnorm_logp_batch(self, positions, dtype=np.float32, device: int = 0, with_grad: bool = False):
+        """BatchedGradientTarget::unnorm_logp_batch (distributions.rs:65-76) evaluated on the GPU;
+        with_grad=True also returns the analytic gradient (GradientTarget::unnorm_logp_and_grad :81-87)."""
+        x = np.ascontiguousarray(positions, dtype=dtype)
+        if x.ndim != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"positions must be [n, {self.dim}]")
+        lp = np.empty(x.shape[0], dtype=dtype)
+        g = np.empty_like(x) if with_grad else None
+        d = self.desc()
+        st = L.lib().mmcmc_logp_grad_batch(
+            C.byref(d), L.F32 if dtype == np.float32 else L.F64, x.ctypes.data, x.shape[0], lp.ctypes.data,
+            g.ctypes.data if with_grad else None, device)
+        L.check(st, "mmcmc_logp_grad_batch")
+        return (lp, g) if with_grad else lp
+
+
+class Gaussian2D(Target):
+    """distributions.rs:158-206 `Gaussian2D { mean, cov }` (Target for Metropolis-Hastings)."""
+    kind = L.GAUSSIAN2D
+
+    def __init__(self, mean, cov):
+        cov = np.asarray(cov, dtype=np.float64).reshape(2, 2)
+        self.mean = np.asarray(mean, dtype=np.float64).reshape(2)
+        self.cov = cov
+        super().__init__(2, [self.mean[0], self.mean[1], cov[0, 0], cov[0, 1], cov[1, 0], cov[1, 1]])
+
+
+class DiffableGaussian2D(Gaussian2D):
+    """distributions.rs:212-316 `DiffableGaussian2D::new(mean, cov)` (gradient target for HMC / NUTS)."""
+    kind = L.DIFFABLE_GAUSSIAN2D
+
+
+class IsotropicGaussian(Target):
+    """distributions.rs:344-402 `IsotropicGaussian::new(std)`: the MH proposal, and a target when given `dim`."""
+    kind = L.ISOTROPIC_GAUSSIAN
+
+    def __init__(self, std: float, dim: int = 1):
+        self.std = float(std)
+        super().__init__(dim, [self.std])
+
+    def set_seed(self, seed: int) -> "IsotropicGaussian":
+        """Proposal::set_seed (distributions.rs:388-391).  The GPU engine draws proposal noise from the sampler's
+        counter-based stream (one key per chain), so the proposal carries no generator of its own: kept for
+        call-site compatibility, no effect (the reference's cloned-generator quirk Q1 is not reproduced)."""
+        self._seed = int(seed)
+        return self
+
+    def proposal_desc(self) -> L.ProposalDesc:
+        p = L.ProposalDesc()
+        p.kind = 0
+        p.std = self.std
+        return p
+
+
+class Rosenbrock2D(Target):
+    """distributions.rs:490-524 `Rosenbrock2D { a, b }`."""
+    kind = L.ROSENBROCK2D
+
+    def __init__(self, a: float = 1.0, b: float = 100.0):
+        self.a, self.b = float(a), float(b)
+        super().__init__(2, [self.a, self.b])
+
+
+class RosenbrockND(Target):
+    """distributions.rs:528-547 `RosenbrockND {}`; the dimension comes from the initial positions."""
+    kind = L.ROSENBROCK_ND
+
+    def __init__(self, dim: int = 3):
+        super().__init__(dim)
+
+
+class StandardNormal(Target):
+    """nuts.rs:1024-1037 (the reference's test target): -1/2 sum x^2."""
+    kind = L.STANDARD_NORMAL
+
+    def __init__(self, dim: int):
+        super().__init__(dim)
+
+
+class GaussianND(Target):
+    """Zero-mean Gaussian with dense precision matrix A: logp = -1/2 x^T A x (BASELINE.json config 5)."""
+    kind = L.GAUSSIAN_ND
+
+    def __init__(self, precision):
+        a = np.asarray(precision, dtype=np.float64)
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError("precision must be square")
+        self.precision = a
+        super().__init__(a.shape[0], matrix=a)
+
+    @staticmethod
+    def ill_conditioned(dim: int = 32, cond: float = 1e4, seed: int = 7) -> "GaussianND":
+        """The synthetic config-5 target: A = Q diag(lambda) Q^T, lambda log-spaced 1..cond, Q from the QR of a
+        seeded normal matrix."""
+        rng = np.random.default_rng(seed)
+        q, _ = np.linalg.qr(rng.standard_normal((dim, dim)))
+        lam = np.logspace(0.0, np.log10(cond), dim)
+        a = (q * lam) @ q.T
+        return GaussianND((a + a.T) / 2.0)

@@ -1,0 +1,216 @@
+/*
+ * oracle/engine_host.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Host (g++) build of the engine's per-chain transition functions -- the very headers the HIP kernels are
+ * compiled from (mini_mcmc_amd/csrc/mm_samplers.h, mm_targets.h, mm_rng.h, mm_math.h) -- driven by a plain loop
+ * over chains and iterations.  Because those headers use only IEEE +,-,*,/,sqrt and explicit fma(), and both sides
+ * are built with -ffp-contract=off, this library must reproduce the GPU's samples, accept masks and accept counts
+ * BIT FOR BIT.  It is what the `-m gpu` parity tests compare the device results with at every size; the
+ * independent, reference-ordered restatement (mh_hmc.c, nuts.c, pinned by the reference's known-answer tests) is
+ * compared with it on the CPU in tests/test_step_parity.py.  Nothing in the product links or loads this file.
+ */
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../mini_mcmc_amd/csrc/mm_params.h"
+#include "../mini_mcmc_amd/csrc/mm_samplers.h"
+
+namespace {
+
+template <class T, class Tgt, int HMC>
+void run_chains(const mm_tparams<T> &P, T scale, int n_leapfrog, T *state, size_t n_chains, uint64_t seed,
+                uint64_t chain_offset, uint32_t iter0, size_t n_collect, size_t n_discard, T *out, uint64_t *accept,
+                int n_threads)
+{
+    constexpr int D = Tgt::dim;
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+            T x[D], g[D], lp;
+            for (int i = 0; i < D; ++i)
+                x[i] = state[c * D + i];
+            lp = HMC ? Tgt::logp_grad(P, x, g) : Tgt::logp(P, x);
+            uint64_t n_acc = 0;
+            uint32_t it = iter0;
+            for (size_t t = 0; t < n_discard + n_collect; ++t, ++it) {
+                int acc = HMC ? mm_hmc_step<T, Tgt>(P, scale, n_leapfrog, x, &lp, g, seed, chain_offset + c, it)
+                              : mm_mh_step<T, Tgt>(P, scale, x, &lp, seed, chain_offset + c, it);
+                n_acc += (uint64_t)acc;
+                if (t >= n_discard && out)
+                    for (int i = 0; i < D; ++i)
+                        out[(c * n_collect + (t - n_discard)) * D + i] = x[i];
+            }
+            for (int i = 0; i < D; ++i)
+                state[c * D + i] = x[i];
+            if (accept)
+                accept[c] = n_acc;
+        }
+    };
+    if (n_threads <= 1 || n_chains < 2) {
+        work(0, n_chains);
+        return;
+    }
+    std::vector<std::thread> th;
+    size_t nt = std::min<size_t>((size_t)n_threads, n_chains);
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back(work, n_chains * t / nt, n_chains * (t + 1) / nt);
+    for (auto &t : th)
+        t.join();
+}
+
+template <class T, int KIND, int D>
+int run_kd(int hmc, const mm_tparams<T> &P, T scale, int L, T *state, size_t n, uint64_t seed, uint64_t off,
+           uint32_t it0, size_t nc, size_t nd, T *out, uint64_t *acc, int nth)
+{
+    using Tgt = mm_target<T, KIND, D>;
+    if (hmc)
+        run_chains<T, Tgt, 1>(P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);
+    else
+        run_chains<T, Tgt, 0>(P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);
+    return 0;
+}
+
+#define ND_CASES(KIND)                                                                                            \
+    switch (dim) {                                                                                                \
+    case 1: return run_kd<T, KIND, 1>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 2: return run_kd<T, KIND, 2>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 3: return run_kd<T, KIND, 3>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 4: return run_kd<T, KIND, 4>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 5: return run_kd<T, KIND, 5>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 6: return run_kd<T, KIND, 6>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 7: return run_kd<T, KIND, 7>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 8: return run_kd<T, KIND, 8>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
+    case 16: return run_kd<T, KIND, 16>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);        \
+    case 32: return run_kd<T, KIND, 32>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);        \
+    default: return -2;                                                                                           \
+    }
+
+template <class T>
+int run_t(int hmc, int kind, int dim, const double params[8], const double *matrix, double scale_d, int L, T *state,
+          size_t n, uint64_t seed, uint64_t off, uint32_t it0, size_t nc, size_t nd, T *out, uint64_t *acc, int nth)
+{
+    mm_tparams<T> P;
+    if (mm_fill_params<T>(kind, params, &P) != 0)
+        return -1;
+    std::vector<T> mat;
+    if (kind == MM_GAUSSIAN_ND) {
+        if (!matrix)
+            return -1;
+        mat.resize((size_t)dim * dim);
+        for (size_t i = 0; i < mat.size(); ++i)
+            mat[i] = (T)matrix[i];
+        P.mat = mat.data();
+    }
+    T scale = (T)scale_d;
+    switch (kind) {
+    case MM_GAUSSIAN2D:
+        return dim == 2 ? run_kd<T, MM_GAUSSIAN2D, 2>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth) : -3;
+    case MM_DIFFABLE_GAUSSIAN2D:
+        return dim == 2 ? run_kd<T, MM_DIFFABLE_GAUSSIAN2D, 2>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth) : -3;
+    case MM_ROSENBROCK2D:
+        return dim == 2 ? run_kd<T, MM_ROSENBROCK2D, 2>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth) : -3;
+    case MM_ISOTROPIC_GAUSSIAN:
+        ND_CASES(MM_ISOTROPIC_GAUSSIAN)
+    case MM_ROSENBROCK_ND:
+        ND_CASES(MM_ROSENBROCK_ND)
+    case MM_STANDARD_NORMAL:
+        ND_CASES(MM_STANDARD_NORMAL)
+    case MM_GAUSSIAN_ND:
+        ND_CASES(MM_GAUSSIAN_ND)
+    default:
+        return -2;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+/* Run n_chains chains for n_discard + n_collect transitions on the host with the engine's own arithmetic.
+ * sampler: 0 = MH (scale = proposal std), 1 = HMC (scale = step size).  dtype: 0 = f32, 1 = f64.
+ * state [n, dim] in/out; out [n, n_collect, dim] or NULL; accept [n] or NULL.  Returns 0, or <0 if unsupported. */
+int eh_run(int sampler, int dtype, int kind, int dim, const double params[8], const double *matrix, double scale,
+           int n_leapfrog, void *state, size_t n_chains, uint64_t seed, uint64_t chain_offset, uint32_t iter0,
+           size_t n_collect, size_t n_discard, void *out, uint64_t *accept, int n_threads)
+{
+    if (dtype == 0)
+        return run_t<float>(sampler, kind, dim, params, matrix, scale, n_leapfrog, (float *)state, n_chains, seed,
+                            chain_offset, iter0, n_collect, n_discard, (float *)out, accept, n_threads);
+    return run_t<double>(sampler, kind, dim, params, matrix, scale, n_leapfrog, (double *)state, n_chains, seed,
+                         chain_offset, iter0, n_collect, n_discard, (double *)out, accept, n_threads);
+}
+
+/* noise of (chain, iteration) as the engine draws it: z [n, dim], u [n] */
+int eh_noise(int dtype, uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n, int dim, void *z, void *u)
+{
+#define NOISE_CASE(DD)                                                                                            \
+    case DD:                                                                                                      \
+        for (size_t c = 0; c < n; ++c) {                                                                          \
+            if (dtype == 0)                                                                                       \
+                mm_draw_noise<DD>(seed, chain_offset + c, iteration, (float *)z + c * DD, (float *)u + c);        \
+            else                                                                                                  \
+                mm_draw_noise<DD>(seed, chain_offset + c, iteration, (double *)z + c * DD, (double *)u + c);      \
+        }                                                                                                         \
+        return 0;
+    switch (dim) {
+        NOISE_CASE(1)
+        NOISE_CASE(2)
+        NOISE_CASE(3)
+        NOISE_CASE(4)
+        NOISE_CASE(5)
+        NOISE_CASE(6)
+        NOISE_CASE(7)
+        NOISE_CASE(8)
+        NOISE_CASE(16)
+        NOISE_CASE(32)
+    default:
+        return -2;
+    }
+}
+
+/* log-density (and gradient if g != NULL) of n rows with the engine's arithmetic */
+int eh_logp_grad(int dtype, int kind, int dim, const double params[8], const double *matrix, const void *x, size_t n,
+                 void *logp, void *grad)
+{
+    /* reuse the sampler dispatch: run HMC with zero transitions is not enough, so evaluate directly */
+    auto eval = [&](auto tag) -> int {
+        using T = decltype(tag);
+        mm_tparams<T> P;
+        if (mm_fill_params<T>(kind, params, &P) != 0)
+            return -1;
+        std::vector<T> mat;
+        if (kind == MM_GAUSSIAN_ND) {
+            mat.resize((size_t)dim * dim);
+            for (size_t i = 0; i < mat.size(); ++i)
+                mat[i] = (T)matrix[i];
+            P.mat = mat.data();
+        }
+        const T *xx = (const T *)x;
+        T *lp = (T *)logp, *gg = (T *)grad;
+#define EV(KIND, DD)                                                                                              \
+    if (kind == KIND && dim == DD) {                                                                              \
+        for (size_t i = 0; i < n; ++i) {                                                                          \
+            T gv[DD];                                                                                             \
+            lp[i] = gg ? mm_target<T, KIND, DD>::logp_grad(P, xx + i * DD, gv)                                    \
+                       : mm_target<T, KIND, DD>::logp(P, xx + i * DD);                                            \
+            if (gg)                                                                                               \
+                for (int k = 0; k < DD; ++k)                                                                      \
+                    gg[i * DD + k] = gv[k];                                                                       \
+        }                                                                                                         \
+        return 0;                                                                                                 \
+    }
+#define EV_ND(KIND) EV(KIND, 1) EV(KIND, 2) EV(KIND, 3) EV(KIND, 4) EV(KIND, 5) EV(KIND, 6) EV(KIND, 7) EV(KIND, 8) EV(KIND, 16) EV(KIND, 32)
+        EV(MM_GAUSSIAN2D, 2)
+        EV(MM_DIFFABLE_GAUSSIAN2D, 2)
+        EV(MM_ROSENBROCK2D, 2)
+        EV_ND(MM_ISOTROPIC_GAUSSIAN)
+        EV_ND(MM_ROSENBROCK_ND)
+        EV_ND(MM_STANDARD_NORMAL)
+        EV_ND(MM_GAUSSIAN_ND)
+        return -2;
+    };
+    return dtype == 0 ? eval(float{}) : eval(double{});
+}
+
+} /* extern "C" */

@@ -46,8 +46,10 @@ def build(force: bool = False) -> str:
 def _stale() -> bool:
     try:
         t = os.path.getmtime(_LIB_PATH)
-        deps = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
-        deps.append(os.path.join(_HERE, "..", "mini_mcmc_amd", "csrc", "mm_math.h"))
+        t = min(t, os.path.getmtime(os.path.join(_HERE, "_build", "libengine_host.so")))
+        deps = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".cpp", ".h", ".inc"))]
+        csrc = os.path.join(_HERE, "..", "mini_mcmc_amd", "csrc")
+        deps += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.startswith("mm_") and f.endswith(".h")]
         return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
     except OSError:
         return True
@@ -508,3 +510,79 @@ def chain_trackers_rhat(init, states):
     pa = np.zeros(chains, dtype=np.float32)
     lib().o_chain_trackers_rhat(_f(i0), _f(s), chains, steps, params, _f(rhat), _f(pa))
     return rhat, pa
+
+
+# ---------------------------------------------------------------- host build of the engine's own arithmetic
+
+_EH_PATH = os.path.join(_HERE, "_build", "libengine_host.so")
+_eh = None
+
+
+def engine_host_lib() -> C.CDLL:
+    """oracle/engine_host.cpp: the product's transition headers compiled for the host (bit-exact GPU<->CPU)."""
+    global _eh
+    if _eh is not None:
+        return _eh
+    build()
+    if not os.path.exists(_EH_PATH):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    E = C.CDLL(_EH_PATH)
+    E.eh_run.restype = C.c_int
+    E.eh_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_void_p, C.c_size_t,
+                         C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_size_t, C.c_void_p, _u64p, C.c_int]
+    E.eh_noise.restype = C.c_int
+    E.eh_noise.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    E.eh_logp_grad.restype = C.c_int
+    E.eh_logp_grad.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    _eh = E
+    return E
+
+
+def _eh_target_args(kind, params, matrix):
+    p = np.zeros(8, dtype=np.float64)
+    p[: len(params)] = params
+    m = None if matrix is None else np.ascontiguousarray(matrix, dtype=np.float64)
+    return p, m
+
+
+def engine_host_run(sampler, kind, dim, params, init, scale, n_collect, n_discard, seed=0, chain_offset=0, iter0=0,
+                    n_leapfrog=0, matrix=None, dtype=np.float32, n_threads=None, want_out=True):
+    """Run chains on the host with the ENGINE's arithmetic and stream. sampler: 'mh' | 'hmc'.
+    `params` are the C-ABI description parameters (mean/cov, std, a/b ...: include/mmcmc.h).
+    Returns (sample [C, n_collect, D] or None, final_state [C, D], accept_counts [C])."""
+    E = engine_host_lib()
+    state = np.ascontiguousarray(init, dtype=dtype).copy()
+    n = state.shape[0]
+    out = np.empty((n, n_collect, dim), dtype=dtype) if want_out else None
+    acc = np.zeros(n, dtype=np.uint64)
+    p, m = _eh_target_args(kind, params, matrix)
+    rc = E.eh_run(0 if sampler == "mh" else 1, 0 if dtype == np.float32 else 1, kind, dim, _d(p),
+                  _d(m) if m is not None else None, float(scale), int(n_leapfrog), state.ctypes.data, n, seed,
+                  chain_offset, iter0, n_collect, n_discard, out.ctypes.data if want_out else None,
+                  acc.ctypes.data_as(_u64p), n_threads or default_threads())
+    if rc != 0:
+        raise ValueError(f"eh_run: {rc}")
+    return out, state, acc
+
+
+def engine_host_noise(seed, chain_offset, iteration, n, dim, dtype=np.float32):
+    E = engine_host_lib()
+    z = np.empty((n, dim), dtype=dtype)
+    u = np.empty(n, dtype=dtype)
+    rc = E.eh_noise(0 if dtype == np.float32 else 1, seed, chain_offset, iteration, n, dim, z.ctypes.data, u.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"eh_noise: {rc}")
+    return z, u
+
+
+def engine_host_logp_grad(kind, dim, params, x, matrix=None, dtype=np.float32, with_grad=True):
+    E = engine_host_lib()
+    x = np.ascontiguousarray(x, dtype=dtype)
+    lp = np.empty(x.shape[0], dtype=dtype)
+    g = np.empty_like(x) if with_grad else None
+    p, m = _eh_target_args(kind, params, matrix)
+    rc = E.eh_logp_grad(0 if dtype == np.float32 else 1, kind, dim, _d(p), _d(m) if m is not None else None,
+                        x.ctypes.data, x.shape[0], lp.ctypes.data, g.ctypes.data if with_grad else None)
+    if rc != 0:
+        raise ValueError(f"eh_logp_grad: {rc}")
+    return lp, g

@@ -1,0 +1,265 @@
+"""GPU parity tests proper: everything goes through the C ABI (libmmcmc.so) on a real MI355X and is compared with
+the CPU checker (oracle/).  Run with `-m gpu`.
+
+  level C (here): GPU == host build of the engine's arithmetic, bit for bit -- samples, states, accept counts,
+                  at small sizes, at ragged sizes, across launch partitions and chain offsets, and at
+                  BASELINE.json's full size through a checksum of per-chain checksums
+  level D (here): GPU vs the reference-ordered restatement (rand-compatible stream): posterior moments within
+                  the reference's own tolerances
+Levels A (oracle vs the reference's known answers) and B (engine arithmetic vs reference-ordered arithmetic on
+identical noise) run on the CPU: tests/test_oracle_pins.py, tests/test_step_parity.py.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mini_mcmc_amd
+    from mini_mcmc_amd import core, distributions, hmc, metropolis_hastings
+
+    mini_mcmc_amd.lib()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.core, ns.dist, ns.hmc, ns.mh = core, distributions, hmc, metropolis_hastings
+    return ns
+
+
+GAUSS = [0.0, 1.0, 4.0, 2.0, 2.0, 3.0]
+
+
+# ---------------------------------------------------------------- stream and densities
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", [1, 2, 3, 5, 8, 32])
+def test_noise_bit_exact(M, O, dtype, dim):
+    z, u = M.core.draw_noise(1234567, 10, 77, 300, dim, dtype)
+    zr, ur = O.engine_host_noise(1234567, 10, 77, 300, dim, dtype)
+    assert np.array_equal(z, zr) and np.array_equal(u, ur)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_logp_grad_bit_exact_and_close_to_reference_order(M, O, dtype):
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((8, 8))
+    A = A @ A.T + np.eye(8)
+    cases = [
+        (M.dist.Gaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), O.GAUSSIAN2D, GAUSS, None, O.gaussian2d([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]])),
+        (M.dist.DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), O.DIFFABLE_GAUSSIAN2D, GAUSS, None,
+         O.diffable_gaussian2d([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]], t_is_f32=(dtype == np.float32))),
+        (M.dist.IsotropicGaussian(1.5, 4), O.ISOTROPIC_GAUSSIAN, [1.5], None, O.isotropic_gaussian(1.5, 4)),
+        (M.dist.Rosenbrock2D(1.0, 100.0), O.ROSENBROCK2D, [1.0, 100.0], None, O.rosenbrock2d(1.0, 100.0)),
+        (M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], None, O.rosenbrock_nd(3)),
+        (M.dist.RosenbrockND(7), O.ROSENBROCK_ND, [], None, O.rosenbrock_nd(7)),
+        (M.dist.StandardNormal(5), O.STANDARD_NORMAL, [], None, O.standard_normal(5)),
+        (M.dist.GaussianND(A), O.GAUSSIAN_ND, [], A, O.gaussian_nd(A)),
+    ]
+    for tgt, kind, params, mat, otgt in cases:
+        x = (rng.standard_normal((257, tgt.dim)) * 0.8).astype(dtype)
+        lp, g = tgt.unnorm_logp_batch(x, dtype, with_grad=True)
+        lpr, gr = O.engine_host_logp_grad(kind, tgt.dim, params, x, matrix=mat, dtype=dtype)
+        assert np.array_equal(lp, lpr) and np.array_equal(g, gr), type(tgt).__name__
+        # against the reference-ordered (unfused) arithmetic: agreement to rounding
+        tol = 2e-5 if dtype == np.float32 else 1e-12
+        for i in range(0, 257, 37):
+            lo, go = otgt.logp_grad(x[i], dtype)
+            scale = max(1.0, abs(float(lo)))
+            assert abs(float(lp[i]) - float(lo)) <= tol * scale
+            np.testing.assert_allclose(g[i], go, rtol=tol * 10, atol=tol * 10 * max(1.0, np.abs(go).max()))
+
+
+# ---------------------------------------------------------------- samplers, bit exact
+
+
+def _run_pair(M, O, sampler, tgt, kind, params, init, scale, nc, nd, seed, L=0, mat=None, offset=0, ipl=0):
+    dtype = init.dtype.type
+    if sampler == "mh":
+        s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(scale), init).seed(seed)
+    else:
+        s = M.hmc.HMC(tgt, init, scale, L).set_seed(seed)
+    if offset:
+        s.set_chain_offset(offset)
+    if ipl:
+        s.set_iters_per_launch(ipl)
+    out = s.run(nc, nd)
+    ref, ref_state, ref_acc = O.engine_host_run(sampler, kind, tgt.dim, params, init, scale, nc, nd, seed=seed,
+                                                chain_offset=offset, n_leapfrog=L, matrix=mat, dtype=dtype)
+    return s, out, ref, ref_state, ref_acc
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n_chains,nc,nd", [(4, 1000, 100), (1, 7, 0), (63, 33, 5), (64, 48, 0), (65, 49, 1), (300, 97, 3)])
+def test_mh_gaussian2d_bit_exact(M, O, dtype, n_chains, nc, nd):
+    # BASELINE.json config 1 (4 x (1000+100), init_det) and ragged shapes around the 64-lane / tile boundaries
+    init = M.core.init_det(n_chains, 2, dtype)
+    tgt = M.dist.Gaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]])
+    s, out, ref, ref_state, ref_acc = _run_pair(M, O, "mh", tgt, O.GAUSSIAN2D, GAUSS, init, 1.0, nc, nd, 42)
+    assert out.shape == (n_chains, nc, 2)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(s.accept_counts, ref_acc)
+    assert np.array_equal(s.state(), ref_state)
+    assert np.array_equal(out[:, -1, :], ref_state)  # MarkovChain::current_state == last collected row
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n_chains,nc,nd", [(4, 400, 50), (130, 65, 7), (64, 32, 0), (64, 31, 2), (200, 1, 0)])
+def test_hmc_rosenbrock3d_bit_exact(M, O, dtype, n_chains, nc, nd):
+    # BASELINE.json config 3 shape (examples/minimal_hmc.rs: eps 0.032, L 10, 400 + 50) at small chain counts
+    init = M.core.init_det(n_chains, 3, dtype)
+    s, out, ref, ref_state, ref_acc = _run_pair(M, O, "hmc", M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], init,
+                                                0.032, nc, nd, 42, L=10)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(s.accept_counts, ref_acc)
+    assert np.array_equal(s.state(), ref_state)
+
+
+def test_other_targets_and_dims_bit_exact(M, O):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((32, 32))
+    A = A @ A.T / 32 + np.eye(32)
+    A16 = A[:16, :16].copy()
+    cases = [
+        ("hmc", M.dist.DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), O.DIFFABLE_GAUSSIAN2D, GAUSS, None, 0.1, 10),
+        ("hmc", M.dist.Rosenbrock2D(1.0, 100.0), O.ROSENBROCK2D, [1.0, 100.0], None, 0.01, 50),
+        ("hmc", M.dist.RosenbrockND(2), O.ROSENBROCK_ND, [], None, 0.02, 8),
+        ("hmc", M.dist.RosenbrockND(8), O.ROSENBROCK_ND, [], None, 0.01, 6),
+        ("hmc", M.dist.StandardNormal(5), O.STANDARD_NORMAL, [], None, 0.3, 4),
+        ("hmc", M.dist.IsotropicGaussian(2.0, 6), O.ISOTROPIC_GAUSSIAN, [2.0], None, 0.5, 3),
+        ("hmc", M.dist.GaussianND(A16), O.GAUSSIAN_ND, [], A16, 0.2, 5),
+        ("hmc", M.dist.GaussianND(A), O.GAUSSIAN_ND, [], A, 0.2, 5),
+        ("mh", M.dist.IsotropicGaussian(1.0, 3), O.ISOTROPIC_GAUSSIAN, [1.0], None, 0.7, 0),
+        ("mh", M.dist.RosenbrockND(4), O.ROSENBROCK_ND, [], None, 0.1, 0),
+        ("mh", M.dist.Rosenbrock2D(1.0, 100.0), O.ROSENBROCK2D, [1.0, 100.0], None, 0.2, 0),
+        ("mh", M.dist.StandardNormal(16), O.STANDARD_NORMAL, [], None, 0.4, 0),
+        ("mh", M.dist.GaussianND(A), O.GAUSSIAN_ND, [], A, 0.15, 0),
+    ]
+    for sampler, tgt, kind, params, mat, scale, L in cases:
+        for dtype in (np.float32, np.float64):
+            init = M.core.init_with_seed(70, tgt.dim, 7, dtype)
+            s, out, ref, ref_state, ref_acc = _run_pair(M, O, sampler, tgt, kind, params, init, scale, 37, 4, 99, L=L, mat=mat)
+            name = f"{sampler} {type(tgt).__name__} D={tgt.dim} {dtype.__name__}"
+            assert np.array_equal(out, ref), name
+            assert np.array_equal(s.accept_counts, ref_acc), name
+
+
+def test_results_independent_of_launch_partition_and_sharding(M, O):
+    # the stream is keyed by (seed, GLOBAL chain id, iteration): splitting the run over launches, continuing a
+    # handle, or sharding chains over handles (= GPUs) must not change a single bit
+    init = M.core.init_with_seed(192, 3, 42, np.float32)
+    whole = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1).run(60, 9)
+    split = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1).set_iters_per_launch(13).run(60, 9)
+    assert np.array_equal(whole, split)
+    h = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1)
+    a = h.run(25, 9)
+    b = h.run(35, 0)  # second run() continues the chains, like the Rust struct
+    assert np.array_equal(np.concatenate([a, b], axis=1), whole)
+    lo = M.hmc.HMC(M.dist.RosenbrockND(3), init[:100], 0.032, 10).set_seed(1).run(60, 9)
+    hi = M.hmc.HMC(M.dist.RosenbrockND(3), init[100:], 0.032, 10).set_seed(1).set_chain_offset(100).run(60, 9)
+    assert np.array_equal(np.concatenate([lo, hi], axis=0), whole)
+    # step(): hmc.rs:304-377
+    h2 = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1)
+    for _ in range(9):
+        h2.step()
+    h2.step()
+    assert np.array_equal(h2.positions, whole[:, 0, :])
+
+
+def test_torch_device_output_matches_host_output(M, O):
+    import torch
+
+    init = M.core.init_with_seed(500, 3, 3, np.float32)
+    a = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(5).run(70, 5)
+    h = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(5)
+    t = h.run(70, 5, to="torch")
+    torch.cuda.synchronize()
+    assert t.is_cuda and tuple(t.shape) == (500, 70, 3)
+    assert np.array_equal(t.cpu().numpy(), a)
+    tm = h.timing()
+    assert tm["kernel_ms"] > 0 and tm["n_launches"] == 1 and tm["out_bytes"] == 500 * 70 * 3 * 4
+
+
+# ---------------------------------------------------------------- full BASELINE sizes: checksum of checksums
+
+
+def _chain_checksums(sample_u32):
+    # per-chain xor-rotate checksum over the raw bits, then a checksum of the per-chain checksums
+    c = np.zeros(sample_u32.shape[0], dtype=np.uint64)
+    flat = sample_u32.reshape(sample_u32.shape[0], -1).astype(np.uint64)
+    for k in range(flat.shape[1]):
+        c = ((c << np.uint64(7)) | (c >> np.uint64(57))) ^ (flat[:, k] * np.uint64(0x9E3779B97F4A7C15))
+    return c
+
+
+def test_config3_full_size_checksum(M, O):
+    # BASELINE.json config 3: 3-D Rosenbrock HMC, 65 536 chains, L = 10, f32, 400 + 50 (examples/minimal_hmc.rs)
+    C, nc, nd = 65536, 400, 50
+    init = M.core.init_with_seed(C, 3, 42, np.float32)
+    h = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(42)
+    out = h.run(nc, nd)
+    ref, _, ref_acc = O.engine_host_run("hmc", O.ROSENBROCK_ND, 3, [], init, 0.032, nc, nd, seed=42, n_leapfrog=10)
+    assert np.array_equal(h.accept_counts, ref_acc)  # bit-exact accept counts for all 65 536 chains
+    a, b = _chain_checksums(out.view(np.uint32)), _chain_checksums(ref.view(np.uint32))
+    assert np.array_equal(a, b)
+    assert np.bitwise_xor.reduce(a) == np.bitwise_xor.reduce(b)
+    assert np.all(np.isfinite(out))
+
+
+def test_config2_full_size_checksum(M, O):
+    # BASELINE.json config 2: Gaussian2D MH, 65 536 chains, f32, 1000 + 100 (examples/minimal_mh.rs shape)
+    C, nc, nd = 65536, 1000, 100
+    init = M.core.init_with_seed(C, 2, 42, np.float32)
+    tgt = M.dist.Gaussian2D([0.0, 0.0], [[1.0, 0.0], [0.0, 1.0]])
+    mh = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(1.0), init).seed(42)
+    out = mh.run(nc, nd)
+    ref, _, ref_acc = O.engine_host_run("mh", O.GAUSSIAN2D, 2, [0.0, 0.0, 1.0, 0.0, 0.0, 1.0], init, 1.0, nc, nd, seed=42)
+    assert np.array_equal(mh.accept_counts, ref_acc)
+    a, b = _chain_checksums(out.view(np.uint32)), _chain_checksums(ref.view(np.uint32))
+    assert np.array_equal(a, b)
+    # posterior moments within 1 % of the truth (north_star), far inside metropolis_hastings.rs:379-380
+    flat = out.reshape(-1, 2).astype(np.float64)
+    assert np.all(np.abs(flat.mean(axis=0)) < 0.01)
+    assert np.all(np.abs(np.cov(flat.T) - np.eye(2)) < 0.01)
+
+
+# ---------------------------------------------------------------- GPU vs reference-ordered restatement (statistical)
+
+
+def test_mh_moments_vs_reference_restatement(M, O, kats):
+    k = kats["mh_statistical"]
+    C, nc, nd = 4096, 500, 500
+    init = M.core.init_with_seed(C, 2, 42, np.float64)
+    tgt = M.dist.Gaussian2D(k["mean"], k["cov"])
+    g = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(1.0), init).seed(42).run(nc, nd)
+    o = O.MetropolisHastings(O.gaussian2d(k["mean"], k["cov"]), 1.0, init, np.float64).use_engine_stream(42).run(nc, nd)
+    # same noise, reference-ordered arithmetic (unfused, q-terms kept): f64 trajectories agree to rounding
+    np.testing.assert_allclose(g, o, rtol=1e-9, atol=1e-9)
+    fg = g.reshape(-1, 2)
+    assert np.all(np.abs(fg.mean(axis=0) - k["mean"]) < 0.03)
+    assert np.all(np.abs(np.cov(fg.T) - np.array(k["cov"])) < 0.06)
+    # and against the reference's own stream (xoshiro + ziggurat, quirks Q1/Q2): statistical agreement only
+    r = O.MetropolisHastings(O.gaussian2d(k["mean"], k["cov"]), 1.0, init[:256], np.float64, proposal_seed=42).seed(42).run(nc, nd)
+    fr = r.reshape(-1, 2)
+    assert np.all(np.abs(fr.mean(axis=0) - fg.mean(axis=0)) < k["mean_atol"])
+    assert np.all(np.abs(np.cov(fr.T) - np.cov(fg.T)) < k["cov_atol"])
+
+
+def test_hmc_gaussian_ess_band_on_gpu(M, O, kats):
+    # hmc.rs:764-786: mean ESS of 3 chains x 1000 (after 500) in [135,185] / [141,191]; many 3-chain groups at once
+    k = kats["hmc_ess_bands"]
+    groups = 200
+    init = M.core.init_with_seed(3 * groups, 2, 11, np.float32)
+    tgt = M.dist.DiffableGaussian2D(k["mean"], k["cov"])
+    s = M.hmc.HMC(tgt, init, k["step_size"], k["n_leapfrog"]).set_seed(3).run(k["n_collect"], k["n_discard"])
+    ess = np.array([O.split_rhat_mean_ess(s[3 * i:3 * i + 3])[1] for i in range(groups)])
+    m = ess.mean(axis=0)
+    assert k["ess1_band"][0] <= m[0] <= k["ess1_band"][1], m
+    assert k["ess2_band"][0] <= m[1] <= k["ess2_band"][1], m
+    flat = s.reshape(-1, 2).astype(np.float64)
+    assert np.all(np.abs(flat.mean(axis=0) - k["mean"]) < 0.05)
+    assert np.all(np.abs(np.cov(flat.T) - np.array(k["cov"])) < 0.1)
