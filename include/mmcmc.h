@@ -147,6 +147,26 @@ int mmcmc_hmc_destroy(mmcmc_hmc *h);
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters);
 int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters);
 
+/* ---- diagnostics: stats.rs ------------------------------------------------------------------------------
+ * split_rhat_mean_ess(sample[chains, n, params]) -> (rhat[params], ess[params])   stats.rs:416-423
+ * (splitcat :396-402, withinvar :429-477, rhat :425-427 = sqrt(W/var+) as the reference defines it, ess :496-546).
+ * sample: [n_chains, n, dim] of dtype, device or host memory; rhat, ess: host [dim] (f32 like the reference). */
+int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n,
+                              size_t dim, float *rhat, float *ess, int device, void *stream);
+/* The two halves of the above, for multi-GPU runs (chains sharded over ranks):
+ * partials: device-side sufficient statistics of the LOCAL chains -- means, ssq: device [2*n_chains, dim] in splitcat
+ * order (first halves of all local chains, then second halves), acov_sum: device [n/2, dim] un-normalised lag sums
+ * over the local half-chains.  All-gather the first two, all-reduce(sum) the third, then
+ * finish (host): the arithmetic of stats.rs:449-465, :425-427, :509-545 on the global statistics. */
+int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
+                         float *ssq, float *acov_sum, int device, void *stream);
+int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_sum, size_t n_half_chains, size_t m,
+                       size_t dim, float *rhat, float *ess);
+/* basic_stats stats.rs:310-336 (host) and RunStats::from stats.rs:360-371 */
+int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out);
+int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,
+                    mmcmc_run_stats *out, int device, void *stream);
+
 /* ---- densities, for parity tests ---------------------------------------------------------------------
  * BatchedGradientTarget::unnorm_logp_batch (distributions.rs:65-76) / unnorm_logp_and_grad (:81-87)
  * x: host [n, dim]; logp: host [n]; grad: host [n, dim] or NULL; all of `dtype` */

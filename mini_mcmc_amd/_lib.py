@@ -83,6 +83,14 @@ SIGNATURES = {
     "mmcmc_hmc_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "mmcmc_hmc_destroy": (C.c_int, [_vp]),
     "mmcmc_hmc_set_iters_per_launch": (C.c_int, [_vp, C.c_uint32]),
+    "mmcmc_split_rhat_mean_ess": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, _vp]),
+    "mmcmc_stats_partials": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, _vp]),
+    "mmcmc_stats_finish": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
+                                     C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mmcmc_basic_stats_from": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.POINTER(BasicStats)]),
+    "mmcmc_run_stats_from": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(RunStats),
+                                  C.c_int, _vp]),
     "mmcmc_logp_grad_batch": (C.c_int, [_TP, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int]),
     "mmcmc_draw_noise": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int]),
 }
@@ -98,6 +106,13 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C mini_mcmc_amd/csrc`). mini_mcmc_amd has no CPU fallback."
         )
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so (soname libamdhip64.so.7).
+    # Importing torch first makes the loader resolve libmmcmc.so's NEEDED entry to that already-loaded copy, so
+    # torch tensors / streams and the engine share one runtime; without torch the system ROCm copy is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -1,0 +1,356 @@
+/*
+ * mm_stats.hip -- split-R-hat / ESS reduction on the GPU (C ABI: mmcmc_stats_*, mmcmc_split_rhat_mean_ess, ...).
+ *
+ * Replaces stats.rs:416-546 (`split_rhat_mean_ess`: splitcat :396-402, withinvar :429-477, rhat :425-427,
+ * ess :496-546, autocov_bf :632-654 / autocov_fft :576-620) and the summaries basic_stats :310-336 /
+ * RunStats :339-371.  In the reference the per-chain autocovariances are computed one chain after another on the
+ * host (the chain loop :499-504 is serial) and averaged; here
+ *
+ *   kernel 1 (mm_half_chain_kernel): one wave per half-chain.  The [m, D] block of a half-chain (m = n/2 rows) is
+ *      read ONCE from HBM with coalesced loads, transposed into LDS ([D][m], zero padded), reduced to the
+ *      half-chain's mean and centred sum of squares per parameter, centred in place, and its biased
+ *      autocovariance sum_t y[t] y[t+lag] is accumulated for every lag into a per-wave LDS slab that is carried
+ *      across all the half-chains the wave processes; the slab is written out once per wave.
+ *   kernel 2 (mm_slab_reduce_kernel): sums the per-wave slabs in a fixed order (bitwise reproducible, no atomics).
+ *   host finish (mm_stats_finish): W, B, var+, the reference's "R-hat" sqrt(W/var+) (quirk Q7), rho_t, Geyer's
+ *      initial monotone sequence and ESS exactly as stats.rs:449-465, :509-545 order them, in f32.
+ *
+ * The autocovariance is evaluated directly (the reference does the same for m <= 100 and switches to an FFT above;
+ * both compute the same biased, mean-removed estimator).  Only sufficient statistics leave the GPU: 2*C*D means
+ * and sums of squares and m*D lag sums -- which is also all a multi-GPU run has to exchange (all-gather of the
+ * former, all-reduce of the latter; mini_mcmc_amd/stats.py).
+ */
+#include "../../include/mmcmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#define MM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return (int)_e;                                                                                       \
+    } while (0)
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+/* sample [C, n, D] of T (f32 or f64; converted to f32 on load like RunStats::from, stats.rs:365).
+ * half-chain index hc in [0, 2C): hc < C -> rows [0, m) of chain hc ; else rows [n-m, n) of chain hc-C.
+ * means / ssq: [2C, D];  slabs: [n_waves, D, m] un-normalised lag sums over the half-chains of each wave. */
+template <class T>
+__global__ __launch_bounds__(64) void mm_half_chain_kernel(const T *__restrict__ sample, unsigned long long C,
+                                                           unsigned int n, unsigned int D, unsigned int m,
+                                                           unsigned int m_pad, float *__restrict__ means,
+                                                           float *__restrict__ ssq, float *__restrict__ slabs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *y = lds;                        /* [D][m_pad], rows zero padded past m */
+    float *acc = lds + (size_t)D * m_pad;  /* [D][m] lag sums carried over this wave's half-chains */
+    const unsigned int lane = threadIdx.x;
+    const unsigned long long n_half = 2ull * C;
+
+    for (unsigned int i = lane; i < D * m; i += 64)
+        acc[i] = 0.f;
+    for (unsigned int i = lane; i < D * m_pad; i += 64)
+        y[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    for (unsigned long long hc = blockIdx.x; hc < n_half; hc += gridDim.x) {
+        const unsigned long long chain = hc < C ? hc : hc - C;
+        const unsigned int row0 = hc < C ? 0u : n - m;
+        const T *src = sample + (chain * n + row0) * D;
+        /* coalesced read of the contiguous [m, D] block, transposed into LDS */
+        for (unsigned int e = lane; e < m * D; e += 64) {
+            const unsigned int t = e / D, d = e - t * D;
+            y[d * m_pad + t] = (float)src[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned int d = 0; d < D; ++d) {
+            float *yd = y + d * m_pad;
+            float s = 0.f;
+            for (unsigned int t = lane; t < m; t += 64)
+                s += yd[t];
+            const float mean = wave_sum(s) / (float)m;
+            float q = 0.f;
+            for (unsigned int t = lane; t < m; t += 64) {
+                const float v = yd[t] - mean;
+                yd[t] = v;
+                q += v * v;
+            }
+            q = wave_sum(q);
+            if (lane == 0) {
+                means[hc * D + d] = mean;
+                ssq[hc * D + d] = q;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            /* lag sums: lane owns lags lane, lane+64, ... ; y[t] is a broadcast read, y[t+lag] a unit-stride
+             * read, rows are zero padded so no bounds test is needed inside the loop */
+            float *accd = acc + d * m;
+            for (unsigned int l0 = 0; l0 < m; l0 += 64) {
+                const unsigned int lag = l0 + lane;
+                float a0 = 0.f, a1 = 0.f;
+                const unsigned int tmax = m - l0; /* wave-uniform */
+                unsigned int t = 0;
+                for (; t + 1 < tmax; t += 2) {
+                    a0 = fmaf(yd[t], yd[t + lag], a0);
+                    a1 = fmaf(yd[t + 1], yd[t + 1 + lag], a1);
+                }
+                if (t < tmax)
+                    a0 = fmaf(yd[t], yd[t + lag], a0);
+                if (lag < m)
+                    accd[lag] += a0 + a1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float *slab = slabs + (size_t)blockIdx.x * D * m;
+    for (unsigned int i = lane; i < D * m; i += 64)
+        slab[i] = acc[i];
+}
+
+/* out[lag, d] = sum over waves of slabs[w, d, lag] (fixed order) */
+__global__ void mm_slab_reduce_kernel(const float *__restrict__ slabs, unsigned int n_slabs, unsigned int D,
+                                      unsigned int m, float *__restrict__ out)
+{
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; /* over d * m + lag */
+    if (i >= D * m)
+        return;
+    float s = 0.f;
+    for (unsigned int w = 0; w < n_slabs; ++w)
+        s += slabs[(size_t)w * D * m + i];
+    const unsigned int d = i / m, lag = i - d * m;
+    out[(size_t)lag * D + d] = s;
+}
+
+int check_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= n)
+        return MMCMC_ERR_INVALID_ARG;
+    return MMCMC_OK;
+}
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        (void)hipSetDevice(d);
+    }
+    ~DevGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+} // namespace
+
+/* number of waves (= per-wave lag-sum slabs) the half-chain kernel is launched with */
+static unsigned int stats_n_slabs(size_t n_chains) { return (unsigned int)std::min<size_t>(2 * n_chains, 2048); }
+
+extern "C" {
+
+int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
+                         float *ssq, float *acov_sum, int device, void *stream_v)
+{
+    if (!sample || !means || !ssq || !acov_sum || n_chains == 0 || dim == 0 ||
+        (dtype != MMCMC_F32 && dtype != MMCMC_F64))
+        return MMCMC_ERR_INVALID_ARG;
+    const size_t m = n / 2;
+    if (m < 1 || n >= (1ull << 31) || dim >= (1u << 16))
+        return MMCMC_ERR_SHAPE;
+    int st = check_device(device);
+    if (st != MMCMC_OK)
+        return st;
+    DevGuard g(device);
+    hipStream_t stream = (hipStream_t)stream_v;
+    const unsigned int m_pad = (unsigned int)(m + 64 + ((m + 64) % 2 == 0 ? 1 : 0)); /* odd row pitch */
+    const size_t lds = ((size_t)dim * m_pad + (size_t)dim * m) * sizeof(float);
+    if (lds > 160 * 1024)
+        return MMCMC_ERR_UNSUPPORTED;
+    const unsigned int n_slabs = stats_n_slabs(n_chains);
+    float *slabs = nullptr;
+    MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+    if (lds > 64 * 1024) {
+        const void *fn = dtype == MMCMC_F32 ? (const void *)mm_half_chain_kernel<float>
+                                            : (const void *)mm_half_chain_kernel<double>;
+        MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (dtype == MMCMC_F32)
+        hipLaunchKernelGGL(mm_half_chain_kernel<float>, dim3(n_slabs), dim3(64), lds, stream, (const float *)sample,
+                           (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, m_pad,
+                           means, ssq, slabs);
+    else
+        hipLaunchKernelGGL(mm_half_chain_kernel<double>, dim3(n_slabs), dim3(64), lds, stream,
+                           (const double *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
+                           (unsigned int)m, m_pad, means, ssq, slabs);
+    MM_HIP(hipGetLastError());
+    const unsigned int total = (unsigned int)(dim * m);
+    hipLaunchKernelGGL(mm_slab_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, slabs, n_slabs,
+                       (unsigned int)dim, (unsigned int)m, acov_sum);
+    MM_HIP(hipGetLastError());
+    MM_HIP(hipFreeAsync(slabs, stream));
+    return MMCMC_OK;
+}
+
+/* stats.rs:449-465 (withinvar), :425-427 (rhat), :509-545 (ess) on the gathered sufficient statistics, f32.
+ * means, ssq: [c2, dim] in splitcat order (first halves of all chains, then second halves); acov_sum [m, dim]. */
+int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_sum, size_t c2, size_t m, size_t dim,
+                       float *rhat, float *ess)
+{
+    if (!means || !ssq || !acov_sum || !rhat || !ess || c2 < 2 || m < 1 || dim == 0)
+        return MMCMC_ERR_INVALID_ARG;
+    const float nf = (float)m, cf = (float)c2;
+    std::vector<float> rho(m);
+    for (size_t d = 0; d < dim; ++d) {
+        float msum = 0.f;
+        for (size_t c = 0; c < c2; ++c)
+            msum += means[c * dim + d];
+        const float overall = msum / cf;
+        float dsum = 0.f, wsum = 0.f;
+        for (size_t c = 0; c < c2; ++c) {
+            const float df = means[c * dim + d] - overall;
+            dsum += df * df;
+            wsum += ssq[c * dim + d] / nf; /* biased per-chain variance (quirk Q8) */
+        }
+        const float b = dsum * (nf / (cf - 1.0f));
+        const float w = wsum / cf;
+        const float v = ((nf - 1.0f) / nf) * w + b / nf;
+        rhat[d] = std::sqrt(w / v); /* sqrt(W / var+): the reference's definition (quirk Q7) */
+        for (size_t t = 0; t < m; ++t) {
+            const float avg_rho = (acov_sum[t * dim + d] / nf) / cf; /* mean over chains of autocov_c(t) */
+            const float diff = -avg_rho + w;
+            rho[t] = -(diff / v) + 1.0f;
+        }
+        float mn = (m >= 2) ? rho[0] + rho[1] : 0.0f;
+        float out = 0.0f;
+        for (size_t t = 0; t + 1 < m; t += 2) {
+            float p_t = rho[t] + rho[t + 1];
+            if (p_t <= 0.0f)
+                break;
+            if (p_t > mn)
+                p_t = mn;
+            mn = p_t;
+            out += p_t;
+        }
+        const float tau = -1.0f + 2.0f * out;
+        ess[d] = (1.0f / tau) * cf * nf;
+    }
+    return MMCMC_OK;
+}
+
+int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n,
+                              size_t dim, float *rhat, float *ess, int device, void *stream_v)
+{
+    if (!sample || !rhat || !ess || n_chains == 0 || dim == 0)
+        return MMCMC_ERR_INVALID_ARG;
+    const size_t m = n / 2;
+    if (m < 1)
+        return MMCMC_ERR_SHAPE;
+    int st = check_device(device);
+    if (st != MMCMC_OK)
+        return st;
+    DevGuard g(device);
+    hipStream_t stream = (hipStream_t)stream_v;
+    const size_t esz = dtype == MMCMC_F32 ? 4 : 8;
+    const size_t c2 = 2 * n_chains;
+    void *d_sample = nullptr;
+    float *d_buf = nullptr;
+    const size_t nb = (2 * c2 * dim + m * dim);
+    std::vector<float> h(nb);
+    int rc = MMCMC_OK;
+    hipError_t e = hipSuccess;
+    do {
+        if (!sample_is_device) {
+            if ((e = hipMalloc(&d_sample, n_chains * n * dim * esz)) != hipSuccess)
+                break;
+            if ((e = hipMemcpyAsync(d_sample, sample, n_chains * n * dim * esz, hipMemcpyHostToDevice, stream)) !=
+                hipSuccess)
+                break;
+        }
+        if ((e = hipMalloc((void **)&d_buf, nb * sizeof(float))) != hipSuccess)
+            break;
+        float *d_means = d_buf, *d_ssq = d_buf + c2 * dim, *d_acov = d_buf + 2 * c2 * dim;
+        rc = mmcmc_stats_partials(sample_is_device ? sample : d_sample, dtype, n_chains, n, dim, d_means, d_ssq,
+                                  d_acov, device, stream_v);
+        if (rc != MMCMC_OK)
+            break;
+        if ((e = hipMemcpyAsync(h.data(), d_buf, nb * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+            break;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+            break;
+        rc = mmcmc_stats_finish(h.data(), h.data() + c2 * dim, h.data() + 2 * c2 * dim, c2, m, dim, rhat, ess);
+    } while (0);
+    if (d_sample)
+        (void)hipFree(d_sample);
+    if (d_buf)
+        (void)hipFree(d_buf);
+    if (e != hipSuccess)
+        return (int)e;
+    return rc;
+}
+
+/* stats.rs:310-336 basic_stats: sorted descending; min = last, median = [len/2], max = first, std with ddof 1 */
+int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out)
+{
+    if (!data || !out || len == 0)
+        return MMCMC_ERR_INVALID_ARG;
+    std::vector<float> s(data, data + len);
+    std::stable_sort(s.begin(), s.end(), [](float a, float b) { return b < a; });
+    out->min = s[len - 1];
+    out->median = s[len / 2];
+    out->max = s[0];
+    float sum = 0.f;
+    for (float v : s)
+        sum += v;
+    out->mean = sum / (float)len;
+    float mu = 0.f, sq = 0.f;
+    for (size_t i = 0; i < len; ++i) {
+        const float delta = s[i] - mu;
+        mu += delta / (float)(i + 1);
+        sq = (s[i] - mu) * delta + sq;
+    }
+    out->std = std::sqrt(sq / ((float)len - 1.0f));
+    return MMCMC_OK;
+}
+
+/* RunStats::from (stats.rs:360-371) */
+int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,
+                    mmcmc_run_stats *out, int device, void *stream)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    std::vector<float> rhat(dim), ess(dim);
+    int rc = mmcmc_split_rhat_mean_ess(sample, sample_is_device, dtype, n_chains, n, dim, rhat.data(), ess.data(),
+                                       device, stream);
+    if (rc != MMCMC_OK)
+        return rc;
+    rc = mmcmc_basic_stats_from(ess.data(), dim, &out->ess);
+    if (rc != MMCMC_OK)
+        return rc;
+    return mmcmc_basic_stats_from(rhat.data(), dim, &out->rhat);
+}
+
+} /* extern "C" */

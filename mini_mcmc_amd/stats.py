@@ -1,0 +1,164 @@
+"""Diagnostics -- host-side mirror of the reference's `stats` module (src/stats.rs) over the GPU reduction.
+
+split_rhat_mean_ess / RunStats / basic_stats keep the reference's semantics, including its definition of the split
+"R-hat" as sqrt(W / var+) (stats.rs:425-427; the inverse of Stan's), and additionally expose the conventional value.
+With chains sharded over ranks (one process per GPU), `split_rhat_mean_ess_distributed` exchanges only sufficient
+statistics: an all-gather of per-half-chain means / sums of squares and an all-reduce of the lag sums (RCCL over
+xGMI through torch.distributed; gloo on CPU tensors in the tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+_fp = C.POINTER(C.c_float)
+
+
+@dataclass
+class BasicStats:
+    """stats.rs:373-381"""
+    name: str
+    min: float
+    median: float
+    max: float
+    mean: float
+    std: float
+
+    def __str__(self):  # stats.rs:383-392
+        return (f"{self.name} in [{self.min:.2f}, {self.max:.2f}], median: {self.median:.2f}, "
+                f"mean: {self.mean:.2f} ± {self.std:.2f}")
+
+
+@dataclass
+class RunStats:
+    """stats.rs:338-342"""
+    ess: BasicStats
+    rhat: BasicStats
+
+    def __str__(self):
+        return f"{self.ess}\n{self.rhat}"
+
+
+def basic_stats(name: str, data) -> BasicStats:
+    """stats.rs:310-336"""
+    x = np.ascontiguousarray(data, dtype=np.float32).ravel()
+    out = L.BasicStats()
+    L.check(L.lib().mmcmc_basic_stats_from(x.ctypes.data_as(_fp), x.size, C.byref(out)), "mmcmc_basic_stats_from")
+    return BasicStats(name, out.min, out.median, out.max, out.mean, out.std)
+
+
+def _sample_args(sample):
+    """-> (pointer, is_device, dtype_code, shape, device index, stream, keepalive)"""
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        torch = None
+    if torch is not None and isinstance(sample, torch.Tensor):
+        t = sample.contiguous()
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.float()
+        code = L.F32 if t.dtype == torch.float32 else L.F64
+        if t.is_cuda:
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+            return t.data_ptr(), 1, code, tuple(t.shape), t.device.index or 0, C.c_void_p(stream), t
+        a = t.numpy()
+        return a.ctypes.data, 0, code, a.shape, 0, None, a
+    a = np.ascontiguousarray(sample)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float32)
+    return a.ctypes.data, 0, L.F32 if a.dtype == np.float32 else L.F64, a.shape, 0, None, a
+
+
+def split_rhat_mean_ess(sample, device: int | None = None):
+    """stats.rs:416-423: sample [chains, n, params] (numpy, or a torch tensor in HBM) -> (rhat[params], ess[params]).
+    `rhat` is the reference's sqrt(W / var+) (quirk Q7)."""
+    ptr, is_dev, code, shape, dev, stream, keep = _sample_args(sample)
+    if len(shape) != 3:
+        raise ValueError("sample must be [chains, n, params]")
+    c, n, p = shape
+    rhat = np.empty(p, dtype=np.float32)
+    ess = np.empty(p, dtype=np.float32)
+    st = L.lib().mmcmc_split_rhat_mean_ess(ptr, is_dev, code, c, n, p, rhat.ctypes.data_as(_fp),
+                                           ess.ctypes.data_as(_fp), dev if device is None else device, stream)
+    L.check(st, "mmcmc_split_rhat_mean_ess")
+    return rhat, ess
+
+
+def standard_split_rhat(sample):
+    """The conventional split R-hat, sqrt(var+ / W) (as MultiChainTracker::rhat / collect_rhat report it)."""
+    rhat, _ = split_rhat_mean_ess(sample)
+    return 1.0 / rhat
+
+
+def run_stats(sample) -> RunStats:
+    """RunStats::from (stats.rs:360-371)."""
+    rhat, ess = split_rhat_mean_ess(sample)
+    return RunStats(basic_stats("ESS", ess), basic_stats("Split R-hat", rhat))
+
+
+def stats_partials(sample):
+    """Device-side sufficient statistics of the local chains (torch CUDA tensor in, torch CUDA tensors out):
+    means [2, C, D], ssq [2, C, D] (splitcat order: half index first) and acov_sum [n/2, D]."""
+    import torch
+
+    assert sample.is_cuda and sample.dim() == 3
+    t = sample.contiguous()
+    code = L.F32 if t.dtype == torch.float32 else L.F64
+    c, n, d = t.shape
+    m = n // 2
+    means = torch.empty((2, c, d), dtype=torch.float32, device=t.device)
+    ssq = torch.empty_like(means)
+    acov = torch.empty((m, d), dtype=torch.float32, device=t.device)
+    stream = torch.cuda.current_stream(t.device).cuda_stream
+    st = L.lib().mmcmc_stats_partials(t.data_ptr(), code, c, n, d, means.data_ptr(), ssq.data_ptr(), acov.data_ptr(),
+                                      t.device.index or 0, C.c_void_p(stream))
+    L.check(st, "mmcmc_stats_partials")
+    return means, ssq, acov
+
+
+def stats_finish(means, ssq, acov_sum):
+    """Host finish (stats.rs:449-465, :425-427, :509-545) on global statistics: means, ssq [2C, D]; acov_sum [m, D]."""
+    mu = np.ascontiguousarray(means, dtype=np.float32).reshape(-1, np.shape(means)[-1])
+    sq = np.ascontiguousarray(ssq, dtype=np.float32).reshape(mu.shape)
+    ac = np.ascontiguousarray(acov_sum, dtype=np.float32)
+    c2, d = mu.shape
+    m = ac.shape[0]
+    rhat = np.empty(d, dtype=np.float32)
+    ess = np.empty(d, dtype=np.float32)
+    st = L.lib().mmcmc_stats_finish(mu.ctypes.data_as(_fp), sq.ctypes.data_as(_fp), ac.ctypes.data_as(_fp), c2, m, d,
+                                    rhat.ctypes.data_as(_fp), ess.ctypes.data_as(_fp))
+    L.check(st, "mmcmc_stats_finish")
+    return rhat, ess
+
+
+def gather_partials(means, ssq, acov_sum, group=None):
+    """The only data-path exchange of a multi-GPU run.  Inputs are this rank's tensors ([2, C_local, D], [2, C_local, D],
+    [m, D]; CUDA tensors with the nccl(=RCCL) backend, CPU tensors with gloo).  Returns global (means [2C, D],
+    ssq [2C, D], acov_sum [m, D]) as numpy, chains ordered by rank -- the same order a single GPU would produce."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    packed = torch.stack([means, ssq], dim=0).contiguous()  # [2(stat), 2(half), C_local, D]
+    gathered = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(gathered, packed, group=group)
+    acov = acov_sum.clone()
+    dist.all_reduce(acov, op=dist.ReduceOp.SUM, group=group)
+    allp = torch.stack(gathered, dim=0)  # [rank, stat, half, C_local, D]
+    allp = allp.permute(1, 2, 0, 3, 4).contiguous()  # [stat, half, rank, C_local, D] = global splitcat order
+    d = allp.shape[-1]
+    g_means = allp[0].reshape(-1, d).cpu().numpy()
+    g_ssq = allp[1].reshape(-1, d).cpu().numpy()
+    return g_means, g_ssq, acov.cpu().numpy()
+
+
+def split_rhat_mean_ess_distributed(sample_local, group=None):
+    """split_rhat_mean_ess over chains sharded across ranks (rank r holds global chains [r*C_local, (r+1)*C_local)).
+    Every rank returns the same (rhat, ess)."""
+    means, ssq, acov = stats_partials(sample_local)
+    g_means, g_ssq, g_acov = gather_partials(means, ssq, acov, group)
+    return stats_finish(g_means, g_ssq, g_acov)

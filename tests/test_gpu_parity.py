@@ -263,3 +263,78 @@ def test_hmc_gaussian_ess_band_on_gpu(M, O, kats):
     flat = s.reshape(-1, 2).astype(np.float64)
     assert np.all(np.abs(flat.mean(axis=0) - k["mean"]) < 0.05)
     assert np.all(np.abs(np.cov(flat.T) - np.array(k["cov"])) < 0.1)
+
+
+# ---------------------------------------------------------------- diagnostics on the GPU (stats.rs:416-546)
+
+
+def _ar1(rng, c, n, p, phi=0.6):
+    x = np.zeros((c, n, p), dtype=np.float32)
+    e = rng.standard_normal((c, n, p)).astype(np.float32)
+    for t in range(1, n):
+        x[:, t] = phi * x[:, t - 1] + e[:, t]
+    return x
+
+
+@pytest.mark.parametrize("c,n,p", [(4, 60, 2), (3, 200, 3), (7, 201, 1), (16, 400, 3), (2, 1000, 2), (5, 2, 2), (1, 50, 4),
+                                   (64, 100, 32)])
+def test_split_rhat_mean_ess_vs_oracle(M, O, c, n, p):
+    from mini_mcmc_amd import stats as S
+
+    rng = np.random.default_rng(c * 1000 + n)
+    x = _ar1(rng, c, n, p)
+    x[:, :, 0] += np.arange(c)[:, None] * 0.25
+    r0, e0 = O.split_rhat_mean_ess(x)
+    r1, e1 = S.split_rhat_mean_ess(x)
+    ok = np.isfinite(r0)
+    np.testing.assert_allclose(r1[ok], r0[ok], rtol=1e-4)
+    ok = np.isfinite(e0)
+    np.testing.assert_allclose(e1[ok], e0[ok], rtol=5e-3)  # n/2 > 100: the oracle (like the reference) uses an f32 FFT
+    # f64 input is cast to f32 first, like RunStats::from (stats.rs:365)
+    r2, e2 = S.split_rhat_mean_ess(x.astype(np.float64))
+    assert np.array_equal(r1, r2) and np.array_equal(e1, e2)
+
+
+def test_stats_kats_on_gpu(M, O, kats):
+    from mini_mcmc_amd import stats as S
+
+    # stats.rs:810-834 ess_1
+    k = kats["ess_1"]
+    r = O.SmallRng(k["seed"])
+    data = np.array([[r.f32() for _ in range(k["n"])] for _ in range(k["chains"])], dtype=np.float32)[:, :, None]
+    st = S.run_stats(data)
+    assert st.ess.min > k["ess_min_gt"] and st.rhat.max < k["rhat_max_lt"]
+    # autocovariance known answers (stats.rs:777-808) through the partial statistics: one chain of 8 = two halves of 4
+    import torch
+
+    for ka in kats["autocov"]:
+        d = np.array(ka["data"], dtype=np.float32)
+        x = np.concatenate([d, d], axis=0)[None]  # [1, 8, p]: both halves equal the 4-point series
+        means, ssq, acov = S.stats_partials(torch.from_numpy(x).cuda())
+        got = acov.cpu().numpy() / 4.0 / 2.0  # /n, mean over the two half-chains
+        np.testing.assert_allclose(got, np.array(ka["expected"], dtype=np.float32), atol=ka["atol"])
+        np.testing.assert_allclose(means.cpu().numpy()[0, 0], d.mean(axis=0), rtol=1e-6)
+
+
+def test_stats_on_device_sample_and_sharded_partials(M, O):
+    import torch
+    from mini_mcmc_amd import stats as S
+
+    init = M.core.init_with_seed(512, 3, 42, np.float32)
+    h = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(42)
+    t = h.run(300, 50, to="torch")
+    torch.cuda.synchronize()
+    r_dev, e_dev = S.split_rhat_mean_ess(t)
+    r_host, e_host = S.split_rhat_mean_ess(t.cpu().numpy())
+    assert np.array_equal(r_dev, r_host) and np.array_equal(e_dev, e_host)
+    r0, e0 = O.split_rhat_mean_ess(t.cpu().numpy())
+    np.testing.assert_allclose(r_dev, r0, rtol=1e-4)
+    np.testing.assert_allclose(e_dev, e0, rtol=5e-3)
+    # sharding the chains over "ranks" and merging sufficient statistics gives the single-GPU answer
+    parts = [S.stats_partials(t[i * 128:(i + 1) * 128]) for i in range(4)]
+    means = torch.cat([p[0] for p in parts], dim=1).reshape(-1, 3).cpu().numpy()  # [2, C, D] -> splitcat order
+    ssq = torch.cat([p[1] for p in parts], dim=1).reshape(-1, 3).cpu().numpy()
+    acov = sum(p[2] for p in parts).cpu().numpy()
+    r_sh, e_sh = S.stats_finish(means, ssq, acov)
+    np.testing.assert_allclose(r_sh, r_dev, rtol=1e-6)
+    np.testing.assert_allclose(e_sh, e_dev, rtol=1e-4)
