@@ -250,6 +250,8 @@ struct o_hmc {
     double *positions;  /* [C, D] holding T values */
     double *mom, *unif; /* per-step noise buffers [C, D], [C] */
     o_rng global;       /* rand_compat backend: ONE stream for everything (burn's global generator) */
+    int blocked;        /* rand_compat backend, one stream per thread-block of chains (CPU baseline timing) */
+    uint64_t blocked_seed;
     o_rng *chain_rng;   /* engine backend: one stream per chain */
     uint64_t *n_accept;
     uint64_t iter;
@@ -295,11 +297,23 @@ void o_hmc_destroy(o_hmc *s)
 void o_hmc_seed_global(o_hmc *s, uint64_t seed)
 {
     s->engine = 0;
+    s->blocked = 0;
     o_rng_init_rand_compat(&s->global, seed);
+}
+
+/* CPU-baseline mode: chains are block-partitioned over threads for the WHOLE run (what rayon's par_iter_mut over
+ * chain blocks would do) and each block draws momenta / uniforms from its own rand-compatible stream, so no thread
+ * waits on a global generator.  Same transition arithmetic as the global-stream mode. */
+void o_hmc_seed_blocked(o_hmc *s, uint64_t seed)
+{
+    s->engine = 0;
+    s->blocked = 1;
+    s->blocked_seed = seed;
 }
 
 void o_hmc_use_engine_stream(o_hmc *s, uint64_t seed, uint64_t chain_offset)
 {
+    s->blocked = 0;
     s->engine = 1;
     for (int i = 0; i < s->n_chains; ++i) {
         s->chain_rng[i].is_f32 = s->is_f32;
@@ -419,15 +433,46 @@ static void hmc_engine_range(void *p, int lo, int hi)
     }
 }
 
+static void hmc_blocked_range(void *p, int lo, int hi)
+{
+    hmc_ctx *x = (hmc_ctx *)p;
+    o_hmc *s = x->s;
+    int d = s->dim;
+    size_t total = x->n_collect + x->n_discard;
+    o_rng r;
+    r.is_f32 = s->is_f32;
+    o_rng_init_rand_compat(&r, s->blocked_seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(lo + 1) + s->iter);
+    for (size_t t = 0; t < total; ++t) {
+        for (int ci = lo; ci < hi; ++ci)
+            for (int i = 0; i < d; ++i) {
+                double z = r.normal_f64(&r);
+                s->mom[(size_t)ci * d + i] = s->is_f32 ? (double)(float)z : z;
+            }
+        for (int ci = lo; ci < hi; ++ci) {
+            double u = r.uniform_f64(&r);
+            s->unif[ci] = s->is_f32 ? (double)(float)u : u;
+        }
+        for (int ci = lo; ci < hi; ++ci) {
+            if (s->is_f32)
+                hmc_chain_step_f32(s, ci);
+            else
+                hmc_chain_step_f64(s, ci);
+            if (t >= x->n_discard && x->out)
+                memcpy(x->out + ((size_t)ci * x->n_collect + (t - x->n_discard)) * d,
+                       s->positions + (size_t)ci * d, sizeof(double) * d);
+        }
+    }
+}
+
 /* HMC::run hmc.rs:137-158 ; out [C, n_collect, D] (already permuted) */
 void o_hmc_run(o_hmc *s, size_t n_collect, size_t n_discard, int n_threads, double *out, uint64_t *accept_counts)
 {
     int d = s->dim;
     uint64_t *before = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)s->n_chains);
     memcpy(before, s->n_accept, sizeof(uint64_t) * (size_t)s->n_chains);
-    if (s->engine) {
+    if (s->engine || s->blocked) {
         hmc_ctx x = {s, n_collect, n_discard, out};
-        par_for(hmc_engine_range, &x, s->n_chains, n_threads);
+        par_for(s->engine ? hmc_engine_range : hmc_blocked_range, &x, s->n_chains, n_threads);
         s->iter += n_collect + n_discard;
     } else {
         for (size_t i = 0; i < n_discard; ++i)

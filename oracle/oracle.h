@@ -56,6 +56,8 @@ void o_hmc_destroy(o_hmc *s);
 /* momenta/uniforms from ONE global rand_compat stream, row-major over [chains, dim] then [chains]
  * (stands in for burn-ndarray's unseeded global generator, hmc.rs:309-313,359-363; unpinned) */
 void o_hmc_seed_global(o_hmc *s, uint64_t seed);
+/* one rand_compat stream per thread-block of chains (CPU-baseline timing; same transition arithmetic) */
+void o_hmc_seed_blocked(o_hmc *s, uint64_t seed);
 void o_hmc_use_engine_stream(o_hmc *s, uint64_t seed, uint64_t chain_offset);
 void o_hmc_run(o_hmc *s, size_t n_collect, size_t n_discard, int n_threads, double *out, uint64_t *accept_counts);
 void o_hmc_state(o_hmc *s, double *out);

@@ -106,6 +106,7 @@ def lib() -> C.CDLL:
         "o_hmc_destroy": (None, [C.c_void_p]),
         "o_hmc_seed_global": (None, [C.c_void_p, C.c_uint64]),
         "o_hmc_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_hmc_seed_blocked": (None, [C.c_void_p, C.c_uint64]),
         "o_hmc_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, _dp, _u64p]),
         "o_hmc_state": (None, [C.c_void_p, _dp]),
         "o_nuts_create": (C.c_void_p, [tp, _dp, C.c_int, C.c_double, C.c_int]),
@@ -355,6 +356,11 @@ class HMC:
 
     def seed_global(self, seed):
         lib().o_hmc_seed_global(self._h, seed)
+        return self
+
+    def seed_blocked(self, seed):
+        """one rand-compatible stream per thread-block of chains: the CPU-baseline timing mode"""
+        lib().o_hmc_seed_blocked(self._h, seed)
         return self
 
     def use_engine_stream(self, seed, chain_offset=0):
