@@ -82,6 +82,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--variant", type=int, default=1, help="kernel variant: 1 producer/consumer (default), 0 single wave")
     args = ap.parse_args()
 
     import numpy as np
@@ -114,6 +115,7 @@ def main() -> None:
     init = np.ascontiguousarray(init_all[rank * C_PER_GPU:(rank + 1) * C_PER_GPU])
     sampler = HMC(RosenbrockND(DIM), init, STEP_SIZE, N_LEAPFROG, device=local_rank).set_seed(SEED)
     sampler.set_chain_offset(rank * C_PER_GPU)
+    sampler.set_kernel_variant(args.variant)
 
     out = torch.empty((C_PER_GPU, N_COLLECT, DIM), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -202,7 +204,8 @@ def main() -> None:
             "split_rhat_max_conventional": float((1.0 / rhat).max()),
             "stats_ms": stats_s * 1e3,
             "roofline": {
-                "kernel": "mm_run_kernel<float, RosenbrockND<3>, HMC>",
+                "kernel": ("mm_run_kernel_pc<float, RosenbrockND<3>, HMC, 1 producer wave>" if args.variant == 1
+                           else "mm_run_kernel<float, RosenbrockND<3>, HMC>"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

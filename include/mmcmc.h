@@ -143,9 +143,13 @@ int mmcmc_hmc_sync(mmcmc_hmc *h);
 int mmcmc_hmc_timing(mmcmc_hmc *h, mmcmc_timing *t);
 int mmcmc_hmc_destroy(mmcmc_hmc *h);
 
-/* knob shared by the samplers: iterations per kernel launch (0 = the whole run in one launch, the default) */
+/* knobs shared by the samplers (results never depend on them):
+ * iterations per kernel launch (0 = the whole run in one launch, the default);
+ * kernel variant: 1 = producer/consumer waves (default), 0 = one wave per 64 chains */
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters);
 int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters);
+int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant);
+int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant);
 
 /* ---- diagnostics: stats.rs ------------------------------------------------------------------------------
  * split_rhat_mean_ess(sample[chains, n, params]) -> (rhat[params], ess[params])   stats.rs:416-423

@@ -83,6 +83,8 @@ SIGNATURES = {
     "mmcmc_hmc_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "mmcmc_hmc_destroy": (C.c_int, [_vp]),
     "mmcmc_hmc_set_iters_per_launch": (C.c_int, [_vp, C.c_uint32]),
+    "mmcmc_mh_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+    "mmcmc_hmc_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "mmcmc_split_rhat_mean_ess": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                             C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, _vp]),
     "mmcmc_stats_partials": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, _vp]),

@@ -50,6 +50,11 @@ class _Sampler:
         L.check(self._fn("set_iters_per_launch")(self._h, int(iters)), "set_iters_per_launch")
         return self
 
+    def set_kernel_variant(self, variant: int):
+        """1 = producer/consumer waves (default), 0 = one wave per 64 chains; results are identical."""
+        L.check(self._fn("set_kernel_variant")(self._h, int(variant)), "set_kernel_variant")
+        return self
+
     def run(self, n_collect: int, n_discard: int = 0, to: str = "numpy", accept_counts: bool = True,
             collect: bool = True):
         """`run(n_collect, n_discard)` of the reference (core.rs:176-186 / hmc.rs:137-158): returns the sample

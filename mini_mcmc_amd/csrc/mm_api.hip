@@ -130,6 +130,7 @@ struct Sampler {
     uint64_t seed = 0, chain_offset = 0;
     uint64_t iter = 0;
     uint32_t iters_per_launch = 0;
+    int variant = 1; /* 0 = one wave per 64 chains (mm_run_kernel), 1 = producer/consumer (mm_run_kernel_pc) */
     unsigned int block = 64;
     void *d_state = nullptr;
     void *d_mat = nullptr;
@@ -276,8 +277,13 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     a.out_t0 = out_t0;
     a.n_total = n_total;
     unsigned int grid = (unsigned int)((s->n_chains + s->block - 1) / s->block);
-    hipError_t e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh(a, grid, s->block, stream)
-                                                 : k->run_hmc(a, grid, s->block, stream);
+    hipError_t e;
+    if (s->variant == 1)
+        e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh_pc(a, grid, s->block, stream)
+                                          : k->run_hmc_pc(a, grid, s->block, stream);
+    else
+        e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh(a, grid, s->block, stream)
+                                          : k->run_hmc(a, grid, s->block, stream);
     if (e != hipSuccess)
         return (int)e;
     s->iter += (uint64_t)n_discard + n_collect;
@@ -563,6 +569,20 @@ int mmcmc_mh_set_chain_offset(mmcmc_mh *h, uint64_t off)
     if (!h)
         return MMCMC_ERR_INVALID_ARG;
     h->s->chain_offset = off;
+    return MMCMC_OK;
+}
+int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
+{
+    if (!h || variant < 0 || variant > 1)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->variant = variant;
+    return MMCMC_OK;
+}
+int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
+{
+    if (!h || variant < 0 || variant > 1)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->variant = variant;
     return MMCMC_OK;
 }
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters)

@@ -60,20 +60,19 @@ template <int D> MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_
     *u = mm_aux_u53(seed, chain, iter, 0);
 }
 
-/* One Metropolis-Hastings transition with the isotropic Gaussian random-walk proposal.
- * x[D], lp = logp(x) are updated in place; returns 1 if the proposal was accepted. */
+/* One Metropolis-Hastings transition with the isotropic Gaussian random-walk proposal, given its noise:
+ * z[D] ~ N(0,1) and ln_u = log of the accept uniform.  x[D], lp = logp(x) are updated in place; returns 1 on accept. */
 template <class T, class Tgt>
-MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t seed, uint64_t chain, uint32_t iter)
+MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, T ln_u)
 {
     constexpr int D = Tgt::dim;
-    T z[D], prop[D], u;
-    mm_draw_noise<D>(seed, chain, iter, z, &u);
+    T prop[D];
     MM_UNROLL
     for (int i = 0; i < D; ++i)
         prop[i] = mm_fma(prop_std, z[i], x[i]);
     T lpp = Tgt::logp(P, prop);
     T log_accept_ratio = lpp - *lp;
-    int acc = log_accept_ratio > mm_logT(u);
+    int acc = log_accept_ratio > ln_u;
     if (acc) {
         MM_UNROLL
         for (int i = 0; i < D; ++i)
@@ -83,14 +82,22 @@ MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t s
     return acc;
 }
 
-/* One HMC transition: x[D], lp = logp(x), g = grad logp(x) updated in place; returns 1 on accept. */
 template <class T, class Tgt>
-MM_HD int mm_hmc_step(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, uint64_t seed,
-                      uint64_t chain, uint32_t iter)
+MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t seed, uint64_t chain, uint32_t iter)
 {
     constexpr int D = Tgt::dim;
-    T p[D], xn[D], gn[D], u;
-    mm_draw_noise<D>(seed, chain, iter, p, &u);
+    T z[D], u;
+    mm_draw_noise<D>(seed, chain, iter, z, &u);
+    return mm_mh_step_noise<T, Tgt>(P, prop_std, x, lp, z, mm_logT(u));
+}
+
+/* One HMC transition given its noise: p[D] ~ N(0,1) (momentum; clobbered) and ln_u.  x[D], lp = logp(x),
+ * g = grad logp(x) are updated in place; returns 1 on accept. */
+template <class T, class Tgt>
+MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, T *p, T ln_u)
+{
+    constexpr int D = Tgt::dim;
+    T xn[D], gn[D];
     const T h = eps * T(0.5);
     T ke = 0;
     MM_UNROLL
@@ -118,7 +125,7 @@ MM_HD int mm_hmc_step(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp
         kp = mm_fma(p[i], p[i], kp);
     T h_proposed = kp * T(0.5) - lpn;
     T accept_logp = h_current - h_proposed;
-    int acc = accept_logp >= mm_logT(u);
+    int acc = accept_logp >= ln_u;
     if (acc) {
         MM_UNROLL
         for (int i = 0; i < D; ++i) {
@@ -128,6 +135,16 @@ MM_HD int mm_hmc_step(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp
         *lp = lpn;
     }
     return acc;
+}
+
+template <class T, class Tgt>
+MM_HD int mm_hmc_step(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, uint64_t seed,
+                      uint64_t chain, uint32_t iter)
+{
+    constexpr int D = Tgt::dim;
+    T p[D], u;
+    mm_draw_noise<D>(seed, chain, iter, p, &u);
+    return mm_hmc_step_noise<T, Tgt>(P, eps, n_leapfrog, x, lp, g, p, mm_logT(u));
 }
 
 #endif /* MM_SAMPLERS_H */
