@@ -145,7 +145,7 @@ int mmcmc_hmc_destroy(mmcmc_hmc *h);
 
 /* knobs shared by the samplers (results never depend on them):
  * iterations per kernel launch (0 = the whole run in one launch, the default);
- * kernel variant: 1 = producer/consumer waves (default), 0 = one wave per 64 chains */
+ * kernel variant: 2 = software-pipelined single wave (default), 1 = producer/consumer waves, 0 = plain single wave */
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters);
 int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters);
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant);

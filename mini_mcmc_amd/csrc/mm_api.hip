@@ -130,7 +130,7 @@ struct Sampler {
     uint64_t seed = 0, chain_offset = 0;
     uint64_t iter = 0;
     uint32_t iters_per_launch = 0;
-    int variant = 1; /* 0 = one wave per 64 chains (mm_run_kernel), 1 = producer/consumer (mm_run_kernel_pc) */
+    int variant = 2; /* 0 = one wave per 64 chains, 1 = producer/consumer waves, 2 = software-pipelined single wave */
     unsigned int block = 64;
     void *d_state = nullptr;
     void *d_mat = nullptr;
@@ -281,6 +281,10 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     if (s->variant == 1)
         e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh_pc(a, grid, s->block, stream)
                                           : k->run_hmc_pc(a, grid, s->block, stream);
+    else if (s->variant == 2)
+        e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh_sp(a, grid, s->block, stream)
+            : (s->n_leapfrog == 10)       ? k->run_hmc_sp10(a, grid, s->block, stream)
+                                          : k->run_hmc_sp(a, grid, s->block, stream);
     else
         e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh(a, grid, s->block, stream)
                                           : k->run_hmc(a, grid, s->block, stream);
@@ -573,14 +577,14 @@ int mmcmc_mh_set_chain_offset(mmcmc_mh *h, uint64_t off)
 }
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 {
-    if (!h || variant < 0 || variant > 1)
+    if (!h || variant < 0 || variant > 2)
         return MMCMC_ERR_INVALID_ARG;
     h->s->variant = variant;
     return MMCMC_OK;
 }
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
 {
-    if (!h || variant < 0 || variant > 1)
+    if (!h || variant < 0 || variant > 2)
         return MMCMC_ERR_INVALID_ARG;
     h->s->variant = variant;
     return MMCMC_OK;

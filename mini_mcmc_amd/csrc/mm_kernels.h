@@ -87,7 +87,12 @@ __device__ __forceinline__ void mm_flush_tile(const mm_run_args<T> &a, const T *
     __builtin_amdgcn_wave_barrier();
 }
 
-template <class T, class Tgt, int SAMPLER>
+/* PIPE = 1: software-pipelined -- the noise of transition t+1 (a pure function of (seed, chain, t+1), independent
+ * of the chain's state) is computed in the same basic block as transition t, so the scheduler can interleave the two
+ * dependency chains; a lone dependent chain issues one VALU instruction per ~5 cycles on gfx950, independent
+ * instructions one per ~2.5 (tools/valu_rate.hip).  LCT > 0: compile-time leapfrog count (loop unrolled into that
+ * block).  Results are bit-identical for every (PIPE, LCT). */
+template <class T, class Tgt, int SAMPLER, int PIPE = 0, int LCT = 0>
 __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
 {
     constexpr int D = Tgt::dim;
@@ -115,13 +120,32 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
 
     unsigned int it = a.iter0;
     unsigned long long n_acc = 0, wave_acc = 0;
+    T zc[D], ln_uc = 0; /* PIPE: noise of the current transition, drawn one transition ahead */
+    if (PIPE) {
+        T u;
+        mm_draw_noise<D>(a.seed, chain, it, zc, &u);
+        ln_uc = mm_logT(u);
+    }
 
     auto step = [&]() {
         int acc;
-        if (SAMPLER == MM_SAMPLER_HMC)
+        if (PIPE) {
+            T zn[D], un;
+            mm_draw_noise<D>(a.seed, chain, it + 1, zn, &un);
+            const T ln_un = mm_logT(un);
+            if (SAMPLER == MM_SAMPLER_HMC)
+                acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, zc, ln_uc);
+            else
+                acc = mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, zc, ln_uc);
+            MM_UNROLL
+            for (int i = 0; i < D; ++i)
+                zc[i] = zn[i];
+            ln_uc = ln_un;
+        } else if (SAMPLER == MM_SAMPLER_HMC) {
             acc = mm_hmc_step<T, Tgt>(a.P, a.scale, a.n_leapfrog, x, &lp, g, a.seed, chain, it);
-        else
+        } else {
             acc = mm_mh_step<T, Tgt>(a.P, a.scale, x, &lp, a.seed, chain, it);
+        }
         acc = acc && active;
         n_acc += (unsigned long long)acc;
         wave_acc += (unsigned long long)__popcll(__ballot(acc)); /* wave-uniform: scalar add */
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
  */
 template <class T, int D> struct mm_pc_cfg {
     static constexpr int nv = D + 1; /* D normals + log(accept uniform) */
-    static constexpr int budget = 16 * 1024;
+    static constexpr int budget = 8 * 1024; /* tile (24.8 KB) + ring <= 40 KB: four workgroups per CU */
     static constexpr int tb_raw = budget / (2 * nv * 64 * (int)sizeof(T));
     static constexpr int tb = tb_raw < 1 ? 1 : (tb_raw > 8 ? 8 : tb_raw);
     static constexpr size_t ring_bytes = (size_t)2 * tb * nv * 64 * sizeof(T);
@@ -321,11 +345,11 @@ __global__ void mm_noise_kernel(unsigned long long seed, unsigned long long chai
 }
 
 /* host-side launchers + dispatch record for one (sampler, dtype, kind, dim) instance */
-template <class T, class Tgt, int SAMPLER>
+template <class T, class Tgt, int SAMPLER, int PIPE = 0, int LCT = 0>
 hipError_t mm_launch_run(const mm_run_args<T> &a, unsigned int grid, unsigned int block, hipStream_t stream)
 {
     const size_t lds = (size_t)(block / 64) * mm_tile<T, Tgt::dim>::lds_bytes_per_wave;
-    hipLaunchKernelGGL((mm_run_kernel<T, Tgt, SAMPLER>), dim3(grid), dim3(block), lds, stream, a);
+    hipLaunchKernelGGL((mm_run_kernel<T, Tgt, SAMPLER, PIPE, LCT>), dim3(grid), dim3(block), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -366,6 +390,9 @@ template <class T> struct mm_kernel_entry {
     hipError_t (*run_hmc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);
     hipError_t (*run_mh_pc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* producer/consumer */
     hipError_t (*run_hmc_pc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* producer/consumer */
+    hipError_t (*run_mh_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* software-pipelined */
+    hipError_t (*run_hmc_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* software-pipelined */
+    hipError_t (*run_hmc_sp10)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* ... n_leapfrog == 10 */
     hipError_t (*logp_grad)(const mm_tparams<T> &, const T *, T *, T *, unsigned long long, hipStream_t);
     size_t lds_bytes_per_wave;
 };

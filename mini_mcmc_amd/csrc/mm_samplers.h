@@ -93,9 +93,11 @@ MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t s
 
 /* One HMC transition given its noise: p[D] ~ N(0,1) (momentum; clobbered) and ln_u.  x[D], lp = logp(x),
  * g = grad logp(x) are updated in place; returns 1 on accept. */
-template <class T, class Tgt>
+template <class T, class Tgt, int LCT = 0>
 MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, T *p, T ln_u)
 {
+    /* LCT > 0: the number of leapfrog steps is the compile-time constant LCT (the loop is fully unrolled so the
+     * scheduler can overlap it with independent work); LCT == 0: run-time n_leapfrog.  Same arithmetic either way. */
     constexpr int D = Tgt::dim;
     T xn[D], gn[D];
     const T h = eps * T(0.5);
@@ -108,7 +110,7 @@ MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x,
     }
     T h_current = ke * T(0.5) - *lp;
     T lpn = *lp;
-    for (int l = 0; l < n_leapfrog; ++l) {
+    auto leap = [&]() {
         MM_UNROLL
         for (int i = 0; i < D; ++i) {
             p[i] = mm_fma(h, gn[i], p[i]);   /* half kick with the gradient of the previous position */
@@ -118,6 +120,14 @@ MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x,
         MM_UNROLL
         for (int i = 0; i < D; ++i)
             p[i] = mm_fma(h, gn[i], p[i]); /* half kick with the new gradient */
+    };
+    if constexpr (LCT > 0) {
+        MM_UNROLL
+        for (int l = 0; l < LCT; ++l)
+            leap();
+    } else {
+        for (int l = 0; l < n_leapfrog; ++l)
+            leap();
     }
     T kp = 0;
     MM_UNROLL

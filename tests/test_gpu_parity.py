@@ -179,6 +179,7 @@ def test_kernel_variants_agree_bit_for_bit(M, O):
     cases = [
         ("hmc", M.dist.RosenbrockND(3), 0.032, 10, 333, 101, 7),
         ("hmc", M.dist.RosenbrockND(3), 0.032, 10, 64, 3, 0),
+        ("hmc", M.dist.RosenbrockND(3), 0.05, 7, 100, 40, 3),
         ("hmc", M.dist.GaussianND(A), 0.2, 4, 70, 19, 2),
         ("mh", M.dist.Gaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), 1.0, 0, 333, 205, 9),
         ("mh", M.dist.StandardNormal(7), 0.5, 0, 65, 50, 1),
@@ -187,15 +188,16 @@ def test_kernel_variants_agree_bit_for_bit(M, O):
         for sampler, tgt, scale, L, C, nc, nd in cases:
             init = M.core.init_with_seed(C, tgt.dim, 21, dtype)
             outs = []
-            for variant in (0, 1):
+            for variant in (0, 1, 2):
                 if sampler == "mh":
                     s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(scale), init).seed(77)
                 else:
                     s = M.hmc.HMC(tgt, init, scale, L).set_seed(77)
                 s.set_kernel_variant(variant)
                 outs.append((s.run(nc, nd), s.accept_counts.copy(), s.state()))
-            for a, b in zip(outs[0], outs[1]):
-                assert np.array_equal(a, b), (sampler, type(tgt).__name__, dtype.__name__)
+            for other in outs[1:]:
+                for a, b in zip(outs[0], other):
+                    assert np.array_equal(a, b), (sampler, type(tgt).__name__, dtype.__name__)
 
 
 def test_torch_device_output_matches_host_output(M, O):
