@@ -143,6 +143,39 @@ int mmcmc_hmc_sync(mmcmc_hmc *h);
 int mmcmc_hmc_timing(mmcmc_hmc *h, mmcmc_timing *t);
 int mmcmc_hmc_destroy(mmcmc_hmc *h);
 
+/* ---- NUTS ------------------------------------------------------------------------------------------------
+ * NUTS::new(target, initial_positions, target_accept_p)   nuts.rs:123-129 over NUTSChain::new nuts.rs:410-434.
+ * init: host [n_chains, dim] doubles (the reference's Vec<Vec<T>>).  mode selects the reference's type split:
+ *   0 = f32 tensors + f64 scalars  (`NUTS<f64, Autodiff<NdArray>, _>`: NdArray elements are f32)
+ *   1 = f32 tensors + f32 scalars  (`NUTS<f32, Autodiff<NdArray>, _>`)
+ *   2 = f64 tensors + f64 scalars  (BASELINE.json config 5 "f64"; no default reference backend has f64 elements)
+ * Samples are of the tensor type (f32 for modes 0/1, f64 for mode 2). */
+typedef struct mmcmc_nuts mmcmc_nuts;
+int mmcmc_nuts_create(mmcmc_nuts **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
+                      double target_accept_p, int mode, int device);
+/* NUTS::set_seed   nuts.rs:347-353 (keys the counter-based stream; chains differ by their global index) */
+int mmcmc_nuts_seed(mmcmc_nuts *h, uint64_t seed);
+int mmcmc_nuts_set_chain_offset(mmcmc_nuts *h, uint64_t chain_offset);
+/* maximum tree depth (doublings per transition), 1..12, default 10.  The reference's `while s` (nuts.rs:578) is
+ * unbounded; a lane that never terminates would stall its whole wave, so the engine caps it. */
+int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
+/* progress = 0: NUTS::run -> NUTSChain::run (nuts.rs:163-170, 457-471): n_collect + n_discard - 1 transitions, and
+ *               with n_discard == 0 row 0 is the initial position (the reference's off-by-one, test_chain_1);
+ * progress = 1: the stepping of run_progress (nuts.rs:491-522): all n_collect + n_discard transitions.
+ * out: [n_chains, n_collect, dim] of the tensor type, device or host memory (may be NULL). */
+int mmcmc_nuts_run(mmcmc_nuts *h, size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress,
+                   void *stream);
+/* NUTSChain::position for every chain (nuts.rs:369); host [n_chains, dim] of the tensor type */
+int mmcmc_nuts_state(mmcmc_nuts *h, void *out);
+/* per-chain adaptation state: host [n_chains, 4] doubles = epsilon, epsilon_bar, h_bar, mu (nuts.rs:374-386) */
+int mmcmc_nuts_adapt_state(mmcmc_nuts *h, double *out);
+/* diagnostics (not in the reference): gradient evaluations per chain so far; histogram[13] of tree depths */
+int mmcmc_nuts_leapfrog_counts(mmcmc_nuts *h, uint64_t *out);
+int mmcmc_nuts_depth_histogram(mmcmc_nuts *h, uint32_t *out);
+int mmcmc_nuts_sync(mmcmc_nuts *h);
+int mmcmc_nuts_timing(mmcmc_nuts *h, mmcmc_timing *t);
+int mmcmc_nuts_destroy(mmcmc_nuts *h);
+
 /* knobs shared by the samplers (results never depend on them):
  * iterations per kernel launch (0 = the whole run in one launch, the default);
  * kernel variant: 2 = software-pipelined single wave (default), 1 = producer/consumer waves, 0 = plain single wave */

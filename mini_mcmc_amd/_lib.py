@@ -85,6 +85,18 @@ SIGNATURES = {
     "mmcmc_hmc_set_iters_per_launch": (C.c_int, [_vp, C.c_uint32]),
     "mmcmc_mh_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "mmcmc_hmc_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+    "mmcmc_nuts_create": (C.c_int, [C.POINTER(_vp), _TP, C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_int, C.c_int]),
+    "mmcmc_nuts_seed": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_nuts_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_nuts_set_max_depth": (C.c_int, [_vp, C.c_int]),
+    "mmcmc_nuts_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.c_int, _vp]),
+    "mmcmc_nuts_state": (C.c_int, [_vp, _vp]),
+    "mmcmc_nuts_adapt_state": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "mmcmc_nuts_leapfrog_counts": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "mmcmc_nuts_depth_histogram": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "mmcmc_nuts_sync": (C.c_int, [_vp]),
+    "mmcmc_nuts_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
+    "mmcmc_nuts_destroy": (C.c_int, [_vp]),
     "mmcmc_split_rhat_mean_ess": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                             C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, _vp]),
     "mmcmc_stats_partials": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, _vp]),

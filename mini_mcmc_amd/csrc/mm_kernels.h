@@ -56,8 +56,21 @@ template <class T, int D> struct mm_tile {
 /* Write the staged tile of one wave to `out`: for each of the wave's 64 chains one contiguous run of nt*D elements
  * starting at row `row0` of that chain.  Whole-wave stores of 64 consecutive elements of the chain-linear image. */
 template <class T, int D>
+__device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_total, unsigned long long n_chains,
+                                                  const T *tile, int lane, unsigned long long wave_c0,
+                                                  unsigned long long row0, unsigned int nt);
+
+template <class T, int D>
 __device__ __forceinline__ void mm_flush_tile(const mm_run_args<T> &a, const T *tile, int lane,
                                               unsigned long long wave_c0, unsigned long long row0, unsigned int nt)
+{
+    mm_flush_tile_raw<T, D>(a.out, a.n_total, a.n_chains, tile, lane, wave_c0, row0, nt);
+}
+
+template <class T, int D>
+__device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_total, unsigned long long n_chains,
+                                                  const T *tile, int lane, unsigned long long wave_c0,
+                                                  unsigned long long row0, unsigned int nt)
 {
     using Tile = mm_tile<T, D>;
     constexpr int TILE_T = Tile::tile_t, RUN = Tile::run, STRIDE = Tile::stride;
@@ -65,9 +78,9 @@ __device__ __forceinline__ void mm_flush_tile(const mm_run_args<T> &a, const T *
     __builtin_amdgcn_wave_barrier();
     /* wave-uniform base of this tile in `out`; a chain's rows are chain_stride elements apart
      * (host guarantees n_total * D < 2^32, so j * chain_stride is one v_mad_u64_u32) */
-    const unsigned int chain_stride = (unsigned int)(a.n_total * D);
-    T *const wbase = a.out + (wave_c0 * a.n_total + row0) * D;
-    const unsigned int n_valid = (unsigned int)min(64ull, a.n_chains > wave_c0 ? a.n_chains - wave_c0 : 0ull);
+    const unsigned int chain_stride = (unsigned int)(n_total * D);
+    T *const wbase = out + (wave_c0 * n_total + row0) * D;
+    const unsigned int n_valid = (unsigned int)min(64ull, n_chains > wave_c0 ? n_chains - wave_c0 : 0ull);
     if (nt == (unsigned int)TILE_T) {
 #pragma unroll 4
         for (int k = 0; k < RUN; ++k) {

@@ -1,0 +1,344 @@
+/*
+ * mm_nuts.h -- one NUTS transition of one chain, iterative (host + device, one definition).
+ *
+ * Restates the reference's per-chain sampler
+ *     NUTSChain::step          nuts.rs:550-691      build_tree (recursive)   nuts.rs:764-946
+ *     leapfrog                 nuts.rs:979-996      stop_criterion           nuts.rs:963-977
+ *     find_reasonable_epsilon  nuts.rs:695-761      init_chain               nuts.rs:528-545
+ * (Hoffman & Gelman Alg. 6, slice variant, dual averaging) without recursion: the 2^j leaves of a doubling are
+ * produced one after the other by leapfrogging from the outer edge, and completed subtrees are merged on an explicit
+ * stack in exactly the order the recursion returns them, so every uniform is drawn at the same point of the
+ * algorithm and early termination (a first child with s' = 0 is handed up unmerged; a second child is merged, draw
+ * included) behaves as in nuts.rs:858-929.  Kept quirks: alpha / n_alpha from the last
+ * doubling only, the inner-merge uniform is always f64, direction v = +1 iff u < 0.5, biased progressive sampling,
+ * tensors of type TT with scalars of type ST (the reference runs f32 tensors with T scalars), the epsilon search's
+ * `&&` and stale gradient.  New: a depth cap (`max_depth`; the reference's `while s` is unbounded).
+ * Arithmetic: the engine's (explicit fma, analytic gradients: mm_targets.h); stream: mm_rng.h (NUTS schedule).
+ */
+#ifndef MM_NUTS_H
+#define MM_NUTS_H
+
+#include "mm_samplers.h"
+
+#define MM_NUTS_JMAX 12 /* storage bound for the subtree stack; run-time max_depth <= MM_NUTS_JMAX */
+
+/* per-chain adaptation state (NUTSChain fields epsilon, epsilon_bar, h_bar, mu; nuts.rs:374-386) */
+template <class ST> struct mm_nuts_adapt {
+    ST epsilon, epsilon_bar, h_bar, mu;
+};
+
+/* constants of NUTSChain::new (nuts.rs:425-427) */
+#define MM_NUTS_GAMMA 0.05
+#define MM_NUTS_T0 10
+#define MM_NUTS_KAPPA 0.75
+
+/* Pending-subtree stack of one chain.  Storage is strided so that on the device consecutive lanes interleave
+ * (element (slot) of lane l at base[slot * stride + l]); on the host stride = 1. */
+template <class TT, class ST, int D> struct mm_nuts_stack {
+    TT *vec;        /* [JMAX][3][D]: first-leaf position, first-leaf momentum, proposal */
+    ST *alpha;      /* [JMAX] */
+    uint32_t *cnt;  /* [JMAX][3]: level, n', n_alpha' */
+    int stride;
+    MM_HD TT &v(int e, int which, int d) const { return vec[(size_t)((e * 3 + which) * D + d) * stride]; }
+    MM_HD ST &a(int e) const { return alpha[(size_t)e * stride]; }
+    MM_HD uint32_t &c(int e, int which) const { return cnt[(size_t)(e * 3 + which) * stride]; }
+    static constexpr int vec_slots = MM_NUTS_JMAX * 3 * D;
+    static constexpr int alpha_slots = MM_NUTS_JMAX;
+    static constexpr int cnt_slots = MM_NUTS_JMAX * 3;
+};
+
+MM_HD float mm_sqrtT(float x) { return sqrtf(x); }
+MM_HD double mm_sqrtT(double x) { return sqrt(x); }
+MM_HD float mm_minT(float a, float b) { return fminf(a, b); }
+MM_HD double mm_minT(double a, double b) { return fmin(a, b); }
+MM_HD bool mm_is_real(float x) { return x == x && x != INFINITY && x != -INFINITY; }
+MM_HD bool mm_is_real(double x) { return x == x && x != (double)INFINITY && x != -(double)INFINITY; }
+
+/* momentum draw: z[0..D) of (chain, iteration) in the element type's schedule (mm_rng.h) */
+template <int D> MM_HD void mm_nuts_momentum(uint64_t seed, uint64_t chain, uint32_t iter, float *z)
+{
+    MM_UNROLL
+    for (int b = 0; b < (D + 3) / 4; ++b) {
+        mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
+        float z0, z1;
+        mm_box_muller_f32(mm_u24(blk.w[0]), mm_u24(blk.w[1]), &z0, &z1);
+        z[4 * b] = z0;
+        if (4 * b + 1 < D)
+            z[4 * b + 1] = z1;
+        if (4 * b + 2 < D) {
+            mm_box_muller_f32(mm_u24(blk.w[2]), mm_u24(blk.w[3]), &z0, &z1);
+            z[4 * b + 2] = z0;
+            if (4 * b + 3 < D)
+                z[4 * b + 3] = z1;
+        }
+    }
+}
+template <int D> MM_HD void mm_nuts_momentum(uint64_t seed, uint64_t chain, uint32_t iter, double *z)
+{
+    MM_UNROLL
+    for (int b = 0; b < (D + 1) / 2; ++b) {
+        mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
+        double z0, z1;
+        mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
+        z[2 * b] = z0;
+        if (2 * b + 1 < D)
+            z[2 * b + 1] = z1;
+    }
+}
+
+/* nuts.rs:979-996, in place: (x, p, g) -> one leapfrog step of signed size eps; returns logp(x') */
+template <class TT, class Tgt> MM_HD TT mm_nuts_leapfrog(const mm_tparams<TT> &P, TT *x, TT *p, TT *g, TT eps)
+{
+    constexpr int D = Tgt::dim;
+    const TT h = eps * TT(0.5);
+    MM_UNROLL
+    for (int i = 0; i < D; ++i) {
+        p[i] = mm_fma(h, g[i], p[i]);
+        x[i] = mm_fma(eps, p[i], x[i]);
+    }
+    TT lp = Tgt::logp_grad(P, x, g);
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        p[i] = mm_fma(h, g[i], p[i]);
+    return lp;
+}
+
+template <class TT, int D> MM_HD TT mm_sumsq(const TT *a)
+{
+    TT s = 0;
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        s = mm_fma(a[i], a[i], s);
+    return s;
+}
+
+/* nuts.rs:963-977 */
+template <class TT, int D>
+MM_HD bool mm_stop_criterion(const TT *x_minus, const TT *x_plus, const TT *p_minus, const TT *p_plus)
+{
+    TT dm = 0, dp = 0;
+    MM_UNROLL
+    for (int i = 0; i < D; ++i) {
+        TT diff = x_plus[i] - x_minus[i];
+        dm = mm_fma(diff, p_minus[i], dm);
+        dp = mm_fma(diff, p_plus[i], dp);
+    }
+    return dm >= TT(0) && dp >= TT(0);
+}
+
+/* nuts.rs:695-761 */
+template <class TT, class ST, class Tgt>
+MM_HD ST mm_find_reasonable_epsilon(const mm_tparams<TT> &P, const TT *position, const TT *mom)
+{
+    constexpr int D = Tgt::dim;
+    ST epsilon = 1;
+    const ST half = ST(0.5);
+    TT g0[D], x[D], p[D], g[D];
+    const TT ulogp = Tgt::logp_grad(P, position, g0);
+    const TT mom_sq = mm_sumsq<TT, D>(mom);
+    auto leap = [&](ST e) -> TT {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            x[i] = position[i];
+            p[i] = mom[i];
+            g[i] = g0[i];
+        }
+        return mm_nuts_leapfrog<TT, Tgt>(P, x, p, g, (TT)e);
+    };
+    TT ulogp_p = leap(epsilon);
+    bool grad_real = true; /* grad_prime of the FIRST leapfrog only: the loop below never refreshes it (Q11) */
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        grad_real = grad_real && mm_is_real(g[i]);
+    ST k = 1;
+    while (!mm_is_real(ulogp_p) && !grad_real) {
+        k = k * half;
+        ulogp_p = leap(epsilon * k);
+    }
+    epsilon = half * k * epsilon;
+    ST lap = (ST)(double)(ulogp_p - ulogp - (mm_sumsq<TT, D>(p) - mom_sq) * TT(0.5));
+    const ST a = (lap > mm_logT(half)) ? ST(1) : ST(-1);
+    const ST ln2 = mm_logT(ST(2));
+    while (a * lap > -a * ln2) {
+        epsilon = (a > ST(0)) ? epsilon * ST(2) : epsilon * half; /* epsilon * 2^a */
+        ulogp_p = leap(epsilon);
+        lap = (ST)(double)(ulogp_p - ulogp - (mm_sumsq<TT, D>(p) - mom_sq) * TT(0.5));
+    }
+    return epsilon;
+}
+
+/* nuts.rs:528-545 init_chain, without the sample bookkeeping: always draws D normals (iteration 0 of the stream);
+ * searches epsilon iff it is still the sentinel -1; mu = ln(10 epsilon). */
+template <class TT, class ST, class Tgt>
+MM_HD void mm_nuts_init_chain(const mm_tparams<TT> &P, const TT *position, mm_nuts_adapt<ST> *ad, ST eps_tol,
+                              uint64_t seed, uint64_t chain)
+{
+    constexpr int D = Tgt::dim;
+    TT mom0[D];
+    mm_nuts_momentum<D>(seed, chain, 0u, mom0);
+    ST d = ad->epsilon + ST(1);
+    if ((d < 0 ? -d : d) <= eps_tol)
+        ad->epsilon = mm_find_reasonable_epsilon<TT, ST, Tgt>(P, position, mom0);
+    ad->mu = mm_logT(ST(10) * ad->epsilon);
+}
+
+/* diagnostics of a transition (not in the reference) */
+struct mm_nuts_info {
+    int depth;          /* doublings performed */
+    uint32_t n_leapfrog; /* gradient evaluations inside the tree */
+};
+
+/* nuts.rs:550-691.  x[D] is updated in place; m is the 1-based global step count (self.m after the increment). */
+template <class TT, class ST, class Tgt>
+MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST> *ad, uint32_t m, uint32_t n_discard,
+                                ST target_accept_p, int max_depth, uint64_t seed, uint64_t chain,
+                                const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
+{
+    constexpr int D = Tgt::dim;
+    uint32_t aux_k = 0;
+    auto aux = [&]() -> double { return mm_aux_u53(seed, chain, m, aux_k++); };
+
+    TT mom0[D], grad[D];
+    mm_nuts_momentum<D>(seed, chain, m, mom0);
+    const TT ulogp = Tgt::logp_grad(P, x, grad);
+    const ST joint = (ST)(double)(ulogp - mm_sumsq<TT, D>(mom0) * TT(0.5));
+    const ST exp1_obs = (ST)(-mm_log(aux())); /* Exp(1) by inversion of the first auxiliary uniform */
+    const ST logu = joint - exp1_obs;
+
+    TT xm[D], xp[D], pm[D], pp[D], gm[D], gp[D];
+    MM_UNROLL
+    for (int i = 0; i < D; ++i) {
+        xm[i] = xp[i] = x[i];
+        pm[i] = pp[i] = mom0[i];
+        gm[i] = gp[i] = grad[i];
+    }
+    int j = 0;
+    uint32_t n = 1;
+    bool s = true;
+    ST alpha = 0;
+    uint32_t n_alpha = 0;
+    mm_nuts_info info;
+    info.depth = 0;
+    info.n_leapfrog = 0;
+
+    while (s) {
+        const ST u_run_1 = (ST)aux();
+        const int v = (u_run_1 < ST(0.5)) ? 1 : -1;
+        /* the outer edge in direction v is advanced in place: after the doubling it IS the returned edge */
+        TT *cx = (v == -1) ? xm : xp;
+        TT *cp = (v == -1) ? pm : pp;
+        TT *cg = (v == -1) ? gm : gp;
+        const TT eps_signed = (TT)((ST)v * ad->epsilon);
+        const uint32_t n_leaves = 1u << j;
+        int sp = 0; /* pending first children on the stack */
+
+        /* the most recently completed subtree S */
+        uint32_t S_level = 0, S_n = 0, S_nalpha = 0;
+        bool S_s = true;
+        ST S_alpha = 0;
+        TT S_first_x[D], S_first_p[D], S_prime[D];
+
+        for (uint32_t leaf = 0; leaf < n_leaves; ++leaf) {
+            const TT lp = mm_nuts_leapfrog<TT, Tgt>(P, cx, cp, cg, eps_signed);
+            info.n_leapfrog += 1;
+            const ST jointp = (ST)(double)(lp - mm_sumsq<TT, D>(cp) * TT(0.5));
+            S_level = 0;
+            S_n = (logu < jointp) ? 1u : 0u;
+            S_s = (logu - ST(1000)) < jointp;
+            S_alpha = mm_minT(ST(1), mm_expT(jointp - joint));
+            S_nalpha = 1;
+            MM_UNROLL
+            for (int i = 0; i < D; ++i) {
+                S_first_x[i] = cx[i];
+                S_first_p[i] = cp[i];
+                S_prime[i] = cx[i];
+            }
+            /* hand S up the (implicit) recursion */
+            for (;;) {
+                if (S_level == (uint32_t)j)
+                    break;
+                if (sp > 0 && stk.c(sp - 1, 0) == S_level) {
+                    /* S is the second child: merge with its sibling T1 (nuts.rs:900-928) */
+                    const int e = sp - 1;
+                    const uint32_t n1 = stk.c(e, 1);
+                    const double u = aux(); /* always f64 (nuts.rs:910) */
+                    uint32_t den = n1 + S_n;
+                    if (den < 1)
+                        den = 1;
+                    const bool take2 = u < ((double)S_n / (double)den);
+                    TT fx[D], fp[D];
+                    MM_UNROLL
+                    for (int i = 0; i < D; ++i) {
+                        fx[i] = stk.v(e, 0, i);
+                        fp[i] = stk.v(e, 1, i);
+                        if (!take2)
+                            S_prime[i] = stk.v(e, 2, i);
+                    }
+                    S_n += n1;
+                    const bool crit = (v == -1) ? mm_stop_criterion<TT, D>(cx, fx, cp, fp)
+                                                : mm_stop_criterion<TT, D>(fx, cx, fp, cp);
+                    S_s = S_s && crit; /* the sibling's s' is 1, or it would not be waiting */
+                    S_alpha = stk.a(e) + S_alpha;
+                    S_nalpha += stk.c(e, 2);
+                    MM_UNROLL
+                    for (int i = 0; i < D; ++i) {
+                        S_first_x[i] = fx[i];
+                        S_first_p[i] = fp[i];
+                    }
+                    S_level += 1;
+                    sp -= 1;
+                } else if (S_s) {
+                    /* first child, still valid: wait for the sibling */
+                    MM_UNROLL
+                    for (int i = 0; i < D; ++i) {
+                        stk.v(sp, 0, i) = S_first_x[i];
+                        stk.v(sp, 1, i) = S_first_p[i];
+                        stk.v(sp, 2, i) = S_prime[i];
+                    }
+                    stk.a(sp) = S_alpha;
+                    stk.c(sp, 0) = S_level;
+                    stk.c(sp, 1) = S_n;
+                    stk.c(sp, 2) = S_nalpha;
+                    sp += 1;
+                    break;
+                } else {
+                    /* first child with s' = 0: the parent returns it as it is (nuts.rs:858 not taken) */
+                    S_level += 1;
+                }
+            }
+            if (S_level == (uint32_t)j)
+                break; /* the doubling is complete, or was cut short */
+        }
+
+        alpha = S_alpha; /* from the LAST doubling only (nuts.rs:614-615, 649-650) */
+        n_alpha = S_nalpha;
+        const ST tmp = mm_minT(ST(1), (ST)S_n / (ST)n);
+        const ST u_run_2 = (ST)aux();
+        if (S_s && (u_run_2 < tmp)) {
+            MM_UNROLL
+            for (int i = 0; i < D; ++i)
+                x[i] = S_prime[i];
+        }
+        n += S_n;
+        s = S_s && mm_stop_criterion<TT, D>(xm, xp, pm, pp);
+        j += 1;
+        if (j >= max_depth)
+            s = false; /* depth cap: not in the reference */
+    }
+    info.depth = j;
+
+    /* dual averaging (nuts.rs:676-690) */
+    ST eta = ST(1) / (ST)(m + MM_NUTS_T0);
+    ad->h_bar = (ST(1) - eta) * ad->h_bar + eta * (target_accept_p - alpha / (ST)n_alpha);
+    if (m <= n_discard) {
+        const ST _m = (ST)m;
+        ad->epsilon = mm_expT(ad->mu - mm_sqrtT(_m) / ST(MM_NUTS_GAMMA) * ad->h_bar);
+        eta = mm_expT(-ST(MM_NUTS_KAPPA) * mm_logT(_m)); /* m^-kappa */
+        ad->epsilon_bar = mm_expT((ST(1) - eta) * mm_logT(ad->epsilon_bar) + eta * mm_logT(ad->epsilon));
+    } else {
+        ad->epsilon = ad->epsilon_bar;
+    }
+    return info;
+}
+
+#endif /* MM_NUTS_H */

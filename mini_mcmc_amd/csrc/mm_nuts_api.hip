@@ -1,0 +1,396 @@
+/*
+ * mm_nuts_api.hip -- C ABI of the NUTS sampler (include/mmcmc.h: mmcmc_nuts_*).  Host logic only.
+ * Mirrors NUTS::{new, set_seed, run, run_progress} (nuts.rs:123-170, 194-353) over NUTSChain (nuts.rs:410-691).
+ */
+#include "../../include/mmcmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mm_nuts_kernels.h"
+#include "mm_params.h"
+
+#define MM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return (int)_e;                                                                                       \
+    } while (0)
+
+namespace {
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        (void)hipSetDevice(d);
+    }
+    ~DevGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+struct NutsBase {
+    virtual ~NutsBase() {}
+    virtual int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream) = 0;
+    virtual int state(void *out) = 0;
+    virtual int adapt_state(double *out) = 0;
+    virtual int leapfrog_counts(uint64_t *out) = 0;
+    virtual int depth_histogram(uint32_t *out) = 0;
+    int device = 0, mode = 0, kind = 0, dim = 0;
+    size_t n_chains = 0;
+    uint64_t seed = 0, chain_offset = 0;
+    uint32_t m = 0; /* self.m: transitions taken so far */
+    int max_depth = 10;
+    double target_accept_p = 0.8;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    mmcmc_timing timing{};
+};
+
+template <class TT, class ST> const mm_nuts_entry<TT, ST> *nuts_table(int *n);
+template <> const mm_nuts_entry<float, double> *nuts_table<float, double>(int *n) { return mm_nuts_table_m0(n); }
+template <> const mm_nuts_entry<float, float> *nuts_table<float, float>(int *n) { return mm_nuts_table_m1(n); }
+template <> const mm_nuts_entry<double, double> *nuts_table<double, double>(int *n) { return mm_nuts_table_m2(n); }
+
+template <class TT, class ST> struct Nuts : NutsBase {
+    const mm_nuts_entry<TT, ST> *k = nullptr;
+    mm_tparams<TT> P;
+    TT *d_state = nullptr, *d_mat = nullptr;
+    mm_nuts_adapt<ST> *d_adapt = nullptr;
+    unsigned long long *d_nlf = nullptr;
+    unsigned int *d_hist = nullptr;
+    unsigned char *d_scratch = nullptr;
+    bool stack_in_lds = true;
+
+    ~Nuts() override
+    {
+        DevGuard g(device);
+        if (stream)
+            (void)hipStreamSynchronize(stream);
+        (void)hipFree(d_state);
+        (void)hipFree(d_mat);
+        (void)hipFree(d_adapt);
+        (void)hipFree(d_nlf);
+        (void)hipFree(d_hist);
+        (void)hipFree(d_scratch);
+        if (ev0)
+            (void)hipEventDestroy(ev0);
+        if (ev1)
+            (void)hipEventDestroy(ev1);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+    }
+
+    int setup(const mmcmc_target_desc *t, const double *init)
+    {
+        int n = 0;
+        const mm_nuts_entry<TT, ST> *tab = nuts_table<TT, ST>(&n);
+        for (int i = 0; i < n; ++i)
+            if (tab[i].kind == t->kind && tab[i].dim == t->dim)
+                k = &tab[i];
+        if (!k)
+            return MMCMC_ERR_UNSUPPORTED;
+        if (mm_fill_params<TT>(t->kind, t->params, &P) != 0)
+            return MMCMC_ERR_INVALID_ARG;
+        DevGuard g(device);
+        const size_t cd = n_chains * (size_t)dim;
+        if (t->kind == MMCMC_GAUSSIAN_ND) {
+            std::vector<TT> h((size_t)dim * dim);
+            for (size_t i = 0; i < h.size(); ++i)
+                h[i] = (TT)t->matrix[i];
+            MM_HIP(hipMalloc((void **)&d_mat, h.size() * sizeof(TT)));
+            MM_HIP(hipMemcpy(d_mat, h.data(), h.size() * sizeof(TT), hipMemcpyHostToDevice));
+            P.mat = d_mat;
+        }
+        std::vector<TT> h(cd);
+        for (size_t i = 0; i < cd; ++i)
+            h[i] = (TT)init[i]; /* Vec<Vec<T>> -> backend float tensor (nuts.rs:411-413) */
+        MM_HIP(hipMalloc((void **)&d_state, cd * sizeof(TT)));
+        MM_HIP(hipMemcpy(d_state, h.data(), cd * sizeof(TT), hipMemcpyHostToDevice));
+        /* NUTSChain::new (nuts.rs:415-433): epsilon = -1 (sentinel), epsilon_bar = 1, h_bar = 0, mu = ln 10 */
+        std::vector<mm_nuts_adapt<ST>> ad(n_chains);
+        for (auto &a : ad) {
+            a.epsilon = (ST)-1;
+            a.epsilon_bar = (ST)1;
+            a.h_bar = (ST)0;
+            a.mu = (ST)std::log(10.0);
+        }
+        MM_HIP(hipMalloc((void **)&d_adapt, n_chains * sizeof(mm_nuts_adapt<ST>)));
+        MM_HIP(hipMemcpy(d_adapt, ad.data(), n_chains * sizeof(mm_nuts_adapt<ST>), hipMemcpyHostToDevice));
+        MM_HIP(hipMalloc((void **)&d_nlf, n_chains * sizeof(unsigned long long)));
+        MM_HIP(hipMemset(d_nlf, 0, n_chains * sizeof(unsigned long long)));
+        MM_HIP(hipMalloc((void **)&d_hist, (MM_NUTS_JMAX + 1) * sizeof(unsigned int)));
+        MM_HIP(hipMemset(d_hist, 0, (MM_NUTS_JMAX + 1) * sizeof(unsigned int)));
+        /* the pending-subtree stack goes to LDS when tile + stack fit comfortably, else to HBM scratch */
+        stack_in_lds = (k->tile_bytes_per_wave + k->stack_bytes_per_wave) <= 40 * 1024;
+        if (!stack_in_lds) {
+            const size_t waves = (n_chains + 63) / 64;
+            MM_HIP(hipMalloc((void **)&d_scratch, waves * k->stack_bytes_per_wave));
+        }
+        MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        MM_HIP(hipEventCreate(&ev0));
+        MM_HIP(hipEventCreate(&ev1));
+        return MMCMC_OK;
+    }
+
+    int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream_v) override
+    {
+        if ((uint64_t)n_collect * (uint64_t)dim >= (1ull << 32) || (uint64_t)m + n_collect + n_discard >= (1ull << 32))
+            return MMCMC_ERR_SHAPE;
+        DevGuard g(device);
+        hipStream_t st = stream_v ? (hipStream_t)stream_v : stream;
+        const size_t out_bytes = n_chains * n_collect * (size_t)dim * sizeof(TT);
+        TT *d_out = nullptr;
+        bool staged = false;
+        if (out && n_collect > 0) {
+            if (out_is_device) {
+                d_out = (TT *)out;
+            } else {
+                MM_HIP(hipMalloc((void **)&d_out, out_bytes));
+                staged = true;
+            }
+        }
+        /* init_chain (nuts.rs:528-545) on every run() call */
+        hipError_t e = k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
+        if (e != hipSuccess)
+            return (int)e;
+        mm_nuts_args<TT, ST> a;
+        a.P = P;
+        a.state = d_state;
+        a.adapt = d_adapt;
+        a.out = d_out;
+        a.n_leapfrog = d_nlf;
+        a.depth_hist = d_hist;
+        a.n_chains = n_chains;
+        a.seed = seed;
+        a.chain_offset = chain_offset;
+        a.n_total = n_collect;
+        a.m0 = m;
+        a.out_t0 = 0;
+        a.n_discard = (unsigned int)n_discard;
+        a.max_depth = max_depth;
+        a.target_accept_p = (ST)target_accept_p;
+        a.stack_in_lds = stack_in_lds ? 1 : 0;
+        a.scratch = d_scratch;
+        const size_t total = n_collect + n_discard;
+        if (progress) {
+            /* run_progress (nuts.rs:491-522): all N transitions, the last n_collect recorded */
+            a.write_initial = 0;
+            a.n_pre = (unsigned int)n_discard;
+            a.n_rec = (unsigned int)n_collect;
+        } else if (total == 0) {
+            a.write_initial = 0;
+            a.n_pre = a.n_rec = 0;
+        } else if (n_discard == 0) {
+            /* run (nuts.rs:457-471): N - 1 transitions; row 0 is the initial point */
+            a.write_initial = n_collect > 0 ? 1 : 0;
+            a.n_pre = 0;
+            a.n_rec = (unsigned int)(n_collect > 0 ? n_collect - 1 : 0);
+        } else {
+            a.write_initial = 0;
+            a.n_pre = (unsigned int)(n_discard - 1);
+            a.n_rec = (unsigned int)n_collect;
+        }
+        MM_HIP(hipEventRecord(ev0, st));
+        e = k->run(a, st);
+        if (e != hipSuccess) {
+            if (staged)
+                (void)hipFree(d_out);
+            return (int)e;
+        }
+        MM_HIP(hipEventRecord(ev1, st));
+        m += a.n_pre + a.n_rec;
+        timed = true;
+        timing.n_launches = 1;
+        timing.out_bytes = d_out ? out_bytes : 0;
+        timing.state_bytes = 2ull * n_chains * dim * sizeof(TT);
+        timing.kernel_ms = -1.f;
+        if (staged) {
+            MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+            MM_HIP(hipStreamSynchronize(st));
+            MM_HIP(hipFree(d_out));
+        }
+        return MMCMC_OK;
+    }
+
+    int state(void *out) override
+    {
+        DevGuard g(device);
+        MM_HIP(hipDeviceSynchronize());
+        MM_HIP(hipMemcpy(out, d_state, n_chains * (size_t)dim * sizeof(TT), hipMemcpyDeviceToHost));
+        return MMCMC_OK;
+    }
+    int adapt_state(double *out) override
+    {
+        DevGuard g(device);
+        MM_HIP(hipDeviceSynchronize());
+        std::vector<mm_nuts_adapt<ST>> ad(n_chains);
+        MM_HIP(hipMemcpy(ad.data(), d_adapt, n_chains * sizeof(mm_nuts_adapt<ST>), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n_chains; ++i) {
+            out[4 * i + 0] = (double)ad[i].epsilon;
+            out[4 * i + 1] = (double)ad[i].epsilon_bar;
+            out[4 * i + 2] = (double)ad[i].h_bar;
+            out[4 * i + 3] = (double)ad[i].mu;
+        }
+        return MMCMC_OK;
+    }
+    int leapfrog_counts(uint64_t *out) override
+    {
+        DevGuard g(device);
+        MM_HIP(hipDeviceSynchronize());
+        MM_HIP(hipMemcpy(out, d_nlf, n_chains * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        return MMCMC_OK;
+    }
+    int depth_histogram(uint32_t *out) override
+    {
+        DevGuard g(device);
+        MM_HIP(hipDeviceSynchronize());
+        MM_HIP(hipMemcpy(out, d_hist, (MM_NUTS_JMAX + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return MMCMC_OK;
+    }
+};
+
+} // namespace
+
+struct mmcmc_nuts {
+    NutsBase *p;
+};
+
+extern "C" {
+
+int mmcmc_nuts_create(mmcmc_nuts **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
+                      double target_accept_p, int mode, int device)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!target || !init || n_chains == 0 || target->dim <= 0 || mode < 0 || mode > 2 ||
+        !(target_accept_p > 0.0 && target_accept_p < 1.0))
+        return MMCMC_ERR_INVALID_ARG;
+    if (target->kind == MMCMC_GAUSSIAN_ND && !target->matrix)
+        return MMCMC_ERR_INVALID_ARG;
+    if ((target->kind == MMCMC_GAUSSIAN2D || target->kind == MMCMC_DIFFABLE_GAUSSIAN2D ||
+         target->kind == MMCMC_ROSENBROCK2D) &&
+        target->dim != 2)
+        return MMCMC_ERR_SHAPE;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= nd)
+        return MMCMC_ERR_INVALID_ARG;
+    NutsBase *p = nullptr;
+    if (mode == 0)
+        p = new (std::nothrow) Nuts<float, double>();
+    else if (mode == 1)
+        p = new (std::nothrow) Nuts<float, float>();
+    else
+        p = new (std::nothrow) Nuts<double, double>();
+    if (!p)
+        return (int)hipErrorOutOfMemory;
+    p->device = device;
+    p->mode = mode;
+    p->kind = target->kind;
+    p->dim = target->dim;
+    p->n_chains = n_chains;
+    p->target_accept_p = target_accept_p;
+    int st;
+    if (mode == 0)
+        st = static_cast<Nuts<float, double> *>(p)->setup(target, init);
+    else if (mode == 1)
+        st = static_cast<Nuts<float, float> *>(p)->setup(target, init);
+    else
+        st = static_cast<Nuts<double, double> *>(p)->setup(target, init);
+    if (st != MMCMC_OK) {
+        delete p;
+        return st;
+    }
+    mmcmc_nuts *h = new (std::nothrow) mmcmc_nuts{p};
+    if (!h) {
+        delete p;
+        return (int)hipErrorOutOfMemory;
+    }
+    *out = h;
+    return MMCMC_OK;
+}
+
+int mmcmc_nuts_seed(mmcmc_nuts *h, uint64_t seed)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->p->seed = seed;
+    return MMCMC_OK;
+}
+int mmcmc_nuts_set_chain_offset(mmcmc_nuts *h, uint64_t off)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->p->chain_offset = off;
+    return MMCMC_OK;
+}
+int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth)
+{
+    if (!h || max_depth < 1 || max_depth > MM_NUTS_JMAX)
+        return MMCMC_ERR_INVALID_ARG;
+    h->p->max_depth = max_depth;
+    return MMCMC_OK;
+}
+int mmcmc_nuts_run(mmcmc_nuts *h, size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress,
+                   void *stream)
+{
+    return h ? h->p->run(n_collect, n_discard, out, out_is_device, progress, stream) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_state(mmcmc_nuts *h, void *out) { return (h && out) ? h->p->state(out) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_nuts_adapt_state(mmcmc_nuts *h, double *out)
+{
+    return (h && out) ? h->p->adapt_state(out) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_leapfrog_counts(mmcmc_nuts *h, uint64_t *out)
+{
+    return (h && out) ? h->p->leapfrog_counts(out) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_depth_histogram(mmcmc_nuts *h, uint32_t *out)
+{
+    return (h && out) ? h->p->depth_histogram(out) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_sync(mmcmc_nuts *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->p->device);
+    MM_HIP(hipStreamSynchronize(h->p->stream));
+    return MMCMC_OK;
+}
+int mmcmc_nuts_timing(mmcmc_nuts *h, mmcmc_timing *t)
+{
+    if (!h || !t)
+        return MMCMC_ERR_INVALID_ARG;
+    if (!h->p->timed)
+        return MMCMC_ERR_STATE;
+    DevGuard g(h->p->device);
+    MM_HIP(hipEventSynchronize(h->p->ev1));
+    float ms = 0.f;
+    MM_HIP(hipEventElapsedTime(&ms, h->p->ev0, h->p->ev1));
+    h->p->timing.kernel_ms = ms;
+    *t = h->p->timing;
+    return MMCMC_OK;
+}
+int mmcmc_nuts_destroy(mmcmc_nuts *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    delete h->p;
+    delete h;
+    return MMCMC_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,193 @@
+/*
+ * mm_nuts_kernels.h -- NUTS on the GPU: one chain per lane, whole run in one launch.
+ *
+ * Replaces NUTS::run (nuts.rs:163-170: rayon par_iter_mut over per-chain structs) and NUTSChain::run /
+ * run_progress stepping (nuts.rs:457-471, 491-522).  Each lane carries its chain's position and adaptation state
+ * in registers across all transitions; trees of different chains have different depths, so lanes of a wave diverge
+ * inside a transition and re-converge at its end (samples are staged and flushed per wave exactly as in
+ * mm_run_kernel).  The pending-subtree stack of mm_nuts_step lives in LDS when it fits (lane-interleaved), else in
+ * a global scratch area with the same interleaving.
+ * This first version keeps D-vectors in VGPRs (fine for D <= 8; at D = 32 the compiler spills) -- the lane-group /
+ * MFMA mapping for BASELINE.json config 5 is described in DESIGN.md as the next step.
+ */
+#ifndef MM_NUTS_KERNELS_H
+#define MM_NUTS_KERNELS_H
+
+#include "mm_kernels.h"
+#include "mm_nuts.h"
+
+template <class TT, class ST> struct mm_nuts_args {
+    mm_tparams<TT> P;
+    TT *state;                 /* [C, D] */
+    mm_nuts_adapt<ST> *adapt;  /* [C] */
+    TT *out;                   /* [C, n_total, D] or NULL */
+    unsigned long long *n_leapfrog; /* [C] running totals, or NULL */
+    unsigned int *depth_hist;  /* [MM_NUTS_JMAX + 1] histogram of tree depths (atomics), or NULL */
+    unsigned long long n_chains, seed, chain_offset, n_total;
+    unsigned int m0;           /* global step count before this launch (self.m) */
+    unsigned int n_pre;        /* transitions without output */
+    unsigned int n_rec;        /* transitions whose result is written */
+    unsigned int write_initial; /* write the current position as row out_t0 first (nuts.rs:534) */
+    unsigned int out_t0;
+    unsigned int n_discard;    /* adaptation horizon: epsilon adapts while m <= n_discard (nuts.rs:682) */
+    int max_depth;
+    ST target_accept_p;
+    int stack_in_lds;
+    unsigned char *scratch;    /* global stack storage when !stack_in_lds: per wave mm_nuts_stack_bytes<>() */
+};
+
+template <class TT, class ST, int D> struct mm_nuts_stack_layout {
+    using S = mm_nuts_stack<TT, ST, D>;
+    /* per-wave bytes, regions 16-byte aligned: vec | alpha | cnt */
+    static constexpr size_t vec_bytes = ((size_t)S::vec_slots * 64 * sizeof(TT) + 15) / 16 * 16;
+    static constexpr size_t alpha_bytes = ((size_t)S::alpha_slots * 64 * sizeof(ST) + 15) / 16 * 16;
+    static constexpr size_t cnt_bytes = ((size_t)S::cnt_slots * 64 * sizeof(uint32_t) + 15) / 16 * 16;
+    static constexpr size_t bytes = vec_bytes + alpha_bytes + cnt_bytes;
+    __device__ static S make(unsigned char *base, int lane)
+    {
+        S s;
+        s.vec = reinterpret_cast<TT *>(base) + lane;
+        s.alpha = reinterpret_cast<ST *>(base + vec_bytes) + lane;
+        s.cnt = reinterpret_cast<uint32_t *>(base + vec_bytes + alpha_bytes) + lane;
+        s.stride = 64;
+        return s;
+    }
+};
+
+/* init_chain for every chain (nuts.rs:528-545): epsilon search on the first run, mu = ln(10 eps) */
+template <class TT, class ST, class Tgt>
+__global__ void mm_nuts_init_kernel(const mm_tparams<TT> P, const TT *state, mm_nuts_adapt<ST> *adapt,
+                                    unsigned long long n_chains, unsigned long long seed,
+                                    unsigned long long chain_offset, ST eps_tol)
+{
+    constexpr int D = Tgt::dim;
+    const unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains)
+        return;
+    TT x[D];
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        x[i] = state[c * D + i];
+    mm_nuts_adapt<ST> ad = adapt[c];
+    mm_nuts_init_chain<TT, ST, Tgt>(P, x, &ad, eps_tol, seed, chain_offset + c);
+    adapt[c] = ad;
+}
+
+template <class TT, class ST, class Tgt>
+__global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, ST> a)
+{
+    constexpr int D = Tgt::dim;
+    using Tile = mm_tile<TT, D>;
+    using Lay = mm_nuts_stack_layout<TT, ST, D>;
+    constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    TT *tile = reinterpret_cast<TT *>(mm_lds_raw);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long wave_c0 = (unsigned long long)blockIdx.x * 64;
+    const unsigned long long c = wave_c0 + lane;
+    const bool active = c < a.n_chains;
+    const unsigned long long chain = a.chain_offset + c;
+
+    unsigned char *stack_base = a.stack_in_lds ? (mm_lds_raw + (Tile::lds_bytes_per_wave + 15) / 16 * 16)
+                                               : (a.scratch + (size_t)blockIdx.x * Lay::bytes);
+    const mm_nuts_stack<TT, ST, D> stk = Lay::make(stack_base, lane);
+
+    TT x[D];
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        x[i] = active ? a.state[c * D + i] : TT(0);
+    mm_nuts_adapt<ST> ad;
+    if (active) {
+        ad = a.adapt[c];
+    } else {
+        ad.epsilon = ST(0.1);
+        ad.epsilon_bar = ST(1);
+        ad.h_bar = ST(0);
+        ad.mu = ST(0);
+    }
+    unsigned long long n_lf = 0;
+    unsigned int m = a.m0;
+    unsigned int tcol = 0, rows_out = 0;
+
+    auto record = [&](bool last) {
+        if (!a.out)
+            return;
+        MM_UNROLL
+        for (int k = 0; k < D; ++k)
+            tile[lane * STRIDE + tcol * D + k] = x[k];
+        ++tcol;
+        if (tcol == (unsigned int)TILE_T || last) {
+            mm_flush_tile_raw<TT, D>(a.out, a.n_total, a.n_chains, tile, lane, wave_c0,
+                                     (unsigned long long)a.out_t0 + rows_out, tcol);
+            rows_out += tcol;
+            tcol = 0;
+        }
+    };
+
+    if (a.write_initial)
+        record(a.n_rec == 0);
+    const unsigned int total = a.n_pre + a.n_rec;
+    for (unsigned int t = 0; t < total; ++t) {
+        ++m;
+        /* inactive lanes take no transition: an arbitrary state could grow an arbitrarily deep tree */
+        if (active) {
+            const mm_nuts_info inf = mm_nuts_step<TT, ST, Tgt>(a.P, x, &ad, m, a.n_discard, a.target_accept_p,
+                                                               a.max_depth, a.seed, chain, stk);
+            n_lf += inf.n_leapfrog;
+            if (a.depth_hist)
+                atomicAdd(&a.depth_hist[inf.depth < MM_NUTS_JMAX ? inf.depth : MM_NUTS_JMAX], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (t >= a.n_pre)
+            record(t + 1 == total);
+    }
+
+    if (active) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            a.state[c * D + i] = x[i];
+        a.adapt[c] = ad;
+        if (a.n_leapfrog)
+            a.n_leapfrog[c] += n_lf;
+    }
+}
+
+template <class TT, class ST, class Tgt>
+hipError_t mm_launch_nuts_init(const mm_tparams<TT> &P, const TT *state, mm_nuts_adapt<ST> *adapt,
+                               unsigned long long n_chains, unsigned long long seed, unsigned long long chain_offset,
+                               hipStream_t stream)
+{
+    const ST eps_tol = sizeof(ST) == 4 ? (ST)1.1920929e-7 : (ST)2.220446049250313e-16; /* T::epsilon() */
+    const unsigned int block = 64;
+    const unsigned int grid = (unsigned int)((n_chains + block - 1) / block);
+    hipLaunchKernelGGL((mm_nuts_init_kernel<TT, ST, Tgt>), dim3(grid), dim3(block), 0, stream, P, state, adapt,
+                       n_chains, seed, chain_offset, eps_tol);
+    return hipGetLastError();
+}
+
+template <class TT, class ST, class Tgt>
+hipError_t mm_launch_nuts_run(const mm_nuts_args<TT, ST> &a, hipStream_t stream)
+{
+    using Lay = mm_nuts_stack_layout<TT, ST, Tgt::dim>;
+    const unsigned int grid = (unsigned int)((a.n_chains + 63) / 64);
+    size_t lds = (mm_tile<TT, Tgt::dim>::lds_bytes_per_wave + 15) / 16 * 16;
+    if (a.stack_in_lds)
+        lds += Lay::bytes;
+    hipLaunchKernelGGL((mm_nuts_run_kernel<TT, ST, Tgt>), dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+/* dispatch record: one (kind, dim) for one (TT, ST) pair */
+template <class TT, class ST> struct mm_nuts_entry {
+    int kind, dim;
+    hipError_t (*init)(const mm_tparams<TT> &, const TT *, mm_nuts_adapt<ST> *, unsigned long long,
+                       unsigned long long, unsigned long long, hipStream_t);
+    hipError_t (*run)(const mm_nuts_args<TT, ST> &, hipStream_t);
+    size_t stack_bytes_per_wave, tile_bytes_per_wave;
+};
+
+const mm_nuts_entry<float, double> *mm_nuts_table_m0(int *n);
+const mm_nuts_entry<float, float> *mm_nuts_table_m1(int *n);
+const mm_nuts_entry<double, double> *mm_nuts_table_m2(int *n);
+
+#endif /* MM_NUTS_KERNELS_H */

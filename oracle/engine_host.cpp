@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../mini_mcmc_amd/csrc/mm_params.h"
+#include "../mini_mcmc_amd/csrc/mm_nuts.h"
 #include "../mini_mcmc_amd/csrc/mm_samplers.h"
 
 namespace {
@@ -139,6 +140,107 @@ int eh_run(int sampler, int dtype, int kind, int dim, const double params[8], co
                             chain_offset, iter0, n_collect, n_discard, (float *)out, accept, n_threads);
     return run_t<double>(sampler, kind, dim, params, matrix, scale, n_leapfrog, (double *)state, n_chains, seed,
                          chain_offset, iter0, n_collect, n_discard, (double *)out, accept, n_threads);
+}
+
+} /* extern "C" */
+
+/* NUTS with the engine's arithmetic: the same call sequence as the GPU path (mm_nuts_api.hip / mm_nuts_kernels.h):
+ * init_chain, then n_pre unrecorded and n_rec recorded transitions, row 0 = initial position for run() with
+ * n_discard == 0.  positions [n, dim] doubles in/out (converted to the tensor type on entry like the C ABI does),
+ * adapt [n, 4] doubles in/out (epsilon, epsilon_bar, h_bar, mu), out [n, n_collect, dim] of the tensor type. */
+template <class TT, class ST, class Tgt>
+static void nuts_chains(const mm_tparams<TT> &P, double *positions, size_t n, double tap, uint64_t seed, uint64_t off,
+                        uint32_t m0, size_t n_collect, size_t n_discard, int progress, int max_depth, double *adapt,
+                        TT *out, uint64_t *nlf, int nth)
+{
+    constexpr int D = Tgt::dim;
+    const ST eps_tol = sizeof(ST) == 4 ? (ST)1.1920929e-7 : (ST)2.220446049250313e-16;
+    unsigned n_pre, n_rec, write_initial;
+    const size_t total = n_collect + n_discard;
+    if (progress) { write_initial = 0; n_pre = (unsigned)n_discard; n_rec = (unsigned)n_collect; }
+    else if (total == 0) { write_initial = 0; n_pre = n_rec = 0; }
+    else if (n_discard == 0) { write_initial = n_collect > 0; n_pre = 0; n_rec = (unsigned)(n_collect > 0 ? n_collect - 1 : 0); }
+    else { write_initial = 0; n_pre = (unsigned)(n_discard - 1); n_rec = (unsigned)n_collect; }
+    auto work = [&](size_t lo, size_t hi) {
+        std::vector<TT> vec(mm_nuts_stack<TT, ST, D>::vec_slots);
+        std::vector<ST> al(mm_nuts_stack<TT, ST, D>::alpha_slots);
+        std::vector<uint32_t> cn(mm_nuts_stack<TT, ST, D>::cnt_slots);
+        mm_nuts_stack<TT, ST, D> stk;
+        stk.vec = vec.data(); stk.alpha = al.data(); stk.cnt = cn.data(); stk.stride = 1;
+        for (size_t c = lo; c < hi; ++c) {
+            TT x[D];
+            for (int i = 0; i < D; ++i) x[i] = (TT)positions[c * D + i];
+            mm_nuts_adapt<ST> ad;
+            ad.epsilon = (ST)adapt[4 * c]; ad.epsilon_bar = (ST)adapt[4 * c + 1];
+            ad.h_bar = (ST)adapt[4 * c + 2]; ad.mu = (ST)adapt[4 * c + 3];
+            mm_nuts_init_chain<TT, ST, Tgt>(P, x, &ad, eps_tol, seed, off + c);
+            size_t row = 0;
+            uint64_t lf = 0;
+            uint32_t m = m0;
+            auto rec = [&]() { if (out) { for (int i = 0; i < D; ++i) out[(c * n_collect + row) * D + i] = x[i]; } ++row; };
+            if (write_initial) rec();
+            for (unsigned t = 0; t < n_pre + n_rec; ++t) {
+                ++m;
+                mm_nuts_info inf = mm_nuts_step<TT, ST, Tgt>(P, x, &ad, m, (uint32_t)n_discard, (ST)tap, max_depth, seed, off + c, stk);
+                lf += inf.n_leapfrog;
+                if (t >= n_pre) rec();
+            }
+            for (int i = 0; i < D; ++i) positions[c * D + i] = (double)x[i];
+            adapt[4 * c] = (double)ad.epsilon; adapt[4 * c + 1] = (double)ad.epsilon_bar;
+            adapt[4 * c + 2] = (double)ad.h_bar; adapt[4 * c + 3] = (double)ad.mu;
+            if (nlf) nlf[c] = lf;
+        }
+    };
+    if (nth <= 1 || n < 2) { work(0, n); return; }
+    std::vector<std::thread> th;
+    size_t nt = std::min<size_t>((size_t)nth, n);
+    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto &t : th) t.join();
+}
+
+template <class TT, class ST>
+static int nuts_t(int kind, int dim, const double params[8], const double *matrix, double *positions, size_t n, double tap,
+                  uint64_t seed, uint64_t off, uint32_t m0, size_t nc, size_t nd, int progress, int max_depth,
+                  double *adapt, void *out, uint64_t *nlf, int nth)
+{
+    mm_tparams<TT> P;
+    if (mm_fill_params<TT>(kind, params, &P) != 0) return -1;
+    std::vector<TT> mat;
+    if (kind == MM_GAUSSIAN_ND) {
+        if (!matrix) return -1;
+        mat.resize((size_t)dim * dim);
+        for (size_t i = 0; i < mat.size(); ++i) mat[i] = (TT)matrix[i];
+        P.mat = mat.data();
+    }
+#define NT(KIND, DD)                                                                                              \
+    if (kind == KIND && dim == DD) {                                                                              \
+        nuts_chains<TT, ST, mm_target<TT, KIND, DD>>(P, positions, n, tap, seed, off, m0, nc, nd, progress, max_depth, \
+                                                     adapt, (TT *)out, nlf, nth);                                 \
+        return 0;                                                                                                 \
+    }
+    NT(MM_DIFFABLE_GAUSSIAN2D, 2) NT(MM_GAUSSIAN2D, 2) NT(MM_ROSENBROCK2D, 2)
+    NT(MM_STANDARD_NORMAL, 1) NT(MM_STANDARD_NORMAL, 2) NT(MM_STANDARD_NORMAL, 3) NT(MM_STANDARD_NORMAL, 4) NT(MM_STANDARD_NORMAL, 8)
+    NT(MM_ISOTROPIC_GAUSSIAN, 2) NT(MM_ISOTROPIC_GAUSSIAN, 3)
+    NT(MM_ROSENBROCK_ND, 2) NT(MM_ROSENBROCK_ND, 3) NT(MM_ROSENBROCK_ND, 4) NT(MM_ROSENBROCK_ND, 8)
+    NT(MM_GAUSSIAN_ND, 2) NT(MM_GAUSSIAN_ND, 4) NT(MM_GAUSSIAN_ND, 8) NT(MM_GAUSSIAN_ND, 16) NT(MM_GAUSSIAN_ND, 32)
+#undef NT
+    return -2;
+}
+
+extern "C" {
+
+int eh_nuts_run(int mode, int kind, int dim, const double params[8], const double *matrix, double *positions, size_t n,
+                double target_accept_p, uint64_t seed, uint64_t chain_offset, uint32_t m0, size_t n_collect,
+                size_t n_discard, int progress, int max_depth, double *adapt, void *out, uint64_t *nlf, int n_threads)
+{
+    if (mode == 0)
+        return nuts_t<float, double>(kind, dim, params, matrix, positions, n, target_accept_p, seed, chain_offset, m0,
+                                     n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);
+    if (mode == 1)
+        return nuts_t<float, float>(kind, dim, params, matrix, positions, n, target_accept_p, seed, chain_offset, m0,
+                                    n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);
+    return nuts_t<double, double>(kind, dim, params, matrix, positions, n, target_accept_p, seed, chain_offset, m0,
+                                  n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);
 }
 
 /* noise of (chain, iteration) as the engine draws it: z [n, dim], u [n] */

@@ -168,7 +168,20 @@ void o_nuts_set_seed(o_nuts *s, uint64_t seed)
         o_nuts_set_chain_seed(s, i, seed + (uint64_t)i + 1);
 }
 
-/* switch every chain to the GPU engine's counter-based stream (philox_stream.c) */
+/* depth cap (0 = none, the reference's behaviour) */
+void o_nuts_set_max_depth(o_nuts *s, int max_depth)
+{
+    for (int i = 0; i < s->n_chains; ++i) {
+        if (s->mode == 0)
+            ((nuts_chain_m0 *)s->chains)[i].max_depth = max_depth;
+        else if (s->mode == 1)
+            ((nuts_chain_m1 *)s->chains)[i].max_depth = max_depth;
+        else
+            ((nuts_chain_m2 *)s->chains)[i].max_depth = max_depth;
+    }
+}
+
+/* switch every chain to the GPU engine's counter-based stream (orng.c) */
 void o_nuts_use_engine_stream(o_nuts *s, uint64_t seed, uint64_t chain_offset)
 {
     for (int i = 0; i < s->n_chains; ++i)

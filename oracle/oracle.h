@@ -70,6 +70,8 @@ void o_nuts_destroy(o_nuts *s);
 void o_nuts_set_chain_seed(o_nuts *s, int chain, uint64_t seed);
 void o_nuts_set_seed(o_nuts *s, uint64_t seed);
 void o_nuts_use_engine_stream(o_nuts *s, uint64_t seed, uint64_t chain_offset);
+/* optional depth cap, 0 = unbounded like the reference (nuts.rs:578) */
+void o_nuts_set_max_depth(o_nuts *s, int max_depth);
 void o_nuts_run(o_nuts *s, size_t n_collect, size_t n_discard, int progress, int n_threads, double *out);
 void o_nuts_chain_state(o_nuts *s, int chain, double out[7]);
 double o_nuts_find_reasonable_epsilon(const ot_target *target, const double *position, const double *mom,

@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
         "o_nuts_set_chain_seed": (None, [C.c_void_p, C.c_int, C.c_uint64]),
         "o_nuts_set_seed": (None, [C.c_void_p, C.c_uint64]),
         "o_nuts_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_nuts_set_max_depth": (None, [C.c_void_p, C.c_int]),
         "o_nuts_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp]),
         "o_nuts_chain_state": (None, [C.c_void_p, C.c_int, _dp]),
         "o_nuts_find_reasonable_epsilon": (C.c_double, [tp, _dp, _dp, C.c_int]),
@@ -416,6 +417,11 @@ class NUTS:
         lib().o_nuts_use_engine_stream(self._h, seed, chain_offset)
         return self
 
+    def set_max_depth(self, max_depth):
+        """0 = unbounded (the reference); > 0 caps the doublings per transition (the GPU engine needs a cap)."""
+        lib().o_nuts_set_max_depth(self._h, int(max_depth))
+        return self
+
     def run(self, n_collect, n_discard, progress=False, n_threads=None):
         out = np.zeros((self.n_chains, n_collect, self.dim), dtype=np.float64)
         lib().o_nuts_run(self._h, n_collect, n_discard, int(progress), n_threads or default_threads(), _d(out))
@@ -536,6 +542,9 @@ def engine_host_lib() -> C.CDLL:
     E.eh_run.restype = C.c_int
     E.eh_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_void_p, C.c_size_t,
                          C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_size_t, C.c_void_p, _u64p, C.c_int]
+    E.eh_nuts_run.restype = C.c_int
+    E.eh_nuts_run.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_size_t, C.c_double, C.c_uint64, C.c_uint64,
+                              C.c_uint32, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp, C.c_void_p, _u64p, C.c_int]
     E.eh_noise.restype = C.c_int
     E.eh_noise.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     E.eh_logp_grad.restype = C.c_int
@@ -592,3 +601,29 @@ def engine_host_logp_grad(kind, dim, params, x, matrix=None, dtype=np.float32, w
     if rc != 0:
         raise ValueError(f"eh_logp_grad: {rc}")
     return lp, g
+
+
+def engine_host_nuts_run(mode, kind, dim, params, init, target_accept_p, n_collect, n_discard, seed=0, chain_offset=0,
+                         m0=0, progress=False, max_depth=10, matrix=None, adapt=None, n_threads=None):
+    """NUTS on the host with the ENGINE's arithmetic/stream (mm_nuts.h compiled by g++).  Returns
+    (sample [C, n_collect, D] of the tensor type, final positions [C, D], adapt [C, 4] f64, leapfrog counts [C])."""
+    E = engine_host_lib()
+    x = np.ascontiguousarray(init, dtype=np.float64).copy()
+    if x.ndim == 1:
+        x = x[None, :]
+    n = x.shape[0]
+    tdt = np.float64 if mode == 2 else np.float32
+    out = np.empty((n, n_collect, dim), dtype=tdt)
+    ad = np.empty((n, 4), dtype=np.float64)
+    if adapt is None:
+        ad[:] = [-1.0, 1.0, 0.0, np.log(10.0)]
+    else:
+        ad[:] = adapt
+    nlf = np.zeros(n, dtype=np.uint64)
+    p, m = _eh_target_args(kind, params, matrix)
+    rc = E.eh_nuts_run(mode, kind, dim, _d(p), _d(m) if m is not None else None, _d(x), n, float(target_accept_p), seed,
+                       chain_offset, m0, n_collect, n_discard, int(progress), int(max_depth), _d(ad), out.ctypes.data,
+                       nlf.ctypes.data_as(_u64p), n_threads or default_threads())
+    if rc != 0:
+        raise ValueError(f"eh_nuts_run: {rc}")
+    return out, x.astype(tdt), ad, nlf

@@ -372,3 +372,87 @@ def test_stats_on_device_sample_and_sharded_partials(M, O):
     r_sh, e_sh = S.stats_finish(means, ssq, acov)
     np.testing.assert_allclose(r_sh, r_dev, rtol=1e-6)
     np.testing.assert_allclose(e_sh, e_dev, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- NUTS on the GPU (nuts.rs)
+
+
+def _nuts_pair(M, O, tgt, kind, params, init, mode, nc, nd, seed, progress=False, mat=None, max_depth=10, offset=0):
+    from mini_mcmc_amd.nuts import NUTS
+
+    s = NUTS(tgt, init, 0.8, mode=mode).set_seed(seed).set_max_depth(max_depth)
+    if offset:
+        s.set_chain_offset(offset)
+    out = s._run(nc, nd, progress, "numpy")
+    ref, pos, ad, nlf = O.engine_host_nuts_run(mode, kind, tgt.dim, params, init, 0.8, nc, nd, seed=seed, matrix=mat,
+                                               progress=progress, max_depth=max_depth, chain_offset=offset)
+    return s, out, ref, pos, ad, nlf
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_nuts_bit_exact_vs_host_build(M, O, mode):
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((8, 8))
+    A = A @ A.T / 8 + np.eye(8)
+    cases = [
+        (M.dist.DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), O.DIFFABLE_GAUSSIAN2D, GAUSS, None, 130, 21, 9, False),
+        (M.dist.DiffableGaussian2D([1.0, 2.0], [[1.0, 2.0], [2.0, 5.0]]), O.DIFFABLE_GAUSSIAN2D, [1.0, 2.0, 1.0, 2.0, 2.0, 5.0], None, 64, 5, 5, False),
+        (M.dist.Rosenbrock2D(1.0, 100.0), O.ROSENBROCK2D, [1.0, 100.0], None, 70, 12, 8, True),
+        (M.dist.StandardNormal(3), O.STANDARD_NORMAL, [], None, 65, 10, 0, False),
+        (M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], None, 64, 9, 6, True),
+        (M.dist.GaussianND(A), O.GAUSSIAN_ND, [], A, 40, 8, 8, False),
+    ]
+    for tgt, kind, params, mat, C, nc, nd, progress in cases:
+        init = M.core.init_with_seed(C, tgt.dim, 31) * 0.8
+        s, out, ref, pos, ad, nlf = _nuts_pair(M, O, tgt, kind, params, init, mode, nc, nd, 77, progress, mat)
+        name = f"{type(tgt).__name__} D={tgt.dim} mode={mode}"
+        assert np.array_equal(out, ref), name
+        assert np.array_equal(s.positions(), pos), name
+        assert np.array_equal(s.leapfrog_counts(), nlf), name  # identical tree shapes
+        a = s.adapt_state()
+        assert np.array_equal(a["epsilon"], ad[:, 0]) and np.array_equal(a["epsilon_bar"], ad[:, 1]), name
+        assert np.array_equal(a["h_bar"], ad[:, 2]) and np.array_equal(a["mu"], ad[:, 3]), name
+        assert s.depth_histogram().sum() == C * (nc + nd - (0 if progress else 1))
+
+
+def test_nuts_reference_semantics_on_gpu(M, O, kats):
+    from mini_mcmc_amd.nuts import NUTS
+
+    # test_chain_1 (nuts.rs:1123-1136): run(1, 0) == the initial position, no transition taken
+    k = kats["nuts_chains"][0]
+    s = NUTS(M.dist.DiffableGaussian2D(k["mean"], k["cov"]), [k["init"]], k["target_accept"], mode=0).set_seed(42)
+    out = s.run(1, 0)
+    assert np.array_equal(out.ravel(), np.array(k["init"], dtype=np.float32)) and s.leapfrog_counts()[0] == 0
+    # a second run() continues the chain: positions persist, step count persists, init_chain re-derives mu
+    a = s.run(5, 3)
+    b = s.run(4, 0)
+    assert np.array_equal(b[:, 0], a[:, -1])  # with n_discard == 0 row 0 is the current (= last) position
+    # sharding by chain offset reproduces the unsharded run
+    tgt = M.dist.StandardNormal(3)
+    init = M.core.init_with_seed(96, 3, 5)
+    whole = NUTS(tgt, init, 0.8, mode=2).set_seed(3).run(12, 6)
+    lo = NUTS(tgt, init[:40], 0.8, mode=2).set_seed(3).run(12, 6)
+    hi = NUTS(tgt, init[40:], 0.8, mode=2).set_seed(3).set_chain_offset(40).run(12, 6)
+    assert np.array_equal(np.concatenate([lo, hi]), whole)
+
+
+def test_nuts_posterior_and_run_progress_stats(M, O):
+    from mini_mcmc_amd.nuts import NUTS
+
+    init = M.core.init_with_seed(2048, 2, 9)
+    s = NUTS(M.dist.DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), init, 0.8, mode=0).set_seed(1)
+    sample, stats = s.run_progress(300, 200)
+    flat = sample.reshape(-1, 2).astype(np.float64)
+    assert np.all(np.abs(flat.mean(axis=0) - [0.0, 1.0]) < 0.03)  # within 1 % of the scale (north_star)
+    assert np.all(np.abs(np.cov(flat.T) - np.array([[4.0, 2.0], [2.0, 3.0]])) < 0.08)
+    assert stats.ess.min > 0.2 * 2048 * 300 and 0.99 < stats.rhat.min <= stats.rhat.max < 1.01
+    h = s.depth_histogram()
+    assert h[:1].sum() == 0 and h.sum() == 2048 * 500
+    # config-5 shaped target (32-D, condition number 1e4, f64) at a small chain count: runs, adapts, stays finite
+    g = M.dist.GaussianND.ill_conditioned(32, 1e4, 7)
+    s5 = NUTS(g, M.core.init_with_seed(64, 32, 42) * 0.1, 0.8, mode=2).set_seed(42)
+    out5 = s5.run(20, 30)
+    assert np.all(np.isfinite(out5)) and s5.depth_histogram()[1:].sum() == 64 * 49
+    ref5, _, _, nlf5 = O.engine_host_nuts_run(2, O.GAUSSIAN_ND, 32, [], M.core.init_with_seed(64, 32, 42) * 0.1, 0.8, 20, 30,
+                                              seed=42, matrix=g.precision)
+    assert np.array_equal(out5, ref5) and np.array_equal(s5.leapfrog_counts(), nlf5)
