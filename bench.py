@@ -82,7 +82,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--variant", type=int, default=2, help="kernel variant: 2 software-pipelined (default), 1 producer/consumer, 0 plain")
+    ap.add_argument("--variant", type=int, default=2, help="kernel variant: 2 paired+pipelined noise (default), 1 pipelined, 0 plain")
     args = ap.parse_args()
 
     import numpy as np
@@ -204,9 +204,9 @@ def main() -> None:
             "split_rhat_max_conventional": float((1.0 / rhat).max()),
             "stats_ms": stats_s * 1e3,
             "roofline": {
-                "kernel": {0: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=0>",
-                           1: "mm_run_kernel_pc<float, RosenbrockND<3>, HMC, 1 producer wave>",
-                           2: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=1, L=10>"}[args.variant],
+                "kernel": {0: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=0, L=0>",
+                           1: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=1, L=10>",
+                           2: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>"}[args.variant],
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

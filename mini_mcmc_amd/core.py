@@ -51,7 +51,7 @@ class _Sampler:
         return self
 
     def set_kernel_variant(self, variant: int):
-        """2 = software-pipelined single wave (default), 1 = producer/consumer waves, 0 = plain; results are identical."""
+        """2 = paired + pipelined noise (default), 1 = pipelined noise, 0 = plain; results are identical."""
         L.check(self._fn("set_kernel_variant")(self._h, int(variant)), "set_kernel_variant")
         return self
 

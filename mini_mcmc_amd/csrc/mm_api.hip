@@ -130,7 +130,7 @@ struct Sampler {
     uint64_t seed = 0, chain_offset = 0;
     uint64_t iter = 0;
     uint32_t iters_per_launch = 0;
-    int variant = 2; /* 0 = one wave per 64 chains, 1 = producer/consumer waves, 2 = software-pipelined single wave */
+    int variant = 2; /* mm_run_kernel PIPE: 0 plain, 1 noise of t+1 pipelined, 2 noise of two iterations packed + pipelined */
     unsigned int block = 64;
     void *d_state = nullptr;
     void *d_mat = nullptr;
@@ -278,16 +278,15 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     a.n_total = n_total;
     unsigned int grid = (unsigned int)((s->n_chains + s->block - 1) / s->block);
     hipError_t e;
-    if (s->variant == 1)
-        e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh_pc(a, grid, s->block, stream)
-                                          : k->run_hmc_pc(a, grid, s->block, stream);
-    else if (s->variant == 2)
-        e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh_sp(a, grid, s->block, stream)
-            : (s->n_leapfrog == 10)       ? k->run_hmc_sp10(a, grid, s->block, stream)
-                                          : k->run_hmc_sp(a, grid, s->block, stream);
+    const bool mh = s->sampler == MM_SAMPLER_MH, l10 = s->n_leapfrog == 10;
+    if (s->variant == 2)
+        e = mh ? k->run_mh_pp(a, grid, s->block, stream)
+               : (l10 ? k->run_hmc_pp10(a, grid, s->block, stream) : k->run_hmc_pp(a, grid, s->block, stream));
+    else if (s->variant == 1)
+        e = mh ? k->run_mh_sp(a, grid, s->block, stream)
+               : (l10 ? k->run_hmc_sp10(a, grid, s->block, stream) : k->run_hmc_sp(a, grid, s->block, stream));
     else
-        e = (s->sampler == MM_SAMPLER_MH) ? k->run_mh(a, grid, s->block, stream)
-                                          : k->run_hmc(a, grid, s->block, stream);
+        e = mh ? k->run_mh(a, grid, s->block, stream) : k->run_hmc(a, grid, s->block, stream);
     if (e != hipSuccess)
         return (int)e;
     s->iter += (uint64_t)n_discard + n_collect;

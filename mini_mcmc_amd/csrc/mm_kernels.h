@@ -100,11 +100,15 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
     __builtin_amdgcn_wave_barrier();
 }
 
-/* PIPE = 1: software-pipelined -- the noise of transition t+1 (a pure function of (seed, chain, t+1), independent
- * of the chain's state) is computed in the same basic block as transition t, so the scheduler can interleave the two
- * dependency chains; a lone dependent chain issues one VALU instruction per ~5 cycles on gfx950, independent
- * instructions one per ~2.5 (tools/valu_rate.hip).  LCT > 0: compile-time leapfrog count (loop unrolled into that
- * block).  Results are bit-identical for every (PIPE, LCT). */
+/* The noise of a transition is a pure function of (seed, chain, iteration), independent of the chain's state, and a
+ * lone dependent chain of VALU instructions issues only one instruction per ~5 cycles on gfx950 while independent or
+ * packed work fills the gaps (tools/valu_rate.hip; more waves per SIMD do not help).  Hence
+ *   PIPE = 0: noise and transition of iteration t back to back (plain);
+ *   PIPE = 1: the noise of t+1 is computed in the same basic block as transition t (software pipelining);
+ *   PIPE = 2: the noise of TWO iterations (t+2, t+3) is computed at once -- both Philox counters interleaved, the
+ *             Box-Muller / log arithmetic packed across the two iterations (v_pk_*_f32) -- next to transitions t, t+1.
+ * LCT > 0: compile-time leapfrog count (the loop is unrolled into that block).  Results are bit-identical for
+ * every (PIPE, LCT): all variants evaluate the same functions (mm_rng.h, mm_samplers.h). */
 template <class T, class Tgt, int SAMPLER, int PIPE = 0, int LCT = 0>
 __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
 {
@@ -165,21 +169,66 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         ++it;
     };
 
-    for (unsigned int i = 0; i < a.n_discard; ++i)
-        step();
-
-    for (unsigned int t0 = 0; t0 < a.n_collect; t0 += TILE_T) {
-        const unsigned int nt = min((unsigned int)TILE_T, a.n_collect - t0);
-        for (unsigned int tt = 0; tt < nt; ++tt) {
-            step();
-            if (a.out) {
+    if (PIPE == 2) {
+        /* pairs of transitions; the noise of the next pair is drawn alongside the current pair's transitions */
+        const unsigned int total = a.n_discard + a.n_collect;
+        T za[D], zb[D], lna, lnb;
+        mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb);
+        unsigned int tcol = 0, rows_out = 0;
+        auto transition = [&](T *z, T ln_u, unsigned int t) {
+            int acc;
+            if (SAMPLER == MM_SAMPLER_HMC)
+                acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u);
+            else
+                acc = mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u);
+            acc = acc && active;
+            n_acc += (unsigned long long)acc;
+            wave_acc += (unsigned long long)__popcll(__ballot(acc));
+            if (t >= a.n_discard && a.out) {
                 MM_UNROLL
                 for (int i = 0; i < D; ++i)
-                    tile[lane * STRIDE + tt * D + i] = x[i];
+                    tile[lane * STRIDE + tcol * D + i] = x[i];
+                ++tcol;
+                if (tcol == (unsigned int)TILE_T || t + 1 == total) {
+                    mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, tcol);
+                    rows_out += tcol;
+                    tcol = 0;
+                }
             }
+        };
+        for (unsigned int t = 0; t < total; t += 2) {
+            T zna[D], znb[D], lnna, lnnb;
+            mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb);
+            transition(za, lna, t);
+            if (t + 1 < total)
+                transition(zb, lnb, t + 1);
+            MM_UNROLL
+            for (int i = 0; i < D; ++i) {
+                za[i] = zna[i];
+                zb[i] = znb[i];
+            }
+            lna = lnna;
+            lnb = lnnb;
+            it += 2u;
         }
-        if (a.out)
-            mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + t0, nt);
+    } else {
+        for (unsigned int i = 0; i < a.n_discard; ++i)
+            step();
+
+        for (unsigned int t0 = 0; t0 < a.n_collect; t0 += TILE_T) {
+            const unsigned int nt = min((unsigned int)TILE_T, a.n_collect - t0);
+            for (unsigned int tt = 0; tt < nt; ++tt) {
+                step();
+                if (a.out) {
+                    MM_UNROLL
+                    for (int i = 0; i < D; ++i)
+                        tile[lane * STRIDE + tt * D + i] = x[i];
+                }
+            }
+            if (a.out)
+                mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + t0, nt);
+        }
+
     }
 
     if (active) {
@@ -191,132 +240,6 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
     }
     if (a.accept_total && lane == 0 && wave_acc)
         atomicAdd(a.accept_total, wave_acc);
-}
-
-/*
- * Producer / consumer variant of the sampling kernel.
- *
- * A lone wave on a CDNA4 SIMD issues one vector instruction every 4 cycles, the SIMD itself one every 2
- * (MI355X_MICROARCH.md).  With one chain per lane, 65 536 chains are only 1024 waves = one per SIMD, and about half
- * of every transition is the noise of (chain, iteration) -- Philox, Box-Muller, log u -- which does not depend on
- * the chain's state.  So a workgroup is 64 chains and 1 + NPROD waves: wave 0 (the consumer) carries the chains'
- * state in VGPRs and performs the transitions; waves 1..NPROD (producers) compute the noise of the NEXT batch of TB
- * iterations into an LDS ring ([2][TB][D+1][64], lane-contiguous => conflict free) while the consumer works through
- * the current batch; one workgroup barrier per batch swaps the buffers.  Twice (or 1+NPROD times) the waves per SIMD
- * interleave their issue slots.  The values are the same pure functions of (seed, chain, iteration) as in
- * mm_run_kernel, so results are bit-identical to it (and to the host build).
- */
-template <class T, int D> struct mm_pc_cfg {
-    static constexpr int nv = D + 1; /* D normals + log(accept uniform) */
-    static constexpr int budget = 8 * 1024; /* tile (24.8 KB) + ring <= 40 KB: four workgroups per CU */
-    static constexpr int tb_raw = budget / (2 * nv * 64 * (int)sizeof(T));
-    static constexpr int tb = tb_raw < 1 ? 1 : (tb_raw > 8 ? 8 : tb_raw);
-    static constexpr size_t ring_bytes = (size_t)2 * tb * nv * 64 * sizeof(T);
-    static constexpr size_t lds_bytes = mm_tile<T, D>::lds_bytes_per_wave + ring_bytes;
-};
-
-template <class T, class Tgt, int SAMPLER, int NPROD>
-__global__ __launch_bounds__(64 * (1 + NPROD)) void mm_run_kernel_pc(const mm_run_args<T> a)
-{
-    constexpr int D = Tgt::dim;
-    using Tile = mm_tile<T, D>;
-    using Cfg = mm_pc_cfg<T, D>;
-    constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride, TB = Cfg::tb, NV = Cfg::nv;
-    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
-    T *tile = reinterpret_cast<T *>(mm_lds_raw);
-    T *ring = tile + (size_t)64 * STRIDE;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const unsigned long long wave_c0 = (unsigned long long)blockIdx.x * 64;
-    const unsigned long long c = wave_c0 + lane;
-    const bool active = c < a.n_chains;
-    const unsigned long long chain = a.chain_offset + c;
-    const unsigned int total = a.n_discard + a.n_collect;
-    const unsigned int n_batches = (total + TB - 1) / TB;
-
-    /* noise of batch `b` into ring buffer `buf`; producer `pid` takes iterations pid, pid + NPROD, ... */
-    auto produce = [&](unsigned int b, int pid) {
-        T *dst = ring + (size_t)(b & 1u) * TB * NV * 64;
-        for (unsigned int i = (unsigned int)pid; i < (unsigned int)TB; i += NPROD) {
-            const unsigned int t = b * TB + i;
-            if (t >= total)
-                break;
-            T z[D], u;
-            mm_draw_noise<D>(a.seed, chain, a.iter0 + t, z, &u);
-            MM_UNROLL
-            for (int k = 0; k < D; ++k)
-                dst[(i * NV + k) * 64 + lane] = z[k];
-            dst[(i * NV + D) * 64 + lane] = mm_logT(u);
-        }
-    };
-
-    T x[D], g[D], lp = 0;
-    unsigned long long n_acc = 0, wave_acc = 0;
-    unsigned int tcol = 0;     /* rows staged in the tile */
-    unsigned int rows_out = 0; /* rows already flushed */
-    if (wave == 0) {
-        MM_UNROLL
-        for (int i = 0; i < D; ++i)
-            x[i] = active ? a.state[c * D + i] : T(0);
-        if (SAMPLER == MM_SAMPLER_HMC)
-            lp = Tgt::logp_grad(a.P, x, g);
-        else
-            lp = Tgt::logp(a.P, x);
-    } else {
-        produce(0, wave - 1);
-    }
-    __syncthreads();
-
-    for (unsigned int b = 0; b < n_batches; ++b) {
-        if (wave != 0) {
-            if (b + 1 < n_batches)
-                produce(b + 1, wave - 1);
-        } else {
-            const T *src = ring + (size_t)(b & 1u) * TB * NV * 64;
-            const unsigned int nb = min((unsigned int)TB, total - b * TB);
-            for (unsigned int i = 0; i < nb; ++i) {
-                T z[D];
-                MM_UNROLL
-                for (int k = 0; k < D; ++k)
-                    z[k] = src[(i * NV + k) * 64 + lane];
-                const T ln_u = src[(i * NV + D) * 64 + lane];
-                int acc;
-                if (SAMPLER == MM_SAMPLER_HMC)
-                    acc = mm_hmc_step_noise<T, Tgt>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u);
-                else
-                    acc = mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u);
-                acc = acc && active;
-                n_acc += (unsigned long long)acc;
-                wave_acc += (unsigned long long)__popcll(__ballot(acc));
-                const unsigned int t = b * TB + i;
-                if (t >= a.n_discard && a.out) {
-                    MM_UNROLL
-                    for (int k = 0; k < D; ++k)
-                        tile[lane * STRIDE + tcol * D + k] = x[k];
-                    ++tcol;
-                    if (tcol == (unsigned int)TILE_T || t + 1 == total) {
-                        mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, tcol);
-                        rows_out += tcol;
-                        tcol = 0;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    if (wave == 0) {
-        if (active) {
-            MM_UNROLL
-            for (int i = 0; i < D; ++i)
-                a.state[c * D + i] = x[i];
-            if (a.accept)
-                a.accept[c] += n_acc;
-        }
-        if (a.accept_total && lane == 0 && wave_acc)
-            atomicAdd(a.accept_total, wave_acc);
-    }
 }
 
 /* BatchedGradientTarget::unnorm_logp_batch / unnorm_logp_and_grad for n rows (parity tests) */
@@ -366,16 +289,6 @@ hipError_t mm_launch_run(const mm_run_args<T> &a, unsigned int grid, unsigned in
     return hipGetLastError();
 }
 
-/* producer/consumer variant: `block` is ignored (64 chains and 1 + NPROD waves per workgroup) */
-template <class T, class Tgt, int SAMPLER, int NPROD>
-hipError_t mm_launch_run_pc(const mm_run_args<T> &a, unsigned int, unsigned int, hipStream_t stream)
-{
-    const unsigned int grid = (unsigned int)((a.n_chains + 63) / 64);
-    const size_t lds = mm_pc_cfg<T, Tgt::dim>::lds_bytes;
-    hipLaunchKernelGGL((mm_run_kernel_pc<T, Tgt, SAMPLER, NPROD>), dim3(grid), dim3(64 * (1 + NPROD)), lds, stream, a);
-    return hipGetLastError();
-}
-
 template <class T, class Tgt>
 hipError_t mm_launch_logp_grad(const mm_tparams<T> &P, const T *x, T *logp, T *grad, unsigned long long n,
                                hipStream_t stream)
@@ -401,11 +314,12 @@ template <class T> struct mm_kernel_entry {
     int kind, dim;
     hipError_t (*run_mh)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);
     hipError_t (*run_hmc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);
-    hipError_t (*run_mh_pc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* producer/consumer */
-    hipError_t (*run_hmc_pc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* producer/consumer */
-    hipError_t (*run_mh_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* software-pipelined */
-    hipError_t (*run_hmc_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* software-pipelined */
-    hipError_t (*run_hmc_sp10)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* ... n_leapfrog == 10 */
+    hipError_t (*run_mh_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* PIPE = 1 */
+    hipError_t (*run_hmc_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 1 */
+    hipError_t (*run_hmc_sp10)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 1, L = 10 */
+    hipError_t (*run_mh_pp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* PIPE = 2 */
+    hipError_t (*run_hmc_pp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 2 */
+    hipError_t (*run_hmc_pp10)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 2, L = 10 */
     hipError_t (*logp_grad)(const mm_tparams<T> &, const T *, T *, T *, unsigned long long, hipStream_t);
     size_t lds_bytes_per_wave;
 };

@@ -145,6 +145,122 @@ MM_HD void mm_sincos2pif(float u, float *s, float *c)
     *c = cc;
 }
 
+/* ------------------------------------------------------------------ f32, two lanes at a time
+ *
+ * A dependent chain of scalar VALU instructions issues one instruction per ~5 cycles on gfx950, a packed
+ * instruction (v_pk_fma_f32, ...) processes two elements in the same time (tools/valu_rate.hip), so functions whose
+ * inputs come in independent pairs are also provided on 2-element vectors.  Element k of every result is computed
+ * by EXACTLY the operations of the scalar function above (same constants, same order, same fused operations), so
+ * mm_logf2(x)[k] == mm_logf(x[k]) bit for bit -- tests/test_engine_stream.py checks this on the host and the GPU
+ * parity tests check it on the device.  GCC vector extensions: accepted by g++ (host build) and clang (hipcc). */
+typedef float mm_f2 __attribute__((vector_size(8)));
+typedef int32_t mm_i2 __attribute__((vector_size(8)));
+typedef uint32_t mm_u2 __attribute__((vector_size(8)));
+typedef uint64_t mm_ul2 __attribute__((vector_size(16)));
+
+MM_HD mm_f2 mm_splat2(float v)
+{
+    mm_f2 r = {v, v};
+    return r;
+}
+MM_HD mm_f2 mm_fma2(mm_f2 a, mm_f2 b, mm_f2 c)
+{
+#if defined(__clang__)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    mm_f2 r = {fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+    return r;
+#endif
+}
+MM_HD mm_f2 mm_rint2(mm_f2 a)
+{
+    mm_f2 r = {rintf(a[0]), rintf(a[1])};
+    return r;
+}
+MM_HD mm_f2 mm_sqrt2(mm_f2 a)
+{
+    mm_f2 r = {sqrtf(a[0]), sqrtf(a[1])};
+    return r;
+}
+MM_HD mm_u2 mm_f2_bits(mm_f2 a)
+{
+    mm_u2 r;
+    memcpy(&r, &a, 8);
+    return r;
+}
+MM_HD mm_f2 mm_bits_f2(mm_u2 a)
+{
+    mm_f2 r;
+    memcpy(&r, &a, 8);
+    return r;
+}
+MM_HD mm_f2 mm_i2_to_f2(mm_i2 a) { return __builtin_convertvector(a, mm_f2); }
+MM_HD mm_f2 mm_u2_to_f2(mm_u2 a) { return __builtin_convertvector(a, mm_f2); }
+MM_HD mm_i2 mm_f2_to_i2(mm_f2 a) { return __builtin_convertvector(a, mm_i2); }
+/* select on a comparison mask (all-ones / all-zeros lanes) */
+MM_HD mm_f2 mm_sel2(mm_i2 mask, mm_f2 a, mm_f2 b)
+{
+    mm_u2 m = (mm_u2)mask;
+    return mm_bits_f2((mm_f2_bits(a) & m) | (mm_f2_bits(b) & ~m));
+}
+
+/* == mm_logf, lane by lane */
+MM_HD mm_f2 mm_logf2(mm_f2 x)
+{
+    mm_u2 ix = mm_f2_bits(x);
+    mm_i2 e = (mm_i2)(ix >> 23) - 127;
+    mm_f2 m = mm_bits_f2((ix & 0x007fffffu) | 0x3f800000u);
+    mm_i2 big = m > mm_splat2(1.41421356237f);
+    m = mm_sel2(big, m * mm_splat2(0.5f), m);
+    e = e - big; /* big lanes are -1 */
+    mm_f2 f = m - mm_splat2(1.0f);
+    mm_f2 z = f * f;
+    mm_f2 p = mm_splat2(7.0376836292e-2f);
+    p = mm_fma2(p, f, mm_splat2(-1.1514610310e-1f));
+    p = mm_fma2(p, f, mm_splat2(1.1676998740e-1f));
+    p = mm_fma2(p, f, mm_splat2(-1.2420140846e-1f));
+    p = mm_fma2(p, f, mm_splat2(1.4249322787e-1f));
+    p = mm_fma2(p, f, mm_splat2(-1.6668057665e-1f));
+    p = mm_fma2(p, f, mm_splat2(2.0000714765e-1f));
+    p = mm_fma2(p, f, mm_splat2(-2.4999993993e-1f));
+    p = mm_fma2(p, f, mm_splat2(3.3333331174e-1f));
+    mm_f2 fe = mm_i2_to_f2(e);
+    mm_f2 y = (p * f) * z;
+    y = mm_fma2(fe, mm_splat2(-2.12194440e-4f), y);
+    y = mm_fma2(mm_splat2(-0.5f), z, y);
+    mm_f2 r = f + y;
+    return mm_fma2(fe, mm_splat2(0.693359375f), r);
+}
+
+/* == mm_sincos2pif, lane by lane */
+MM_HD void mm_sincos2pif2(mm_f2 u, mm_f2 *s, mm_f2 *c)
+{
+    mm_f2 t = u * mm_splat2(4.0f);
+    mm_f2 qf = mm_rint2(t);
+    mm_f2 r = t - qf;
+    mm_f2 y = r * mm_splat2(1.57079632679489662f);
+    mm_f2 y2 = y * y;
+    mm_f2 sp = mm_splat2(2.7557313707e-6f);
+    sp = mm_fma2(sp, y2, mm_splat2(-1.9841269841e-4f));
+    sp = mm_fma2(sp, y2, mm_splat2(8.3333333333e-3f));
+    sp = mm_fma2(sp, y2, mm_splat2(-1.6666666667e-1f));
+    mm_f2 sy = mm_fma2(sp * y2, y, y);
+    mm_f2 cp = mm_splat2(-2.7557319224e-7f);
+    cp = mm_fma2(cp, y2, mm_splat2(2.4801587302e-5f));
+    cp = mm_fma2(cp, y2, mm_splat2(-1.3888888889e-3f));
+    cp = mm_fma2(cp, y2, mm_splat2(4.1666666667e-2f));
+    cp = mm_fma2(cp, y2, mm_splat2(-0.5f));
+    mm_f2 cy = mm_fma2(cp, y2, mm_splat2(1.0f));
+    mm_i2 q = mm_f2_to_i2(qf) & 3;
+    mm_i2 odd = (q & 1) != 0;
+    mm_f2 ss = mm_sel2(odd, cy, sy);
+    mm_f2 cc = mm_sel2(odd, sy, cy);
+    mm_i2 negc = (q == 1) | (q == 2);
+    mm_i2 negs = q >= 2;
+    *c = mm_sel2(negc, -cc, cc);
+    *s = mm_sel2(negs, -ss, ss);
+}
+
 /* ------------------------------------------------------------------ f64 */
 
 /* natural log, normal positive finite x. fdlibm-style: s = f/(2+f), odd polynomial in s, ~1 ulp. */

@@ -121,6 +121,62 @@ MM_HD void mm_normals2_f64(mm_u32x4 b, double z[2])
     mm_box_muller_f64(mm_u53(b.w[0], b.w[1]), mm_u53(b.w[2], b.w[3]), &z[0], &z[1]);
 }
 
+/* ---- two iterations at a time (f32): lane 0 = (chain, iteration), lane 1 = (chain, iteration + 1) ----
+ * The same functions of (seed, chain, iteration, block) as above, evaluated for two consecutive iterations with the
+ * integer rounds interleaved and the float work packed (mm_math.h, two-lane section). */
+typedef struct {
+    mm_u2 w[4];
+} mm_u32x4x2;
+
+MM_HD mm_u32x4x2 mm_block_pair(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t block)
+{
+    mm_u2 c0 = {(uint32_t)chain, (uint32_t)chain};
+    mm_u2 c1 = {(uint32_t)(chain >> 32), (uint32_t)(chain >> 32)};
+    mm_u2 c2 = {iteration, iteration + 1u};
+    mm_u2 c3 = {block, block};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        mm_ul2 p0 = __builtin_convertvector(c0, mm_ul2) * 0xD2511F53ull;
+        mm_ul2 p1 = __builtin_convertvector(c2, mm_ul2) * 0xCD9E8D57ull;
+        mm_u2 hi0 = __builtin_convertvector(p0 >> 32, mm_u2), lo0 = __builtin_convertvector(p0, mm_u2);
+        mm_u2 hi1 = __builtin_convertvector(p1 >> 32, mm_u2), lo1 = __builtin_convertvector(p1, mm_u2);
+        mm_u2 n0 = hi1 ^ c1 ^ k0;
+        mm_u2 n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    mm_u32x4x2 o;
+    o.w[0] = c0;
+    o.w[1] = c1;
+    o.w[2] = c2;
+    o.w[3] = c3;
+    return o;
+}
+
+MM_HD mm_f2 mm_u24x2(mm_u2 w) { return mm_u2_to_f2((w >> 8) + 1u) * mm_splat2(0x1.0p-24f); }
+
+MM_HD mm_f2 mm_spare_u24x2(mm_u32x4x2 b)
+{
+    mm_u2 s = (b.w[0] & 255u) | ((b.w[1] & 255u) << 8) | ((b.w[2] & 255u) << 16);
+    return mm_u2_to_f2(s + 1u) * mm_splat2(0x1.0p-24f);
+}
+
+MM_HD void mm_box_muller_f32x2(mm_f2 u1, mm_f2 u2, mm_f2 *z0, mm_f2 *z1)
+{
+    mm_f2 r = mm_sqrt2(mm_splat2(-2.0f) * mm_logf2(u1));
+    mm_f2 s, c;
+    mm_sincos2pif2(u2, &s, &c);
+    *z0 = r * c;
+    *z1 = r * s;
+}
+
 /* auxiliary 53-bit uniform k of an iteration (NUTS; f64 accept uniform uses k = 0) */
 MM_HD double mm_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t k)
 {

@@ -60,6 +60,50 @@ template <int D> MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_
     *u = mm_aux_u53(seed, chain, iter, 0);
 }
 
+/* noise of (chain, iter) AND (chain, iter + 1) in one go: za/lna for iter, zb/lnb for iter + 1, ln* = log of the
+ * accept uniform.  f32: both iterations ride in the two lanes of packed instructions; values are bit-identical to
+ * mm_draw_noise + mm_logT.  f64: two scalar evaluations (there is no packed f64 arithmetic to gain from). */
+template <int D>
+MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, float *za, float *lna, float *zb, float *lnb)
+{
+    MM_UNROLL
+    for (int b = 0; b < (D + 3) / 4; ++b) {
+        mm_u32x4x2 blk = mm_block_pair(seed, chain, iter, (uint32_t)b);
+        if (b == 0) {
+            mm_f2 ln = mm_logf2(mm_spare_u24x2(blk));
+            *lna = ln[0];
+            *lnb = ln[1];
+        }
+        mm_f2 z0, z1;
+        mm_box_muller_f32x2(mm_u24x2(blk.w[0]), mm_u24x2(blk.w[1]), &z0, &z1);
+        za[4 * b] = z0[0];
+        zb[4 * b] = z0[1];
+        if (4 * b + 1 < D) {
+            za[4 * b + 1] = z1[0];
+            zb[4 * b + 1] = z1[1];
+        }
+        if (4 * b + 2 < D) {
+            mm_box_muller_f32x2(mm_u24x2(blk.w[2]), mm_u24x2(blk.w[3]), &z0, &z1);
+            za[4 * b + 2] = z0[0];
+            zb[4 * b + 2] = z0[1];
+            if (4 * b + 3 < D) {
+                za[4 * b + 3] = z1[0];
+                zb[4 * b + 3] = z1[1];
+            }
+        }
+    }
+}
+
+template <int D>
+MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, double *za, double *lna, double *zb, double *lnb)
+{
+    double u;
+    mm_draw_noise<D>(seed, chain, iter, za, &u);
+    *lna = mm_log(u);
+    mm_draw_noise<D>(seed, chain, iter + 1u, zb, &u);
+    *lnb = mm_log(u);
+}
+
 /* One Metropolis-Hastings transition with the isotropic Gaussian random-walk proposal, given its noise:
  * z[D] ~ N(0,1) and ln_u = log of the accept uniform.  x[D], lp = logp(x) are updated in place; returns 1 on accept. */
 template <class T, class Tgt>

@@ -115,3 +115,40 @@ def test_mm_math_f64_accuracy(mmath):
         mmath.w_scd(float(u), C.byref(s), C.byref(c))
         err = max(err, abs(s.value - math.sin(2 * math.pi * u)), abs(c.value - math.cos(2 * math.pi * u)))
     assert err < 2e-15  # the libm reference itself rounds 2*pi*u
+
+
+def test_paired_noise_equals_scalar_noise_bit_for_bit(tmp_path):
+    """mm_draw_noise_pair (two iterations in the two lanes of packed arithmetic, Philox counters interleaved) must
+    return exactly mm_draw_noise + mm_logf of each iteration -- compiled here with g++ like the host build."""
+    src = tmp_path / "pair.cpp"
+    src.write_text(r'''
+#include "mm_samplers.h"
+#include <cstdio>
+template <int D> int check(uint64_t seed) {
+  int bad = 0;
+  for (uint64_t chain = 0; chain < 2000; ++chain) for (uint32_t it = 0; it < 8; it += 2) {
+    float za[D], zb[D], la, lb, z1[D], z2[D], u1, u2;
+    mm_draw_noise_pair<D>(seed, chain * 7919u, it, za, &la, zb, &lb);
+    mm_draw_noise<D>(seed, chain * 7919u, it, z1, &u1);
+    mm_draw_noise<D>(seed, chain * 7919u, it + 1, z2, &u2);
+    for (int i = 0; i < D; ++i) bad += (za[i] != z1[i]) + (zb[i] != z2[i]);
+    bad += (la != mm_logf(u1)) + (lb != mm_logf(u2));
+  }
+  return bad;
+}
+int main() {
+  int bad = check<1>(1) + check<2>(42) + check<3>(42) + check<4>(5) + check<5>(6) + check<8>(7) + check<16>(8) + check<32>(9);
+  double za[3], zb[3], la, lb, z1[3], z2[3], u1, u2;
+  mm_draw_noise_pair<3>(42, 5, 10, za, &la, zb, &lb);
+  mm_draw_noise<3>(42, 5, 10, z1, &u1); mm_draw_noise<3>(42, 5, 11, z2, &u2);
+  for (int i = 0; i < 3; ++i) bad += (za[i] != z1[i]) + (zb[i] != z2[i]);
+  bad += (la != mm_log(u1)) + (lb != mm_log(u2));
+  std::printf("%d\n", bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / "pair"
+    subprocess.run(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17", "-I",
+                    os.path.join(ROOT, "mini_mcmc_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout
