@@ -205,7 +205,7 @@ def main() -> None:
             "stats_ms": stats_s * 1e3,
             "roofline": {
                 "kernel": {0: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=0, L=0>",
-                           1: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=1, L=10>",
+                           1: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>",
                            2: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>"}[args.variant],
                 "bound": "hbm",
                 "achieved": achieved,

@@ -178,7 +178,7 @@ int mmcmc_nuts_destroy(mmcmc_nuts *h);
 
 /* knobs shared by the samplers (results never depend on them):
  * iterations per kernel launch (0 = the whole run in one launch, the default);
- * kernel variant: 2 = noise of two iterations packed and pipelined (default), 1 = noise pipelined, 0 = plain */
+ * kernel variant: 2 = noise of two iterations packed and software-pipelined (default), 0 = plain */
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters);
 int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters);
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant);

@@ -130,7 +130,8 @@ struct Sampler {
     uint64_t seed = 0, chain_offset = 0;
     uint64_t iter = 0;
     uint32_t iters_per_launch = 0;
-    int variant = 2; /* mm_run_kernel PIPE: 0 plain, 1 noise of t+1 pipelined, 2 noise of two iterations packed + pipelined */
+    int variant = 2; /* mm_run_kernel PIPE: 0 plain; 2 (default) noise of two iterations packed + pipelined (PIPE = 1,
+                        noise of t+1 pipelined, measured equal to 2 and is no longer instantiated; 1 selects 2) */
     unsigned int block = 64;
     void *d_state = nullptr;
     void *d_mat = nullptr;
@@ -279,12 +280,9 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     unsigned int grid = (unsigned int)((s->n_chains + s->block - 1) / s->block);
     hipError_t e;
     const bool mh = s->sampler == MM_SAMPLER_MH, l10 = s->n_leapfrog == 10;
-    if (s->variant == 2)
+    if (s->variant != 0)
         e = mh ? k->run_mh_pp(a, grid, s->block, stream)
                : (l10 ? k->run_hmc_pp10(a, grid, s->block, stream) : k->run_hmc_pp(a, grid, s->block, stream));
-    else if (s->variant == 1)
-        e = mh ? k->run_mh_sp(a, grid, s->block, stream)
-               : (l10 ? k->run_hmc_sp10(a, grid, s->block, stream) : k->run_hmc_sp(a, grid, s->block, stream));
     else
         e = mh ? k->run_mh(a, grid, s->block, stream) : k->run_hmc(a, grid, s->block, stream);
     if (e != hipSuccess)
@@ -302,7 +300,7 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
         return MMCMC_ERR_STATE;
     if (n_collect + n_discard == 0)
         return MMCMC_OK;
-    if ((uint64_t)n_collect * (uint64_t)s->dim >= (1ull << 32) || s->iter + n_collect + n_discard >= (1ull << 32))
+    if ((uint64_t)n_collect * (uint64_t)s->dim >= (1ull << 30) || s->iter + n_collect + n_discard >= (1ull << 32))
         return MMCMC_ERR_SHAPE;
     DeviceGuard g(s->device);
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : s->stream;

@@ -74,21 +74,58 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
 {
     using Tile = mm_tile<T, D>;
     constexpr int TILE_T = Tile::tile_t, RUN = Tile::run, STRIDE = Tile::stride;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    /* LDS operations of one wave execute in order, so the reads below see the rows staged by all 64 lanes and the
+     * next tile's writes cannot overtake them: only the compiler has to keep program order (wave_barrier). */
     __builtin_amdgcn_wave_barrier();
     /* wave-uniform base of this tile in `out`; a chain's rows are chain_stride elements apart
      * (host guarantees n_total * D < 2^32, so j * chain_stride is one v_mad_u64_u32) */
     const unsigned int chain_stride = (unsigned int)(n_total * D);
     T *const wbase = out + (wave_c0 * n_total + row0) * D;
     const unsigned int n_valid = (unsigned int)min(64ull, n_chains > wave_c0 ? n_chains - wave_c0 : 0ull);
-    if (nt == (unsigned int)TILE_T) {
+    constexpr int EPL = 16 / (int)sizeof(T); /* elements per 16-byte store: 4 (f32) or 2 (f64) */
+    if (nt == (unsigned int)TILE_T && (RUN % EPL) == 0) {
+        /* Full tile.  A wave's store instructions are issue-bound (~100 cycles each, whatever their width), so the
+         * tile leaves as 16-byte stores: the chain-linear image is cut into 16-byte pieces, piece p = k*64 + lane
+         * belongs to chain p / V at element EPL * (p % V) (V = RUN / EPL pieces per chain, compile-time divisor).
+         * 64 chains x RUN elements = V store instructions instead of RUN. */
+        typedef T mm_vec16 __attribute__((ext_vector_type(EPL), aligned(sizeof(T))));
+        constexpr int V = RUN / EPL;
+        const bool full = n_valid == 64u;
 #pragma unroll 4
-        for (int k = 0; k < RUN; ++k) {
-            const int idx = k * 64 + lane;
-            const int j = idx / RUN; /* compile-time divisor */
-            const int e = idx - j * RUN;
-            if ((unsigned int)j < n_valid)
-                wbase[(unsigned long long)j * chain_stride + e] = tile[j * STRIDE + e];
+        for (int k = 0; k < V; ++k) {
+            const int piece = k * 64 + lane;
+            const int j = piece / V;
+            const int e = (piece - j * V) * EPL;
+            const T *src = tile + j * STRIDE + e;
+            mm_vec16 v;
+            MM_UNROLL
+            for (int i = 0; i < EPL; ++i)
+                v[i] = src[i];
+            if (full || (unsigned int)j < n_valid)
+                *reinterpret_cast<mm_vec16 *>(wbase + (unsigned long long)j * chain_stride + e) = v;
+        }
+    } else if (nt == (unsigned int)TILE_T) {
+        /* full tile, generic RUN: RUN whole-wave stores of 64 consecutive elements of the chain-linear image */
+        constexpr int G = 8;
+        const bool full = n_valid == 64u;
+#pragma unroll 1
+        for (int k0 = 0; k0 < RUN; k0 += G) {
+            T v[G];
+            unsigned long long off[G];
+            bool ok[G];
+            MM_UNROLL
+            for (int gi = 0; gi < G; ++gi) {
+                const int idx = (k0 + gi) * 64 + lane;
+                const int j = idx / RUN; /* compile-time divisor */
+                const int e = idx - j * RUN;
+                ok[gi] = (k0 + gi < RUN) && (full || (unsigned int)j < n_valid);
+                v[gi] = tile[(k0 + gi < RUN) ? j * STRIDE + e : 0];
+                off[gi] = (unsigned long long)j * chain_stride + e;
+            }
+            MM_UNROLL
+            for (int gi = 0; gi < G; ++gi)
+                if (ok[gi])
+                    wbase[off[gi]] = v[gi];
         }
     } else {
         const int runv = (int)nt * D;
@@ -96,7 +133,6 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
             for (int e = lane; e < runv; e += 64)
                 wbase[(unsigned long long)j * chain_stride + e] = tile[j * STRIDE + e];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -175,6 +211,9 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         T za[D], zb[D], lna, lnb;
         mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb);
         unsigned int tcol = 0, rows_out = 0;
+        /* (Staggering the waves' flush phases was measured and bought nothing: the output path is bound by the
+         * issue of store instructions per wave, not by HBM bursts -- see mm_flush_tile_raw.) */
+        const unsigned int cap = (unsigned int)TILE_T;
         auto transition = [&](T *z, T ln_u, unsigned int t) {
             int acc;
             if (SAMPLER == MM_SAMPLER_HMC)
@@ -189,7 +228,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
                 for (int i = 0; i < D; ++i)
                     tile[lane * STRIDE + tcol * D + i] = x[i];
                 ++tcol;
-                if (tcol == (unsigned int)TILE_T || t + 1 == total) {
+                if (tcol == cap || t + 1 == total) {
                     mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, tcol);
                     rows_out += tcol;
                     tcol = 0;
@@ -214,21 +253,22 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
     } else {
         for (unsigned int i = 0; i < a.n_discard; ++i)
             step();
-
-        for (unsigned int t0 = 0; t0 < a.n_collect; t0 += TILE_T) {
-            const unsigned int nt = min((unsigned int)TILE_T, a.n_collect - t0);
-            for (unsigned int tt = 0; tt < nt; ++tt) {
-                step();
-                if (a.out) {
-                    MM_UNROLL
-                    for (int i = 0; i < D; ++i)
-                        tile[lane * STRIDE + tt * D + i] = x[i];
+        unsigned int tcol = 0, rows_out = 0;
+        const unsigned int cap = (unsigned int)TILE_T;
+        for (unsigned int t = 0; t < a.n_collect; ++t) {
+            step();
+            if (a.out) {
+                MM_UNROLL
+                for (int i = 0; i < D; ++i)
+                    tile[lane * STRIDE + tcol * D + i] = x[i];
+                ++tcol;
+                if (tcol == cap || t + 1 == a.n_collect) {
+                    mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, tcol);
+                    rows_out += tcol;
+                    tcol = 0;
                 }
             }
-            if (a.out)
-                mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + t0, nt);
         }
-
     }
 
     if (active) {
@@ -314,9 +354,6 @@ template <class T> struct mm_kernel_entry {
     int kind, dim;
     hipError_t (*run_mh)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);
     hipError_t (*run_hmc)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);
-    hipError_t (*run_mh_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* PIPE = 1 */
-    hipError_t (*run_hmc_sp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 1 */
-    hipError_t (*run_hmc_sp10)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 1, L = 10 */
     hipError_t (*run_mh_pp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t);  /* PIPE = 2 */
     hipError_t (*run_hmc_pp)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 2 */
     hipError_t (*run_hmc_pp10)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 2, L = 10 */

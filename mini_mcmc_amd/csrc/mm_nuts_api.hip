@@ -145,7 +145,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream_v) override
     {
-        if ((uint64_t)n_collect * (uint64_t)dim >= (1ull << 32) || (uint64_t)m + n_collect + n_discard >= (1ull << 32))
+        if ((uint64_t)n_collect * (uint64_t)dim >= (1ull << 30) || (uint64_t)m + n_collect + n_discard >= (1ull << 32))
             return MMCMC_ERR_SHAPE;
         DevGuard g(device);
         hipStream_t st = stream_v ? (hipStream_t)stream_v : stream;

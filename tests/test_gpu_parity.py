@@ -171,7 +171,7 @@ def test_results_independent_of_launch_partition_and_sharding(M, O):
 
 
 def test_kernel_variants_agree_bit_for_bit(M, O):
-    # variant 1 (producer/consumer waves, the default) and variant 0 (one wave per 64 chains) compute the same
+    # variant 2 (noise of two iterations packed + software-pipelined, the default) and variant 0 (plain) compute the same
     # pure function of (seed, chain, iteration): every output must be identical, including ragged tails
     rng = np.random.default_rng(9)
     A = rng.standard_normal((16, 16))
@@ -188,7 +188,7 @@ def test_kernel_variants_agree_bit_for_bit(M, O):
         for sampler, tgt, scale, L, C, nc, nd in cases:
             init = M.core.init_with_seed(C, tgt.dim, 21, dtype)
             outs = []
-            for variant in (0, 1, 2):
+            for variant in (0, 2):
                 if sampler == "mh":
                     s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(scale), init).seed(77)
                 else:

@@ -1,0 +1,21 @@
+"""One configuration per process, for rocprofv3 --pmc passes: python3 tools/pmc_probe.py {hmc|mh} {collect|nocollect} [variant]"""
+import sys, os, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mini_mcmc_amd.core import init_with_seed
+from mini_mcmc_amd.distributions import Gaussian2D, IsotropicGaussian, RosenbrockND
+from mini_mcmc_amd.hmc import HMC
+from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+what, mode = sys.argv[1], sys.argv[2]
+variant = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+C = 65536
+if what == "hmc":
+    s = HMC(RosenbrockND(3), init_with_seed(C, 3, 42, np.float32), 0.032, 10).set_seed(42).set_kernel_variant(variant)
+    nc, nd = (400, 50) if mode == "collect" else (0, 450)
+else:
+    s = MetropolisHastings(Gaussian2D([0, 0], [[1, 0], [0, 1]]), IsotropicGaussian(1.0), init_with_seed(C, 2, 42, np.float32)).seed(42).set_kernel_variant(variant)
+    nc, nd = (1000, 100) if mode == "collect" else (0, 1100)
+for _ in range(3):
+    s.run(nc, nd, to="torch", accept_counts=False, collect=(mode == "collect"))
+torch.cuda.synchronize()
+print(what, mode, s.timing())
