@@ -1,0 +1,258 @@
+/*
+ * mmcmc.hpp -- header-only C++17 facade over the C ABI (mmcmc.h), shaped like the reference crate's surface.
+ *
+ * The reference is Rust; with no Rust toolchain in this image the host side above the C ABI is C++ (this file) and
+ * Python (mini_mcmc_amd/).  Names, argument meaning and error behaviour follow the crate:
+ *     mini_mcmc::core::{init_det, init_with_seed}              core.rs:394-435
+ *     mini_mcmc::distributions::{Gaussian2D, DiffableGaussian2D, IsotropicGaussian, Rosenbrock2D, RosenbrockND}
+ *     mini_mcmc::metropolis_hastings::MetropolisHastings::{new, seed} + ChainRunner::run   (core.rs:176-186)
+ *     mini_mcmc::hmc::HMC::{new, set_seed, run, step}          hmc.rs:87-158, 304-377
+ *     mini_mcmc::nuts::NUTS::{new, set_seed, run}              nuts.rs:123-170, 347-353
+ *     mini_mcmc::stats::{split_rhat_mean_ess, RunStats}        stats.rs:339-423
+ * Samples come back as a flat row-major std::vector with shape [n_chains, n_collect, dim] (Array3 / Tensor<B,3>).
+ * Rust's `Result<_, ShapeError>` / panics become the exception mmcmc::Error carrying the C status.
+ */
+#ifndef MMCMC_HPP
+#define MMCMC_HPP
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "mmcmc.h"
+
+namespace mmcmc {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string &where)
+        : std::runtime_error(where + ": " + mmcmc_status_string(st) + " (" + std::to_string(st) + ")"), status(st)
+    {
+    }
+};
+inline void check(int st, const char *where)
+{
+    if (st != MMCMC_OK)
+        throw Error(st, where);
+}
+
+template <class T> constexpr int dtype_of()
+{
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "f32 or f64");
+    return std::is_same<T, float>::value ? MMCMC_F32 : MMCMC_F64;
+}
+
+/* core.rs:413-419 / :404-409 : row-major [n, d] */
+template <class T> std::vector<T> init_with_seed(size_t n, size_t d, uint64_t seed)
+{
+    std::vector<double> tmp(n * d);
+    check(mmcmc_init_with_seed(n, d, seed, tmp.data()), "mmcmc_init_with_seed");
+    return std::vector<T>(tmp.begin(), tmp.end());
+}
+template <class T> std::vector<T> init_det(size_t n, size_t d) { return init_with_seed<T>(n, d, 42); }
+
+/* ---- distributions ---- */
+struct Target {
+    mmcmc_target_desc d{};
+    std::vector<double> matrix;
+    const mmcmc_target_desc *desc()
+    {
+        d.matrix = matrix.empty() ? nullptr : matrix.data();
+        return &d;
+    }
+};
+inline Target Gaussian2D(std::array<double, 2> mean, std::array<std::array<double, 2>, 2> cov, bool diffable = false)
+{
+    Target t;
+    t.d.kind = diffable ? MMCMC_DIFFABLE_GAUSSIAN2D : MMCMC_GAUSSIAN2D;
+    t.d.dim = 2;
+    t.d.params[0] = mean[0];
+    t.d.params[1] = mean[1];
+    t.d.params[2] = cov[0][0];
+    t.d.params[3] = cov[0][1];
+    t.d.params[4] = cov[1][0];
+    t.d.params[5] = cov[1][1];
+    return t;
+}
+inline Target DiffableGaussian2D(std::array<double, 2> mean, std::array<std::array<double, 2>, 2> cov)
+{
+    return Gaussian2D(mean, cov, true);
+}
+inline Target Rosenbrock2D(double a, double b)
+{
+    Target t;
+    t.d.kind = MMCMC_ROSENBROCK2D;
+    t.d.dim = 2;
+    t.d.params[0] = a;
+    t.d.params[1] = b;
+    return t;
+}
+inline Target RosenbrockND(int dim)
+{
+    Target t;
+    t.d.kind = MMCMC_ROSENBROCK_ND;
+    t.d.dim = dim;
+    return t;
+}
+inline Target StandardNormal(int dim)
+{
+    Target t;
+    t.d.kind = MMCMC_STANDARD_NORMAL;
+    t.d.dim = dim;
+    return t;
+}
+inline Target GaussianND(int dim, std::vector<double> precision)
+{
+    Target t;
+    t.d.kind = MMCMC_GAUSSIAN_ND;
+    t.d.dim = dim;
+    t.matrix = std::move(precision);
+    return t;
+}
+struct IsotropicGaussian {
+    double std;
+    explicit IsotropicGaussian(double s) : std(s) {}
+    IsotropicGaussian set_seed(uint64_t) const { return *this; } /* the engine's stream is keyed by the sampler */
+    Target as_target(int dim) const
+    {
+        Target t;
+        t.d.kind = MMCMC_ISOTROPIC_GAUSSIAN;
+        t.d.dim = dim;
+        t.d.params[0] = std;
+        return t;
+    }
+};
+
+/* ---- stats ---- */
+struct RunStats {
+    mmcmc_run_stats s{};
+};
+inline std::pair<std::vector<float>, std::vector<float>> split_rhat_mean_ess(const std::vector<float> &sample,
+                                                                              size_t chains, size_t n, size_t dim,
+                                                                              int device = 0)
+{
+    std::vector<float> rhat(dim), ess(dim);
+    check(mmcmc_split_rhat_mean_ess(sample.data(), 0, MMCMC_F32, chains, n, dim, rhat.data(), ess.data(), device,
+                                    nullptr),
+          "mmcmc_split_rhat_mean_ess");
+    return {rhat, ess};
+}
+
+/* ---- MetropolisHastings<T> ---- */
+template <class T> class MetropolisHastings {
+    mmcmc_mh *h_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    /* MetropolisHastings::new(target, proposal, initial_states); initial_states row-major [n_chains, dim] */
+    MetropolisHastings(Target target, IsotropicGaussian proposal, const std::vector<T> &initial_states, size_t n_chains,
+                       int device = 0)
+        : n_chains_(n_chains), dim_(initial_states.size() / n_chains)
+    {
+        mmcmc_proposal_desc p{MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN, 0, proposal.std};
+        check(mmcmc_mh_create(&h_, target.desc(), &p, initial_states.data(), n_chains, dtype_of<T>(), device),
+              "mmcmc_mh_create");
+    }
+    MetropolisHastings(const MetropolisHastings &) = delete;
+    MetropolisHastings &operator=(const MetropolisHastings &) = delete;
+    ~MetropolisHastings() { mmcmc_mh_destroy(h_); }
+    MetropolisHastings &seed(uint64_t s)
+    {
+        check(mmcmc_mh_seed(h_, s), "mmcmc_mh_seed");
+        return *this;
+    }
+    /* ChainRunner::run -> [n_chains, n_collect, dim] */
+    std::vector<T> run(size_t n_collect, size_t n_discard, std::vector<uint64_t> *accept_counts = nullptr)
+    {
+        std::vector<T> out(n_chains_ * n_collect * dim_);
+        if (accept_counts)
+            accept_counts->assign(n_chains_, 0);
+        check(mmcmc_mh_run(h_, n_collect, n_discard, out.data(), 0, accept_counts ? accept_counts->data() : nullptr,
+                           nullptr),
+              "mmcmc_mh_run");
+        check(mmcmc_mh_sync(h_), "mmcmc_mh_sync");
+        return out;
+    }
+    size_t n_chains() const { return n_chains_; }
+    size_t dim() const { return dim_; }
+};
+
+/* ---- HMC<T> ---- */
+template <class T> class HMC {
+    mmcmc_hmc *h_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    HMC(Target target, const std::vector<T> &initial_positions, size_t n_chains, T step_size, int n_leapfrog,
+        int device = 0)
+        : n_chains_(n_chains), dim_(initial_positions.size() / n_chains)
+    {
+        check(mmcmc_hmc_create(&h_, target.desc(), initial_positions.data(), n_chains, (double)step_size, n_leapfrog,
+                               dtype_of<T>(), device),
+              "mmcmc_hmc_create");
+    }
+    HMC(const HMC &) = delete;
+    HMC &operator=(const HMC &) = delete;
+    ~HMC() { mmcmc_hmc_destroy(h_); }
+    HMC &set_seed(uint64_t s)
+    {
+        check(mmcmc_hmc_seed(h_, s), "mmcmc_hmc_seed");
+        return *this;
+    }
+    std::vector<T> run(size_t n_collect, size_t n_discard)
+    {
+        std::vector<T> out(n_chains_ * n_collect * dim_);
+        check(mmcmc_hmc_run(h_, n_collect, n_discard, out.data(), 0, nullptr, nullptr), "mmcmc_hmc_run");
+        check(mmcmc_hmc_sync(h_), "mmcmc_hmc_sync");
+        return out;
+    }
+    void step()
+    {
+        check(mmcmc_hmc_step(h_, nullptr), "mmcmc_hmc_step");
+        check(mmcmc_hmc_sync(h_), "mmcmc_hmc_sync");
+    }
+    std::vector<T> positions()
+    {
+        std::vector<T> out(n_chains_ * dim_);
+        check(mmcmc_hmc_state(h_, out.data()), "mmcmc_hmc_state");
+        return out;
+    }
+};
+
+/* ---- NUTS: tensors f32, scalars T (mode 0 for T = double, 1 for T = float), like the reference backend ---- */
+template <class T> class NUTS {
+    mmcmc_nuts *h_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    NUTS(Target target, const std::vector<T> &initial_positions, size_t n_chains, T target_accept_p, int device = 0)
+        : n_chains_(n_chains), dim_(initial_positions.size() / n_chains)
+    {
+        std::vector<double> init(initial_positions.begin(), initial_positions.end());
+        check(mmcmc_nuts_create(&h_, target.desc(), init.data(), n_chains, (double)target_accept_p,
+                                std::is_same<T, double>::value ? 0 : 1, device),
+              "mmcmc_nuts_create");
+    }
+    NUTS(const NUTS &) = delete;
+    NUTS &operator=(const NUTS &) = delete;
+    ~NUTS() { mmcmc_nuts_destroy(h_); }
+    NUTS &set_seed(uint64_t s)
+    {
+        check(mmcmc_nuts_seed(h_, s), "mmcmc_nuts_seed");
+        return *this;
+    }
+    /* NUTS::run -> [n_chains, n_collect, dim] (f32, the backend's element type) */
+    std::vector<float> run(size_t n_collect, size_t n_discard)
+    {
+        std::vector<float> out(n_chains_ * n_collect * dim_);
+        check(mmcmc_nuts_run(h_, n_collect, n_discard, out.data(), 0, 0, nullptr), "mmcmc_nuts_run");
+        check(mmcmc_nuts_sync(h_), "mmcmc_nuts_sync");
+        return out;
+    }
+};
+
+} // namespace mmcmc
+#endif /* MMCMC_HPP */

@@ -126,18 +126,39 @@ __global__ __launch_bounds__(64) void mm_half_chain_kernel(const T *__restrict__
         slab[i] = acc[i];
 }
 
-/* out[lag, d] = sum over waves of slabs[w, d, lag] (fixed order) */
-__global__ void mm_slab_reduce_kernel(const float *__restrict__ slabs, unsigned int n_slabs, unsigned int D,
-                                      unsigned int m, float *__restrict__ out)
+/* out[lag, d] = sum over waves of slabs[w, d, lag].  One wave per group of 64 outputs would serialise n_slabs loads;
+ * instead a 256-thread block owns 64 consecutive outputs, its four waves each sum a quarter of the slabs (coalesced
+ * 256-byte rows), and the four partial sums are combined in a fixed order -- bitwise reproducible, no atomics. */
+__global__ __launch_bounds__(256) void mm_slab_reduce_kernel(const float *__restrict__ slabs, unsigned int n_slabs,
+                                                             unsigned int D, unsigned int m, float *__restrict__ out)
 {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; /* over d * m + lag */
-    if (i >= D * m)
-        return;
+    __shared__ float part[4][64];
+    const unsigned int lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const unsigned int i = blockIdx.x * 64u + lane; /* over d * m + lag */
+    const unsigned int total = D * m;
     float s = 0.f;
-    for (unsigned int w = 0; w < n_slabs; ++w)
-        s += slabs[(size_t)w * D * m + i];
-    const unsigned int d = i / m, lag = i - d * m;
-    out[(size_t)lag * D + d] = s;
+    if (i < total) {
+        const unsigned int per = (n_slabs + 3u) / 4u;
+        const unsigned int lo = w * per, hi = min(n_slabs, lo + per);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        unsigned int k = lo;
+        for (; k + 3 < hi; k += 4) {
+            s0 += slabs[(size_t)k * total + i];
+            s1 += slabs[(size_t)(k + 1) * total + i];
+            s2 += slabs[(size_t)(k + 2) * total + i];
+            s3 += slabs[(size_t)(k + 3) * total + i];
+        }
+        for (; k < hi; ++k)
+            s0 += slabs[(size_t)k * total + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < total) {
+        const float r = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        const unsigned int d = i / m, lag = i - d * m;
+        out[(size_t)lag * D + d] = r;
+    }
 }
 
 int check_device(int device)
@@ -208,7 +229,7 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
                            (unsigned int)m, m_pad, means, ssq, slabs);
     MM_HIP(hipGetLastError());
     const unsigned int total = (unsigned int)(dim * m);
-    hipLaunchKernelGGL(mm_slab_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, slabs, n_slabs,
+    hipLaunchKernelGGL(mm_slab_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, slabs, n_slabs,
                        (unsigned int)dim, (unsigned int)m, acov_sum);
     MM_HIP(hipGetLastError());
     MM_HIP(hipFreeAsync(slabs, stream));

