@@ -204,6 +204,11 @@ int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out
 int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,
                     mmcmc_run_stats *out, int device, void *stream);
 
+/* ---- sample sink: io/csv.rs:47-69 save_csv -- header `chain,observation,dim_0,...`, one record per (chain,
+ *      observation), values in Rust `Display` formatting (shortest round-trip, no exponent).  sample: HOST
+ *      [n_chains, n, dim] of dtype. */
+int mmcmc_save_csv(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, const char *filename);
+
 /* ---- densities, for parity tests ---------------------------------------------------------------------
  * BatchedGradientTarget::unnorm_logp_batch (distributions.rs:65-76) / unnorm_logp_and_grad (:81-87)
  * x: host [n, dim]; logp: host [n]; grad: host [n, dim] or NULL; all of `dtype` */

@@ -150,6 +150,59 @@ template <class T, int D> struct mm_target<T, MM_ROSENBROCK_ND, D> {
     }
 };
 
+/* f32 RosenbrockND gradient with coordinates processed in pairs (v_pk_*_f32 on the device): every element goes
+ * through the same operations as in the generic template above -- 2(1 - x) is formed as fma(-2, x, 2), which is the
+ * same number because scaling by two commutes with rounding -- so the results are bit-identical to it; the packed
+ * form just issues ~4 fewer instructions per leapfrog step at D = 3 (the kernels are instruction-issue bound). */
+template <int D> struct mm_target<float, MM_ROSENBROCK_ND, D> {
+    static constexpr int dim = D;
+    MM_HD static float logp(const mm_tparams<float> &, const float *x)
+    {
+        float acc = 0;
+        MM_UNROLL
+        for (int i = 0; i + 1 < D; ++i) {
+            float t = fmaf(-x[i], x[i], x[i + 1]);
+            float u = 1.0f - x[i];
+            acc = fmaf(100.0f * t, t, acc);
+            acc = fmaf(u, u, acc);
+        }
+        return -acc;
+    }
+    MM_HD static float logp_grad(const mm_tparams<float> &, const float *x, float *g)
+    {
+        float t[D > 1 ? D - 1 : 1];
+        float acc = 0;
+        MM_UNROLL
+        for (int i = 0; i + 1 < D; ++i) {
+            t[i] = fmaf(-x[i], x[i], x[i + 1]);
+            float u = 1.0f - x[i];
+            acc = fmaf(100.0f * t[i], t[i], acc);
+            acc = fmaf(u, u, acc);
+        }
+        /* a_i = fma(400 x_i, t_i, 2 - 2 x_i) for i < D-1, two coordinates per packed instruction */
+        MM_UNROLL
+        for (int i = 0; i + 1 < D; i += 2) {
+            if (i + 2 < D) {
+                mm_f2 xx = {x[i], x[i + 1]};
+                mm_f2 tt = {t[i], t[i + 1]};
+                mm_f2 u2 = mm_fma2(mm_splat2(-2.0f), xx, mm_splat2(2.0f));
+                mm_f2 a = mm_fma2(xx * mm_splat2(400.0f), tt, u2);
+                g[i] = (i > 0) ? fmaf(-200.0f, t[i - 1], a[0]) : a[0];
+                g[i + 1] = fmaf(-200.0f, t[i], a[1]);
+            } else {
+                float u2 = fmaf(-2.0f, x[i], 2.0f);
+                float a = fmaf(400.0f * x[i], t[i], u2);
+                g[i] = (i > 0) ? fmaf(-200.0f, t[i - 1], a) : a;
+            }
+        }
+        if (D >= 2)
+            g[D - 1] = -200.0f * t[D - 2];
+        else
+            g[0] = 0;
+        return -acc;
+    }
+};
+
 /* StandardNormal: -1/2 sum(x^2) */
 template <class T, int D> struct mm_target<T, MM_STANDARD_NORMAL, D> {
     static constexpr int dim = D;
