@@ -159,6 +159,15 @@ int mmcmc_nuts_set_chain_offset(mmcmc_nuts *h, uint64_t chain_offset);
 /* maximum tree depth (doublings per transition), 1..12, default 10.  The reference's `while s` (nuts.rs:578) is
  * unbounded; a lane that never terminates would stall its whole wave, so the engine caps it. */
 int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
+/* Kernel mapping (not in the reference).  0 = one chain per lane (every target / mode).  1 = lane-group mapping with
+ * the gradient on the matrix cores: 16 chains per wave, four lanes per chain, v_mfma_f64_16x16x4 for A x -- exists
+ * for mode 2 + MMCMC_GAUSSIAN_ND with dim 16 or 32 (BASELINE.json config 5), where it is the default; elsewhere
+ * setting 1 returns MMCMC_ERR_UNSUPPORTED.  The two mappings sum the D-term dot products in a different order
+ * (sequential vs four interleaved partial sums), so their samples differ in the last bits and, over long trajectories
+ * of a stiff target, visibly; each is bit-exact against its own host build (oracle/engine_host.cpp modes 2 and 3).
+ * mmcmc_nuts_kernel_variant returns the mapping in use (>= 0) or a negative status. */
+int mmcmc_nuts_set_kernel_variant(mmcmc_nuts *h, int variant);
+int mmcmc_nuts_kernel_variant(mmcmc_nuts *h);
 /* progress = 0: NUTS::run -> NUTSChain::run (nuts.rs:163-170, 457-471): n_collect + n_discard - 1 transitions, and
  *               with n_discard == 0 row 0 is the initial position (the reference's off-by-one, test_chain_1);
  * progress = 1: the stepping of run_progress (nuts.rs:491-522): all n_collect + n_discard transitions.

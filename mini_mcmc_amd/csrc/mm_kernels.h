@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
 {
     constexpr int D = Tgt::dim;
     using Tile = mm_tile<T, D>;
-    constexpr int TILE_T = Tile::tile_t, RUN = Tile::run, STRIDE = Tile::stride;
+    constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride;
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
     T *lds = reinterpret_cast<T *>(mm_lds_raw);
 

@@ -54,6 +54,58 @@ MM_HD double mm_minT(double a, double b) { return fmin(a, b); }
 MM_HD bool mm_is_real(float x) { return x == x && x != INFINITY && x != -INFINITY; }
 MM_HD bool mm_is_real(double x) { return x == x && x != (double)INFINITY && x != -(double)INFINITY; }
 
+/* Order of the D-term dot products inside a transition.
+ *   mm_red_seq : one fma chain over i = 0..D-1 (what one lane per chain does).
+ *   mm_red_grp4: four interleaved chains -- chain q sums the terms i = q (mod 4) in ascending order -- combined as
+ *                (c0 + c1) + (c2 + c3).  This is the order the lane-group kernel (mm_nuts_lg.h: four lanes per chain,
+ *                lane q owning the coordinates i = q mod 4, butterfly over the four lanes) produces, so the host build
+ *                of mm_nuts_step with this policy is its bit-exact twin. */
+template <class TT, int D> struct mm_red_seq {
+    MM_HD static TT dot(const TT *a, const TT *b)
+    {
+        TT s = 0;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            s = mm_fma(a[i], b[i], s);
+        return s;
+    }
+};
+template <class TT, int D> struct mm_red_grp4 {
+    MM_HD static TT dot(const TT *a, const TT *b)
+    {
+        TT c[4] = {0, 0, 0, 0};
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            c[i & 3] = mm_fma(a[i], b[i], c[i & 3]);
+        return (c[0] + c[1]) + (c[2] + c[3]);
+    }
+};
+
+/* GaussianND with the grouped reduction for x.y (the matrix-vector product itself stays the in-order fma chain over
+ * the columns, which is exactly what v_mfma_f64_16x16x4_f64 computes -- tools/mfma_f64_check.hip). */
+template <class T, int D> struct mm_target_gnd_grp4 {
+    static constexpr int dim = D;
+    MM_HD static T logp_grad(const mm_tparams<T> &P, const T *x, T *g)
+    {
+        T y[D];
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            T acc = 0;
+            MM_UNROLL
+            for (int j = 0; j < D; ++j)
+                acc = mm_fma(P.mat[i * D + j], x[j], acc);
+            y[i] = acc;
+            g[i] = -acc;
+        }
+        return T(-0.5) * mm_red_grp4<T, D>::dot(x, y);
+    }
+    MM_HD static T logp(const mm_tparams<T> &P, const T *x)
+    {
+        T g[D];
+        return logp_grad(P, x, g);
+    }
+};
+
 /* momentum draw: z[0..D) of (chain, iteration) in the element type's schedule (mm_rng.h) */
 template <int D> MM_HD void mm_nuts_momentum(uint64_t seed, uint64_t chain, uint32_t iter, float *z)
 {
@@ -103,31 +155,19 @@ template <class TT, class Tgt> MM_HD TT mm_nuts_leapfrog(const mm_tparams<TT> &P
     return lp;
 }
 
-template <class TT, int D> MM_HD TT mm_sumsq(const TT *a)
-{
-    TT s = 0;
-    MM_UNROLL
-    for (int i = 0; i < D; ++i)
-        s = mm_fma(a[i], a[i], s);
-    return s;
-}
-
 /* nuts.rs:963-977 */
-template <class TT, int D>
+template <class TT, int D, class Red>
 MM_HD bool mm_stop_criterion(const TT *x_minus, const TT *x_plus, const TT *p_minus, const TT *p_plus)
 {
-    TT dm = 0, dp = 0;
+    TT diff[D];
     MM_UNROLL
-    for (int i = 0; i < D; ++i) {
-        TT diff = x_plus[i] - x_minus[i];
-        dm = mm_fma(diff, p_minus[i], dm);
-        dp = mm_fma(diff, p_plus[i], dp);
-    }
-    return dm >= TT(0) && dp >= TT(0);
+    for (int i = 0; i < D; ++i)
+        diff[i] = x_plus[i] - x_minus[i];
+    return Red::dot(diff, p_minus) >= TT(0) && Red::dot(diff, p_plus) >= TT(0);
 }
 
 /* nuts.rs:695-761 */
-template <class TT, class ST, class Tgt>
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
 MM_HD ST mm_find_reasonable_epsilon(const mm_tparams<TT> &P, const TT *position, const TT *mom)
 {
     constexpr int D = Tgt::dim;
@@ -135,7 +175,7 @@ MM_HD ST mm_find_reasonable_epsilon(const mm_tparams<TT> &P, const TT *position,
     const ST half = ST(0.5);
     TT g0[D], x[D], p[D], g[D];
     const TT ulogp = Tgt::logp_grad(P, position, g0);
-    const TT mom_sq = mm_sumsq<TT, D>(mom);
+    const TT mom_sq = Red::dot(mom, mom);
     auto leap = [&](ST e) -> TT {
         MM_UNROLL
         for (int i = 0; i < D; ++i) {
@@ -156,20 +196,20 @@ MM_HD ST mm_find_reasonable_epsilon(const mm_tparams<TT> &P, const TT *position,
         ulogp_p = leap(epsilon * k);
     }
     epsilon = half * k * epsilon;
-    ST lap = (ST)(double)(ulogp_p - ulogp - (mm_sumsq<TT, D>(p) - mom_sq) * TT(0.5));
+    ST lap = (ST)(double)(ulogp_p - ulogp - (Red::dot(p, p) - mom_sq) * TT(0.5));
     const ST a = (lap > mm_logT(half)) ? ST(1) : ST(-1);
     const ST ln2 = mm_logT(ST(2));
     while (a * lap > -a * ln2) {
         epsilon = (a > ST(0)) ? epsilon * ST(2) : epsilon * half; /* epsilon * 2^a */
         ulogp_p = leap(epsilon);
-        lap = (ST)(double)(ulogp_p - ulogp - (mm_sumsq<TT, D>(p) - mom_sq) * TT(0.5));
+        lap = (ST)(double)(ulogp_p - ulogp - (Red::dot(p, p) - mom_sq) * TT(0.5));
     }
     return epsilon;
 }
 
 /* nuts.rs:528-545 init_chain, without the sample bookkeeping: always draws D normals (iteration 0 of the stream);
  * searches epsilon iff it is still the sentinel -1; mu = ln(10 epsilon). */
-template <class TT, class ST, class Tgt>
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
 MM_HD void mm_nuts_init_chain(const mm_tparams<TT> &P, const TT *position, mm_nuts_adapt<ST> *ad, ST eps_tol,
                               uint64_t seed, uint64_t chain)
 {
@@ -178,7 +218,7 @@ MM_HD void mm_nuts_init_chain(const mm_tparams<TT> &P, const TT *position, mm_nu
     mm_nuts_momentum<D>(seed, chain, 0u, mom0);
     ST d = ad->epsilon + ST(1);
     if ((d < 0 ? -d : d) <= eps_tol)
-        ad->epsilon = mm_find_reasonable_epsilon<TT, ST, Tgt>(P, position, mom0);
+        ad->epsilon = mm_find_reasonable_epsilon<TT, ST, Tgt, Red>(P, position, mom0);
     ad->mu = mm_logT(ST(10) * ad->epsilon);
 }
 
@@ -189,7 +229,7 @@ struct mm_nuts_info {
 };
 
 /* nuts.rs:550-691.  x[D] is updated in place; m is the 1-based global step count (self.m after the increment). */
-template <class TT, class ST, class Tgt>
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
 MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST> *ad, uint32_t m, uint32_t n_discard,
                                 ST target_accept_p, int max_depth, uint64_t seed, uint64_t chain,
                                 const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
@@ -201,7 +241,7 @@ MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST
     TT mom0[D], grad[D];
     mm_nuts_momentum<D>(seed, chain, m, mom0);
     const TT ulogp = Tgt::logp_grad(P, x, grad);
-    const ST joint = (ST)(double)(ulogp - mm_sumsq<TT, D>(mom0) * TT(0.5));
+    const ST joint = (ST)(double)(ulogp - Red::dot(mom0, mom0) * TT(0.5));
     const ST exp1_obs = (ST)(-mm_log(aux())); /* Exp(1) by inversion of the first auxiliary uniform */
     const ST logu = joint - exp1_obs;
 
@@ -241,7 +281,7 @@ MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST
         for (uint32_t leaf = 0; leaf < n_leaves; ++leaf) {
             const TT lp = mm_nuts_leapfrog<TT, Tgt>(P, cx, cp, cg, eps_signed);
             info.n_leapfrog += 1;
-            const ST jointp = (ST)(double)(lp - mm_sumsq<TT, D>(cp) * TT(0.5));
+            const ST jointp = (ST)(double)(lp - Red::dot(cp, cp) * TT(0.5));
             S_level = 0;
             S_n = (logu < jointp) ? 1u : 0u;
             S_s = (logu - ST(1000)) < jointp;
@@ -275,8 +315,8 @@ MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST
                             S_prime[i] = stk.v(e, 2, i);
                     }
                     S_n += n1;
-                    const bool crit = (v == -1) ? mm_stop_criterion<TT, D>(cx, fx, cp, fp)
-                                                : mm_stop_criterion<TT, D>(fx, cx, fp, cp);
+                    const bool crit = (v == -1) ? mm_stop_criterion<TT, D, Red>(cx, fx, cp, fp)
+                                                : mm_stop_criterion<TT, D, Red>(fx, cx, fp, cp);
                     S_s = S_s && crit; /* the sibling's s' is 1, or it would not be waiting */
                     S_alpha = stk.a(e) + S_alpha;
                     S_nalpha += stk.c(e, 2);
@@ -320,7 +360,7 @@ MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST
                 x[i] = S_prime[i];
         }
         n += S_n;
-        s = S_s && mm_stop_criterion<TT, D>(xm, xp, pm, pp);
+        s = S_s && mm_stop_criterion<TT, D, Red>(xm, xp, pm, pp);
         j += 1;
         if (j >= max_depth)
             s = false; /* depth cap: not in the reference */

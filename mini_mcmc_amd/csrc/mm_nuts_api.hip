@@ -11,7 +11,10 @@
 #include <new>
 #include <vector>
 
+#include <type_traits>
+
 #include "mm_nuts_kernels.h"
+#include "mm_nuts_lg.h"
 #include "mm_params.h"
 
 #define MM_HIP(expr)                                                                                              \
@@ -45,6 +48,8 @@ struct NutsBase {
     virtual int adapt_state(double *out) = 0;
     virtual int leapfrog_counts(uint64_t *out) = 0;
     virtual int depth_histogram(uint32_t *out) = 0;
+    virtual int set_variant(int v) = 0;
+    int variant = 0; /* 0: one chain per lane; 1: lane-group / MFMA (mm_nuts_lg.h) */
     int device = 0, mode = 0, kind = 0, dim = 0;
     size_t n_chains = 0;
     uint64_t seed = 0, chain_offset = 0;
@@ -71,6 +76,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
     unsigned int *d_hist = nullptr;
     unsigned char *d_scratch = nullptr;
     bool stack_in_lds = true;
+    const mm_nuts_lg_entry *lg = nullptr;
+    double *d_lg_scratch = nullptr;
 
     ~Nuts() override
     {
@@ -83,6 +90,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
         (void)hipFree(d_nlf);
         (void)hipFree(d_hist);
         (void)hipFree(d_scratch);
+        (void)hipFree(d_lg_scratch);
         if (ev0)
             (void)hipEventDestroy(ev0);
         if (ev1)
@@ -137,10 +145,70 @@ template <class TT, class ST> struct Nuts : NutsBase {
             const size_t waves = (n_chains + 63) / 64;
             MM_HIP(hipMalloc((void **)&d_scratch, waves * k->stack_bytes_per_wave));
         }
+        if (std::is_same<TT, double>::value && std::is_same<ST, double>::value && t->kind == MMCMC_GAUSSIAN_ND) {
+            int nl = 0;
+            const mm_nuts_lg_entry *lt = mm_nuts_lg_table(&nl);
+            for (int i = 0; i < nl; ++i)
+                if (lt[i].dim == t->dim)
+                    lg = &lt[i];
+            if (lg) {
+                const size_t waves = (n_chains + 15) / 16;
+                MM_HIP(hipMalloc((void **)&d_lg_scratch, waves * lg->scratch_doubles_per_wave * sizeof(double)));
+                variant = 1; /* the default where it exists */
+            }
+        }
         MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         MM_HIP(hipEventCreate(&ev0));
         MM_HIP(hipEventCreate(&ev1));
         return MMCMC_OK;
+    }
+
+    int set_variant(int v) override
+    {
+        if (v == 0 || (v == 1 && lg)) {
+            variant = v;
+            return MMCMC_OK;
+        }
+        return (v == 1) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
+    }
+
+    /* the lane-group launch exists for <double, double> only; the other instantiations never reach it */
+    hipError_t run_lg(const mm_nuts_args<TT, ST> &a, hipStream_t st)
+    {
+        if constexpr (std::is_same<TT, double>::value && std::is_same<ST, double>::value) {
+            mm_nuts_lg_args g;
+            g.mat = d_mat;
+            g.state = a.state;
+            g.adapt = a.adapt;
+            g.out = a.out;
+            g.n_leapfrog = a.n_leapfrog;
+            g.depth_hist = a.depth_hist;
+            g.n_chains = a.n_chains;
+            g.seed = a.seed;
+            g.chain_offset = a.chain_offset;
+            g.n_total = a.n_total;
+            g.m0 = a.m0;
+            g.n_pre = a.n_pre;
+            g.n_rec = a.n_rec;
+            g.write_initial = a.write_initial;
+            g.out_t0 = a.out_t0;
+            g.n_discard = a.n_discard;
+            g.max_depth = a.max_depth;
+            g.target_accept_p = a.target_accept_p;
+            g.scratch = d_lg_scratch;
+            return lg->run(g, st);
+        } else {
+            (void)a;
+            (void)st;
+            return hipErrorInvalidValue;
+        }
+    }
+    hipError_t init_lg(hipStream_t st)
+    {
+        if constexpr (std::is_same<TT, double>::value && std::is_same<ST, double>::value)
+            return lg->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
+        else
+            return hipErrorInvalidValue;
     }
 
     int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream_v) override
@@ -161,7 +229,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
             }
         }
         /* init_chain (nuts.rs:528-545) on every run() call */
-        hipError_t e = k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
+        const bool use_lg = variant == 1 && lg;
+        hipError_t e = use_lg ? init_lg(st) : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
         if (e != hipSuccess)
             return (int)e;
         mm_nuts_args<TT, ST> a;
@@ -202,7 +271,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
             a.n_rec = (unsigned int)n_collect;
         }
         MM_HIP(hipEventRecord(ev0, st));
-        e = k->run(a, st);
+        e = use_lg ? run_lg(a, st) : k->run(a, st);
         if (e != hipSuccess) {
             if (staged)
                 (void)hipFree(d_out);
@@ -344,6 +413,11 @@ int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth)
     h->p->max_depth = max_depth;
     return MMCMC_OK;
 }
+int mmcmc_nuts_set_kernel_variant(mmcmc_nuts *h, int variant)
+{
+    return h ? h->p->set_variant(variant) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_kernel_variant(mmcmc_nuts *h) { return h ? h->p->variant : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_nuts_run(mmcmc_nuts *h, size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress,
                    void *stream)
 {

@@ -7,8 +7,8 @@
  * inside a transition and re-converge at its end (samples are staged and flushed per wave exactly as in
  * mm_run_kernel).  The pending-subtree stack of mm_nuts_step lives in LDS when it fits (lane-interleaved), else in
  * a global scratch area with the same interleaving.
- * This first version keeps D-vectors in VGPRs (fine for D <= 8; at D = 32 the compiler spills) -- the lane-group /
- * MFMA mapping for BASELINE.json config 5 is described in DESIGN.md as the next step.
+ * D-vectors stay in VGPRs (fine for D <= 8; at D = 32 the compiler spills): the dense f64 Gaussian of
+ * BASELINE.json config 5 has its own lane-group / MFMA kernel, mm_nuts_lg.h.
  */
 #ifndef MM_NUTS_KERNELS_H
 #define MM_NUTS_KERNELS_H
@@ -55,7 +55,7 @@ template <class TT, class ST, int D> struct mm_nuts_stack_layout {
 };
 
 /* init_chain for every chain (nuts.rs:528-545): epsilon search on the first run, mu = ln(10 eps) */
-template <class TT, class ST, class Tgt>
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
 __global__ void mm_nuts_init_kernel(const mm_tparams<TT> P, const TT *state, mm_nuts_adapt<ST> *adapt,
                                     unsigned long long n_chains, unsigned long long seed,
                                     unsigned long long chain_offset, ST eps_tol)
@@ -69,7 +69,7 @@ __global__ void mm_nuts_init_kernel(const mm_tparams<TT> P, const TT *state, mm_
     for (int i = 0; i < D; ++i)
         x[i] = state[c * D + i];
     mm_nuts_adapt<ST> ad = adapt[c];
-    mm_nuts_init_chain<TT, ST, Tgt>(P, x, &ad, eps_tol, seed, chain_offset + c);
+    mm_nuts_init_chain<TT, ST, Tgt, Red>(P, x, &ad, eps_tol, seed, chain_offset + c);
     adapt[c] = ad;
 }
 
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, 
     }
 }
 
-template <class TT, class ST, class Tgt>
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
 hipError_t mm_launch_nuts_init(const mm_tparams<TT> &P, const TT *state, mm_nuts_adapt<ST> *adapt,
                                unsigned long long n_chains, unsigned long long seed, unsigned long long chain_offset,
                                hipStream_t stream)
@@ -160,7 +160,7 @@ hipError_t mm_launch_nuts_init(const mm_tparams<TT> &P, const TT *state, mm_nuts
     const ST eps_tol = sizeof(ST) == 4 ? (ST)1.1920929e-7 : (ST)2.220446049250313e-16; /* T::epsilon() */
     const unsigned int block = 64;
     const unsigned int grid = (unsigned int)((n_chains + block - 1) / block);
-    hipLaunchKernelGGL((mm_nuts_init_kernel<TT, ST, Tgt>), dim3(grid), dim3(block), 0, stream, P, state, adapt,
+    hipLaunchKernelGGL((mm_nuts_init_kernel<TT, ST, Tgt, Red>), dim3(grid), dim3(block), 0, stream, P, state, adapt,
                        n_chains, seed, chain_offset, eps_tol);
     return hipGetLastError();
 }
@@ -189,5 +189,16 @@ template <class TT, class ST> struct mm_nuts_entry {
 const mm_nuts_entry<float, double> *mm_nuts_table_m0(int *n);
 const mm_nuts_entry<float, float> *mm_nuts_table_m1(int *n);
 const mm_nuts_entry<double, double> *mm_nuts_table_m2(int *n);
+
+/* lane-group / MFMA kernels (mm_nuts_lg.h): GaussianND, f64 */
+struct mm_nuts_lg_args;
+struct mm_nuts_lg_entry {
+    int dim;
+    hipError_t (*init)(const mm_tparams<double> &, const double *, mm_nuts_adapt<double> *, unsigned long long,
+                       unsigned long long, unsigned long long, hipStream_t);
+    hipError_t (*run)(const mm_nuts_lg_args &, hipStream_t);
+    size_t scratch_doubles_per_wave;
+};
+const mm_nuts_lg_entry *mm_nuts_lg_table(int *n);
 
 #endif /* MM_NUTS_KERNELS_H */

@@ -1,0 +1,409 @@
+/*
+ * mm_nuts_lg.h -- NUTS for the dense Gaussian target in f64, lane-GROUP mapping with the gradient on the matrix cores
+ * (BASELINE.json config 5: 32-D ill-conditioned Gaussian, f64).  Device only; its bit-exact host twin is
+ * mm_nuts_step<double, double, mm_target_gnd_grp4<D>, mm_red_grp4<D>> (mm_nuts.h), which in turn is checked against
+ * the recursive restatement of nuts.rs (tests/test_nuts_parity_cpu.py).
+ *
+ * Why not one chain per lane here: at D = 32 in f64 a chain's vectors (both trajectory edges with momenta and
+ * gradients, the proposal, the working leaf) are ~350 doubles -- the lane-per-chain kernel spills 1200 registers --
+ * and the gradient -A x is a 32 x 32 matrix-vector product per leapfrog step, the one dense contraction of the path.
+ *
+ * Mapping.  A wave = 16 chains x 4 lanes.  Lane l = (c = l & 15, q = l >> 4) owns the coordinates d = 4 s + q
+ * (s = 0..D/4-1) of chain c.  That is simultaneously
+ *   - the B-operand layout of v_mfma_f64_16x16x4_f64 for X^T (k = 4 s + q, column c) at k-step s, and
+ *   - the D-result layout of the product tile (row 16 t + 4 r + q, column c) = coordinate s = 4 t + r,
+ * so G^T = A . X^T (A in the A-operand layout, loaded once per kernel into registers) returns the gradient in the
+ * registers' own distribution: no lane movement between leapfrog steps, D/16 * D/4 MFMAs per gradient for 16 chains.
+ * The MFMA accumulates k in order with one rounding per product (tools/mfma_f64_check.hip), i.e. exactly the fma
+ * chain of the host twin.  Dot products over a chain's coordinates: per-lane fma chain over s, then a butterfly over
+ * the four lanes ((c0 + c1) + (c2 + c3), identical in all four) = mm_red_grp4.
+ *
+ * Tree building in lock-step.  All chains of a wave start a transition together and run the same doubling j and
+ * the same leaf index at the same time; a chain whose subtree stopped (or whose transition ended) idles until the
+ * wave's last chain is done -- the cost of SIMT here, bounded by the 16 chains of a wave instead of 64.  Because the
+ * live chains share the leaf index, their pending-subtree stacks have the same shape: the level index is
+ * wave-uniform, so levels live at fixed addresses: 0..LL-1 in LDS, deeper (touched every 2^(k+1) leaves) in an HBM
+ * scratch area.  A chain that fails early walks up the remaining levels at once (merging where it is a second
+ * child, drawing the merge uniform, exactly as the recursion returns through nuts.rs:858-929).
+ */
+#ifndef MM_NUTS_LG_H
+#define MM_NUTS_LG_H
+
+#include <hip/hip_runtime.h>
+
+#include "mm_nuts.h"
+
+#define MM_LG_LDS_LEVELS 3
+
+struct mm_nuts_lg_args {
+    const double *mat;              /* precision matrix A, row-major [D, D] */
+    double *state;                  /* [C, D] */
+    mm_nuts_adapt<double> *adapt;   /* [C] */
+    double *out;                    /* [C, n_total, D] or NULL */
+    unsigned long long *n_leapfrog; /* [C] or NULL */
+    unsigned int *depth_hist;       /* [MM_NUTS_JMAX + 1] or NULL */
+    unsigned long long n_chains, seed, chain_offset, n_total;
+    unsigned int m0, n_pre, n_rec, write_initial, out_t0, n_discard;
+    int max_depth;
+    double target_accept_p;
+    double *scratch;                /* per wave: (MM_NUTS_JMAX - MM_LG_LDS_LEVELS) * entry_slots * 64 doubles */
+};
+
+template <int D> struct mm_lg_cfg {
+    static_assert(D % 16 == 0, "lane-group kernel: D must be a multiple of 16");
+    static constexpr int NS = D / 4;             /* coordinates per lane */
+    static constexpr int NT = D / 16;            /* 16-row result tiles */
+    static constexpr int entry_slots = 3 * NS + 2; /* first_x, first_p, prime, alpha, (n | n_alpha << 32) */
+    static constexpr size_t lds_bytes = (size_t)MM_LG_LDS_LEVELS * entry_slots * 64 * sizeof(double);
+    static constexpr size_t scratch_doubles_per_wave = (size_t)(MM_NUTS_JMAX - MM_LG_LDS_LEVELS) * entry_slots * 64;
+};
+
+typedef double mm_d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double mm_lg_shfl_xor(double v, int mask)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+
+/* sum over the four lanes of a chain: (c0 + c1) + (c2 + c3), the same value in all four lanes */
+__device__ __forceinline__ double mm_lg_group_sum(double c)
+{
+    c = c + mm_lg_shfl_xor(c, 16);
+    c = c + mm_lg_shfl_xor(c, 32);
+    return c;
+}
+
+template <int NS> __device__ __forceinline__ double mm_lg_dot(const double *a, const double *b)
+{
+    double c = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        c = fma(a[s], b[s], c);
+    return mm_lg_group_sum(c);
+}
+
+/* y = A x for the 16 chains of the wave; returns logp = -1/2 x.y and g = -y */
+template <int D>
+__device__ __forceinline__ double mm_lg_logp_grad(const double (&Aop)[D / 16][D / 4], const double *x, double *g)
+{
+    constexpr int NS = D / 4, NT = D / 16;
+    double y[NS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        mm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[t][s], x[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            y[4 * t + r] = acc[r];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        g[s] = -y[s];
+    return -0.5 * mm_lg_dot<NS>(x, y);
+}
+
+template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const mm_nuts_lg_args a)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS, NT = Cfg::NT, ES = Cfg::entry_slots;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    double *lds = reinterpret_cast<double *>(mm_lds_raw);
+
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const unsigned long long cl = (unsigned long long)blockIdx.x * 16 + c;
+    const bool active = cl < a.n_chains;
+    const unsigned long long chain = a.chain_offset + cl;
+    double *scratch = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave;
+
+    /* stack entry of level k: slot i of this lane at base[i * 64 + lane] */
+    auto entry = [&](int k) -> double * {
+        return (k < MM_LG_LDS_LEVELS) ? lds + (size_t)k * ES * 64 + lane
+                                      : scratch + (size_t)(k - MM_LG_LDS_LEVELS) * ES * 64 + lane;
+    };
+
+    /* A-operand blocks: lane (i = l & 15, k = l >> 4) holds A[16 t + i][4 s + k] */
+    double Aop[NT][NS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            Aop[t][s] = a.mat[(size_t)(16 * t + c) * D + 4 * s + q];
+
+    double x[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        x[s] = active ? a.state[cl * D + 4 * s + q] : 0.0;
+    mm_nuts_adapt<double> ad;
+    if (active) {
+        ad = a.adapt[cl];
+    } else {
+        ad.epsilon = 0.1;
+        ad.epsilon_bar = 1.0;
+        ad.h_bar = 0.0;
+        ad.mu = 0.0;
+    }
+    unsigned long long n_lf = 0;
+    unsigned int m = a.m0;
+    unsigned int rows_out = 0;
+
+    auto record = [&]() {
+        if (a.out && active) {
+            double *dst = a.out + (cl * a.n_total + a.out_t0 + rows_out) * D;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                dst[4 * s + q] = x[s];
+        }
+        ++rows_out;
+    };
+
+    if (a.write_initial)
+        record();
+    const unsigned int total = a.n_pre + a.n_rec;
+    for (unsigned int t = 0; t < total; ++t) {
+        ++m;
+        /* ---------------- one transition of the wave's 16 chains (nuts.rs:550-691) ---------------- */
+        unsigned int aux_k = 0;
+        auto aux_peek = [&]() -> double { return mm_aux_u53(a.seed, chain, m, aux_k); };
+
+        double p0[NS], grad[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int d = 4 * s + q;
+            mm_u32x4 blk = mm_block(a.seed, chain, m, (uint32_t)(d >> 1));
+            double z0, z1;
+            mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
+            p0[s] = (d & 1) ? z1 : z0;
+        }
+        const double ulogp = mm_lg_logp_grad<D>(Aop, x, grad);
+        const double joint = ulogp - mm_lg_dot<NS>(p0, p0) * 0.5;
+        const double exp1_obs = -mm_log(aux_peek());
+        aux_k += 1;
+        const double logu = joint - exp1_obs;
+
+        double xm[NS], xp[NS], pm[NS], pp[NS], gm[NS], gp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            xm[s] = xp[s] = x[s];
+            pm[s] = pp[s] = p0[s];
+            gm[s] = gp[s] = grad[s];
+        }
+        int j = 0;
+        unsigned int n = 1;
+        bool alive = active; /* the reference's `s` */
+        double alpha = 0.0;
+        unsigned int n_alpha = 0;
+        int depth = 0;
+
+        while (__ballot(alive) != 0ull) {
+            const double u_run_1 = aux_peek();
+            if (alive)
+                aux_k += 1;
+            const bool neg = !(u_run_1 < 0.5); /* v = -1 */
+            double cx[NS], cp[NS], cg[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cx[s] = neg ? xm[s] : xp[s];
+                cp[s] = neg ? pm[s] : pp[s];
+                cg[s] = neg ? gm[s] : gp[s];
+            }
+            const double epsv = neg ? -ad.epsilon : ad.epsilon;
+            const double h = epsv * 0.5;
+            const unsigned int n_leaves = 1u << j;
+
+            bool done = !alive;
+            unsigned int S_n = 0, S_nalpha = 0;
+            bool S_s = true;
+            double S_alpha = 0.0;
+            double S_fx[NS], S_fp[NS], S_prime[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                S_fx[s] = S_fp[s] = S_prime[s] = 0.0;
+
+            for (unsigned int leaf = 0; leaf < n_leaves; ++leaf) {
+                if (__ballot(!done) == 0ull)
+                    break;
+                /* leapfrog of the outer edge (nuts.rs:979-996); chains that are done compute and discard */
+                double tx[NS], tp[NS], tg[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    tp[s] = fma(h, cg[s], cp[s]);
+                    tx[s] = fma(epsv, tp[s], cx[s]);
+                }
+                const double lp = mm_lg_logp_grad<D>(Aop, tx, tg);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    tp[s] = fma(h, tg[s], tp[s]);
+                const double jointp = lp - mm_lg_dot<NS>(tp, tp) * 0.5;
+                if (!done) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        cx[s] = tx[s];
+                        cp[s] = tp[s];
+                        cg[s] = tg[s];
+                        S_fx[s] = tx[s];
+                        S_fp[s] = tp[s];
+                        S_prime[s] = tx[s];
+                    }
+                    n_lf += 1;
+                    S_n = (logu < jointp) ? 1u : 0u;
+                    S_s = (logu - 1000.0) < jointp;
+                    S_alpha = fmin(1.0, mm_exp(jointp - joint));
+                    S_nalpha = 1;
+                }
+                /* hand S up the implicit recursion; walking lanes have S at level k at the top of iteration k */
+                bool walking = !done;
+                for (int k = 0; k < j; ++k) {
+                    if (__ballot(walking) == 0ull)
+                        break;
+                    double *e = entry(k);
+                    if ((leaf >> k) & 1u) {
+                        /* a sibling waits at level k: S is the second child, merge (nuts.rs:900-928) */
+                        const double u = aux_peek();
+                        if (walking) {
+                            aux_k += 1;
+                            const unsigned long long cnt = (unsigned long long)__double_as_longlong(e[(3 * NS + 1) * 64]);
+                            const unsigned int n1 = (unsigned int)cnt, na1 = (unsigned int)(cnt >> 32);
+                            unsigned int den = n1 + S_n;
+                            if (den < 1)
+                                den = 1;
+                            const bool take2 = u < ((double)S_n / (double)den);
+                            double fx[NS], fp[NS];
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                fx[s] = e[s * 64];
+                                fp[s] = e[(NS + s) * 64];
+                                if (!take2)
+                                    S_prime[s] = e[(2 * NS + s) * 64];
+                            }
+                            S_n += n1;
+                            S_alpha = e[(3 * NS) * 64] + S_alpha;
+                            S_nalpha += na1;
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                S_fx[s] = fx[s];
+                                S_fp[s] = fp[s];
+                            }
+                        }
+                        /* stop criterion on (first leaf of the sibling, current leaf), oriented by v; the reductions
+                         * are wave-wide instructions, so they sit outside the `walking` branch */
+                        double diff[NS], pa[NS], pb[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            const double xa = neg ? cx[s] : S_fx[s];
+                            const double xb = neg ? S_fx[s] : cx[s];
+                            pa[s] = neg ? cp[s] : S_fp[s];
+                            pb[s] = neg ? S_fp[s] : cp[s];
+                            diff[s] = xb - xa;
+                        }
+                        const double dm = mm_lg_dot<NS>(diff, pa);
+                        const double dp = mm_lg_dot<NS>(diff, pb);
+                        if (walking)
+                            S_s = S_s && (dm >= 0.0) && (dp >= 0.0);
+                    } else if (walking) {
+                        if (S_s) {
+                            /* first child, still valid: wait for the sibling */
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                e[s * 64] = S_fx[s];
+                                e[(NS + s) * 64] = S_fp[s];
+                                e[(2 * NS + s) * 64] = S_prime[s];
+                            }
+                            e[(3 * NS) * 64] = S_alpha;
+                            e[(3 * NS + 1) * 64] =
+                                __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
+                            walking = false;
+                        }
+                        /* else: first child with s' = 0 -- the parent returns it as it is: keep walking */
+                    }
+                }
+                done = done || walking; /* reached level j: the doubling is complete, or was cut short */
+            }
+
+            if (alive) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (neg) {
+                        xm[s] = cx[s];
+                        pm[s] = cp[s];
+                        gm[s] = cg[s];
+                    } else {
+                        xp[s] = cx[s];
+                        pp[s] = cp[s];
+                        gp[s] = cg[s];
+                    }
+                }
+                alpha = S_alpha;
+                n_alpha = S_nalpha;
+            }
+            const double tmp = fmin(1.0, (double)S_n / (double)n);
+            const double u_run_2 = aux_peek();
+            /* whole-trajectory criterion (reductions outside the branch) */
+            double diff[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                diff[s] = xp[s] - xm[s];
+            const double dm = mm_lg_dot<NS>(diff, pm);
+            const double dp = mm_lg_dot<NS>(diff, pp);
+            if (alive) {
+                aux_k += 1;
+                if (S_s && (u_run_2 < tmp)) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        x[s] = S_prime[s];
+                }
+                n += S_n;
+                bool s_new = S_s && (dm >= 0.0) && (dp >= 0.0);
+                depth = j + 1;
+                if (j + 1 >= a.max_depth)
+                    s_new = false; /* depth cap: not in the reference */
+                alive = s_new;
+            }
+            j += 1;
+        }
+
+        /* dual averaging (nuts.rs:676-690) */
+        if (active) {
+            double eta = 1.0 / (double)(m + MM_NUTS_T0);
+            ad.h_bar = (1.0 - eta) * ad.h_bar + eta * (a.target_accept_p - alpha / (double)n_alpha);
+            if (m <= a.n_discard) {
+                const double _m = (double)m;
+                ad.epsilon = mm_exp(ad.mu - sqrt(_m) / MM_NUTS_GAMMA * ad.h_bar);
+                eta = mm_exp(-MM_NUTS_KAPPA * mm_log(_m));
+                ad.epsilon_bar = mm_exp((1.0 - eta) * mm_log(ad.epsilon_bar) + eta * mm_log(ad.epsilon));
+            } else {
+                ad.epsilon = ad.epsilon_bar;
+            }
+            if (a.depth_hist && q == 0)
+                atomicAdd(&a.depth_hist[depth < MM_NUTS_JMAX ? depth : MM_NUTS_JMAX], 1u);
+        }
+        if (t >= a.n_pre)
+            record();
+    }
+
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            a.state[cl * D + 4 * s + q] = x[s];
+        if (q == 0) {
+            a.adapt[cl] = ad;
+            if (a.n_leapfrog)
+                a.n_leapfrog[cl] += n_lf;
+        }
+    }
+}
+
+template <int D> hipError_t mm_launch_nuts_lg(const mm_nuts_lg_args &a, hipStream_t stream)
+{
+    const unsigned int grid = (unsigned int)((a.n_chains + 15) / 16);
+    const size_t lds = mm_lg_cfg<D>::lds_bytes;
+    hipLaunchKernelGGL((mm_nuts_lg_kernel<D>), dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+#endif /* MM_NUTS_LG_H */

@@ -50,6 +50,15 @@ class NUTS:
         L.check(L.lib().mmcmc_nuts_set_max_depth(self._h, int(max_depth)), "mmcmc_nuts_set_max_depth")
         return self
 
+    def set_kernel_variant(self, variant: int) -> "NUTS":
+        """0 = one chain per lane; 1 = lane-group / MFMA mapping (mode 2, GaussianND, dim 16 or 32; default there)."""
+        L.check(L.lib().mmcmc_nuts_set_kernel_variant(self._h, int(variant)), "mmcmc_nuts_set_kernel_variant")
+        return self
+
+    @property
+    def kernel_variant(self) -> int:
+        return int(L.lib().mmcmc_nuts_kernel_variant(self._h))
+
     def _run(self, n_collect, n_discard, progress, to):
         if to == "torch":
             import torch

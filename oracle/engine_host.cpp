@@ -148,7 +148,7 @@ int eh_run(int sampler, int dtype, int kind, int dim, const double params[8], co
  * init_chain, then n_pre unrecorded and n_rec recorded transitions, row 0 = initial position for run() with
  * n_discard == 0.  positions [n, dim] doubles in/out (converted to the tensor type on entry like the C ABI does),
  * adapt [n, 4] doubles in/out (epsilon, epsilon_bar, h_bar, mu), out [n, n_collect, dim] of the tensor type. */
-template <class TT, class ST, class Tgt>
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
 static void nuts_chains(const mm_tparams<TT> &P, double *positions, size_t n, double tap, uint64_t seed, uint64_t off,
                         uint32_t m0, size_t n_collect, size_t n_discard, int progress, int max_depth, double *adapt,
                         TT *out, uint64_t *nlf, int nth)
@@ -173,7 +173,7 @@ static void nuts_chains(const mm_tparams<TT> &P, double *positions, size_t n, do
             mm_nuts_adapt<ST> ad;
             ad.epsilon = (ST)adapt[4 * c]; ad.epsilon_bar = (ST)adapt[4 * c + 1];
             ad.h_bar = (ST)adapt[4 * c + 2]; ad.mu = (ST)adapt[4 * c + 3];
-            mm_nuts_init_chain<TT, ST, Tgt>(P, x, &ad, eps_tol, seed, off + c);
+            mm_nuts_init_chain<TT, ST, Tgt, Red>(P, x, &ad, eps_tol, seed, off + c);
             size_t row = 0;
             uint64_t lf = 0;
             uint32_t m = m0;
@@ -181,7 +181,7 @@ static void nuts_chains(const mm_tparams<TT> &P, double *positions, size_t n, do
             if (write_initial) rec();
             for (unsigned t = 0; t < n_pre + n_rec; ++t) {
                 ++m;
-                mm_nuts_info inf = mm_nuts_step<TT, ST, Tgt>(P, x, &ad, m, (uint32_t)n_discard, (ST)tap, max_depth, seed, off + c, stk);
+                mm_nuts_info inf = mm_nuts_step<TT, ST, Tgt, Red>(P, x, &ad, m, (uint32_t)n_discard, (ST)tap, max_depth, seed, off + c, stk);
                 lf += inf.n_leapfrog;
                 if (t >= n_pre) rec();
             }
@@ -233,6 +233,23 @@ int eh_nuts_run(int mode, int kind, int dim, const double params[8], const doubl
                 double target_accept_p, uint64_t seed, uint64_t chain_offset, uint32_t m0, size_t n_collect,
                 size_t n_discard, int progress, int max_depth, double *adapt, void *out, uint64_t *nlf, int n_threads)
 {
+    if (mode == 3) {
+        /* host twin of the lane-group / MFMA kernel (mm_nuts_lg.h): f64, GaussianND, grouped dot-product order */
+        if (kind != MM_GAUSSIAN_ND || !matrix || (dim != 16 && dim != 32))
+            return -2;
+        mm_tparams<double> P;
+        mm_fill_params<double>(kind, params, &P);
+        P.mat = matrix;
+        if (dim == 32)
+            nuts_chains<double, double, mm_target_gnd_grp4<double, 32>, mm_red_grp4<double, 32>>(
+                P, positions, n, target_accept_p, seed, chain_offset, m0, n_collect, n_discard, progress, max_depth, adapt,
+                (double *)out, nlf, n_threads);
+        else
+            nuts_chains<double, double, mm_target_gnd_grp4<double, 16>, mm_red_grp4<double, 16>>(
+                P, positions, n, target_accept_p, seed, chain_offset, m0, n_collect, n_discard, progress, max_depth, adapt,
+                (double *)out, nlf, n_threads);
+        return 0;
+    }
     if (mode == 0)
         return nuts_t<float, double>(kind, dim, params, matrix, positions, n, target_accept_p, seed, chain_offset, m0,
                                      n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);

@@ -612,7 +612,7 @@ def engine_host_nuts_run(mode, kind, dim, params, init, target_accept_p, n_colle
     if x.ndim == 1:
         x = x[None, :]
     n = x.shape[0]
-    tdt = np.float64 if mode == 2 else np.float32
+    tdt = np.float64 if mode >= 2 else np.float32  # mode 3: host twin of the lane-group / MFMA kernel (f64)
     out = np.empty((n, n_collect, dim), dtype=tdt)
     ad = np.empty((n, 4), dtype=np.float64)
     if adapt is None:

@@ -415,6 +415,57 @@ def test_nuts_bit_exact_vs_host_build(M, O, mode):
         assert s.depth_histogram().sum() == C * (nc + nd - (0 if progress else 1))
 
 
+def test_nuts_lane_group_mfma_bit_exact_vs_host_twin(M, O):
+    """mm_nuts_lg.h (16 chains per wave, gradient on v_mfma_f64_16x16x4) against the host build of mm_nuts_step with
+    the grouped reduction order (engine_host mode 3): samples, positions, adaptation state and tree shapes."""
+    from mini_mcmc_amd.nuts import NUTS
+
+    cases = [
+        # dim, cond, chains, n_collect, n_discard, progress, max_depth, offset
+        (32, 1e4, 70, 12, 25, False, 10, 0),
+        (32, 50.0, 33, 9, 0, False, 10, 5),
+        (32, 1e4, 48, 6, 10, True, 4, 0),   # depth cap hit
+        (16, 1e3, 100, 10, 20, False, 10, 1 << 33),
+        (16, 10.0, 16, 5, 5, True, 10, 0),
+    ]
+    for dim, cond, C, nc, nd, progress, cap, off in cases:
+        g = M.dist.GaussianND.ill_conditioned(dim, cond, 7)
+        init = M.core.init_with_seed(C, dim, 3) * 0.3
+        s = NUTS(g, init, 0.8, mode=2).set_seed(19).set_max_depth(cap)
+        assert s.kernel_variant == 1  # the default where it exists
+        if off:
+            s.set_chain_offset(off)
+        out = s._run(nc, nd, progress, "numpy")
+        ref, pos, ad, nlf = O.engine_host_nuts_run(3, O.GAUSSIAN_ND, dim, [], init, 0.8, nc, nd, seed=19, matrix=g.precision,
+                                                   progress=progress, max_depth=cap, chain_offset=off)
+        name = f"D={dim} cond={cond} C={C}"
+        assert np.array_equal(s.leapfrog_counts(), nlf), name
+        assert np.array_equal(out, ref), name
+        assert np.array_equal(s.positions(), pos), name
+        a = s.adapt_state()
+        assert np.array_equal(a["epsilon"], ad[:, 0]) and np.array_equal(a["epsilon_bar"], ad[:, 1]), name
+        assert np.array_equal(a["h_bar"], ad[:, 2]) and np.array_equal(a["mu"], ad[:, 3]), name
+        assert s.depth_histogram().sum() == C * (nc + nd - (0 if progress else 1))
+    # sharding: the wave a chain sits in (and its neighbours' tree depths) must not matter
+    g = M.dist.GaussianND.ill_conditioned(32, 1e3, 1)
+    init = M.core.init_with_seed(50, 32, 8) * 0.3
+    whole = NUTS(g, init, 0.8, mode=2).set_seed(2).run(8, 12)
+    lo = NUTS(g, init[:21], 0.8, mode=2).set_seed(2).run(8, 12)
+    hi = NUTS(g, init[21:], 0.8, mode=2).set_seed(2).set_chain_offset(21).run(8, 12)
+    assert np.array_equal(np.concatenate([lo, hi]), whole)
+    # only where it exists
+    with pytest.raises(Exception):
+        NUTS(M.dist.StandardNormal(3), M.core.init_with_seed(4, 3, 1), 0.8, mode=2).set_kernel_variant(1)
+    # posterior: whitened draws have unit covariance (32-D, cond 100, 1024 chains)
+    g = M.dist.GaussianND.ill_conditioned(32, 100.0, 5)
+    s = NUTS(g, M.core.init_with_seed(1024, 32, 4) * 0.1, 0.8, mode=2).set_seed(6)
+    smp = s.run(60, 150).reshape(-1, 32)
+    Lc = np.linalg.cholesky(g.precision)  # A = L L^T  ->  L^T x ~ N(0, I)
+    w = smp @ Lc
+    assert np.abs(w.mean(axis=0)).max() < 0.03
+    assert np.abs(np.cov(w.T) - np.eye(32)).max() < 0.05
+
+
 def test_nuts_reference_semantics_on_gpu(M, O, kats):
     from mini_mcmc_amd.nuts import NUTS
 
@@ -450,7 +501,7 @@ def test_nuts_posterior_and_run_progress_stats(M, O):
     assert h[:1].sum() == 0 and h.sum() == 2048 * 500
     # config-5 shaped target (32-D, condition number 1e4, f64) at a small chain count: runs, adapts, stays finite
     g = M.dist.GaussianND.ill_conditioned(32, 1e4, 7)
-    s5 = NUTS(g, M.core.init_with_seed(64, 32, 42) * 0.1, 0.8, mode=2).set_seed(42)
+    s5 = NUTS(g, M.core.init_with_seed(64, 32, 42) * 0.1, 0.8, mode=2).set_seed(42).set_kernel_variant(0)
     out5 = s5.run(20, 30)
     assert np.all(np.isfinite(out5)) and s5.depth_histogram()[1:].sum() == 64 * 49
     ref5, _, _, nlf5 = O.engine_host_nuts_run(2, O.GAUSSIAN_ND, 32, [], M.core.init_with_seed(64, 32, 42) * 0.1, 0.8, 20, 30,

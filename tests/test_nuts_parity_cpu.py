@@ -37,6 +37,34 @@ def test_iterative_tree_equals_recursive_tree_f64(O):
             np.testing.assert_allclose(ad_e[:, 0], eps_o, rtol=1e-6)
 
 
+def test_grouped_reduction_twin_keeps_the_tree_shapes(O):
+    """engine_host mode 3 = mm_nuts_step with the dot products summed as four interleaved partial sums (the order the
+    lane-group / MFMA kernel mm_nuts_lg.h produces; it is that kernel's bit-exact host twin).  Against the pinned
+    recursive restatement on the config-5 shaped target (32-D / 16-D dense Gaussian, f64): same tree shapes, samples
+    equal up to the rounding drift a stiff trajectory amplifies."""
+    for dim, cond in ((32, 1e4), (16, 100.0)):
+        rng = np.random.default_rng(7)
+        q, _ = np.linalg.qr(rng.standard_normal((dim, dim)))
+        A = (q * np.logspace(0.0, np.log10(cond), dim)) @ q.T
+        A = (A + A.T) / 2.0
+        init = O.init_with_seed(6, dim, 42) * 0.1
+        out_g, _, ad_g, nlf_g = O.engine_host_nuts_run(3, O.GAUSSIAN_ND, dim, [], init, 0.8, 10, 20, seed=42, matrix=A, n_threads=2)
+        out_s, _, _, nlf_s = O.engine_host_nuts_run(2, O.GAUSSIAN_ND, dim, [], init, 0.8, 10, 20, seed=42, matrix=A, n_threads=2)
+        s = O.NUTS(O.gaussian_nd(A), init, 0.8, mode=2).use_engine_stream(42).set_max_depth(10)
+        out_o = s.run(10, 20, n_threads=2)
+        lf_o = np.array([s.chain_state(i)["n_leapfrog_total"] for i in range(6)])
+        assert np.array_equal(nlf_g, nlf_s) and np.array_equal(nlf_g.astype(np.int64), lf_o.astype(np.int64))
+        assert not np.array_equal(out_g, out_s)  # a different summation order, really
+        # ~6000 leapfrog steps of a cond-1e4 system amplify the 1e-16 differences; the shapes above are the check
+        np.testing.assert_allclose(out_g, out_s, atol=2e-2)
+        np.testing.assert_allclose(out_g, out_o, atol=2e-2)
+        # early in the run (the first transitions from the initial point) the three agree tightly
+        e_g, _, _, l_g = O.engine_host_nuts_run(3, O.GAUSSIAN_ND, dim, [], init, 0.8, 4, 0, seed=42, matrix=A, n_threads=2)
+        e_s, _, _, l_s = O.engine_host_nuts_run(2, O.GAUSSIAN_ND, dim, [], init, 0.8, 4, 0, seed=42, matrix=A, n_threads=2)
+        assert np.array_equal(l_g, l_s)
+        np.testing.assert_allclose(e_g, e_s, rtol=1e-9, atol=1e-10)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_first_transitions_agree_in_f32_modes(O, mode):
     # f32 tensors: compare the first few transitions (before rounding drift can flip a tree decision)
