@@ -35,6 +35,20 @@
 
 #define MM_LG_LDS_LEVELS 3
 
+/* Section timers for tools/lg_profile.hip (s_memtime deltas of lane 0 per wave); compiled out of the product. */
+#ifdef MM_LG_PROFILE
+#define MM_LG_TICK(sec)                                                                                           \
+    do {                                                                                                          \
+        const unsigned long long _now = __builtin_amdgcn_s_memtime();                                             \
+        mm_lg_prof_acc[sec] += _now - mm_lg_prof_t;                                                               \
+        mm_lg_prof_t = _now;                                                                                      \
+    } while (0)
+#define MM_LG_COUNT(sec) (mm_lg_prof_acc[sec] += 1)
+#else
+#define MM_LG_TICK(sec) ((void)0)
+#define MM_LG_COUNT(sec) ((void)0)
+#endif
+
 struct mm_nuts_lg_args {
     const double *mat;              /* precision matrix A, row-major [D, D] */
     double *state;                  /* [C, D] */
@@ -47,6 +61,9 @@ struct mm_nuts_lg_args {
     int max_depth;
     double target_accept_p;
     double *scratch;                /* per wave: (MM_NUTS_JMAX - MM_LG_LDS_LEVELS) * entry_slots * 64 doubles */
+#ifdef MM_LG_PROFILE
+    unsigned long long *prof;       /* [waves][8] */
+#endif
 };
 
 template <int D> struct mm_lg_cfg {
@@ -60,20 +77,22 @@ template <int D> struct mm_lg_cfg {
 
 typedef double mm_d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double mm_lg_shfl_xor(double v, int mask)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_xor(lo, mask, 64);
-    hi = __shfl_xor(hi, mask, 64);
-    return __hiloint2double(hi, lo);
-}
-
-/* sum over the four lanes of a chain: (c0 + c1) + (c2 + c3), the same value in all four lanes */
+/* sum over the four lanes of a chain (lanes c, c + 16, c + 32, c + 48): (c0 + c1) + (c2 + c3), the same value in all
+ * four.  v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- / 32-lane rows between two registers in the VALU
+ * -- no LDS round trip as with ds_bpermute: with both operands = c they return {own row pair's first, second}, whose
+ * sum is the butterfly step (IEEE addition commutes, so all four lanes get the same bits). */
 __device__ __forceinline__ double mm_lg_group_sum(double c)
 {
-    c = c + mm_lg_shfl_xor(c, 16);
-    c = c + mm_lg_shfl_xor(c, 32);
-    return c;
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    unsigned int lo = (unsigned int)__double2loint(c), hi = (unsigned int)__double2hiint(c);
+    u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    c = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    lo = (unsigned int)__double2loint(c);
+    hi = (unsigned int)__double2hiint(c);
+    l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
 }
 
 template <int NS> __device__ __forceinline__ double mm_lg_dot(const double *a, const double *b)
@@ -151,6 +170,10 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
     unsigned long long n_lf = 0;
     unsigned int m = a.m0;
     unsigned int rows_out = 0;
+#ifdef MM_LG_PROFILE
+    unsigned long long mm_lg_prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long mm_lg_prof_t = __builtin_amdgcn_s_memtime();
+#endif
 
     auto record = [&]() {
         if (a.out && active) {
@@ -199,6 +222,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
         double alpha = 0.0;
         unsigned int n_alpha = 0;
         int depth = 0;
+        MM_LG_TICK(0);
 
         while (__ballot(alive) != 0ull) {
             const double u_run_1 = aux_peek();
@@ -225,9 +249,11 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
             for (int s = 0; s < NS; ++s)
                 S_fx[s] = S_fp[s] = S_prime[s] = 0.0;
 
+            MM_LG_TICK(1);
             for (unsigned int leaf = 0; leaf < n_leaves; ++leaf) {
                 if (__ballot(!done) == 0ull)
                     break;
+                MM_LG_COUNT(6);
                 /* leapfrog of the outer edge (nuts.rs:979-996); chains that are done compute and discard */
                 double tx[NS], tp[NS], tg[NS];
 #pragma unroll
@@ -258,9 +284,11 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
                 }
                 /* hand S up the implicit recursion; walking lanes have S at level k at the top of iteration k */
                 bool walking = !done;
+                MM_LG_TICK(2);
                 for (int k = 0; k < j; ++k) {
                     if (__ballot(walking) == 0ull)
                         break;
+                    MM_LG_COUNT(7);
                     double *e = entry(k);
                     if ((leaf >> k) & 1u) {
                         /* a sibling waits at level k: S is the second child, merge (nuts.rs:900-928) */
@@ -323,6 +351,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
                     }
                 }
                 done = done || walking; /* reached level j: the doubling is complete, or was cut short */
+                MM_LG_TICK(3);
             }
 
             if (alive) {
@@ -365,6 +394,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
                 alive = s_new;
             }
             j += 1;
+            MM_LG_TICK(4);
         }
 
         /* dual averaging (nuts.rs:676-690) */
@@ -384,7 +414,13 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
         }
         if (t >= a.n_pre)
             record();
+        MM_LG_TICK(5);
     }
+#ifdef MM_LG_PROFILE
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i)
+            a.prof[(size_t)blockIdx.x * 8 + i] = mm_lg_prof_acc[i];
+#endif
 
     if (active) {
 #pragma unroll
