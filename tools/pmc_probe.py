@@ -1,4 +1,5 @@
-"""One configuration per process, for rocprofv3 --pmc passes: python3 tools/pmc_probe.py {hmc|mh} {collect|nocollect} [variant]"""
+"""One configuration per process, for rocprofv3 --pmc passes: python3 tools/pmc_probe.py {hmc|mh} {collect|nocollect} [variant]
+or python3 tools/pmc_probe.py nuts5 <chains> [warmup draws]  (config-5 target, lane-group kernel)"""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,6 +8,17 @@ from mini_mcmc_amd.distributions import Gaussian2D, IsotropicGaussian, Rosenbroc
 from mini_mcmc_amd.hmc import HMC
 from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
 what, mode = sys.argv[1], sys.argv[2]
+if what == "nuts5":
+    from mini_mcmc_amd.distributions import GaussianND
+    from mini_mcmc_amd.nuts import NUTS
+    n = int(mode)
+    nd, nc = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (50, 50)
+    g = GaussianND.ill_conditioned(32, 1e4, 7)
+    s = NUTS(g, init_with_seed(n, 32, 42) * 0.1, 0.8, mode=2).set_seed(42).set_max_depth(10)
+    s.run_progress(nc, nd, to="torch")
+    torch.cuda.synchronize()
+    print("nuts5", n, s.timing(), int(s.leapfrog_counts().sum()))
+    sys.exit(0)
 variant = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 C = 65536
 if what == "hmc":
