@@ -160,14 +160,24 @@ int mmcmc_nuts_set_chain_offset(mmcmc_nuts *h, uint64_t chain_offset);
  * unbounded; a lane that never terminates would stall its whole wave, so the engine caps it. */
 int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
 /* Kernel mapping (not in the reference).  0 = one chain per lane (every target / mode).  1 = lane-group mapping with
- * the gradient on the matrix cores: 16 chains per wave, four lanes per chain, v_mfma_f64_16x16x4 for A x -- exists
- * for mode 2 + MMCMC_GAUSSIAN_ND with dim 16 or 32 (BASELINE.json config 5), where it is the default; elsewhere
- * setting 1 returns MMCMC_ERR_UNSUPPORTED.  The two mappings sum the D-term dot products in a different order
- * (sequential vs four interleaved partial sums), so their samples differ in the last bits and, over long trajectories
- * of a stiff target, visibly; each is bit-exact against its own host build (oracle/engine_host.cpp modes 2 and 3).
- * mmcmc_nuts_kernel_variant returns the mapping in use (>= 0) or a negative status. */
+ * the gradient on the matrix cores: 16 chains per wave, four lanes per chain, v_mfma_f64_16x16x4 for A x, the whole
+ * run in one launch, every wave keeping its 16 chains.  2 and 3 = the same arithmetic with tree-depth compaction
+ * (BASELINE.json config 5): a transition is cut at the doubling boundaries and the chains that still double are
+ * re-packed into full waves -- 2: one launch per tree level and transition; 3: one persistent kernel whose waves take
+ * work units from per-level queues, chains advancing independently of each other (the fastest from a few thousand
+ * chains on; below 2048 chains it runs as 1).
+ * 1..3 exist for mode 2 + MMCMC_GAUSSIAN_ND with dim 16 or 32, where 3 is the default; elsewhere setting them returns
+ * MMCMC_ERR_UNSUPPORTED.  1, 2 and 3 give bit-identical results.  They sum the D-term dot products in a different
+ * order than 0 (four interleaved partial sums vs sequential), so their samples differ from 0's in the last bits and,
+ * over long trajectories of a stiff target, visibly; each is bit-exact against its own host build
+ * (oracle/engine_host.cpp modes 3 and 2).  With variant 3 mmcmc_nuts_run returns after the kernel has finished.
+ * mmcmc_nuts_kernel_variant returns the mapping in use (>= 0) or a negative status.
+ * mmcmc_nuts_set_compaction (variants 2, 3): doublings below `first_level` (default 5) run before the first
+ * re-packing; variant 2 splits the chains into `n_groups` contiguous groups (1..16; 0 = one per 16 384 chains), each
+ * with its own launch sequence on its own stream.  Neither setting changes a result. */
 int mmcmc_nuts_set_kernel_variant(mmcmc_nuts *h, int variant);
 int mmcmc_nuts_kernel_variant(mmcmc_nuts *h);
+int mmcmc_nuts_set_compaction(mmcmc_nuts *h, int first_level, int n_groups);
 /* progress = 0: NUTS::run -> NUTSChain::run (nuts.rs:163-170, 457-471): n_collect + n_discard - 1 transitions, and
  *               with n_discard == 0 row 0 is the initial position (the reference's off-by-one, test_chain_1);
  * progress = 1: the stepping of run_progress (nuts.rs:491-522): all n_collect + n_discard transitions.

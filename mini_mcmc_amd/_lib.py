@@ -91,6 +91,7 @@ SIGNATURES = {
     "mmcmc_nuts_set_max_depth": (C.c_int, [_vp, C.c_int]),
     "mmcmc_nuts_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "mmcmc_nuts_kernel_variant": (C.c_int, [_vp]),
+    "mmcmc_nuts_set_compaction": (C.c_int, [_vp, C.c_int, C.c_int]),
     "mmcmc_nuts_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int, C.c_int, _vp]),
     "mmcmc_nuts_state": (C.c_int, [_vp, _vp]),
     "mmcmc_nuts_adapt_state": (C.c_int, [_vp, C.POINTER(C.c_double)]),

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -49,7 +51,10 @@ struct NutsBase {
     virtual int leapfrog_counts(uint64_t *out) = 0;
     virtual int depth_histogram(uint32_t *out) = 0;
     virtual int set_variant(int v) = 0;
-    int variant = 0; /* 0: one chain per lane; 1: lane-group / MFMA (mm_nuts_lg.h) */
+    int variant = 0; /* 0: one chain per lane; 1: lane-group / MFMA (mm_nuts_lg.h); 2: + tree-depth compaction, one
+                        launch per level; 3: + compaction by a persistent scheduler */
+    int compaction_start = 5; /* variant 2: doublings below this run before the first compaction */
+    int compaction_groups = 0; /* variant 2: chain groups with their own launch sequence (0 = choose) */
     int device = 0, mode = 0, kind = 0, dim = 0;
     size_t n_chains = 0;
     uint64_t seed = 0, chain_offset = 0;
@@ -77,7 +82,14 @@ template <class TT, class ST> struct Nuts : NutsBase {
     unsigned char *d_scratch = nullptr;
     bool stack_in_lds = true;
     const mm_nuts_lg_entry *lg = nullptr;
-    double *d_lg_scratch = nullptr;
+    double *d_lg_scratch = nullptr, *d_lg_rec = nullptr;
+    unsigned int *d_lg_lists = nullptr, *d_lg_counts = nullptr;
+    mm_lgq_ctrl *d_lg_ctrl = nullptr;
+    unsigned int n_resident_waves = 1024;
+    size_t c_pad = 0;
+    static constexpr int kMaxGroups = 16;
+    hipStream_t lg_streams[kMaxGroups] = {};
+    hipEvent_t lg_fork = nullptr, lg_join[kMaxGroups] = {};
 
     ~Nuts() override
     {
@@ -91,6 +103,18 @@ template <class TT, class ST> struct Nuts : NutsBase {
         (void)hipFree(d_hist);
         (void)hipFree(d_scratch);
         (void)hipFree(d_lg_scratch);
+        (void)hipFree(d_lg_rec);
+        (void)hipFree(d_lg_lists);
+        (void)hipFree(d_lg_counts);
+        (void)hipFree(d_lg_ctrl);
+        for (int i = 0; i < kMaxGroups; ++i) {
+            if (lg_streams[i])
+                (void)hipStreamDestroy(lg_streams[i]);
+            if (lg_join[i])
+                (void)hipEventDestroy(lg_join[i]);
+        }
+        if (lg_fork)
+            (void)hipEventDestroy(lg_fork);
         if (ev0)
             (void)hipEventDestroy(ev0);
         if (ev1)
@@ -153,8 +177,17 @@ template <class TT, class ST> struct Nuts : NutsBase {
                     lg = &lt[i];
             if (lg) {
                 const size_t waves = (n_chains + 15) / 16;
+                c_pad = waves * 16;
                 MM_HIP(hipMalloc((void **)&d_lg_scratch, waves * lg->scratch_doubles_per_wave * sizeof(double)));
-                variant = 1; /* the default where it exists */
+                MM_HIP(hipMalloc((void **)&d_lg_rec, c_pad * lg->rec_doubles_per_chain * sizeof(double)));
+                MM_HIP(hipMemset(d_lg_rec, 0, c_pad * lg->rec_doubles_per_chain * sizeof(double)));
+                MM_HIP(hipMalloc((void **)&d_lg_lists, (size_t)MM_LGQ_SHARDS * MM_LGQ_NQ * c_pad * sizeof(unsigned int)));
+                MM_HIP(hipMalloc((void **)&d_lg_ctrl, sizeof(mm_lgq_ctrl)));
+                hipDeviceProp_t prop;
+                MM_HIP(hipGetDeviceProperties(&prop, device));
+                n_resident_waves = (unsigned int)prop.multiProcessorCount * 4u; /* one wave per SIMD */
+                MM_HIP(hipMalloc((void **)&d_lg_counts, (size_t)kMaxGroups * 2 * (MM_NUTS_JMAX + 1) * sizeof(unsigned int)));
+                variant = 3; /* the default where it exists */
             }
         }
         MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -165,11 +198,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int set_variant(int v) override
     {
-        if (v == 0 || (v == 1 && lg)) {
+        if (v == 0 || (v >= 1 && v <= 3 && lg)) {
             variant = v;
             return MMCMC_OK;
         }
-        return (v == 1) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
+        return (v >= 1 && v <= 3) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
     }
 
     /* the lane-group launch exists for <double, double> only; the other instantiations never reach it */
@@ -196,7 +229,98 @@ template <class TT, class ST> struct Nuts : NutsBase {
             g.max_depth = a.max_depth;
             g.target_accept_p = a.target_accept_p;
             g.scratch = d_lg_scratch;
-            return lg->run(g, st);
+            g.rec = d_lg_rec;
+            g.c_pad = c_pad;
+            g.lists = d_lg_lists;
+            g.counts = d_lg_counts;
+            g.j0 = compaction_start < max_depth ? compaction_start : max_depth;
+            g.j = 0;
+            g.m = 0;
+            g.row = 0xffffffffu;
+            g.ctrl = nullptr;
+            g.slots = nullptr;
+            const unsigned int total = a.n_pre + a.n_rec;
+            /* few chains cannot fill the queues of a scheduler: one launch, every wave keeps its chains */
+            if (variant == 1 || total == 0 || (variant == 3 && n_chains < 2048))
+                return lg->run(g, st);
+            if (variant == 3 && c_pad < (1ull << MM_LGQ_ID_BITS)) {
+                /* persistent scheduler: one resident wave per SIMD (fewer if there are fewer groups of 16 chains) */
+                g.ctrl = d_lg_ctrl;
+                g.slots = d_lg_lists;
+                const unsigned int groups16 = (unsigned int)(c_pad / 16);
+                unsigned int nw = groups16 < n_resident_waves ? groups16 : n_resident_waves;
+                if (const char *ev = getenv("MMCMC_LGQ_WAVES")) {
+                    const unsigned int w = (unsigned int)atoi(ev);
+                    if (w >= 1 && w < nw)
+                        nw = w;
+                }
+                hipError_t e = lg->run_queue(g, nw, st);
+                if (e != hipSuccess)
+                    return e;
+                /* the kernel reports a stuck queue instead of hanging */
+                mm_lgq_ctrl hc;
+                if ((e = hipMemcpyAsync(&hc, d_lg_ctrl, sizeof(hc), hipMemcpyDeviceToHost, st)) != hipSuccess)
+                    return e;
+                if ((e = hipStreamSynchronize(st)) != hipSuccess)
+                    return e;
+                if (getenv("MMCMC_LGQ_STATS"))
+                    fprintf(stderr, "lgq: units %llu chains %llu (%.2f per unit) idle polls %llu error %u ticks pick %.3g fetch %.3g work %.3g handover %.3g\n", hc.stat_units,
+                            hc.stat_chains, (double)hc.stat_chains / (double)(hc.stat_units ? hc.stat_units : 1), hc.stat_polls,
+                            (unsigned int)hc.error, (double)hc.stat_t[0], (double)hc.stat_t[1], (double)hc.stat_t[2], (double)hc.stat_t[3]);
+                return (hc.error != 0ull || hc.remaining != 0ull) ? hipErrorLaunchFailure : hipSuccess;
+            }
+            /* Tree-depth compaction: 1 + (max_depth - j0) launches per transition.  The late launches of a
+             * transition hold few chains (a few per cent reach the deepest level), so the chains are split into
+             * groups, each with its own launch sequence on its own stream: one group's narrow launches run beside
+             * another's wide ones.  Groups are contiguous blocks of chains (a multiple of 16 each). */
+            int n_groups = compaction_groups > 0 ? compaction_groups : (int)(n_chains / 16384);
+            n_groups = n_groups < 1 ? 1 : (n_groups > kMaxGroups ? kMaxGroups : n_groups);
+            const size_t waves = c_pad / 16;
+            if ((size_t)n_groups > waves)
+                n_groups = (int)waves;
+            hipError_t e = hipMemsetAsync(d_lg_counts, 0, (size_t)kMaxGroups * 2 * (MM_NUTS_JMAX + 1) * sizeof(unsigned int), st);
+            if (e != hipSuccess)
+                return e;
+            if (!lg_fork && (e = hipEventCreateWithFlags(&lg_fork, hipEventDisableTiming)) != hipSuccess)
+                return e;
+            if ((e = hipEventRecord(lg_fork, st)) != hipSuccess)
+                return e;
+            for (int gi = 0; gi < n_groups; ++gi) {
+                if (!lg_streams[gi] && (e = hipStreamCreateWithFlags(&lg_streams[gi], hipStreamNonBlocking)) != hipSuccess)
+                    return e;
+                if (!lg_join[gi] && (e = hipEventCreateWithFlags(&lg_join[gi], hipEventDisableTiming)) != hipSuccess)
+                    return e;
+                const size_t w0 = waves * gi / n_groups, w1 = waves * (gi + 1) / n_groups;
+                const size_t off = w0 * 16;
+                mm_nuts_lg_args q = g;
+                q.n_chains = (w1 * 16 < a.n_chains ? w1 * 16 : a.n_chains) - off;
+                q.c_pad = (w1 - w0) * 16;
+                q.chain_offset = a.chain_offset + off;
+                q.state = a.state + off * (size_t)dim;
+                q.adapt = a.adapt + off;
+                q.out = a.out ? a.out + off * a.n_total * (size_t)dim : nullptr;
+                q.n_leapfrog = a.n_leapfrog ? a.n_leapfrog + off : nullptr;
+                q.scratch = d_lg_scratch + w0 * lg->scratch_doubles_per_wave;
+                q.rec = d_lg_rec + off * lg->rec_doubles_per_chain;
+                q.lists = d_lg_lists + (size_t)MM_NUTS_JMAX * off;
+                q.counts = d_lg_counts + (size_t)gi * 2 * (MM_NUTS_JMAX + 1);
+                hipStream_t gs = lg_streams[gi];
+                if ((e = hipStreamWaitEvent(gs, lg_fork, 0)) != hipSuccess)
+                    return e;
+                for (unsigned int t = 0; t < total && e == hipSuccess; ++t) {
+                    q.m = a.m0 + t + 1;
+                    q.write_initial = (t == 0) ? a.write_initial : 0u;
+                    q.row = (t >= a.n_pre) ? (a.out_t0 + (a.write_initial ? 1u : 0u) + (t - a.n_pre)) : 0xffffffffu;
+                    e = lg->run_transition(q, gs);
+                }
+                if (e != hipSuccess)
+                    return e;
+                if ((e = hipEventRecord(lg_join[gi], gs)) != hipSuccess)
+                    return e;
+                if ((e = hipStreamWaitEvent(st, lg_join[gi], 0)) != hipSuccess)
+                    return e;
+            }
+            return hipSuccess;
         } else {
             (void)a;
             (void)st;
@@ -229,7 +353,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
             }
         }
         /* init_chain (nuts.rs:528-545) on every run() call */
-        const bool use_lg = variant == 1 && lg;
+        const bool use_lg = variant >= 1 && lg;
         hipError_t e = use_lg ? init_lg(st) : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
         if (e != hipSuccess)
             return (int)e;
@@ -418,6 +542,14 @@ int mmcmc_nuts_set_kernel_variant(mmcmc_nuts *h, int variant)
     return h ? h->p->set_variant(variant) : MMCMC_ERR_INVALID_ARG;
 }
 int mmcmc_nuts_kernel_variant(mmcmc_nuts *h) { return h ? h->p->variant : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_nuts_set_compaction(mmcmc_nuts *h, int first_level, int n_groups)
+{
+    if (!h || first_level < 0 || first_level > MM_NUTS_JMAX || n_groups < 0 || n_groups > 16)
+        return MMCMC_ERR_INVALID_ARG;
+    h->p->compaction_start = first_level;
+    h->p->compaction_groups = n_groups;
+    return MMCMC_OK;
+}
 int mmcmc_nuts_run(mmcmc_nuts *h, size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress,
                    void *stream)
 {

@@ -196,8 +196,11 @@ struct mm_nuts_lg_entry {
     int dim;
     hipError_t (*init)(const mm_tparams<double> &, const double *, mm_nuts_adapt<double> *, unsigned long long,
                        unsigned long long, unsigned long long, hipStream_t);
-    hipError_t (*run)(const mm_nuts_lg_args &, hipStream_t);
+    hipError_t (*run)(const mm_nuts_lg_args &, hipStream_t);            /* all transitions, one launch */
+    hipError_t (*run_transition)(mm_nuts_lg_args, hipStream_t);         /* one transition, tree-depth compaction */
+    hipError_t (*run_queue)(const mm_nuts_lg_args &, unsigned int, hipStream_t); /* persistent scheduler */
     size_t scratch_doubles_per_wave;
+    size_t rec_doubles_per_chain;
 };
 const mm_nuts_lg_entry *mm_nuts_lg_table(int *n);
 

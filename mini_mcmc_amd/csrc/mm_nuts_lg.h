@@ -18,30 +18,41 @@
  * chain of the host twin.  Dot products over a chain's coordinates: per-lane fma chain over s, then a butterfly over
  * the four lanes ((c0 + c1) + (c2 + c3), identical in all four) = mm_red_grp4.
  *
- * Tree building in lock-step.  All chains of a wave start a transition together and run the same doubling j and
- * the same leaf index at the same time; a chain whose subtree stopped (or whose transition ended) idles until the
- * wave's last chain is done -- the cost of SIMT here, bounded by the 16 chains of a wave instead of 64.  Because the
- * live chains share the leaf index, their pending-subtree stacks have the same shape and the level index is
- * wave-uniform.  A chain that fails early walks up the remaining levels at once (merging where it is a second
- * child, drawing the merge uniform, exactly as the recursion returns through nuts.rs:858-929).
+ * Tree building in lock-step.  The 16 chains of a wave run the same doubling j and the same leaf index at the same
+ * time; a chain whose subtree stopped idles until the doubling ends.  Because the live chains share the leaf index,
+ * their pending-subtree stacks have the same shape and the level index is wave-uniform.  A chain that fails early
+ * walks up the remaining levels at once (merging where it is a second child, drawing the merge uniform, exactly as
+ * the recursion returns through nuts.rs:858-929).
  *
- * Cost model (tools/f64_rate.hip, tools/lg_profile.py).  On gfx950 the f64 matrix rate equals the f64 vector rate
- * (v_mfma_f64_16x16x4: 64 cycles; v_fma_f64 / v_add_f64: ~5 cycles per wave instruction at ANY occupancy) and the two
- * do not overlap -- 2 MFMA + 8 FMA take 128 + 43 cycles whether one or four waves share the SIMD.  A leaf therefore
- * costs 16 MFMA = 1024 cycles plus ~5 cycles for every vector instruction around it, and occupancy buys nothing:
- * the kernel runs one wave per SIMD with the 512-register budget and 40 KB of LDS, and the work is to keep the
- * instruction count per leaf down:
+ * Tree-depth compaction (BASELINE.json config 5: "divergent-tree wavefront compaction").  Trees of different chains
+ * have different depths (at the config: 2^7 .. 2^9 leaves for most, a few per cent at 2^10), and a wave that keeps
+ * its chains for the whole transition runs as long as its deepest tree: 38 % of the leapfrogs it executes are wanted.
+ * So a transition is cut at the doubling boundaries: the `begin` kernel draws the momentum and runs doublings
+ * 0 .. j0-1 with the chains in their natural waves; every chain that still wants to double is appended to a work
+ * list, its state (sample, both edges, log-joint, slice, counters: mm_lg_rec) parked in HBM; then one `double` kernel
+ * per level j >= j0 takes the list 16 chains at a time -- full waves of chains that all run 2^j leaves -- and appends
+ * the survivors to the next list.  A chain whose transition ends is finished (dual averaging, output row) by the
+ * kernel that ran its last doubling.  Which chains share a wave depends on the order of the atomic appends and
+ * changes from run to run; what a chain computes does not (its stream is keyed by its global index, MFMA columns are
+ * independent), so the samples are bit-identical to the single-launch kernel and to the host twin.
+ *
+ *
+ * Cost model (tools/f64_rate.hip, tools/lg_profile.py, profiles/).  On gfx950 the f64 matrix rate equals the f64
+ * vector rate (v_mfma_f64_16x16x4: 64 cycles; v_fma_f64 / v_add_f64: ~5 cycles per wave instruction at ANY occupancy)
+ * and the two do not overlap -- 2 MFMA + 8 FMA take 128 + 43 cycles whether one or four waves share the SIMD.  A leaf
+ * costs 16 MFMA = 1024 cycles plus ~4-5 cycles for every other instruction around it, and a second wave per SIMD
+ * bought 1.25x at twice the register pressure: the kernels run one wave per SIMD with the 512-register budget and
+ * 40 KB of LDS, and the work is to keep the instruction count per leaf down:
  *   - registers hold the edge being extended (x, p, g), the subtree proposal, the current sample and the A-operand
- *     blocks; everything else is addressed by wave-uniform indices and lives in memory, lane-interleaved (slot i of
- *     lane l at base[i * 64 + l]);
- *   - pending first children, per level k: proposal, alpha sum, counts (10 slots).  Levels 0..2 in LDS, deeper
- *     (touched every 2^(k+1) leaves) in an HBM scratch area;
+ *     blocks; everything else is addressed by wave-uniform indices and lives in memory;
+ *   - pending first children, per level k: proposal, alpha sum, counts (10 slots, lane-interleaved: slot i of lane l
+ *     at base[i * 64 + l]).  Levels 0..2 in LDS, deeper (touched every 2^(k+1) leaves) in a per-wave HBM scratch;
  *   - "first leaf" table: the (x, p) of the leaf that starts a subtree.  The first leaf of the pending sibling at
  *     level k of leaf i is leaf i0 = i with its k + 1 low bits cleared, and its data is filed under c = ctz(i0)
  *     (leaf 0 under c = JMAX): every even leaf is written once, under the highest level it starts, instead of being
  *     copied from stack entry to stack entry.  c = 1..3 in LDS, the rest in HBM;
- *   - both trajectory edges (HBM): the one being extended is loaded at the start of a doubling and written back at
- *     its end;
+ *   - both trajectory edges live in the chain's record (HBM): the one being extended is loaded at the start of a
+ *     doubling and written back at its end;
  *   - the U-turn test needs no per-lane orientation: with d = x_cur - x_first, A = d.p_first, B = d.p_cur it is
  *     (A >= 0 and B >= 0) for v = +1 and (A <= 0 and B <= 0) for v = -1 -- negating every term of an fma chain negates
  *     the result exactly, so this equals the twin's (x_plus - x_minus).p_minus/plus >= 0 bit for bit;
@@ -55,20 +66,39 @@
 
 #include "mm_nuts.h"
 
-
 /* Section timers for tools/lg_profile.hip (s_memtime deltas of lane 0 per wave); compiled out of the product. */
 #ifdef MM_LG_PROFILE
-#define MM_LG_TICK(sec)                                                                                           \
+#define MM_LG_TICK(L, sec)                                                                                        \
     do {                                                                                                          \
         const unsigned long long _now = __builtin_amdgcn_s_memtime();                                             \
-        mm_lg_prof_acc[sec] += _now - mm_lg_prof_t;                                                               \
-        mm_lg_prof_t = _now;                                                                                      \
+        (L).prof_acc[sec] += _now - (L).prof_t;                                                                   \
+        (L).prof_t = _now;                                                                                        \
     } while (0)
-#define MM_LG_COUNT(sec) (mm_lg_prof_acc[sec] += 1)
+#define MM_LG_COUNT(L, sec) ((L).prof_acc[sec] += 1)
 #else
-#define MM_LG_TICK(sec) ((void)0)
-#define MM_LG_COUNT(sec) ((void)0)
+#define MM_LG_TICK(L, sec) ((void)0)
+#define MM_LG_COUNT(L, sec) ((void)0)
 #endif
+
+/* Work queues of the persistent kernel: queue 0 = chains ready to begin a transition, queue 1 + j = chains wanting
+ * doubling j.  The queues exist MM_LGQ_SHARDS times; a wave appends to and takes from the shard of its workgroup
+ * index (mod SHARDS: the XCD it runs on) and looks at the others only when its own has no full wave of work.  A
+ * chain is in at most one queue, so c_pad entries per ring suffice. */
+#define MM_LGQ_NQ (MM_NUTS_JMAX + 1)
+#define MM_LGQ_SHARDS 8
+#define MM_LGQ_ID_BITS 20 /* an entry = (lap tag << 20) | local chain index */
+struct mm_lgq_ctrl {
+    /* Per shard one 128-byte line, so that a wave reads the state of the shard's queues with ONE load (lane i reads
+     * word i): word q < MM_LGQ_NQ = (entries appended << 32) | entries handed out, counted from the start of the run.
+     * (Separate head / tail words read one by one by a thousand waves, all on one line, spent 80 % of the kernel in
+     * the scheduler.) */
+    unsigned long long w[MM_LGQ_SHARDS][16];
+    unsigned long long remaining; /* chains with transitions left */
+    unsigned long long error;     /* != 0 after a watchdog fired: every wave leaves */
+    unsigned long long pad[14];
+    unsigned long long stat_units, stat_chains, stat_polls; /* work units taken, chains in them, idle polls */
+    unsigned long long stat_t[4];                           /* s_memtime ticks: pick, fetch, work, hand-over */
+};
 
 struct mm_nuts_lg_args {
     const double *mat;              /* precision matrix A, row-major [D, D] */
@@ -82,6 +112,18 @@ struct mm_nuts_lg_args {
     int max_depth;
     double target_accept_p;
     double *scratch;                /* per wave: mm_lg_cfg<D>::scratch_doubles_per_wave */
+    double *rec;                    /* per-chain records (mm_lg_rec), c_pad chains */
+    unsigned long long c_pad;       /* n_chains rounded up to a multiple of 16 */
+    /* compaction kernels only */
+    unsigned int *lists;            /* [MM_NUTS_JMAX][c_pad] local chain indices wanting doubling j */
+    unsigned int *counts;           /* [2][MM_NUTS_JMAX + 1], by transition parity */
+    int j0;                         /* doublings < j0 run in the begin kernel */
+    int j;                          /* double kernel: the doubling to run */
+    unsigned int m;                 /* 1-based transition index (self.m after the increment) */
+    unsigned int row;               /* output row of this transition, or 0xffffffff */
+    /* persistent kernel only */
+    struct mm_lgq_ctrl *ctrl;       /* queue heads / tails, chains left, error flag */
+    unsigned int *slots;            /* [MM_LGQ_SHARDS][MM_LGQ_NQ][c_pad] rings of tagged local chain indices */
 #ifdef MM_LG_PROFILE
     unsigned long long *prof;       /* [waves][8] */
 #endif
@@ -93,22 +135,19 @@ template <int D> struct mm_lg_cfg {
     static constexpr int NT = D / 16;          /* 16-row result tiles */
     static constexpr int ES = NS + 2;          /* pending entry: proposal[NS], alpha, (n | n_alpha << 32) */
     static constexpr int FS = 2 * NS;          /* first-leaf record: x[NS], p[NS] */
-#ifndef MM_LG_WAVES_PER_SIMD
-#define MM_LG_WAVES_PER_SIMD 1
-#endif
-#if MM_LG_WAVES_PER_SIMD == 1
     static constexpr int LE = 3;               /* entry(k), k < LE, in LDS */
     static constexpr int LF = 3;               /* first(c), 1 <= c <= LF, in LDS */
-#else
-    static constexpr int LE = 2;
-    static constexpr int LF = 1;
-#endif
     static constexpr int lds_E = 0, lds_F = LE * ES, lds_slots = LE * ES + LF * FS;
     static constexpr size_t lds_bytes = (size_t)lds_slots * 64 * sizeof(double);
-    /* HBM slots per wave: entry(k), k = LE..JMAX-1 | first(c), c = LF+1..JMAX | minus edge (x, p, g) | plus edge */
-    static constexpr int hbm_E = 0, hbm_F = (MM_NUTS_JMAX - LE) * ES, hbm_G = hbm_F + (MM_NUTS_JMAX - LF) * FS,
-                         hbm_slots = hbm_G + 6 * NS;
+    /* HBM slots per wave: entry(k), k = LE..JMAX-1 | first(c), c = LF+1..JMAX */
+    static constexpr int hbm_E = 0, hbm_F = (MM_NUTS_JMAX - LE) * ES, hbm_slots = hbm_F + (MM_NUTS_JMAX - LF) * FS;
     static constexpr size_t scratch_doubles_per_wave = (size_t)hbm_slots * 64;
+    /* per-chain record, structure of arrays over the (padded) chains: vector v, coordinate 4 s + q of chain c at
+     * rec[((v * NS + s) * c_pad + c) * 4 + q] -- a wave of 16 consecutive chains reads 512 contiguous bytes, a wave of
+     * 16 arbitrary chains 16 x 32 bytes; then the scalars, field f of chain c at rec[vec_doubles + f * c_pad + c] */
+    enum { V_XM = 0, V_PM = 1, V_GM = 2, V_XP = 3, V_PP = 4, V_GP = 5, V_X = 6, n_vec = 7 };
+    enum { F_JOINT = 0, F_LOGU = 1, F_COUNTS = 2, F_M = 3, n_scalar = 4 }; /* counts = n | aux_k << 32; m: transitions done */
+    static constexpr size_t rec_doubles(size_t c_pad) { return (size_t)(n_vec * D + n_scalar) * c_pad; }
 };
 
 typedef double mm_d4 __attribute__((ext_vector_type(4)));
@@ -166,19 +205,142 @@ __device__ __forceinline__ double mm_lg_logp_grad(const double (&Aop)[D / 16][D 
     return -0.5 * mm_lg_dot<NS>(x, y);
 }
 
-template <int D> __global__ __launch_bounds__(64, MM_LG_WAVES_PER_SIMD) void mm_nuts_lg_kernel(const mm_nuts_lg_args a)
+/* Loads / stores of data that is handed from wave to wave INSIDE a kernel (persistent scheduler): agent-scope relaxed
+ * atomics, i.e. global_load / global_store with sc1 -- they go past the per-CU cache and the per-XCD L2, so no
+ * whole-cache write-back / invalidate (what an agent-scope fence costs; with 1024 waves doing that per work unit the
+ * kernel ran 10x slower) is needed.  COH = false: plain accesses, for the kernels that hand over at launch boundaries */
+template <bool COH> __device__ __forceinline__ double mm_lg_ld(const double *p)
+{
+    if (COH)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ void mm_lg_st(double *p, double v)
+{
+    if (COH)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+template <bool COH> __device__ __forceinline__ mm_nuts_adapt<double> mm_lg_ld_adapt(const mm_nuts_adapt<double> *p)
+{
+    mm_nuts_adapt<double> ad;
+    ad.epsilon = mm_lg_ld<COH>(&p->epsilon);
+    ad.epsilon_bar = mm_lg_ld<COH>(&p->epsilon_bar);
+    ad.h_bar = mm_lg_ld<COH>(&p->h_bar);
+    ad.mu = mm_lg_ld<COH>(&p->mu);
+    return ad;
+}
+template <bool COH> __device__ __forceinline__ void mm_lg_st_adapt(mm_nuts_adapt<double> *p, const mm_nuts_adapt<double> &ad)
+{
+    mm_lg_st<COH>(&p->epsilon, ad.epsilon);
+    mm_lg_st<COH>(&p->epsilon_bar, ad.epsilon_bar);
+    mm_lg_st<COH>(&p->h_bar, ad.h_bar);
+    mm_lg_st<COH>(&p->mu, ad.mu);
+}
+
+/* What a lane carries for its chain across the doublings of a transition */
+template <int D> struct mm_lg_lane {
+    static constexpr int NS = D / 4, NT = D / 16;
+    double Aop[NT][NS];   /* A-operand blocks: lane (i = l & 15, k = l >> 4) holds A[16 t + i][4 s + k] */
+    double x[NS];         /* current sample */
+    double joint, logu;   /* log joint at the start of the transition, log slice level */
+    unsigned int n;       /* points of the trajectory inside the slice */
+    unsigned int aux_k, aux_have;
+    mm_u32x4 aux_blk;     /* auxiliary uniforms: draw k of (chain, m) is a half of Philox block AUX + (k >> 1) */
+    double alpha;         /* of the last doubling (Q11) */
+    unsigned int n_alpha;
+    int depth;
+    unsigned long long n_lf;
+    unsigned long long chain; /* global chain index (keys the stream) */
+    unsigned long long cl;    /* local chain index (record, state, adaptation state) */
+    unsigned int m;
+    int lane, q;
+    bool active;
+#ifdef MM_LG_PROFILE
+    unsigned long long prof_acc[8], prof_t;
+#endif
+};
+
+template <int D> __device__ __forceinline__ void mm_lg_load_A(mm_lg_lane<D> &L, const double *mat)
+{
+    const int c = L.lane & 15;
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t)
+#pragma unroll
+        for (int s = 0; s < D / 4; ++s)
+            L.Aop[t][s] = mat[(size_t)(16 * t + c) * D + 4 * s + L.q];
+}
+
+template <int D> __device__ __forceinline__ double mm_lg_aux_peek(mm_lg_lane<D> &L, unsigned long long seed)
+{
+    const unsigned int b = L.aux_k >> 1;
+    if (b != L.aux_have) {
+        L.aux_blk = mm_block(seed, L.chain, L.m, MM_AUX_BLOCK + b);
+        L.aux_have = b;
+    }
+    return (L.aux_k & 1u) ? mm_u53(L.aux_blk.w[2], L.aux_blk.w[3]) : mm_u53(L.aux_blk.w[0], L.aux_blk.w[1]);
+}
+
+template <int D> __device__ __forceinline__ double *mm_lg_rec_vec(const mm_nuts_lg_args &a, const mm_lg_lane<D> &L, int v)
+{
+    return a.rec + ((size_t)v * (D / 4) * a.c_pad + L.cl) * 4 + L.q; /* coordinate s at [s * c_pad * 4] */
+}
+template <int D> __device__ __forceinline__ double *mm_lg_rec_scalar(const mm_nuts_lg_args &a, const mm_lg_lane<D> &L, int f)
+{
+    return a.rec + (size_t)mm_lg_cfg<D>::n_vec * D * a.c_pad + (size_t)f * a.c_pad + L.cl;
+}
+
+/* start of a transition (nuts.rs:550-576): momentum, log joint, slice; both edges = (x, p0, grad) */
+template <int D, bool COH = false> __device__ __forceinline__ void mm_lg_begin(mm_lg_lane<D> &L, const mm_nuts_lg_args &a)
 {
     using Cfg = mm_lg_cfg<D>;
-    constexpr int NS = Cfg::NS, NT = Cfg::NT, ES = Cfg::ES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    constexpr int NS = Cfg::NS;
+    L.aux_k = 0;
+    L.aux_have = 0xffffffffu;
+    L.aux_blk.w[0] = L.aux_blk.w[1] = L.aux_blk.w[2] = L.aux_blk.w[3] = 0u;
+    double p0[NS], grad[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int d = 4 * s + L.q;
+        mm_u32x4 blk = mm_block(a.seed, L.chain, L.m, (uint32_t)(d >> 1));
+        double z0, z1;
+        mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
+        p0[s] = (d & 1) ? z1 : z0;
+    }
+    const double ulogp = mm_lg_logp_grad<D>(L.Aop, L.x, grad);
+    L.joint = ulogp - mm_lg_dot<NS>(p0, p0) * 0.5;
+    const double exp1_obs = -mm_log(mm_lg_aux_peek<D>(L, a.seed));
+    L.aux_k += 1;
+    L.logu = L.joint - exp1_obs;
+    L.n = 1;
+    L.alpha = 0.0;
+    L.n_alpha = 0;
+    L.depth = 0;
+    const size_t st = (size_t)a.c_pad * 4;
+    double *xm = mm_lg_rec_vec<D>(a, L, Cfg::V_XM), *pm = mm_lg_rec_vec<D>(a, L, Cfg::V_PM),
+           *gm = mm_lg_rec_vec<D>(a, L, Cfg::V_GM), *xp = mm_lg_rec_vec<D>(a, L, Cfg::V_XP),
+           *pp = mm_lg_rec_vec<D>(a, L, Cfg::V_PP), *gp = mm_lg_rec_vec<D>(a, L, Cfg::V_GP);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        mm_lg_st<COH>(&xm[s * st], L.x[s]);
+        mm_lg_st<COH>(&pm[s * st], p0[s]);
+        mm_lg_st<COH>(&gm[s * st], grad[s]);
+        mm_lg_st<COH>(&xp[s * st], L.x[s]);
+        mm_lg_st<COH>(&pp[s * st], p0[s]);
+        mm_lg_st<COH>(&gp[s * st], grad[s]);
+    }
+}
 
-    const int lane = threadIdx.x & 63;
-    const int c = lane & 15, q = lane >> 4;
-    const unsigned long long cl = (unsigned long long)blockIdx.x * 16 + c;
-    const bool active = cl < a.n_chains;
-    const unsigned long long chain = a.chain_offset + cl;
-    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + lane;
-    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + lane;
+/* doubling j of the wave's chains (one iteration of `while s`, nuts.rs:578-671); `alive` in: the chain takes part,
+ * out: it wants another doubling */
+template <int D, bool COH = false>
+__device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, int j, bool &alive,
+                                               double epsilon, mm_lds_double *lds, double *scr)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS, ES = Cfg::ES;
+    const size_t st = (size_t)a.c_pad * 4;
 
     /* records of the merge at level k (wave-uniform k, cc): the sibling's entry and its first leaf */
     struct rec {
@@ -222,351 +384,874 @@ template <int D> __global__ __launch_bounds__(64, MM_LG_WAVES_PER_SIMD) void mm_
         return i0 ? (__ffs((int)i0) - 1) : MM_NUTS_JMAX;
     };
 
-    /* A-operand blocks: lane (i = l & 15, k = l >> 4) holds A[16 t + i][4 s + k] */
-    double Aop[NT][NS];
+    const double u_run_1 = mm_lg_aux_peek<D>(L, a.seed);
+    if (alive)
+        L.aux_k += 1;
+    const bool neg = !(u_run_1 < 0.5); /* v = -1 */
+    /* the outer edge in direction v, advanced in place: after the doubling it IS the returned edge */
+    double *const ex = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_XM : Cfg::V_XP);
+    double *const ep = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_PM : Cfg::V_PP);
+    double *const eg = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_GM : Cfg::V_GP);
+    const double *const ox = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_XP : Cfg::V_XM);
+    const double *const op = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_PP : Cfg::V_PM);
+    double cx[NS], cp[NS], cg[NS];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            Aop[t][s] = a.mat[(size_t)(16 * t + c) * D + 4 * s + q];
+    for (int s = 0; s < NS; ++s) {
+        cx[s] = mm_lg_ld<COH>(&ex[s * st]);
+        cp[s] = mm_lg_ld<COH>(&ep[s * st]);
+        cg[s] = mm_lg_ld<COH>(&eg[s * st]);
+    }
+    const double epsv = neg ? -epsilon : epsilon;
+    const double h = epsv * 0.5;
+    const unsigned int n_leaves = 1u << j;
+    /* nothing in flight when the leaf loop starts: otherwise every use of these loop-carried registers gets a
+     * conservative vmcnt wait that also drains the records requested ahead of the leapfrog */
+    __builtin_amdgcn_s_waitcnt(0);
 
-    double x[NS];
+    bool done = !alive;
+    unsigned int S_n = 0, S_nalpha = 0;
+    bool S_s = true;
+    double S_alpha = 0.0;
+    double S_prime[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-        x[s] = active ? a.state[cl * D + 4 * s + q] : 0.0;
+        S_prime[s] = 0.0;
+
+    MM_LG_TICK(L, 1);
+    for (unsigned int leaf = 0; leaf < n_leaves; ++leaf) {
+        if (__ballot(!done) == 0ull)
+            break;
+        MM_LG_COUNT(L, 6);
+        /* an odd leaf merges with its left neighbour first: request those records now */
+        rec r0;
+        const bool merge0 = j > 0 && (leaf & 1u);
+        if (merge0)
+            load_rec(0, first_slot(leaf, 0), r0);
+        /* leapfrog of the outer edge (nuts.rs:979-996), in place; chains that are done keep their edge (the
+         * matrix product runs for all 64 lanes: MFMA has no per-lane mask, their columns are recomputed) */
+        if (!done) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cp[s] = fma(h, cg[s], cp[s]);
+                cx[s] = fma(epsv, cp[s], cx[s]);
+            }
+        }
+        double y[NS];
+        const double lp = mm_lg_logp_grad<D>(L.Aop, cx, y); /* y = -A x */
+        if (!done) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cg[s] = y[s];
+                cp[s] = fma(h, y[s], cp[s]);
+            }
+        }
+        const double jointp = lp - mm_lg_dot<NS>(cp, cp) * 0.5;
+        if (!done) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                S_prime[s] = cx[s];
+            L.n_lf += 1;
+            S_n = (L.logu < jointp) ? 1u : 0u;
+            S_s = (L.logu - 1000.0) < jointp;
+            S_alpha = fmin(1.0, mm_exp(jointp - L.joint));
+            S_nalpha = 1;
+            /* an even leaf starts subtrees: file its (x, p) under the highest level it starts */
+            if (j > 0 && (leaf & 1u) == 0u) {
+                const int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
+                if (cc <= Cfg::LF) {
+                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 1) * Cfg::FS) * 64;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        f[s * 64] = cx[s];
+                        f[(NS + s) * 64] = cp[s];
+                    }
+                } else {
+                    double *f = scr + (size_t)(Cfg::hbm_F + (cc - Cfg::LF - 1) * Cfg::FS) * 64;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        f[s * 64] = cx[s];
+                        f[(NS + s) * 64] = cp[s];
+                    }
+                }
+            }
+        }
+        /* hand S up the implicit recursion; walking lanes have S at level k at the top of iteration k */
+        bool walking = !done;
+        MM_LG_TICK(L, 2);
+        /* a sibling waits at level k: S is the second child, merge (nuts.rs:900-928) */
+        auto merge = [&](const rec &r) {
+            const double u = mm_lg_aux_peek<D>(L, a.seed);
+            /* stop criterion on (first leaf of the sibling, current leaf): d = x_cur - x_first */
+            double ca = 0.0, cb = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double d = cx[s] - r.fx[s];
+                ca = fma(d, r.fp[s], ca);
+                cb = fma(d, cp[s], cb);
+            }
+            ca = mm_lg_group_sum(ca);
+            cb = mm_lg_group_sum(cb);
+            const bool crit = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
+            if (walking) {
+                L.aux_k += 1;
+                const unsigned long long cnt = (unsigned long long)__double_as_longlong(r.cnt);
+                const unsigned int n1 = (unsigned int)cnt, na1 = (unsigned int)(cnt >> 32);
+                unsigned int den = n1 + S_n;
+                if (den < 1)
+                    den = 1;
+                const bool take2 = u < ((double)S_n / (double)den);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    S_prime[s] = take2 ? S_prime[s] : r.prime[s];
+                S_n += n1;
+                S_alpha = r.alpha + S_alpha;
+                S_nalpha += na1;
+                S_s = S_s && crit;
+            }
+        };
+        /* first child at level k: wait for the sibling if still valid; with s' = 0 the parent returns it as it is, so
+         * it keeps walking */
+        auto push = [&](int k) {
+            if (walking && S_s) {
+                const double cnt =
+                    __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
+                if (k < Cfg::LE) {
+                    mm_lds_double *e = lds + (size_t)(Cfg::lds_E + k * ES) * 64;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        e[s * 64] = S_prime[s];
+                    e[NS * 64] = S_alpha;
+                    e[(NS + 1) * 64] = cnt;
+                } else {
+                    double *e = scr + (size_t)(Cfg::hbm_E + (k - Cfg::LE) * ES) * 64;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        e[s * 64] = S_prime[s];
+                    e[NS * 64] = S_alpha;
+                    e[(NS + 1) * 64] = cnt;
+                }
+                walking = false;
+            }
+        };
+        if (j > 0) {
+            MM_LG_COUNT(L, 7);
+            if (merge0)
+                merge(r0); /* level 0, records requested before the leapfrog */
+            else
+                push(0);
+            for (int k = 1; k < j; ++k) {
+                if (__ballot(walking) == 0ull)
+                    break;
+                MM_LG_COUNT(L, 7);
+                if ((leaf >> k) & 1u) {
+                    rec rk;
+                    load_rec(k, first_slot(leaf, k), rk);
+                    merge(rk);
+                } else {
+                    push(k);
+                }
+            }
+        }
+        done = done || walking; /* reached level j: the doubling is complete, or was cut short */
+        MM_LG_TICK(L, 3);
+    }
+
+    /* write the advanced edge back; whole-trajectory criterion against the other edge (d = x_cur - x_other) */
+    double ca = 0.0, cb = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double oxs = mm_lg_ld<COH>(&ox[s * st]), ops = mm_lg_ld<COH>(&op[s * st]);
+        if (alive) {
+            mm_lg_st<COH>(&ex[s * st], cx[s]);
+            mm_lg_st<COH>(&ep[s * st], cp[s]);
+            mm_lg_st<COH>(&eg[s * st], cg[s]);
+        }
+        const double d = cx[s] - oxs;
+        ca = fma(d, ops, ca);
+        cb = fma(d, cp[s], cb);
+    }
+    ca = mm_lg_group_sum(ca);
+    cb = mm_lg_group_sum(cb);
+    const bool crit_all = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
+    const double tmp = fmin(1.0, (double)S_n / (double)L.n);
+    const double u_run_2 = mm_lg_aux_peek<D>(L, a.seed);
+    if (alive) {
+        L.alpha = S_alpha;
+        L.n_alpha = S_nalpha;
+        L.aux_k += 1;
+        if (S_s && (u_run_2 < tmp)) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                L.x[s] = S_prime[s];
+        }
+        L.n += S_n;
+        bool s_new = S_s && crit_all;
+        L.depth = j + 1;
+        if (j + 1 >= a.max_depth)
+            s_new = false; /* depth cap: not in the reference */
+        alive = s_new;
+    }
+    MM_LG_TICK(L, 4);
+}
+
+/* end of a transition: dual averaging (nuts.rs:676-690), depth histogram */
+template <int D>
+__device__ __forceinline__ void mm_lg_finish(const mm_lg_lane<D> &L, const mm_nuts_lg_args &a, mm_nuts_adapt<double> &ad)
+{
+    double eta = 1.0 / (double)(L.m + MM_NUTS_T0);
+    ad.h_bar = (1.0 - eta) * ad.h_bar + eta * (a.target_accept_p - L.alpha / (double)L.n_alpha);
+    if (L.m <= a.n_discard) {
+        const double _m = (double)L.m;
+        ad.epsilon = mm_exp(ad.mu - sqrt(_m) / MM_NUTS_GAMMA * ad.h_bar);
+        eta = mm_exp(-MM_NUTS_KAPPA * mm_log(_m));
+        ad.epsilon_bar = mm_exp((1.0 - eta) * mm_log(ad.epsilon_bar) + eta * mm_log(ad.epsilon));
+    } else {
+        ad.epsilon = ad.epsilon_bar;
+    }
+    if (a.depth_hist && L.q == 0)
+        atomicAdd(&a.depth_hist[L.depth < MM_NUTS_JMAX ? L.depth : MM_NUTS_JMAX], 1u);
+}
+
+template <int D> __device__ __forceinline__ void mm_lg_write_row(const mm_lg_lane<D> &L, const mm_nuts_lg_args &a, unsigned long long row)
+{
+    double *dst = a.out + (L.cl * a.n_total + row) * D;
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s)
+        dst[4 * s + L.q] = L.x[s];
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Single launch: every wave keeps its 16 chains for all transitions (no compaction)
+ * ---------------------------------------------------------------------------------------------------------------- */
+template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const mm_nuts_lg_args a)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    mm_lg_lane<D> L;
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    L.cl = (unsigned long long)blockIdx.x * 16 + (L.lane & 15);
+    L.active = L.cl < a.n_chains;
+    L.chain = a.chain_offset + L.cl;
+    L.n_lf = 0;
+    L.m = a.m0;
+    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
+    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
+    mm_lg_load_A<D>(L, a.mat);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        L.x[s] = L.active ? a.state[L.cl * D + 4 * s + L.q] : 0.0;
     mm_nuts_adapt<double> ad;
-    if (active) {
-        ad = a.adapt[cl];
+    if (L.active) {
+        ad = a.adapt[L.cl];
     } else {
         ad.epsilon = 0.1;
         ad.epsilon_bar = 1.0;
         ad.h_bar = 0.0;
         ad.mu = 0.0;
     }
-    unsigned long long n_lf = 0;
-    unsigned int m = a.m0;
     unsigned int rows_out = 0;
 #ifdef MM_LG_PROFILE
-    unsigned long long mm_lg_prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long mm_lg_prof_t = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; ++i)
+        L.prof_acc[i] = 0;
+    L.prof_t = __builtin_amdgcn_s_memtime();
 #endif
-
-    auto record = [&]() {
-        if (a.out && active) {
-            double *dst = a.out + (cl * a.n_total + a.out_t0 + rows_out) * D;
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                dst[4 * s + q] = x[s];
-        }
+    if (a.write_initial) {
+        if (a.out && L.active)
+            mm_lg_write_row<D>(L, a, a.out_t0 + rows_out);
         ++rows_out;
-    };
-
-    if (a.write_initial)
-        record();
+    }
     const unsigned int total = a.n_pre + a.n_rec;
     for (unsigned int t = 0; t < total; ++t) {
-        ++m;
-        /* ---------------- one transition of the wave's 16 chains (nuts.rs:550-691) ---------------- */
-        /* auxiliary uniforms: draw k of (chain, m) is a half of Philox block AUX + (k >> 1) (mm_rng.h); the block is
-         * kept so that two consecutive draws cost one evaluation */
-        unsigned int aux_k = 0, aux_have = 0xffffffffu;
-        mm_u32x4 aux_blk;
-        aux_blk.w[0] = aux_blk.w[1] = aux_blk.w[2] = aux_blk.w[3] = 0u;
-        auto aux_peek = [&]() -> double {
-            const unsigned int b = aux_k >> 1;
-            if (b != aux_have) {
-                aux_blk = mm_block(a.seed, chain, m, MM_AUX_BLOCK + b);
-                aux_have = b;
-            }
-            return (aux_k & 1u) ? mm_u53(aux_blk.w[2], aux_blk.w[3]) : mm_u53(aux_blk.w[0], aux_blk.w[1]);
-        };
-
-        double joint, logu;
-        {
-            double p0[NS], grad[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int d = 4 * s + q;
-                mm_u32x4 blk = mm_block(a.seed, chain, m, (uint32_t)(d >> 1));
-                double z0, z1;
-                mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
-                p0[s] = (d & 1) ? z1 : z0;
-            }
-            const double ulogp = mm_lg_logp_grad<D>(Aop, x, grad);
-            joint = ulogp - mm_lg_dot<NS>(p0, p0) * 0.5;
-            const double exp1_obs = -mm_log(aux_peek());
-            aux_k += 1;
-            logu = joint - exp1_obs;
-            /* both edges start at (x, p0, grad) */
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                scr[(Cfg::hbm_G + s) * 64] = x[s];
-                scr[(Cfg::hbm_G + NS + s) * 64] = p0[s];
-                scr[(Cfg::hbm_G + 2 * NS + s) * 64] = grad[s];
-                scr[(Cfg::hbm_G + 3 * NS + s) * 64] = x[s];
-                scr[(Cfg::hbm_G + 4 * NS + s) * 64] = p0[s];
-                scr[(Cfg::hbm_G + 5 * NS + s) * 64] = grad[s];
-            }
+        L.m += 1;
+        mm_lg_begin<D>(L, a);
+        bool alive = L.active; /* the reference's `s` */
+        MM_LG_TICK(L, 0);
+        for (int j = 0; __ballot(alive) != 0ull; ++j)
+            mm_lg_doubling<D>(L, a, j, alive, ad.epsilon, lds, scr);
+        if (L.active)
+            mm_lg_finish<D>(L, a, ad);
+        if (t >= a.n_pre) {
+            if (a.out && L.active)
+                mm_lg_write_row<D>(L, a, a.out_t0 + rows_out);
+            ++rows_out;
         }
-        int j = 0;
-        unsigned int n = 1;
-        bool alive = active; /* the reference's `s` */
-        double alpha = 0.0;
-        unsigned int n_alpha = 0;
-        int depth = 0;
-        MM_LG_TICK(0);
-
-        while (__ballot(alive) != 0ull) {
-            const double u_run_1 = aux_peek();
-            if (alive)
-                aux_k += 1;
-            const bool neg = !(u_run_1 < 0.5); /* v = -1 */
-            /* the outer edge in direction v, advanced in place: after the doubling it IS the returned edge */
-            double *const edge = scr + (size_t)(Cfg::hbm_G + (neg ? 0 : 3 * NS)) * 64;
-            double *const other = scr + (size_t)(Cfg::hbm_G + (neg ? 3 * NS : 0)) * 64;
-            double cx[NS], cp[NS], cg[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                cx[s] = edge[s * 64];
-                cp[s] = edge[(NS + s) * 64];
-                cg[s] = edge[(2 * NS + s) * 64];
-            }
-            const double epsv = neg ? -ad.epsilon : ad.epsilon;
-            const double h = epsv * 0.5;
-            const unsigned int n_leaves = 1u << j;
-            /* nothing in flight when the leaf loop starts: otherwise every use of these loop-carried registers gets a
-             * conservative vmcnt wait that also drains the records requested ahead of the leapfrog */
-            __builtin_amdgcn_s_waitcnt(0);
-
-            bool done = !alive;
-            unsigned int S_n = 0, S_nalpha = 0;
-            bool S_s = true;
-            double S_alpha = 0.0;
-            double S_prime[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                S_prime[s] = 0.0;
-
-            MM_LG_TICK(1);
-            for (unsigned int leaf = 0; leaf < n_leaves; ++leaf) {
-                if (__ballot(!done) == 0ull)
-                    break;
-                MM_LG_COUNT(6);
-                /* an odd leaf merges with its left neighbour first: request those records now */
-                rec r0;
-                const bool merge0 = j > 0 && (leaf & 1u);
-                if (merge0)
-                    load_rec(0, first_slot(leaf, 0), r0);
-                /* leapfrog of the outer edge (nuts.rs:979-996), in place; chains that are done keep their edge (the
-                 * matrix product runs for all 64 lanes: MFMA has no per-lane mask, their columns are recomputed) */
-                if (!done) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        cp[s] = fma(h, cg[s], cp[s]);
-                        cx[s] = fma(epsv, cp[s], cx[s]);
-                    }
-                }
-                double y[NS];
-                const double lp = mm_lg_logp_grad<D>(Aop, cx, y); /* y = -A x */
-                if (!done) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        cg[s] = y[s];
-                        cp[s] = fma(h, y[s], cp[s]);
-                    }
-                }
-                const double jointp = lp - mm_lg_dot<NS>(cp, cp) * 0.5;
-                if (!done) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        S_prime[s] = cx[s];
-                    n_lf += 1;
-                    S_n = (logu < jointp) ? 1u : 0u;
-                    S_s = (logu - 1000.0) < jointp;
-                    S_alpha = fmin(1.0, mm_exp(jointp - joint));
-                    S_nalpha = 1;
-                    /* an even leaf starts subtrees: file its (x, p) under the highest level it starts */
-                    if (j > 0 && (leaf & 1u) == 0u) {
-                        const int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
-                        if (cc <= Cfg::LF) {
-                            mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 1) * Cfg::FS) * 64;
-#pragma unroll
-                            for (int s = 0; s < NS; ++s) {
-                                f[s * 64] = cx[s];
-                                f[(NS + s) * 64] = cp[s];
-                            }
-                        } else {
-                            double *f = scr + (size_t)(Cfg::hbm_F + (cc - Cfg::LF - 1) * Cfg::FS) * 64;
-#pragma unroll
-                            for (int s = 0; s < NS; ++s) {
-                                f[s * 64] = cx[s];
-                                f[(NS + s) * 64] = cp[s];
-                            }
-                        }
-                    }
-                }
-                /* hand S up the implicit recursion; walking lanes have S at level k at the top of iteration k */
-                bool walking = !done;
-                MM_LG_TICK(2);
-                /* a sibling waits at level k: S is the second child, merge (nuts.rs:900-928) */
-                auto merge = [&](const rec &r) {
-                    const double u = aux_peek();
-                    /* stop criterion on (first leaf of the sibling, current leaf): d = x_cur - x_first */
-                    double ca = 0.0, cb = 0.0;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        const double d = cx[s] - r.fx[s];
-                        ca = fma(d, r.fp[s], ca);
-                        cb = fma(d, cp[s], cb);
-                    }
-                    ca = mm_lg_group_sum(ca);
-                    cb = mm_lg_group_sum(cb);
-                    const bool crit = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
-                    if (walking) {
-                        aux_k += 1;
-                        const unsigned long long cnt = (unsigned long long)__double_as_longlong(r.cnt);
-                        const unsigned int n1 = (unsigned int)cnt, na1 = (unsigned int)(cnt >> 32);
-                        unsigned int den = n1 + S_n;
-                        if (den < 1)
-                            den = 1;
-                        const bool take2 = u < ((double)S_n / (double)den);
-#pragma unroll
-                        for (int s = 0; s < NS; ++s)
-                            S_prime[s] = take2 ? S_prime[s] : r.prime[s];
-                        S_n += n1;
-                        S_alpha = r.alpha + S_alpha;
-                        S_nalpha += na1;
-                        S_s = S_s && crit;
-                    }
-                };
-                /* first child at level k: wait for the sibling if still valid; with s' = 0 the parent returns it as it
-                 * is, so it keeps walking */
-                auto push = [&](int k) {
-                    if (walking && S_s) {
-                        const double cnt =
-                            __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
-                        if (k < Cfg::LE) {
-                            mm_lds_double *e = lds + (size_t)(Cfg::lds_E + k * ES) * 64;
-#pragma unroll
-                            for (int s = 0; s < NS; ++s)
-                                e[s * 64] = S_prime[s];
-                            e[NS * 64] = S_alpha;
-                            e[(NS + 1) * 64] = cnt;
-                        } else {
-                            double *e = scr + (size_t)(Cfg::hbm_E + (k - Cfg::LE) * ES) * 64;
-#pragma unroll
-                            for (int s = 0; s < NS; ++s)
-                                e[s * 64] = S_prime[s];
-                            e[NS * 64] = S_alpha;
-                            e[(NS + 1) * 64] = cnt;
-                        }
-                        walking = false;
-                    }
-                };
-                if (j > 0) {
-                    MM_LG_COUNT(7);
-                    if (merge0)
-                        merge(r0); /* level 0, records requested before the leapfrog */
-                    else
-                        push(0);
-                    for (int k = 1; k < j; ++k) {
-                        if (__ballot(walking) == 0ull)
-                            break;
-                        MM_LG_COUNT(7);
-                        if ((leaf >> k) & 1u) {
-                            rec rk;
-                            load_rec(k, first_slot(leaf, k), rk);
-                            merge(rk);
-                        } else {
-                            push(k);
-                        }
-                    }
-                }
-                done = done || walking; /* reached level j: the doubling is complete, or was cut short */
-                MM_LG_TICK(3);
-            }
-
-            /* write the advanced edge back; whole-trajectory criterion against the other edge (d = x_cur - x_other) */
-            double ca = 0.0, cb = 0.0;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double ox = other[s * 64], op = other[(NS + s) * 64];
-                if (alive) {
-                    edge[s * 64] = cx[s];
-                    edge[(NS + s) * 64] = cp[s];
-                    edge[(2 * NS + s) * 64] = cg[s];
-                }
-                const double d = cx[s] - ox;
-                ca = fma(d, op, ca);
-                cb = fma(d, cp[s], cb);
-            }
-            ca = mm_lg_group_sum(ca);
-            cb = mm_lg_group_sum(cb);
-            const bool crit_all = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
-            const double tmp = fmin(1.0, (double)S_n / (double)n);
-            const double u_run_2 = aux_peek();
-            if (alive) {
-                alpha = S_alpha;
-                n_alpha = S_nalpha;
-                aux_k += 1;
-                if (S_s && (u_run_2 < tmp)) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        x[s] = S_prime[s];
-                }
-                n += S_n;
-                bool s_new = S_s && crit_all;
-                depth = j + 1;
-                if (j + 1 >= a.max_depth)
-                    s_new = false; /* depth cap: not in the reference */
-                alive = s_new;
-            }
-            j += 1;
-            MM_LG_TICK(4);
-        }
-
-        /* dual averaging (nuts.rs:676-690) */
-        if (active) {
-            double eta = 1.0 / (double)(m + MM_NUTS_T0);
-            ad.h_bar = (1.0 - eta) * ad.h_bar + eta * (a.target_accept_p - alpha / (double)n_alpha);
-            if (m <= a.n_discard) {
-                const double _m = (double)m;
-                ad.epsilon = mm_exp(ad.mu - sqrt(_m) / MM_NUTS_GAMMA * ad.h_bar);
-                eta = mm_exp(-MM_NUTS_KAPPA * mm_log(_m));
-                ad.epsilon_bar = mm_exp((1.0 - eta) * mm_log(ad.epsilon_bar) + eta * mm_log(ad.epsilon));
-            } else {
-                ad.epsilon = ad.epsilon_bar;
-            }
-            if (a.depth_hist && q == 0)
-                atomicAdd(&a.depth_hist[depth < MM_NUTS_JMAX ? depth : MM_NUTS_JMAX], 1u);
-        }
-        if (t >= a.n_pre)
-            record();
-        MM_LG_TICK(5);
+        MM_LG_TICK(L, 5);
     }
 #ifdef MM_LG_PROFILE
-    if (lane == 0)
+    if (L.lane == 0)
         for (int i = 0; i < 8; ++i)
-            a.prof[(size_t)blockIdx.x * 8 + i] = mm_lg_prof_acc[i];
+            a.prof[(size_t)blockIdx.x * 8 + i] = L.prof_acc[i];
 #endif
-
-    if (active) {
+    if (L.active) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            a.state[cl * D + 4 * s + q] = x[s];
-        if (q == 0) {
-            a.adapt[cl] = ad;
+            a.state[L.cl * D + 4 * s + L.q] = L.x[s];
+        if (L.q == 0) {
+            a.adapt[L.cl] = ad;
             if (a.n_leapfrog)
-                a.n_leapfrog[cl] += n_lf;
+                a.n_leapfrog[L.cl] += L.n_lf;
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Tree-depth compaction: one `begin` launch and one `double` launch per level j0 <= j < max_depth per transition
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/* the chain's transition is over: dual averaging, state, output row; or it wants doubling j_next: park it */
+template <int D>
+__device__ __forceinline__ void mm_lgc_hand_over(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, bool valid, bool alive,
+                                                 mm_nuts_adapt<double> &ad, int j_next)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS;
+    const size_t st = (size_t)a.c_pad * 4;
+    unsigned int *const count = a.counts + (size_t)(L.m & 1u) * (MM_NUTS_JMAX + 1) + j_next;
+    /* one atomic per wave: chains are ranked by lane among the lanes q == 0 that append */
+    const unsigned long long app = __ballot(valid && alive && L.q == 0);
+    unsigned int base = 0;
+    if (app != 0ull) {
+        if (L.lane == (int)__ffsll((long long)app) - 1)
+            base = atomicAdd(count, (unsigned int)__popcll(app));
+        base = (unsigned int)__shfl((int)base, (int)__ffsll((long long)app) - 1, 64);
+    }
+    if (valid && alive) {
+        double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            xs[s * st] = L.x[s];
+        if (L.q == 0) {
+            *mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT) = L.joint;
+            *mm_lg_rec_scalar<D>(a, L, Cfg::F_LOGU) = L.logu;
+            *mm_lg_rec_scalar<D>(a, L, Cfg::F_COUNTS) =
+                __longlong_as_double((long long)((unsigned long long)L.n | ((unsigned long long)L.aux_k << 32)));
+            const unsigned int rank = (unsigned int)__popcll(app & ((1ull << L.lane) - 1ull));
+            a.lists[(size_t)j_next * a.c_pad + base + rank] = (unsigned int)L.cl;
+        }
+    } else if (valid) {
+        mm_lg_finish<D>(L, a, ad);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            a.state[L.cl * D + 4 * s + L.q] = L.x[s];
+        if (a.out && a.row != 0xffffffffu)
+            mm_lg_write_row<D>(L, a, a.row);
+        if (L.q == 0)
+            a.adapt[L.cl] = ad;
+    }
+    if (valid && L.q == 0 && a.n_leapfrog)
+        a.n_leapfrog[L.cl] += L.n_lf;
+}
+
+template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgc_begin_kernel(const mm_nuts_lg_args a)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    mm_lg_lane<D> L;
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    L.cl = (unsigned long long)blockIdx.x * 16 + (L.lane & 15);
+    L.active = L.cl < a.n_chains;
+    L.chain = a.chain_offset + L.cl;
+    L.n_lf = 0;
+    L.m = a.m;
+    /* the next transition's counters (this parity was last used two transitions ago) */
+    if (blockIdx.x == 0 && L.lane <= MM_NUTS_JMAX)
+        a.counts[(size_t)((a.m + 1u) & 1u) * (MM_NUTS_JMAX + 1) + L.lane] = 0u;
+    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
+    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
+    mm_lg_load_A<D>(L, a.mat);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        L.x[s] = L.active ? a.state[L.cl * D + 4 * s + L.q] : 0.0;
+    mm_nuts_adapt<double> ad;
+    if (L.active) {
+        ad = a.adapt[L.cl];
+    } else {
+        ad.epsilon = 0.1;
+        ad.epsilon_bar = 1.0;
+        ad.h_bar = 0.0;
+        ad.mu = 0.0;
+    }
+    if (a.write_initial && a.out && L.active)
+        mm_lg_write_row<D>(L, a, a.out_t0); /* row 0 = the initial position (nuts.rs:534) */
+    mm_lg_begin<D>(L, a);
+    bool alive = L.active;
+    for (int j = 0; j < a.j0 && __ballot(alive) != 0ull; ++j)
+        mm_lg_doubling<D>(L, a, j, alive, ad.epsilon, lds, scr);
+    mm_lgc_hand_over<D>(L, a, L.active, alive, ad, a.j0);
+}
+
+template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgc_double_kernel(const mm_nuts_lg_args a)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    const unsigned int cnt = a.counts[(size_t)(a.m & 1u) * (MM_NUTS_JMAX + 1) + a.j];
+    const unsigned int base = blockIdx.x * 16u;
+    if (base >= cnt)
+        return;
+    mm_lg_lane<D> L;
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    const unsigned int idx = base + (unsigned int)(L.lane & 15);
+    const bool valid = idx < cnt;
+    /* a short last wave repeats its first chain in the unused columns: read-only there */
+    L.cl = a.lists[(size_t)a.j * a.c_pad + (valid ? idx : base)];
+    L.active = valid;
+    L.chain = a.chain_offset + L.cl;
+    L.n_lf = 0;
+    L.m = a.m;
+    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
+    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
+    mm_lg_load_A<D>(L, a.mat);
+    const size_t st = (size_t)a.c_pad * 4;
+    const double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        L.x[s] = xs[s * st];
+    L.joint = *mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT);
+    L.logu = *mm_lg_rec_scalar<D>(a, L, Cfg::F_LOGU);
+    const unsigned long long pk = (unsigned long long)__double_as_longlong(*mm_lg_rec_scalar<D>(a, L, Cfg::F_COUNTS));
+    L.n = (unsigned int)pk;
+    L.aux_k = (unsigned int)(pk >> 32);
+    L.aux_have = 0xffffffffu;
+    L.aux_blk.w[0] = L.aux_blk.w[1] = L.aux_blk.w[2] = L.aux_blk.w[3] = 0u;
+    L.alpha = 0.0;
+    L.n_alpha = 0;
+    L.depth = a.j;
+    mm_nuts_adapt<double> ad = a.adapt[L.cl];
+    bool alive = valid;
+    mm_lg_doubling<D>(L, a, a.j, alive, ad.epsilon, lds, scr);
+    mm_lgc_hand_over<D>(L, a, valid, alive, ad, a.j + 1);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Persistent scheduler: compaction without launch boundaries.  With one launch per tree level (above) every launch
+ * lasts as long as its longest wave and the late levels of a transition hold too few chains to fill the GPU; here
+ * one resident wave per SIMD loops { take up to 16 chains from one queue, run that unit of work, append each chain
+ * to the queue of its next unit }, units being "begin a transition and run doublings 0 .. j0-1" (queue 0) and
+ * "doubling j" (queue 1 + j).  Chains advance independently -- a chain parked before a 512-leaf doubling does not
+ * hold back the others, which go on to their next transitions -- so every chain carries its own transition count.
+ * Queues are rings of chain indices; an append reserves entries with one atomic add on `tail` per wave and then
+ * fills them (CAS from EMPTY), a take claims entries with a CAS on `head` and then waits for each to be filled
+ * (exchange with EMPTY).  Data handed from wave to wave goes through write-through stores and cache-bypassing loads
+ * (mm_lg_ld / mm_lg_st<true>), completed (s_waitcnt) before the chain is appended.
+ * ---------------------------------------------------------------------------------------------------------------- */
+template <int D> __global__ void mm_nuts_lgq_init_kernel(const mm_nuts_lg_args a, size_t scalar_base)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n_slots = (size_t)MM_LGQ_SHARDS * MM_LGQ_NQ * a.c_pad;
+    /* queue 0 of shard s starts with the chains of the 16-blocks b = s (mod SHARDS), in order; entry e of a ring is
+     * tagged with its lap e / c_pad + 1, so the zero-filled rest never looks like an entry */
+    if (i < n_slots) {
+        const size_t shard = i / ((size_t)MM_LGQ_NQ * a.c_pad), r = i % ((size_t)MM_LGQ_NQ * a.c_pad);
+        unsigned int v = 0u;
+        if (r < a.c_pad) {
+            const size_t blk = (r / 16) * MM_LGQ_SHARDS + shard, chain = blk * 16 + (r % 16);
+            if (chain < a.n_chains)
+                v = (1u << MM_LGQ_ID_BITS) | (unsigned int)chain;
+        }
+        a.slots[i] = v;
+    }
+    if (i < a.c_pad)
+        a.rec[scalar_base + (size_t)3 * a.c_pad + i] = __longlong_as_double((long long)a.m0); /* F_M */
+    if (i < MM_LGQ_SHARDS) {
+        for (int q = 0; q < 16; ++q)
+            a.ctrl->w[i][q] = 0ull;
+        /* chains of shard i: full 16-blocks b = i (mod SHARDS) plus possibly a short last one */
+        const size_t n_blk = (a.n_chains + 15) / 16;
+        size_t cnt = 0;
+        for (size_t b = i; b < n_blk; b += MM_LGQ_SHARDS)
+            cnt += (b * 16 + 16 <= a.n_chains) ? 16 : (a.n_chains - b * 16);
+        a.ctrl->w[i][0] = (unsigned long long)cnt << 32;
+    }
+    if (i == 0) {
+        a.ctrl->remaining = a.n_chains;
+        a.ctrl->error = 0ull;
+        a.ctrl->stat_units = a.ctrl->stat_chains = a.ctrl->stat_polls = 0ull;
+        a.ctrl->stat_t[0] = a.ctrl->stat_t[1] = a.ctrl->stat_t[2] = a.ctrl->stat_t[3] = 0ull;
+    }
+}
+
+#define MM_LGQ_SPIN_LIMIT (1u << 23) /* polls of ~1000 cycles: several seconds without progress */
+
+__device__ __forceinline__ unsigned int *mm_lgq_slot(const mm_nuts_lg_args &a, int shard, int qi, unsigned int e, unsigned int *tag)
+{
+    const unsigned int cap = (unsigned int)a.c_pad;
+    *tag = (e / cap + 1u) << MM_LGQ_ID_BITS;
+    return a.slots + ((size_t)shard * MM_LGQ_NQ + (size_t)qi) * a.c_pad + (size_t)(e % cap);
+}
+
+/* append the chains flagged by `pred` (their q == 0 lanes) to queue qi of `shard`: one atomic add reserves the
+ * entries, write-through stores fill them */
+template <int D>
+__device__ __forceinline__ void mm_lgq_append(const mm_lg_lane<D> &L, const mm_nuts_lg_args &a, int shard, int qi, bool pred)
+{
+    const unsigned long long app = __ballot(pred && L.q == 0);
+    if (app == 0ull)
+        return;
+    const int leader = (int)__ffsll((long long)app) - 1;
+    unsigned long long base = 0ull;
+    if (L.lane == leader)
+        base = atomicAdd(&a.ctrl->w[shard][qi], (unsigned long long)__popcll(app) << 32) >> 32;
+    base = (unsigned long long)__shfl((long long)base, leader, 64);
+    if (pred && L.q == 0) {
+        unsigned int tag;
+        unsigned int *slot =
+            mm_lgq_slot(a, shard, qi, (unsigned int)base + (unsigned int)__popcll(app & ((1ull << L.lane) - 1ull)), &tag);
+        __hip_atomic_store(slot, tag | (unsigned int)L.cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const mm_nuts_lg_args a)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    mm_lg_lane<D> L;
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    L.cl = 0;
+    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
+    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
+    mm_lg_load_A<D>(L, a.mat);
+    const size_t st = (size_t)a.c_pad * 4;
+    const unsigned int m_end = a.m0 + a.n_pre + a.n_rec;
+    mm_lgq_ctrl *const ctrl = a.ctrl;
+    const unsigned int col = (unsigned int)(L.lane & 15);
+    const int home = (int)(blockIdx.x % MM_LGQ_SHARDS);
+    unsigned long long st_units = 0, st_chains = 0, st_polls = 0, st_t[4] = {0, 0, 0, 0};
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define MM_LGQ_T(i)                                                                                               \
+    do {                                                                                                          \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                                               \
+        st_t[i] += _n - t_prev;                                                                                   \
+        t_prev = _n;                                                                                              \
+    } while (0)
+
+    /* chains this wave keeps from its last unit (they all want doubling keep_level): their columns stay theirs */
+    bool keep = false;
+    int keep_level = 0;
+
+    for (;;) {
+        /* ---- compose the next unit: the kept chains plus entries of the queue of their level; with nothing kept (or
+         *      too few to be worth a unit), the deepest level that fills a wave -- own shard first, then the others --
+         *      else, after a while, the fullest queue ---- */
+        const unsigned int keep16 = (unsigned int)(__ballot(keep && L.q == 0) & 0xffffull);
+        const unsigned int n_keep = (unsigned int)__popc(keep16);
+        const int keep_q = 1 + keep_level;
+        int qi = -1, shard = home;
+        unsigned int n_take = 0, first = 0;
+        bool give_back = false; /* too few kept chains and nothing to top them up with: queue them (own shard) */
+        bool quit = false;
+        /* claim `want` entries of queue q of shard sh, whose word was read as `old`; retries on the value the failed
+         * compare-and-swap returned while the queue still holds enough */
+        auto claim = [&](int sh, int q, unsigned long long old, unsigned int want_max, unsigned int want_min) -> bool {
+            for (int tries = 0; tries < 4; ++tries) {
+                const unsigned int av = (unsigned int)(old >> 32) - (unsigned int)old;
+                const unsigned int want = av < want_max ? av : want_max;
+                if (want < want_min || want == 0u)
+                    return false;
+                unsigned long long got = old;
+                if (L.lane == 0)
+                    got = atomicCAS(&ctrl->w[sh][q], old, old + want);
+                got = (unsigned long long)__shfl((long long)got, 0, 64);
+                if (got == old) {
+                    shard = sh;
+                    qi = q;
+                    n_take = want;
+                    first = (unsigned int)old;
+                    return true;
+                }
+                old = got;
+            }
+            return false;
+        };
+        for (unsigned int polls = 0;;) {
+            /* the state of the own shard's queues in one load: lane i < 16 reads word i */
+            unsigned long long w = 0ull;
+            if (L.lane < 16)
+                w = __hip_atomic_load(&ctrl->w[home][L.lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool is_queue = L.lane == 0 || (L.lane > a.j0 && L.lane <= a.max_depth);
+            unsigned int avail = is_queue ? (unsigned int)(w >> 32) - (unsigned int)w : 0u;
+            if (n_keep > 0u && !give_back) {
+                /* stay with the kept chains if the queue of their level tops them up to 12 or more */
+                unsigned int want = (unsigned int)__shfl((int)avail, keep_q, 64);
+                want = want < 16u - n_keep ? want : 16u - n_keep;
+                if (n_keep + want >= 12u) {
+                    if (want > 0u)
+                        (void)claim(home, keep_q, (unsigned long long)__shfl((long long)w, keep_q, 64), want, 1u);
+                    qi = keep_q; /* a lost race: the kept chains run alone */
+                    shard = home;
+                    break;
+                }
+                give_back = true;
+            }
+            /* the deepest level that fills a wave (the kept chains about to be queued count for their level) */
+            const unsigned int eff = avail + ((give_back && L.lane == keep_q) ? n_keep : 0u);
+            const unsigned long long full = __ballot(eff >= 16u) & 0xffffull;
+            if (full != 0ull) {
+                const int best = 63 - (int)__clzll((long long)full);
+                const unsigned long long old = (unsigned long long)__shfl((long long)w, best, 64);
+                if (give_back && best == keep_q) {
+                    /* the kept chains complete a wave after all: top up instead of queueing them */
+                    give_back = false;
+                    (void)claim(home, best, old, 16u - n_keep, 1u);
+                    qi = best;
+                    shard = home;
+                    break;
+                }
+                if (claim(home, best, old, 16u, 16u))
+                    break;
+                continue; /* lost the race for it: look again */
+            }
+            /* nothing here fills a wave: the other shards, nearest first */
+            bool found = false;
+            for (int k = 1; k < MM_LGQ_SHARDS && !found; ++k) {
+                const int sh = (home + k) % MM_LGQ_SHARDS;
+                unsigned long long wo = 0ull;
+                if (L.lane < 16)
+                    wo = __hip_atomic_load(&ctrl->w[sh][L.lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int avo = is_queue ? (unsigned int)(wo >> 32) - (unsigned int)wo : 0u;
+                const unsigned long long fo = __ballot(avo >= 16u) & 0xffffull;
+                if (fo != 0ull) {
+                    const int best = 63 - (int)__clzll((long long)fo);
+                    found = claim(sh, best, (unsigned long long)__shfl((long long)wo, best, 64), 16u, 16u);
+                }
+            }
+            if (found)
+                break;
+            if (polls >= 64u) {
+                /* waited long enough: the fullest queue of the own shard, whatever it holds; else of another shard */
+                unsigned int mx = 0u;
+                int best = -1;
+                for (int q = 0; q <= a.max_depth; ++q) {
+                    const unsigned int e = (unsigned int)__shfl((int)eff, q, 64);
+                    if (e > mx) {
+                        mx = e;
+                        best = q;
+                    }
+                }
+                if (best >= 0) {
+                    const unsigned long long old = (unsigned long long)__shfl((long long)w, best, 64);
+                    if (give_back && best == keep_q) {
+                        give_back = false;
+                        (void)claim(home, best, old, 16u - n_keep, 1u);
+                        qi = best;
+                        shard = home;
+                        break;
+                    }
+                    if (claim(home, best, old, 16u, 1u))
+                        break;
+                } else {
+                    for (int k = 1; k < MM_LGQ_SHARDS && !found; ++k) {
+                        const int sh = (home + k) % MM_LGQ_SHARDS;
+                        unsigned long long wo = 0ull;
+                        if (L.lane < 16)
+                            wo = __hip_atomic_load(&ctrl->w[sh][L.lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned int avo = is_queue ? (unsigned int)(wo >> 32) - (unsigned int)wo : 0u;
+                        const unsigned long long fo = __ballot(avo >= 1u) & 0xffffull;
+                        if (fo != 0ull) {
+                            const int bq = 63 - (int)__clzll((long long)fo);
+                            found = claim(sh, bq, (unsigned long long)__shfl((long long)wo, bq, 64), 16u, 1u);
+                        }
+                    }
+                    if (found)
+                        break;
+                }
+            }
+            /* idle: is the run over? */
+            unsigned long long rem = 1ull, err = 0ull;
+            if (L.lane == 0) {
+                rem = __hip_atomic_load(&ctrl->remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                err = __hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            rem = (unsigned long long)__shfl((long long)rem, 0, 64);
+            err = (unsigned long long)__shfl((long long)err, 0, 64);
+            if ((rem == 0ull || err != 0ull) && !(give_back && n_keep > 0u)) {
+                quit = true;
+                break;
+            }
+            if (err != 0ull) {
+                quit = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+            ++st_polls;
+            if (++polls > MM_LGQ_SPIN_LIMIT) {
+                if (L.lane == 0)
+                    atomicExch(&ctrl->error, 1ull);
+                quit = true;
+                break;
+            }
+        }
+        if (give_back) {
+            /* their state is already parked in the records (hand-over below) */
+            mm_lgq_append<D>(L, a, home, keep_q, keep);
+            keep = false;
+        }
+        MM_LGQ_T(0);
+        if (quit || qi < 0)
+            break;
+        const bool use_keep = n_keep > 0u && !give_back; /* wave-uniform; then qi == keep_q in the own shard */
+        /* free columns take the claimed entries in order */
+        const unsigned int free16 = use_keep ? (~keep16 & 0xffffu) : 0xffffu;
+        const unsigned int my_rank = (unsigned int)__popc(free16 & ((1u << col) - 1u));
+        const bool is_new = ((free16 >> col) & 1u) && my_rank < n_take;
+        unsigned int id = (unsigned int)L.cl;
+        if (is_new && L.q == 0) {
+            /* wait for the appender's store: the entry carries the tag of its lap */
+            unsigned int tag;
+            const unsigned int *slot = mm_lgq_slot(a, shard, qi, first + my_rank, &tag);
+            unsigned int v, spins = 0;
+            while (((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> MM_LGQ_ID_BITS) !=
+                   (tag >> MM_LGQ_ID_BITS)) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > MM_LGQ_SPIN_LIMIT) {
+                    atomicExch(&ctrl->error, 3ull);
+                    break;
+                }
+            }
+            id = v & ((1u << MM_LGQ_ID_BITS) - 1u);
+        }
+        id = (unsigned int)__shfl((int)id, (int)col, 64); /* from the chain's q == 0 lane */
+        const bool valid = is_new || (use_keep && ((keep16 >> col) & 1u));
+        const unsigned long long vmask = __ballot(valid);
+        if (vmask == 0ull)
+            continue; /* a top-up lost its race and nothing was kept: look again */
+        const unsigned int id_any = (unsigned int)__shfl((int)id, (int)__ffsll((long long)vmask) - 1, 64);
+        /* unused columns repeat a valid chain: read-only there */
+        L.cl = valid ? id : id_any;
+        L.active = valid;
+        L.chain = a.chain_offset + L.cl;
+        L.n_lf = 0;
+        keep = false;
+        st_units += 1;
+        st_chains += (unsigned long long)__popcll(vmask) / 4ull;
+        MM_LGQ_T(1);
+        /* what the previous owner of these chains wrote is read with coherent loads (mm_lg_ld<true>), whose addresses
+         * depend on the index just taken from the queue */
+        mm_nuts_adapt<double> ad = mm_lg_ld_adapt<true>(&a.adapt[L.cl]);
+        bool alive = valid;
+        int j_first, j_next;
+        if (qi == 0) {
+            const unsigned int m_done = (unsigned int)__double_as_longlong(mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_M)));
+            L.m = m_done + 1u;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                L.x[s] = mm_lg_ld<true>(&a.state[L.cl * D + 4 * s + L.q]);
+            if (a.write_initial && a.out && valid && m_done == a.m0)
+                mm_lg_write_row<D>(L, a, a.out_t0); /* row 0 = the initial position (nuts.rs:534) */
+            mm_lg_begin<D, true>(L, a);
+            j_first = 0;
+            j_next = a.j0;
+        } else {
+            const int j = qi - 1;
+            const double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                L.x[s] = mm_lg_ld<true>(&xs[s * st]);
+            L.joint = mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT));
+            L.logu = mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_LOGU));
+            const unsigned long long pk =
+                (unsigned long long)__double_as_longlong(mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_COUNTS)));
+            L.n = (unsigned int)pk;
+            L.aux_k = (unsigned int)(pk >> 32);
+            L.aux_have = 0xffffffffu;
+            L.aux_blk.w[0] = L.aux_blk.w[1] = L.aux_blk.w[2] = L.aux_blk.w[3] = 0u;
+            L.alpha = 0.0;
+            L.n_alpha = 0;
+            L.depth = j;
+            L.m = (unsigned int)__double_as_longlong(mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_M))) + 1u;
+            j_first = j;
+            j_next = j + 1;
+        }
+        /* one copy of the doubling code for both kinds of unit (the kernel's hot loop should stay small) */
+        for (int j = j_first; j < j_next && __ballot(alive) != 0ull; ++j)
+            mm_lg_doubling<D, true>(L, a, j, alive, ad.epsilon, lds, scr);
+
+        MM_LGQ_T(2);
+        /* ---- hand the chains on ---- */
+        bool again = false; /* finished this transition, more to go */
+        if (valid && alive) {
+            double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                mm_lg_st<true>(&xs[s * st], L.x[s]);
+            if (L.q == 0) {
+                mm_lg_st<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT), L.joint);
+                mm_lg_st<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_LOGU), L.logu);
+                mm_lg_st<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_COUNTS),
+                               __longlong_as_double((long long)((unsigned long long)L.n | ((unsigned long long)L.aux_k << 32))));
+            }
+        } else if (valid) {
+            mm_lg_finish<D>(L, a, ad);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                mm_lg_st<true>(&a.state[L.cl * D + 4 * s + L.q], L.x[s]);
+            const unsigned int t = L.m - a.m0 - 1u;
+            if (a.out && t >= a.n_pre)
+                mm_lg_write_row<D>(L, a, (unsigned long long)a.out_t0 + (a.write_initial ? 1u : 0u) + (t - a.n_pre));
+            if (L.q == 0) {
+                mm_lg_st_adapt<true>(&a.adapt[L.cl], ad);
+                mm_lg_st<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_M), __longlong_as_double((long long)L.m));
+            }
+            again = L.m < m_end;
+        }
+        if (valid && L.q == 0 && a.n_leapfrog)
+            atomicAdd(&a.n_leapfrog[L.cl], L.n_lf);
+        /* the write-through stores above have completed before a chain becomes visible in a queue */
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        /* chains that go on doubling stay with this wave (their records are parked all the same: the next unit loads
+         * every column alike); finished ones go back to queue 0 or retire */
+        keep = valid && alive;
+        keep_level = j_next;
+        mm_lgq_append<D>(L, a, home, 0, again);
+        const unsigned long long fin = __ballot(valid && !alive && !again && L.q == 0);
+        if (fin != 0ull && L.lane == (int)__ffsll((long long)fin) - 1)
+            atomicAdd(&ctrl->remaining, 0ull - (unsigned long long)__popcll(fin));
+        MM_LGQ_T(3);
+    }
+    if (L.lane == 0) {
+        for (int i = 0; i < 4; ++i)
+            atomicAdd(&ctrl->stat_t[i], st_t[i]);
+        atomicAdd(&ctrl->stat_units, st_units);
+        atomicAdd(&ctrl->stat_chains, st_chains);
+        atomicAdd(&ctrl->stat_polls, st_polls);
+    }
+#undef MM_LGQ_T
+}
+
+template <int D> hipError_t mm_launch_nuts_lgq(const mm_nuts_lg_args &a, unsigned int n_waves, hipStream_t stream)
+{
+    const size_t n_slots = (size_t)MM_LGQ_SHARDS * MM_LGQ_NQ * a.c_pad;
+    const size_t scalar_base = (size_t)mm_lg_cfg<D>::n_vec * D * a.c_pad;
+    hipLaunchKernelGGL((mm_nuts_lgq_init_kernel<D>), dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0, stream, a, scalar_base);
+    hipLaunchKernelGGL((mm_nuts_lgq_kernel<D>), dim3(n_waves), dim3(64), mm_lg_cfg<D>::lds_bytes, stream, a);
+    return hipGetLastError();
 }
 
 template <int D> hipError_t mm_launch_nuts_lg(const mm_nuts_lg_args &a, hipStream_t stream)
 {
     const unsigned int grid = (unsigned int)((a.n_chains + 15) / 16);
-    const size_t lds = mm_lg_cfg<D>::lds_bytes;
-    hipLaunchKernelGGL((mm_nuts_lg_kernel<D>), dim3(grid), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((mm_nuts_lg_kernel<D>), dim3(grid), dim3(64), mm_lg_cfg<D>::lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+/* one transition with compaction: a.m, a.row, a.write_initial set by the caller */
+template <int D> hipError_t mm_launch_nuts_lgc_transition(mm_nuts_lg_args a, hipStream_t stream)
+{
+    const unsigned int grid = (unsigned int)((a.n_chains + 15) / 16);
+    hipLaunchKernelGGL((mm_nuts_lgc_begin_kernel<D>), dim3(grid), dim3(64), mm_lg_cfg<D>::lds_bytes, stream, a);
+    for (int j = a.j0; j < a.max_depth; ++j) {
+        a.j = j;
+        hipLaunchKernelGGL((mm_nuts_lgc_double_kernel<D>), dim3(grid), dim3(64), mm_lg_cfg<D>::lds_bytes, stream, a);
+    }
     return hipGetLastError();
 }
 

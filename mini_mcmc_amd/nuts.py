@@ -51,8 +51,16 @@ class NUTS:
         return self
 
     def set_kernel_variant(self, variant: int) -> "NUTS":
-        """0 = one chain per lane; 1 = lane-group / MFMA mapping (mode 2, GaussianND, dim 16 or 32; default there)."""
+        """0 = one chain per lane; 1 = lane-group / MFMA mapping in one launch; 2 / 3 = the same with tree-depth compaction
+        by one launch per level / by a persistent scheduler (1..3: mode 2, GaussianND, dim 16 or 32, where 3 is the
+        default; all three give bit-identical samples)."""
         L.check(L.lib().mmcmc_nuts_set_kernel_variant(self._h, int(variant)), "mmcmc_nuts_set_kernel_variant")
+        return self
+
+    def set_compaction(self, first_level: int = 5, n_groups: int = 0) -> "NUTS":
+        """variants 2, 3: doublings below `first_level` run before the first re-packing; variant 2: `n_groups` chain groups
+        with their own launch sequences (0 = one per 16 384 chains).  Neither changes a result."""
+        L.check(L.lib().mmcmc_nuts_set_compaction(self._h, int(first_level), int(n_groups)), "mmcmc_nuts_set_compaction")
         return self
 
     @property

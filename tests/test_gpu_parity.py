@@ -431,21 +431,51 @@ def test_nuts_lane_group_mfma_bit_exact_vs_host_twin(M, O):
     for dim, cond, C, nc, nd, progress, cap, off in cases:
         g = M.dist.GaussianND.ill_conditioned(dim, cond, 7)
         init = M.core.init_with_seed(C, dim, 3) * 0.3
-        s = NUTS(g, init, 0.8, mode=2).set_seed(19).set_max_depth(cap)
-        assert s.kernel_variant == 1  # the default where it exists
-        if off:
-            s.set_chain_offset(off)
-        out = s._run(nc, nd, progress, "numpy")
         ref, pos, ad, nlf = O.engine_host_nuts_run(3, O.GAUSSIAN_ND, dim, [], init, 0.8, nc, nd, seed=19, matrix=g.precision,
                                                    progress=progress, max_depth=cap, chain_offset=off)
-        name = f"D={dim} cond={cond} C={C}"
-        assert np.array_equal(s.leapfrog_counts(), nlf), name
-        assert np.array_equal(out, ref), name
-        assert np.array_equal(s.positions(), pos), name
-        a = s.adapt_state()
-        assert np.array_equal(a["epsilon"], ad[:, 0]) and np.array_equal(a["epsilon_bar"], ad[:, 1]), name
-        assert np.array_equal(a["h_bar"], ad[:, 2]) and np.array_equal(a["mu"], ad[:, 3]), name
-        assert s.depth_histogram().sum() == C * (nc + nd - (0 if progress else 1))
+        # variants 2 / 3 = tree-depth compaction by launches / by the persistent scheduler (below 2048 chains 3 runs as
+        # 1; the scheduler itself is exercised further down), variant 1 = one launch, no compaction
+        for variant, start, groups in ((2, None, 0), (2, 0, 2), (2, 3, 3), (1, None, 0), (3, None, 0), (3, 2, 0)):
+            s = NUTS(g, init, 0.8, mode=2).set_seed(19).set_max_depth(cap)
+            assert s.kernel_variant == 3  # the default where it exists
+            s.set_kernel_variant(variant)
+            if start is not None:
+                s.set_compaction(start, groups)
+            if off:
+                s.set_chain_offset(off)
+            out = s._run(nc, nd, progress, "numpy")
+            name = f"D={dim} cond={cond} C={C} variant={variant} start={start} groups={groups}"
+            assert np.array_equal(s.leapfrog_counts(), nlf), name
+            assert np.array_equal(out, ref), name
+            assert np.array_equal(s.positions(), pos), name
+            a = s.adapt_state()
+            assert np.array_equal(a["epsilon"], ad[:, 0]) and np.array_equal(a["epsilon_bar"], ad[:, 1]), name
+            assert np.array_equal(a["h_bar"], ad[:, 2]) and np.array_equal(a["mu"], ad[:, 3]), name
+            assert s.depth_histogram().sum() == C * (nc + nd - (0 if progress else 1)), name
+    # a second run() continues where the first stopped, in either variant
+    g = M.dist.GaussianND.ill_conditioned(32, 100.0, 2)
+    init = M.core.init_with_seed(37, 32, 6) * 0.3
+    outs = []
+    for variant in (1, 2, 3):
+        s = NUTS(g, init, 0.8, mode=2).set_seed(4).set_kernel_variant(variant)
+        outs.append(np.concatenate([s.run(5, 7), s.run(4, 0), s.run_progress(3, 2)[0]], axis=1))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    # the persistent scheduler proper (>= 2048 chains): chains advance independently, through 8 queue shards, and still
+    # every chain's samples, adaptation state and tree shapes are those of the single-launch kernel and of the host twin
+    g = M.dist.GaussianND.ill_conditioned(32, 1e3, 11)
+    init = M.core.init_with_seed(2500, 32, 12) * 0.3
+    res = {}
+    for variant, start in ((3, 5), (3, 2), (1, 5)):
+        s = NUTS(g, init, 0.8, mode=2).set_seed(23).set_kernel_variant(variant).set_compaction(start, 0)
+        out = s.run(6, 14)
+        res[(variant, start)] = (out, s.positions(), s.leapfrog_counts(), s.adapt_state(), s.depth_histogram())
+    for key in ((3, 2), (1, 5)):
+        for x, y in zip(res[(3, 5)][:3], res[key][:3]):
+            assert np.array_equal(x, y), key
+        assert all(np.array_equal(res[(3, 5)][3][k], res[key][3][k]) for k in ("epsilon", "epsilon_bar", "h_bar", "mu")), key
+        assert np.array_equal(res[(3, 5)][4], res[key][4]), key
+    ref, pos, ad, nlf = O.engine_host_nuts_run(3, O.GAUSSIAN_ND, 32, [], init[:96], 0.8, 6, 14, seed=23, matrix=g.precision)
+    assert np.array_equal(res[(3, 5)][0][:96], ref) and np.array_equal(res[(3, 5)][2][:96], nlf)
     # sharding: the wave a chain sits in (and its neighbours' tree depths) must not matter
     g = M.dist.GaussianND.ill_conditioned(32, 1e3, 1)
     init = M.core.init_with_seed(50, 32, 8) * 0.3

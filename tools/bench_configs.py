@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--nuts-warmup", type=int, default=200)
     ap.add_argument("--nuts-draws", type=int, default=100)
     ap.add_argument("--nuts-variant", type=int, default=-1, help="-1: the default mapping; 0: lane per chain; 1: lane group / MFMA")
+    ap.add_argument("--nuts-compaction-start", type=int, default=-1)
+    ap.add_argument("--nuts-groups", type=int, default=0)
     ap.add_argument("--skip", default="")
     args = ap.parse_args()
     import torch
@@ -100,6 +102,8 @@ def main():
         s = NUTS(g, init, 0.8, mode=2).set_seed(42).set_max_depth(10)
         if args.nuts_variant >= 0:
             s.set_kernel_variant(args.nuts_variant)
+        if args.nuts_compaction_start >= 0 or args.nuts_groups > 0:
+            s.set_compaction(args.nuts_compaction_start if args.nuts_compaction_start >= 0 else 5, args.nuts_groups)
         t0 = time.perf_counter()
         out = s.run_progress(args.nuts_draws, args.nuts_warmup, to="torch")[0]
         torch.cuda.synchronize()
@@ -113,7 +117,7 @@ def main():
         rel = np.abs(np.diag(cov) - np.diag(true_cov)) / np.diag(true_cov)
         rhat, ess = S.split_rhat_mean_ess(out)
         print(json.dumps({"config": 5, "what": f"NUTS 32-D Gaussian cond 1e4 f64, {n} chains, {args.nuts_warmup}+{args.nuts_draws}, max depth 10",
-                          "variant": s.kernel_variant, "kernel_ms": kms, "wall_s": wall, "leapfrogs_total": int(lf.sum()),
+                          "variant": s.kernel_variant, "compaction_start": args.nuts_compaction_start, "groups": args.nuts_groups, "kernel_ms": kms, "wall_s": wall, "leapfrogs_total": int(lf.sum()),
                           "leapfrog_steps_per_s": float(lf.sum()) / (kms * 1e-3),
                           "samples_per_s": n * args.nuts_draws / (kms * 1e-3), "depth_hist": hist.tolist(),
                           "eps_mean": float(s.adapt_state()["epsilon"].mean()), "var_rel_err_max": float(rel.max()),

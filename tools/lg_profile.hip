@@ -6,7 +6,7 @@
 
 extern "C" int lgprof_run(const double *mat, double *state, void *adapt, unsigned long long n_chains,
                           unsigned long long seed, unsigned int m0, unsigned int n_steps, unsigned int n_discard,
-                          int max_depth, double *scratch, unsigned long long *prof)
+                          int max_depth, double *scratch, double *rec, unsigned long long *prof)
 {
     mm_nuts_lg_args a;
     a.mat = mat;
@@ -28,6 +28,16 @@ extern "C" int lgprof_run(const double *mat, double *state, void *adapt, unsigne
     a.max_depth = max_depth;
     a.target_accept_p = 0.8;
     a.scratch = scratch;
+    a.rec = rec;
+    a.c_pad = (n_chains + 15) / 16 * 16;
+    a.lists = nullptr;
+    a.counts = nullptr;
+    a.j0 = 0;
+    a.j = 0;
+    a.m = 0;
+    a.row = 0xffffffffu;
+    a.ctrl = nullptr;
+    a.slots = nullptr;
     a.prof = prof;
     hipError_t e = mm_launch_nuts_lg<32>(a, nullptr);
     if (e != hipSuccess)
@@ -36,3 +46,4 @@ extern "C" int lgprof_run(const double *mat, double *state, void *adapt, unsigne
 }
 
 extern "C" unsigned long long lgprof_scratch_doubles_per_wave() { return mm_lg_cfg<32>::scratch_doubles_per_wave; }
+extern "C" unsigned long long lgprof_rec_doubles_per_chain() { return mm_lg_cfg<32>::rec_doubles(1); }

@@ -26,9 +26,10 @@ def main():
 
     lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblgprof.so"))
     lib.lgprof_scratch_doubles_per_wave.restype = C.c_ulonglong
+    lib.lgprof_rec_doubles_per_chain.restype = C.c_ulonglong
     g = GaussianND.ill_conditioned(32, 1e4, 7)
     n = args.chains
-    s = NUTS(g, init_with_seed(n, 32, 42) * 0.1, 0.8, mode=2).set_seed(42).set_max_depth(10)
+    s = NUTS(g, init_with_seed(n, 32, 42) * 0.1, 0.8, mode=2).set_seed(42).set_max_depth(10).set_kernel_variant(1)
     s._run(0, args.warmup, True, "numpy")
     pos = s.positions()
     ad = s.adapt_state()
@@ -39,12 +40,14 @@ def main():
     t_state = torch.tensor(pos, device=dev)
     t_adapt = torch.tensor(adapt, device=dev)
     t_scr = torch.empty(waves * lib.lgprof_scratch_doubles_per_wave(), dtype=torch.float64, device=dev)
+    t_rec = torch.zeros(waves * 16 * lib.lgprof_rec_doubles_per_chain(), dtype=torch.float64, device=dev)
     t_prof = torch.zeros((waves, 8), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rc = lib.lgprof_run(C.c_void_p(t_mat.data_ptr()), C.c_void_p(t_state.data_ptr()), C.c_void_p(t_adapt.data_ptr()),
                         C.c_ulonglong(n), C.c_ulonglong(42), C.c_uint(args.warmup), C.c_uint(args.steps),
-                        C.c_uint(args.warmup), C.c_int(10), C.c_void_p(t_scr.data_ptr()), C.c_void_p(t_prof.data_ptr()))
+                        C.c_uint(args.warmup), C.c_int(10), C.c_void_p(t_scr.data_ptr()), C.c_void_p(t_rec.data_ptr()),
+                        C.c_void_p(t_prof.data_ptr()))
     dt = time.perf_counter() - t0
     assert rc == 0, rc
     p = t_prof.cpu().numpy().astype(np.float64)
@@ -56,7 +59,7 @@ def main():
     leaves, levels = p[:, 6], p[:, 7]
     print(f"  leaf iterations per wave per transition: {leaves.mean() / args.steps:.1f};  walk levels per leaf: {levels.sum() / leaves.sum():.2f}")
     print(f"  ticks per leaf iteration: leapfrog {p[:, 2].sum() / leaves.sum():.1f}  walk {p[:, 3].sum() / leaves.sum():.1f}"
-          f"  (s_memtime runs at 100 MHz: x {2400 / 100:.0f} for shader cycles at 2.4 GHz)")
+          f"  (s_memtime ticks; the counter ran at ~2.1 GHz in these runs)")
 
 
 if __name__ == "__main__":

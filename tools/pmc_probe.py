@@ -15,6 +15,8 @@ if what == "nuts5":
     nd, nc = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (50, 50)
     g = GaussianND.ill_conditioned(32, 1e4, 7)
     s = NUTS(g, init_with_seed(n, 32, 42) * 0.1, 0.8, mode=2).set_seed(42).set_max_depth(10)
+    if os.environ.get("NUTS_VARIANT"):
+        s.set_kernel_variant(int(os.environ["NUTS_VARIANT"]))
     s.run_progress(nc, nd, to="torch")
     torch.cuda.synchronize()
     print("nuts5", n, s.timing(), int(s.leapfrog_counts().sum()))
