@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r1d
+python tools/bench_configs.py --skip nuts > gpurun_out/r1d/configs.jsonl 2> gpurun_out/r1d/configs.err
+for v in 0 1 2 3; do
+  c=65536; [ $v = 0 ] && c=4096
+  timeout 600 python tools/bench_configs.py --skip mh,hmc,stats --nuts-chains $c --nuts-variant $v 2>/dev/null | grep '"config": 5' >> gpurun_out/r1d/configs.jsonl
+done
+timeout 600 python tools/bench_configs.py --skip mh,hmc,stats --nuts-chains 16384 --nuts-variant 3 2>/dev/null | grep '"config": 5' >> gpurun_out/r1d/configs.jsonl
+timeout 600 python tools/bench_configs.py --skip mh,hmc,stats --nuts-chains 16384 --nuts-variant 1 2>/dev/null | grep '"config": 5' >> gpurun_out/r1d/configs.jsonl
+python bench.py > gpurun_out/r1d/bench.json 2> gpurun_out/r1d/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r1d/prof_bench -o bench --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/gpurun_out/r1d/bench_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r1d/prof_nuts -o nuts --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --skip mh,hmc,stats --nuts-chains 65536 > $GRAFT_REPO_ROOT/gpurun_out/r1d/nuts_prof.json 2>/dev/null
+cat $GRAFT_REPO_ROOT/gpurun_out/r1d/bench.json
+ls $GRAFT_REPO_ROOT/gpurun_out/r1d/prof_bench $GRAFT_REPO_ROOT/gpurun_out/r1d/prof_nuts
