@@ -183,12 +183,13 @@ template <int NS> __device__ __forceinline__ double mm_lg_dot(const double *a, c
     return mm_lg_group_sum(c);
 }
 
-/* y = A x for the 16 chains of the wave; returns logp = -1/2 x.y and g = -y */
+/* y = A x for the 16 chains of the wave; returns logp = -1/2 x.y.  The gradient is -y: the kernels carry y itself
+ * (registers and edge records) and kick with -h -- fma(-h, y, p) and fma(h, -y, p) round the same exact product, so
+ * this is the twin's fma(h, g, p) bit for bit, without eight negations per leaf */
 template <int D>
-__device__ __forceinline__ double mm_lg_logp_grad(const double (&Aop)[D / 16][D / 4], const double *x, double *g)
+__device__ __forceinline__ double mm_lg_logp_ax(const double (&Aop)[D / 16][D / 4], const double *x, double *y)
 {
     constexpr int NS = D / 4, NT = D / 16;
-    double y[NS];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         mm_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -199,9 +200,6 @@ __device__ __forceinline__ double mm_lg_logp_grad(const double (&Aop)[D / 16][D 
         for (int r = 0; r < 4; ++r)
             y[4 * t + r] = acc[r];
     }
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-        g[s] = -y[s];
     return -0.5 * mm_lg_dot<NS>(x, y);
 }
 
@@ -308,7 +306,7 @@ template <int D, bool COH = false> __device__ __forceinline__ void mm_lg_begin(m
         mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
         p0[s] = (d & 1) ? z1 : z0;
     }
-    const double ulogp = mm_lg_logp_grad<D>(L.Aop, L.x, grad);
+    const double ulogp = mm_lg_logp_ax<D>(L.Aop, L.x, grad); /* grad holds A x = -gradient (see mm_lg_logp_ax) */
     L.joint = ulogp - mm_lg_dot<NS>(p0, p0) * 0.5;
     const double exp1_obs = -mm_log(mm_lg_aux_peek<D>(L, a.seed));
     L.aux_k += 1;
@@ -402,7 +400,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         cg[s] = mm_lg_ld<COH>(&eg[s * st]);
     }
     const double epsv = neg ? -epsilon : epsilon;
-    const double h = epsv * 0.5;
+    const double h = epsv * 0.5, nh = -h; /* cg holds A x = -gradient */
     const unsigned int n_leaves = 1u << j;
     /* nothing in flight when the leaf loop starts: otherwise every use of these loop-carried registers gets a
      * conservative vmcnt wait that also drains the records requested ahead of the leapfrog */
@@ -423,26 +421,29 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             break;
         MM_LG_COUNT(L, 6);
         /* an odd leaf merges with its left neighbour first: request those records now */
-        rec r0;
+        rec r0, r1;
         const bool merge0 = j > 0 && (leaf & 1u);
+        const bool merge1 = j > 1 && (leaf & 3u) == 3u; /* ... and then with the pair before it */
         if (merge0)
             load_rec(0, first_slot(leaf, 0), r0);
+        if (merge1)
+            load_rec(1, first_slot(leaf, 1), r1);
         /* leapfrog of the outer edge (nuts.rs:979-996), in place; chains that are done keep their edge (the
          * matrix product runs for all 64 lanes: MFMA has no per-lane mask, their columns are recomputed) */
         if (!done) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                cp[s] = fma(h, cg[s], cp[s]);
+                cp[s] = fma(nh, cg[s], cp[s]);
                 cx[s] = fma(epsv, cp[s], cx[s]);
             }
         }
         double y[NS];
-        const double lp = mm_lg_logp_grad<D>(L.Aop, cx, y); /* y = -A x */
+        const double lp = mm_lg_logp_ax<D>(L.Aop, cx, y); /* y = A x */
         if (!done) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 cg[s] = y[s];
-                cp[s] = fma(h, y[s], cp[s]);
+                cp[s] = fma(nh, y[s], cp[s]);
             }
         }
         const double jointp = lp - mm_lg_dot<NS>(cp, cp) * 0.5;
@@ -539,7 +540,20 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 merge(r0); /* level 0, records requested before the leapfrog */
             else
                 push(0);
-            for (int k = 1; k < j; ++k) {
+            if (j > 1 && __ballot(walking) != 0ull) {
+                MM_LG_COUNT(L, 7);
+                if (merge1)
+                    merge(r1);
+                else if ((leaf >> 1) & 1u) {
+                    /* bit 1 set but bit 0 clear: the level-0 child was first, a failing one was handed up */
+                    rec rk;
+                    load_rec(1, first_slot(leaf, 1), rk);
+                    merge(rk);
+                } else {
+                    push(1);
+                }
+            }
+            for (int k = 2; k < j; ++k) {
                 if (__ballot(walking) == 0ull)
                     break;
                 MM_LG_COUNT(L, 7);
