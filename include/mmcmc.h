@@ -223,6 +223,33 @@ int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out
 int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,
                     mmcmc_run_stats *out, int device, void *stream);
 
+/* ---- Metropolis-Hastings on integer states ---------------------------------------------------------------------
+ * MHMarkovChain / MetropolisHastings are generic over the state type (metropolis_hastings.rs:28-48, 149-160); the
+ * reference's own discrete users are the targets + proposals below.  One chain per lane, state i32, log-densities
+ * f64 (a table per target, built with the reference's operation order), step = metropolis_hastings.rs:303-315.
+ *   MMCMC_POISSON_REFLECT  params {lambda}: PoissonDist + PoissonRandomWalk      tests/metrohast_poisson_test.rs:18-85
+ *   MMCMC_BINOMIAL_CLAMP   params {n, p}:   BinomialDist + BinomialRandomWalk    tests/metrohast_poisson_test.rs:150-212
+ *   MMCMC_POISSON_NONNEG   params {lambda}: PoissonTarget + NonnegativeProposal  examples/poisson_mh.rs:8-76
+ * (lambda <= 256: states above 1023 have probability zero here.)  init: host [n_chains] i32;
+ * out: [n_chains, n_collect] i32 (the reference's Array3<i32>[C, n, 1]).  Integer states and accept counts are
+ * bit-exact against the host build of the same header (oracle/engine_host.cpp) and against the oracle's independent
+ * restatement on the same stream. */
+#define MMCMC_POISSON_REFLECT 16
+#define MMCMC_BINOMIAL_CLAMP 17
+#define MMCMC_POISSON_NONNEG 18
+typedef struct mmcmc_mh_discrete mmcmc_mh_discrete;
+int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *params, const int32_t *init,
+                             size_t n_chains, int device);
+int mmcmc_mh_discrete_seed(mmcmc_mh_discrete *h, uint64_t seed);                 /* MetropolisHastings::seed :187-193 */
+int mmcmc_mh_discrete_set_chain_offset(mmcmc_mh_discrete *h, uint64_t chain_offset);
+/* ChainRunner::run core.rs:176-186: n_discard + n_collect transitions, the last n_collect states kept */
+int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_discard, int32_t *out, int out_is_device,
+                          void *stream);
+int mmcmc_mh_discrete_state(mmcmc_mh_discrete *h, int32_t *out);                 /* host [n_chains] */
+int mmcmc_mh_discrete_accept_counts(mmcmc_mh_discrete *h, uint64_t *out);        /* host [n_chains], since creation */
+int mmcmc_mh_discrete_sync(mmcmc_mh_discrete *h);
+int mmcmc_mh_discrete_destroy(mmcmc_mh_discrete *h);
+
 /* ---- sample sink: io/csv.rs:47-69 save_csv -- header `chain,observation,dim_0,...`, one record per (chain,
  *      observation), values in Rust `Display` formatting (shortest round-trip, no exponent).  sample: HOST
  *      [n_chains, n, dim] of dtype. */

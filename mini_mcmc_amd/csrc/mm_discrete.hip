@@ -1,0 +1,268 @@
+/*
+ * mm_discrete.hip -- integer-state Metropolis-Hastings on the GPU and its C ABI (include/mmcmc.h: mmcmc_mh_discrete_*).
+ * One chain per lane, the whole run in one launch (ChainRunner::run over MHMarkovChain<i32 / usize>,
+ * core.rs:55-73, 176-186); the transition is mm_discrete_step (mm_discrete.h).  Samples [C, n_collect] i32 are staged
+ * per wave in LDS (64 chains x 64 iterations) and written as 256-byte rows.
+ */
+#include "../../include/mmcmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "mm_discrete.h"
+
+#define MM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return (int)_e;                                                                                       \
+    } while (0)
+
+namespace {
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        (void)hipSetDevice(d);
+    }
+    ~DevGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+struct run_args {
+    mm_discrete_params P;
+    int32_t *state;                 /* [C] */
+    int32_t *out;                   /* [C, n_collect] or NULL */
+    unsigned long long *accept;     /* [C] running totals */
+    unsigned long long n_chains, seed, chain_offset;
+    unsigned int iter0, n_discard, n_collect;
+};
+
+constexpr int TILE = 64;
+
+__global__ __launch_bounds__(64) void mm_discrete_kernel(const run_args a)
+{
+    __shared__ int32_t tile[64][TILE + 1];
+    const int lane = threadIdx.x;
+    const unsigned long long c0 = (unsigned long long)blockIdx.x * 64, c = c0 + lane;
+    const bool active = c < a.n_chains;
+    int32_t x = active ? a.state[c] : 0;
+    unsigned long long n_acc = 0;
+    const unsigned int total = a.n_discard + a.n_collect;
+    unsigned int col = 0, t0 = 0;
+    for (unsigned int t = 0; t < total; ++t) {
+        n_acc += (unsigned long long)mm_discrete_step(a.P, &x, a.seed, a.chain_offset + c, a.iter0 + t);
+        if (t >= a.n_discard && a.out) {
+            tile[lane][col++] = x;
+            if (col == TILE || t + 1 == total) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                /* row r of the tile = chain c0 + r: `col` consecutive samples, one coalesced store per chain */
+                for (int r = 0; r < 64; ++r)
+                    if (c0 + r < a.n_chains && (unsigned int)lane < col)
+                        a.out[(c0 + r) * a.n_collect + t0 + lane] = tile[r][lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                t0 += col;
+                col = 0;
+            }
+        }
+    }
+    if (active) {
+        a.state[c] = x;
+        a.accept[c] += n_acc;
+    }
+}
+
+} // namespace
+
+struct mmcmc_mh_discrete {
+    int device = 0, kind = 0;
+    size_t n_chains = 0;
+    uint64_t seed = 0, chain_offset = 0;
+    uint32_t iter = 0;
+    mm_discrete_params P{};
+    double *d_table = nullptr;
+    int32_t *d_state = nullptr;
+    unsigned long long *d_accept = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+extern "C" {
+
+int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *params, const int32_t *init,
+                             size_t n_chains, int device)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!params || !init || n_chains == 0)
+        return MMCMC_ERR_INVALID_ARG;
+    if (kind != MMCMC_POISSON_REFLECT && kind != MMCMC_BINOMIAL_CLAMP && kind != MMCMC_POISSON_NONNEG)
+        return MMCMC_ERR_UNSUPPORTED;
+    if (kind == MMCMC_BINOMIAL_CLAMP) {
+        if (!(params[0] >= 1.0 && params[0] < 1e6) || !(params[1] > 0.0 && params[1] < 1.0))
+            return MMCMC_ERR_INVALID_ARG;
+    } else if (!(params[0] > 0.0 && params[0] <= 256.0)) {
+        return MMCMC_ERR_INVALID_ARG; /* the Poisson table ends at 1023 */
+    }
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= nd)
+        return MMCMC_ERR_INVALID_ARG;
+    mmcmc_mh_discrete *h = new (std::nothrow) mmcmc_mh_discrete();
+    if (!h)
+        return (int)hipErrorOutOfMemory;
+    h->device = device;
+    h->kind = kind;
+    h->n_chains = n_chains;
+    DevGuard g(device);
+    const int cap = kind == MMCMC_BINOMIAL_CLAMP ? (int)params[0] + 1 : MM_DISCRETE_POISSON_TABLE;
+    std::vector<double> tab((size_t)cap);
+    const int len = mm_discrete_fill_table(kind, params, tab.data(), cap);
+    h->P.kind = kind;
+    h->P.n = kind == MMCMC_BINOMIAL_CLAMP ? (int)params[0] : 0;
+    h->P.table_len = len;
+    h->P.ln_half = mm_log(0.5);
+    auto fail = [&](int st) {
+        mmcmc_mh_discrete_destroy(h);
+        return st;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&h->d_table, (size_t)len * sizeof(double))) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMemcpy(h->d_table, tab.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+        return fail((int)e);
+    h->P.logp = h->d_table;
+    if ((e = hipMalloc((void **)&h->d_state, n_chains * sizeof(int32_t))) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMemcpy(h->d_state, init, n_chains * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMalloc((void **)&h->d_accept, n_chains * sizeof(unsigned long long))) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipMemset(h->d_accept, 0, n_chains * sizeof(unsigned long long))) != hipSuccess)
+        return fail((int)e);
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
+        return fail((int)e);
+    *out = h;
+    return MMCMC_OK;
+}
+
+int mmcmc_mh_discrete_seed(mmcmc_mh_discrete *h, uint64_t seed)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->seed = seed;
+    return MMCMC_OK;
+}
+
+int mmcmc_mh_discrete_set_chain_offset(mmcmc_mh_discrete *h, uint64_t off)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->chain_offset = off;
+    return MMCMC_OK;
+}
+
+int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_discard, int32_t *out, int out_is_device,
+                          void *stream)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    if ((uint64_t)h->iter + n_collect + n_discard >= (1ull << 32) || n_collect >= (1ull << 31))
+        return MMCMC_ERR_SHAPE;
+    DevGuard g(h->device);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t out_bytes = h->n_chains * n_collect * sizeof(int32_t);
+    int32_t *d_out = nullptr;
+    bool staged = false;
+    if (out && n_collect > 0) {
+        if (out_is_device) {
+            d_out = out;
+        } else {
+            MM_HIP(hipMalloc((void **)&d_out, out_bytes));
+            staged = true;
+        }
+    }
+    run_args a;
+    a.P = h->P;
+    a.state = h->d_state;
+    a.out = d_out;
+    a.accept = h->d_accept;
+    a.n_chains = h->n_chains;
+    a.seed = h->seed;
+    a.chain_offset = h->chain_offset;
+    a.iter0 = h->iter;
+    a.n_discard = (unsigned int)n_discard;
+    a.n_collect = (unsigned int)n_collect;
+    hipLaunchKernelGGL(mm_discrete_kernel, dim3((unsigned int)((h->n_chains + 63) / 64)), dim3(64), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (staged)
+            (void)hipFree(d_out);
+        return (int)e;
+    }
+    h->iter += (uint32_t)(n_collect + n_discard);
+    if (staged) {
+        MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(hipFree(d_out));
+    }
+    return MMCMC_OK;
+}
+
+int mmcmc_mh_discrete_state(mmcmc_mh_discrete *h, int32_t *out)
+{
+    if (!h || !out)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    MM_HIP(hipDeviceSynchronize());
+    MM_HIP(hipMemcpy(out, h->d_state, h->n_chains * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MMCMC_OK;
+}
+
+int mmcmc_mh_discrete_accept_counts(mmcmc_mh_discrete *h, uint64_t *out)
+{
+    if (!h || !out)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    MM_HIP(hipDeviceSynchronize());
+    MM_HIP(hipMemcpy(out, h->d_accept, h->n_chains * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MMCMC_OK;
+}
+
+int mmcmc_mh_discrete_sync(mmcmc_mh_discrete *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    MM_HIP(hipStreamSynchronize(h->stream));
+    return MMCMC_OK;
+}
+
+int mmcmc_mh_discrete_destroy(mmcmc_mh_discrete *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_table);
+    (void)hipFree(h->d_state);
+    (void)hipFree(h->d_accept);
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MMCMC_OK;
+}
+
+} /* extern "C" */

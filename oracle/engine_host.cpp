@@ -333,3 +333,34 @@ int eh_logp_grad(int dtype, int kind, int dim, const double params[8], const dou
 }
 
 } /* extern "C" */
+
+/* ---- integer-state MH: the product's mm_discrete.h compiled for the host (the GPU must match it bit for bit) ---- */
+#include "../mini_mcmc_amd/csrc/mm_discrete.h"
+
+extern "C" int eh_discrete_run(int kind, const double *params, const int32_t *init, size_t n_chains, uint64_t seed,
+                               uint64_t chain_offset, uint32_t iter0, size_t n_collect, size_t n_discard, int32_t *out,
+                               int32_t *state_out, uint64_t *accept_counts)
+{
+    const int cap = kind == MM_BINOMIAL_CLAMP ? (int)params[0] + 1 : MM_DISCRETE_POISSON_TABLE;
+    std::vector<double> tab((size_t)cap);
+    mm_discrete_params P;
+    P.kind = kind;
+    P.n = kind == MM_BINOMIAL_CLAMP ? (int)params[0] : 0;
+    P.table_len = mm_discrete_fill_table(kind, params, tab.data(), cap);
+    P.logp = tab.data();
+    P.ln_half = mm_log(0.5);
+    for (size_t c = 0; c < n_chains; ++c) {
+        int32_t x = init[c];
+        uint64_t acc = 0;
+        for (size_t t = 0; t < n_collect + n_discard; ++t) {
+            acc += (uint64_t)mm_discrete_step(P, &x, seed, chain_offset + c, iter0 + (uint32_t)t);
+            if (t >= n_discard && out)
+                out[c * n_collect + (t - n_discard)] = x;
+        }
+        if (state_out)
+            state_out[c] = x;
+        if (accept_counts)
+            accept_counts[c] = acc;
+    }
+    return 0;
+}

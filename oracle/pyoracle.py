@@ -122,6 +122,13 @@ def lib() -> C.CDLL:
             None,
             [tp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_int, _dp, _dp],
         ),
+        "o_discrete_create": (C.c_void_p, [C.c_int, _dp, C.POINTER(C.c_int32), C.c_int]),
+        "o_discrete_destroy": (None, [C.c_void_p]),
+        "o_discrete_seed": (None, [C.c_void_p, C.c_uint64]),
+        "o_discrete_proposal_seed": (None, [C.c_void_p, C.c_uint64]),
+        "o_discrete_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_discrete_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), _u64p]),
+        "o_discrete_state": (None, [C.c_void_p, C.POINTER(C.c_int32)]),
         "o_split_rhat_mean_ess": (None, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
         "o_autocov_bf": (None, [_fp, C.c_size_t, C.c_size_t, _fp]),
         "o_autocov_fft": (None, [_fp, C.c_size_t, C.c_size_t, _fp]),
@@ -547,6 +554,9 @@ def engine_host_lib() -> C.CDLL:
                               C.c_uint32, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp, C.c_void_p, _u64p, C.c_int]
     E.eh_noise.restype = C.c_int
     E.eh_noise.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    E.eh_discrete_run.restype = C.c_int
+    E.eh_discrete_run.argtypes = [C.c_int, _dp, C.POINTER(C.c_int32), C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32,
+                                  C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u64p]
     E.eh_logp_grad.restype = C.c_int
     E.eh_logp_grad.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     _eh = E
@@ -601,6 +611,66 @@ def engine_host_logp_grad(kind, dim, params, x, matrix=None, dtype=np.float32, w
     if rc != 0:
         raise ValueError(f"eh_logp_grad: {rc}")
     return lp, g
+
+
+POISSON_REFLECT, BINOMIAL_CLAMP, POISSON_NONNEG = 16, 17, 18
+_i32p = C.POINTER(C.c_int32)
+
+
+class DiscreteMH:
+    """oracle/discrete.c: MetropolisHastings over the reference's discrete test targets (i32 states)."""
+
+    def __init__(self, kind, params, init):
+        self.init = np.ascontiguousarray(init, dtype=np.int32).ravel()
+        self.n_chains = self.init.size
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        self._h = lib().o_discrete_create(int(kind), p.ctypes.data_as(_dp), self.init.ctypes.data_as(_i32p), self.n_chains)
+        if not self._h:
+            raise ValueError("o_discrete_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().o_discrete_destroy(self._h)
+            self._h = None
+
+    def seed(self, seed):
+        lib().o_discrete_seed(self._h, int(seed))
+        return self
+
+    def proposal_seed(self, seed):
+        lib().o_discrete_proposal_seed(self._h, int(seed))
+        return self
+
+    def use_engine_stream(self, seed, chain_offset=0):
+        lib().o_discrete_use_engine_stream(self._h, int(seed), int(chain_offset))
+        return self
+
+    def run(self, n_collect, n_discard):
+        out = np.zeros((self.n_chains, n_collect), dtype=np.int32)
+        acc = np.zeros(self.n_chains, dtype=np.uint64)
+        lib().o_discrete_run(self._h, n_collect, n_discard, out.ctypes.data_as(_i32p), acc.ctypes.data_as(_u64p))
+        self.accept_counts = acc
+        return out
+
+    def state(self):
+        out = np.zeros(self.n_chains, dtype=np.int32)
+        lib().o_discrete_state(self._h, out.ctypes.data_as(_i32p))
+        return out
+
+
+def engine_host_discrete_run(kind, params, init, n_collect, n_discard, seed=0, chain_offset=0, iter0=0):
+    """The product's mm_discrete.h on the host: (samples [C, n_collect] i32, final states, accept counts)."""
+    E = engine_host_lib()
+    init = np.ascontiguousarray(init, dtype=np.int32).ravel()
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    out = np.zeros((init.size, n_collect), dtype=np.int32)
+    st = np.zeros(init.size, dtype=np.int32)
+    acc = np.zeros(init.size, dtype=np.uint64)
+    rc = E.eh_discrete_run(int(kind), p.ctypes.data_as(_dp), init.ctypes.data_as(_i32p), init.size, int(seed),
+                           int(chain_offset), int(iter0), n_collect, n_discard, out.ctypes.data_as(_i32p),
+                           st.ctypes.data_as(_i32p), acc.ctypes.data_as(_u64p))
+    assert rc == 0
+    return out, st, acc
 
 
 def engine_host_nuts_run(mode, kind, dim, params, init, target_accept_p, n_collect, n_discard, seed=0, chain_offset=0,
