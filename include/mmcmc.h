@@ -14,8 +14,10 @@
  *   - a handle owns its device state (current positions, iteration counter, seed), so calling run() twice
  *     continues the chains exactly as the Rust sampler structs do
  *   - handles are not thread-safe; one handle = one device; `stream` arguments are hipStream_t passed as
- *     void* (NULL = the handle's own stream); run() is asynchronous when `out` is device memory and no
- *     host-side result (accept counts) is requested -- call mmcmc_*_sync() or synchronise the stream.
+ *     void* (NULL = the handle's own stream, a BLOCKING stream: it orders itself with work on the legacy default
+ *     stream, so a caller working on the default stream -- e.g. torch's -- sees the results without a host
+ *     synchronisation); run() is asynchronous when `out` is device memory and no host-side result (accept
+ *     counts) is requested -- call mmcmc_*_sync() or synchronise the stream.
  *   - the library has NO CPU fallback: without a usable HIP device every compute entry point fails.
  */
 #ifndef MMCMC_H
@@ -222,6 +224,24 @@ int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_s
 int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out);
 int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,
                     mmcmc_run_stats *out, int device, void *stream);
+
+/* ---- running diagnostics: MultiChainTracker (stats.rs:189-306) -------------------------------------------------
+ * What run_progress shows while sampling (hmc.rs:242-281: `p(accept)` and `max(rhat)` after every step).  The tracker
+ * keeps per-chain running mean / mean of squares (the reference's f32 recurrences, exactly), the exponentially
+ * averaged acceptance indicator and the running R-hat sqrt(var+ / W) (the conventional one, unlike split_rhat's,
+ * quirk Q7) on the device; it is fed blocks of consecutive states and polled by the host between launches.
+ *   mmcmc_tracker_steps: MultiChainTracker::step (stats.rs:236-262) for rows t0 .. t0+k-1 of every chain of
+ *       states [n_chains, n_rows, dim] of dtype (device or host pointer) -- e.g. a slice of a sampler's output, or the
+ *       current positions with n_rows = 1.
+ *   mmcmc_tracker_stats: rhat [dim] (MultiChainTracker::rhat :280-286), its maximum (max_rhat :270-274) and p_accept;
+ *       needs at least two steps.  Any of the outputs may be NULL. */
+typedef struct mmcmc_tracker mmcmc_tracker;
+int mmcmc_tracker_create(mmcmc_tracker **out, size_t n_chains, size_t dim, int device);
+int mmcmc_tracker_steps(mmcmc_tracker *h, const void *states, int states_is_device, int dtype, size_t n_rows, size_t t0,
+                        size_t k, void *stream);
+int mmcmc_tracker_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *p_accept, void *stream);
+int mmcmc_tracker_n(mmcmc_tracker *h, uint64_t *n);
+int mmcmc_tracker_destroy(mmcmc_tracker *h);
 
 /* ---- Metropolis-Hastings on integer states ---------------------------------------------------------------------
  * MHMarkovChain / MetropolisHastings are generic over the state type (metropolis_hastings.rs:28-48, 149-160); the

@@ -80,6 +80,38 @@ class _Sampler:
         self.accept_counts = acc
         return out
 
+    def run_progress(self, n_collect: int, n_discard: int = 0, every: int = 0, callback=None, to: str = "numpy"):
+        """`run_progress(n_collect, n_discard)` of the reference (hmc.rs:222-294 / core.rs:208-360): burn-in, then
+        sampling with a MultiChainTracker fed the state before the loop and every collected state; returns
+        (sample [n_chains, n_collect, dim], RunStats).  Instead of a progress bar redrawn after each step, the run is
+        cut into launches of `every` transitions (default: 10 segments) and after each `callback(done, p_accept,
+        max_rhat)` is called -- the two numbers the reference's bar shows.  The tracker ends up in `self.tracker`."""
+        import torch
+
+        from . import stats as S
+
+        dev = torch.device("cuda", self.device)
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        if n_discard:
+            self.run(0, n_discard, to="torch", accept_counts=False, collect=False)
+        tracker = S.MultiChainTracker(self.n_chains, self.dim, self.device)
+        tracker.step(torch.as_tensor(self.state(), device=dev))  # the state the sampling starts from (hmc.rs:244-247)
+        out = torch.empty((self.n_chains, n_collect, self.dim), dtype=tdt, device=dev)
+        every = int(every) if every else max(1, (n_collect + 9) // 10)
+        done = 0
+        while done < n_collect:
+            k = min(every, n_collect - done)
+            seg = self.run(k, 0, to="torch", accept_counts=False)
+            out[:, done:done + k, :] = seg
+            tracker.step(out, t0=done, k=k)
+            done += k
+            if callback is not None:
+                _, mx, p = tracker._stats()
+                callback(done, float(p), float(mx))
+        self.tracker = tracker
+        stats = S.run_stats(out)
+        return (out if to == "torch" else out.cpu().numpy()), stats
+
     def sync(self):
         L.check(self._fn("sync")(self._h), "sync")
 

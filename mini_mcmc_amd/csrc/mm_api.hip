@@ -226,7 +226,7 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         return fail((int)e);
     if ((e = hipMemset(s->d_accept_total, 0, sizeof(unsigned long long))) != hipSuccess)
         return fail((int)e);
-    if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess)
+    if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamDefault)) != hipSuccess)
         return fail((int)e);
     if ((e = hipEventCreate(&s->ev0)) != hipSuccess)
         return fail((int)e);

@@ -151,7 +151,7 @@ int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *pa
         return fail((int)e);
     if ((e = hipMemset(h->d_accept, 0, n_chains * sizeof(unsigned long long))) != hipSuccess)
         return fail((int)e);
-    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamDefault)) != hipSuccess)
         return fail((int)e);
     *out = h;
     return MMCMC_OK;

@@ -190,7 +190,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 variant = 3; /* the default where it exists */
             }
         }
-        MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamDefault));
         MM_HIP(hipEventCreate(&ev0));
         MM_HIP(hipEventCreate(&ev1));
         return MMCMC_OK;

@@ -1,0 +1,303 @@
+/*
+ * mm_tracker.hip -- running multi-chain diagnostics on the GPU (include/mmcmc.h: mmcmc_tracker_*).
+ *
+ * Replaces MultiChainTracker (stats.rs:189-306), which run_progress feeds one [n_chains, n_params] state per step
+ * (hmc.rs:242-281, core.rs:326-344 through ChainTracker) to show `p(accept)` and `max(rhat)` while sampling.  Here
+ * the tracker lives next to the sample in HBM and is fed BLOCKS of consecutive states [n_chains, k, n_params] (a slice
+ * of the sampler's output); the host polls it between launches.
+ *   step kernel   one lane per chain, the reference's f32 recurrences in the reference's order (stats.rs:244-249):
+ *                     mean    = (mean * (n-1) + x) / n
+ *                     mean_sq = n == 1 ? x^2 : (mean_sq * (n-1) + x^2) / n
+ *                 -- per chain these are exactly the reference's values -- and a flag "this state differs from the
+ *                 chain's previous one" per (step, chain).
+ *   p_accept      the reference folds p <- (1-a) p + a * flag over the chains of a step IN ORDER, step after step
+ *                 (a = 0.01, stats.rs:252-258): one long recurrence.  Its value forgets its start at the rate
+ *                 0.99^m, so one lane replays the last 16 384 flags sequentially (0.99^16384 ~ 1e-72): the same f32
+ *                 operations in the same order as the reference over the part of the sequence that still matters.
+ *   rhat          within_and_var (stats.rs:288-306) from the per-chain means: block reduction with f64 accumulators
+ *                 (the reference sums f32 in ndarray's order; parity to ~1e-6 relative, tests/test_tracker.py).
+ */
+#include "../../include/mmcmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <new>
+#include <vector>
+
+#define MM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return (int)_e;                                                                                       \
+    } while (0)
+
+namespace {
+
+constexpr float kAlpha = 0.01f;      /* stats.rs:13 */
+constexpr size_t kTail = 16384;      /* flags replayed sequentially for p_accept */
+constexpr int kMaxDim = 64;
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        (void)hipSetDevice(d);
+    }
+    ~DevGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+/* states [C, n_rows, D] of T; this call consumes rows t0 .. t0+k-1 of every chain; n_before = steps taken so far */
+template <class T>
+__global__ void tracker_step_kernel(const T *__restrict__ states, unsigned long long C, unsigned long long n_rows,
+                                    unsigned long long t0, unsigned int k, unsigned int D, unsigned long long n_before,
+                                    float *__restrict__ mean, float *__restrict__ mean_sq, float *__restrict__ last,
+                                    unsigned char *__restrict__ flags /* [k, C] */)
+{
+    const unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C)
+        return;
+    float m[kMaxDim], q[kMaxDim], l[kMaxDim];
+    for (unsigned int d = 0; d < D; ++d) {
+        m[d] = mean[c * D + d];
+        q[d] = mean_sq[c * D + d];
+        l[d] = last[c * D + d];
+    }
+    for (unsigned int t = 0; t < k; ++t) {
+        const unsigned long long n_i = n_before + t + 1;
+        const float n = (float)n_i;
+        const T *row = states + (c * n_rows + t0 + t) * D;
+        int ne = 0;
+        for (unsigned int d = 0; d < D; ++d) {
+            const float x = (float)row[d];
+            m[d] = (m[d] * (n - 1.0f) + x) / n;
+            q[d] = (n_i == 1) ? x * x : (q[d] * (n - 1.0f) + x * x) / n;
+            ne |= (x != l[d]) ? 1 : 0;
+            l[d] = x;
+        }
+        flags[(size_t)t * C + c] = (unsigned char)ne;
+    }
+    for (unsigned int d = 0; d < D; ++d) {
+        mean[c * D + d] = m[d];
+        mean_sq[c * D + d] = q[d];
+        last[c * D + d] = l[d];
+    }
+}
+
+/* sequential replay of the last `len` flags (time-major, chain-minor order) */
+__global__ void tracker_paccept_kernel(const unsigned char *__restrict__ flags, size_t first, size_t len, int restart,
+                                       float *p_accept)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    float p = restart ? 0.5f : *p_accept; /* restart: the sequence before `first` is forgotten anyway */
+    for (size_t i = 0; i < len; ++i) {
+        const float accepted = (float)flags[first + i];
+        p = (1.0f - kAlpha) * p + kAlpha * accepted;
+    }
+    *p_accept = p;
+}
+
+/* within_and_var: out[d] = rhat; one block per parameter */
+__global__ __launch_bounds__(1024) void tracker_rhat_kernel(const float *__restrict__ mean,
+                                                            const float *__restrict__ mean_sq, unsigned long long C,
+                                                            unsigned int D, unsigned long long n_i, float *out)
+{
+    __shared__ double red[1024];
+    const unsigned int d = blockIdx.x, tid = threadIdx.x;
+    auto block_sum = [&](double v) -> double {
+        red[tid] = v;
+        __syncthreads();
+        for (unsigned int s = 512; s > 0; s >>= 1) {
+            if (tid < s)
+                red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    const float n = (float)n_i, nch = (float)C;
+    double s = 0.0;
+    for (unsigned long long c = tid; c < C; c += 1024)
+        s += (double)mean[c * D + d];
+    const float mean_chain = (float)(block_sum(s) / (double)nch);
+    double b = 0.0, w = 0.0;
+    for (unsigned long long c = tid; c < C; c += 1024) {
+        const float mc = mean[c * D + d];
+        const float df = mc - mean_chain;
+        b += (double)(df * df);
+        const float sm2 = (mean_sq[c * D + d] - mc * mc) * n / (n - 1.0f);
+        w += (double)sm2;
+    }
+    const float between = (float)block_sum(b) * (n / (nch - 1.0f));
+    const float within = (float)(block_sum(w) / (double)nch);
+    if (tid == 0) {
+        const float var = within * ((n - 1.0f) / n) + between * (1.0f / n);
+        out[d] = sqrtf(var / within);
+    }
+}
+
+} // namespace
+
+struct mmcmc_tracker {
+    int device = 0;
+    size_t n_chains = 0, dim = 0;
+    unsigned long long n = 0; /* steps taken */
+    float *d_mean = nullptr, *d_mean_sq = nullptr, *d_last = nullptr, *d_p = nullptr, *d_rhat = nullptr;
+    unsigned char *d_flags = nullptr;
+    size_t flags_cap = 0;
+};
+
+extern "C" {
+
+int mmcmc_tracker_create(mmcmc_tracker **out, size_t n_chains, size_t dim, int device)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_chains < 2 || dim == 0 || dim > (size_t)kMaxDim)
+        return MMCMC_ERR_INVALID_ARG;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= nd)
+        return MMCMC_ERR_INVALID_ARG;
+    mmcmc_tracker *h = new (std::nothrow) mmcmc_tracker();
+    if (!h)
+        return (int)hipErrorOutOfMemory;
+    h->device = device;
+    h->n_chains = n_chains;
+    h->dim = dim;
+    DevGuard g(device);
+    const size_t cd = n_chains * dim * sizeof(float);
+    hipError_t e = hipSuccess;
+    auto alloc0 = [&](float **p, size_t bytes) {
+        if (e == hipSuccess)
+            e = hipMalloc((void **)p, bytes);
+        if (e == hipSuccess)
+            e = hipMemset(*p, 0, bytes);
+    };
+    /* MultiChainTracker::new (stats.rs:216-228): n = 0, p_accept = 0, everything else zero */
+    alloc0(&h->d_mean, cd);
+    alloc0(&h->d_mean_sq, cd);
+    alloc0(&h->d_last, cd);
+    alloc0(&h->d_p, sizeof(float));
+    alloc0(&h->d_rhat, dim * sizeof(float));
+    if (e != hipSuccess) {
+        mmcmc_tracker_destroy(h);
+        return (int)e;
+    }
+    *out = h;
+    return MMCMC_OK;
+}
+
+int mmcmc_tracker_steps(mmcmc_tracker *h, const void *states, int states_is_device, int dtype, size_t n_rows, size_t t0,
+                        size_t k, void *stream)
+{
+    if (!h || !states || (dtype != MMCMC_F32 && dtype != MMCMC_F64) || k == 0 || t0 + k > n_rows)
+        return MMCMC_ERR_INVALID_ARG;
+    if (k >= (1ull << 31))
+        return MMCMC_ERR_SHAPE;
+    DevGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esz = dtype == MMCMC_F32 ? 4 : 8;
+    const void *d_states = states;
+    void *tmp = nullptr;
+    if (!states_is_device) {
+        const size_t bytes = h->n_chains * n_rows * h->dim * esz;
+        MM_HIP(hipMalloc(&tmp, bytes));
+        MM_HIP(hipMemcpyAsync(tmp, states, bytes, hipMemcpyHostToDevice, st));
+        d_states = tmp;
+    }
+    const size_t need = k * h->n_chains;
+    if (need > h->flags_cap) {
+        MM_HIP(hipStreamSynchronize(st));
+        (void)hipFree(h->d_flags);
+        h->d_flags = nullptr;
+        h->flags_cap = 0;
+        MM_HIP(hipMalloc((void **)&h->d_flags, need));
+        h->flags_cap = need;
+    }
+    const unsigned int grid = (unsigned int)((h->n_chains + 255) / 256);
+    if (dtype == MMCMC_F32)
+        hipLaunchKernelGGL(tracker_step_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)d_states,
+                           (unsigned long long)h->n_chains, (unsigned long long)n_rows, (unsigned long long)t0,
+                           (unsigned int)k, (unsigned int)h->dim, h->n, h->d_mean, h->d_mean_sq, h->d_last, h->d_flags);
+    else
+        hipLaunchKernelGGL(tracker_step_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)d_states,
+                           (unsigned long long)h->n_chains, (unsigned long long)n_rows, (unsigned long long)t0,
+                           (unsigned int)k, (unsigned int)h->dim, h->n, h->d_mean, h->d_mean_sq, h->d_last, h->d_flags);
+    MM_HIP(hipGetLastError());
+    const size_t len = need < kTail ? need : kTail;
+    hipLaunchKernelGGL(tracker_paccept_kernel, dim3(1), dim3(64), 0, st, h->d_flags, need - len, len,
+                       need > kTail ? 1 : 0, h->d_p);
+    MM_HIP(hipGetLastError());
+    h->n += k;
+    if (tmp) {
+        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(hipFree(tmp));
+    }
+    return MMCMC_OK;
+}
+
+int mmcmc_tracker_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *p_accept, void *stream)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    if (h->n < 2)
+        return MMCMC_ERR_STATE; /* n / (n - 1) */
+    DevGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tracker_rhat_kernel, dim3((unsigned int)h->dim), dim3(1024), 0, st, h->d_mean, h->d_mean_sq,
+                       (unsigned long long)h->n_chains, (unsigned int)h->dim, h->n, h->d_rhat);
+    MM_HIP(hipGetLastError());
+    std::vector<float> r(h->dim);
+    float p = 0.f;
+    MM_HIP(hipMemcpyAsync(r.data(), h->d_rhat, h->dim * sizeof(float), hipMemcpyDeviceToHost, st));
+    MM_HIP(hipMemcpyAsync(&p, h->d_p, sizeof(float), hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    float mx = r[0];
+    for (size_t d = 0; d < h->dim; ++d) {
+        if (rhat)
+            rhat[d] = r[d];
+        mx = r[d] > mx ? r[d] : mx; /* max_rhat (stats.rs:270-274) */
+    }
+    if (max_rhat)
+        *max_rhat = mx;
+    if (p_accept)
+        *p_accept = p;
+    return MMCMC_OK;
+}
+
+int mmcmc_tracker_n(mmcmc_tracker *h, uint64_t *n)
+{
+    if (!h || !n)
+        return MMCMC_ERR_INVALID_ARG;
+    *n = h->n;
+    return MMCMC_OK;
+}
+
+int mmcmc_tracker_destroy(mmcmc_tracker *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(h->d_mean);
+    (void)hipFree(h->d_mean_sq);
+    (void)hipFree(h->d_last);
+    (void)hipFree(h->d_p);
+    (void)hipFree(h->d_rhat);
+    (void)hipFree(h->d_flags);
+    delete h;
+    return MMCMC_OK;
+}
+
+} /* extern "C" */

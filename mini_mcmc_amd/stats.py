@@ -162,3 +162,59 @@ def split_rhat_mean_ess_distributed(sample_local, group=None):
     means, ssq, acov = stats_partials(sample_local)
     g_means, g_ssq, g_acov = gather_partials(means, ssq, acov, group)
     return stats_finish(g_means, g_ssq, g_acov)
+
+
+class MultiChainTracker:
+    """stats.rs:189-306 on the GPU: per-chain running means, exponentially averaged acceptance indicator, running
+    R-hat.  `step(states)` takes what the reference's `step` takes -- the current states [n_chains, n_params] -- or a
+    block of consecutive states [n_chains, k, n_params] (numpy, or a torch tensor in HBM: no host copy)."""
+
+    def __init__(self, n_chains: int, n_params: int, device: int = 0):
+        self.n_chains, self.n_params, self.device = int(n_chains), int(n_params), device
+        self._h = C.c_void_p()
+        L.check(L.lib().mmcmc_tracker_create(C.byref(self._h), self.n_chains, self.n_params, device), "mmcmc_tracker_create")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                L.lib().mmcmc_tracker_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def step(self, states, t0: int = 0, k: int | None = None) -> "MultiChainTracker":
+        ptr, is_dev, code, shape, dev, stream, keep = _sample_args(states)
+        if len(shape) == 2:
+            shape = (shape[0], 1, shape[1])
+        if len(shape) != 3 or shape[0] != self.n_chains or shape[2] != self.n_params:
+            raise ValueError(f"states must be [{self.n_chains}, k, {self.n_params}]")
+        k = shape[1] - t0 if k is None else k
+        L.check(L.lib().mmcmc_tracker_steps(self._h, C.c_void_p(ptr), is_dev, code, shape[1], t0, k, stream),
+                "mmcmc_tracker_steps")
+        return self
+
+    def _stats(self):
+        r = np.zeros(self.n_params, dtype=np.float32)
+        mx, p = C.c_float(), C.c_float()
+        L.check(L.lib().mmcmc_tracker_stats(self._h, r.ctypes.data_as(_fp), C.byref(mx), C.byref(p), None),
+                "mmcmc_tracker_stats")
+        return r, np.float32(mx.value), np.float32(p.value)
+
+    def rhat(self) -> np.ndarray:
+        """stats.rs:280-286"""
+        return self._stats()[0]
+
+    def max_rhat(self) -> np.float32:
+        """stats.rs:270-274"""
+        return self._stats()[1]
+
+    @property
+    def p_accept(self) -> np.float32:
+        return self._stats()[2]
+
+    @property
+    def n(self) -> int:
+        n = C.c_uint64()
+        L.check(L.lib().mmcmc_tracker_n(self._h, C.byref(n)), "mmcmc_tracker_n")
+        return int(n.value)

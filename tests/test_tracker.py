@@ -1,0 +1,80 @@
+"""Running diagnostics on the GPU: MultiChainTracker (stats.rs:189-306) as a device-side tracker fed
+blocks of states, against the oracle's restatement (pinned to stats.rs:704-752 in tests/test_oracle_pins.py)."""
+import numpy as np
+import pytest
+
+
+def test_tracker_abi_symbols():
+    import mini_mcmc_amd
+
+    lib = mini_mcmc_amd.lib()
+    for sym in ("create", "steps", "stats", "n", "destroy"):
+        assert hasattr(lib, "mmcmc_tracker_" + sym)
+
+
+@pytest.mark.gpu
+def test_tracker_matches_reference_semantics(O):
+    import torch
+
+    from mini_mcmc_amd import stats as S
+
+    rng = np.random.default_rng(8)
+    for chains, steps, params in ((4, 30, 2), (300, 57, 3), (20000, 12, 3)):
+        # states with repeats (rejections): a chain keeps its previous state with probability 0.35
+        x = rng.standard_normal((steps, chains, params)).astype(np.float32)
+        keep = rng.random((steps, chains)) < 0.35
+        for t in range(1, steps):
+            x[t][keep[t]] = x[t - 1][keep[t]]
+        rhat_o, p_o = O.multichain_tracker_rhat(x)  # [steps, chains, params]
+        cm = np.ascontiguousarray(x.transpose(1, 0, 2))  # [chains, steps, params]
+        # (a) one call with the whole block, from the host; (b) step by step / in uneven blocks, from HBM; (c) f64 input
+        ta = S.MultiChainTracker(chains, params).step(cm)
+        tb = S.MultiChainTracker(chains, params)
+        tdev = torch.as_tensor(cm, device="cuda")
+        tb.step(tdev[:, 0, :].contiguous())
+        t = 1
+        for k in (1, 5, 3, steps):
+            k = min(k, steps - t)
+            if k > 0:
+                tb.step(tdev, t0=t, k=k)
+                t += k
+        tc = S.MultiChainTracker(chains, params).step(cm.astype(np.float64))
+        for tr in (ta, tb, tc):
+            assert tr.n == steps
+            np.testing.assert_allclose(tr.rhat(), rhat_o, rtol=2e-5)
+            assert abs(float(tr.max_rhat()) - float(rhat_o.max())) <= 2e-5 * float(rhat_o.max())
+            if chains * steps <= 16384:
+                assert tr.p_accept == p_o  # the same f32 operations in the same order: exact
+            else:
+                assert abs(float(tr.p_accept) - float(p_o)) < 1e-6  # start forgotten at rate 0.99^16384
+        assert ta.p_accept == tb.p_accept or chains * steps > 16384
+
+
+@pytest.mark.gpu
+def test_run_progress_with_tracker_on_gpu(O):
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import DiffableGaussian2D, Gaussian2D, IsotropicGaussian
+    from mini_mcmc_amd.hmc import HMC
+    from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+
+    seen = []
+    s = HMC(DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), init_with_seed(4096, 2, 3, np.float32), 0.1, 10).set_seed(5)
+    sample, stats = s.run_progress(200, 50, every=40, callback=lambda d, p, r: seen.append((d, p, r)))
+    assert sample.shape == (4096, 200, 2) and [d for d, _, _ in seen] == [40, 80, 120, 160, 200]
+    assert all(0.8 < p < 1.001 for _, p, _ in seen), seen       # HMC at eps 0.1 accepts nearly always (f32 EMA: 1 + 1 ulp possible)
+    assert seen[-1][2] < seen[0][2] and 1.0 <= seen[-1][2] < 1.1  # running R-hat falls towards 1
+    assert s.tracker.n == 201                                   # the start state + every collected state
+    # the tracker fed by run_progress equals the oracle's tracker fed the same states
+    start = None
+    s2 = HMC(DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), init_with_seed(256, 2, 3, np.float32), 0.1, 10).set_seed(5)
+    s2.run(0, 20, collect=False)
+    start = s2.state()
+    smp, _ = s2.run_progress(30, 0, every=7)
+    states = np.concatenate([start[None], smp.transpose(1, 0, 2)], axis=0)
+    rhat_o, p_o = O.multichain_tracker_rhat(states)
+    np.testing.assert_allclose(s2.tracker.rhat(), rhat_o, rtol=2e-5)
+    assert s2.tracker.p_accept == p_o
+    # MH: acceptance near the textbook rate for a unit Gaussian with a unit proposal (~0.5-0.6 in 2-D)
+    mh = MetropolisHastings(Gaussian2D([0, 0], [[1, 0], [0, 1]]), IsotropicGaussian(1.0), init_with_seed(8192, 2, 42, np.float32)).seed(42)
+    _, st = mh.run_progress(100, 100)
+    assert 0.4 < float(mh.tracker.p_accept) < 0.75 and st.rhat.max < 1.05
