@@ -254,5 +254,121 @@ template <class T> class NUTS {
     }
 };
 
+/* NUTS in f64 tensors / f64 scalars (mode 2 of the C ABI; BASELINE.json config 5): for mmcmc::GaussianND of dim 16
+ * or 32 this runs the lane-group / MFMA kernel with tree-depth compaction (include/mmcmc.h, kernel variants). */
+class NUTS64 {
+    mmcmc_nuts *h_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    NUTS64(Target target, const std::vector<double> &initial_positions, size_t n_chains, double target_accept_p,
+           int device = 0)
+        : n_chains_(n_chains), dim_(initial_positions.size() / n_chains)
+    {
+        check(mmcmc_nuts_create(&h_, target.desc(), initial_positions.data(), n_chains, target_accept_p, 2, device),
+              "mmcmc_nuts_create");
+    }
+    NUTS64(const NUTS64 &) = delete;
+    NUTS64 &operator=(const NUTS64 &) = delete;
+    ~NUTS64() { mmcmc_nuts_destroy(h_); }
+    NUTS64 &set_seed(uint64_t s)
+    {
+        check(mmcmc_nuts_seed(h_, s), "mmcmc_nuts_seed");
+        return *this;
+    }
+    NUTS64 &set_max_depth(int d)
+    {
+        check(mmcmc_nuts_set_max_depth(h_, d), "mmcmc_nuts_set_max_depth");
+        return *this;
+    }
+    NUTS64 &set_kernel_variant(int v)
+    {
+        check(mmcmc_nuts_set_kernel_variant(h_, v), "mmcmc_nuts_set_kernel_variant");
+        return *this;
+    }
+    int kernel_variant() const { return mmcmc_nuts_kernel_variant(h_); }
+    std::vector<double> run(size_t n_collect, size_t n_discard)
+    {
+        std::vector<double> out(n_chains_ * n_collect * dim_);
+        check(mmcmc_nuts_run(h_, n_collect, n_discard, out.data(), 0, 0, nullptr), "mmcmc_nuts_run");
+        check(mmcmc_nuts_sync(h_), "mmcmc_nuts_sync");
+        return out;
+    }
+};
+
+/* MetropolisHastings<i32, f64, ...> over the reference's discrete test models (include/mmcmc.h: MMCMC_POISSON_REFLECT,
+ * MMCMC_BINOMIAL_CLAMP, MMCMC_POISSON_NONNEG); run() -> [n_chains, n_collect] */
+class DiscreteMetropolisHastings {
+    mmcmc_mh_discrete *h_ = nullptr;
+    size_t n_chains_;
+
+  public:
+    DiscreteMetropolisHastings(int kind, const std::vector<double> &params, const std::vector<int32_t> &initial_states,
+                               int device = 0)
+        : n_chains_(initial_states.size())
+    {
+        check(mmcmc_mh_discrete_create(&h_, kind, params.data(), initial_states.data(), n_chains_, device),
+              "mmcmc_mh_discrete_create");
+    }
+    DiscreteMetropolisHastings(const DiscreteMetropolisHastings &) = delete;
+    DiscreteMetropolisHastings &operator=(const DiscreteMetropolisHastings &) = delete;
+    ~DiscreteMetropolisHastings() { mmcmc_mh_discrete_destroy(h_); }
+    DiscreteMetropolisHastings &seed(uint64_t s)
+    {
+        check(mmcmc_mh_discrete_seed(h_, s), "mmcmc_mh_discrete_seed");
+        return *this;
+    }
+    std::vector<int32_t> run(size_t n_collect, size_t n_discard)
+    {
+        std::vector<int32_t> out(n_chains_ * n_collect);
+        check(mmcmc_mh_discrete_run(h_, n_collect, n_discard, out.data(), 0, nullptr), "mmcmc_mh_discrete_run");
+        return out;
+    }
+    std::vector<uint64_t> accept_counts()
+    {
+        std::vector<uint64_t> a(n_chains_);
+        check(mmcmc_mh_discrete_accept_counts(h_, a.data()), "mmcmc_mh_discrete_accept_counts");
+        return a;
+    }
+};
+
+/* MultiChainTracker (stats.rs:189-306): step() takes host states [n_chains, k, dim] */
+class MultiChainTracker {
+    mmcmc_tracker *h_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    MultiChainTracker(size_t n_chains, size_t n_params, int device = 0) : n_chains_(n_chains), dim_(n_params)
+    {
+        check(mmcmc_tracker_create(&h_, n_chains, n_params, device), "mmcmc_tracker_create");
+    }
+    MultiChainTracker(const MultiChainTracker &) = delete;
+    MultiChainTracker &operator=(const MultiChainTracker &) = delete;
+    ~MultiChainTracker() { mmcmc_tracker_destroy(h_); }
+    template <class T> void step(const std::vector<T> &states)
+    {
+        const size_t k = states.size() / (n_chains_ * dim_);
+        check(mmcmc_tracker_steps(h_, states.data(), 0, dtype_of<T>(), k, 0, k, nullptr), "mmcmc_tracker_steps");
+    }
+    std::vector<float> rhat()
+    {
+        std::vector<float> r(dim_);
+        check(mmcmc_tracker_stats(h_, r.data(), nullptr, nullptr, nullptr), "mmcmc_tracker_stats");
+        return r;
+    }
+    float max_rhat()
+    {
+        float m = 0.f;
+        check(mmcmc_tracker_stats(h_, nullptr, &m, nullptr, nullptr), "mmcmc_tracker_stats");
+        return m;
+    }
+    float p_accept()
+    {
+        float p = 0.f;
+        check(mmcmc_tracker_stats(h_, nullptr, nullptr, &p, nullptr), "mmcmc_tracker_stats");
+        return p;
+    }
+};
+
 } // namespace mmcmc
 #endif /* MMCMC_HPP */

@@ -57,6 +57,16 @@ int main(int argc, char **argv)
             threw = true;
         }
         (void)threw;
+        // tests/metrohast_poisson_test.rs::test_poisson_mh: one chain from 0, seed 42, run(20000, 2000), histogram within 0.05
+        DiscreteMetropolisHastings dmh(MMCMC_POISSON_REFLECT, {4.0}, {0});
+        auto ks = dmh.seed(42).run(20000, 2000);
+        double f4 = 0;
+        for (int32_t k : ks) f4 += (k == 4);
+        REQUIRE(std::fabs(f4 / 20000.0 - 0.1954) < 0.05 && dmh.accept_counts()[0] > 0);
+        // MultiChainTracker over the HMC sample (hmc.rs:242-281)
+        MultiChainTracker tr(4, 3);
+        tr.step(s3);
+        REQUIRE(tr.max_rhat() > 0.9f && tr.p_accept() > 0.3f && tr.rhat().size() == 3);
         std::printf("facade ok (gpu)\n");
         return 0;
     } catch (const Error &e) {
