@@ -6,7 +6,8 @@
  * RunStats :339-371.  In the reference the per-chain autocovariances are computed one chain after another on the
  * host (the chain loop :499-504 is serial) and averaged; here
  *
- *   kernel 1 (mm_half_chain_kernel): one wave per half-chain.  The [m, D] block of a half-chain (m = n/2 rows) is
+ *   kernel 1 (mm_half_chain_mfma_kernel, or mm_half_chain_kernel when a half-chain does not fit the MFMA kernel's
+ *      LDS layout): one wave per half-chain.  The [m, D] block of a half-chain (m = n/2 rows) is
  *      read ONCE from HBM with coalesced loads, transposed into LDS ([D][m], zero padded), reduced to the
  *      half-chain's mean and centred sum of squares per parameter, centred in place, and its biased
  *      autocovariance sum_t y[t] y[t+lag] is accumulated for every lag into a per-wave LDS slab that is carried
@@ -26,6 +27,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -126,6 +128,122 @@ __global__ __launch_bounds__(64) void mm_half_chain_kernel(const T *__restrict__
         slab[i] = acc[i];
 }
 
+/* The same half-chain statistics with the lag sums on the matrix cores.  For one parameter of one half-chain the
+ * biased autocovariance sums c_k = sum_t y[t] y[t+k] are a product of two Hankel/Toeplitz operands:
+ *     A[i][t] = y[t + i]  (16 x K),   B[t][j] = y[t - 16 j - 256 tau]  (K x 16)   =>   (A B)[i][j] = c_(i + 16 j + 256 tau)
+ * (y = 0 outside [0, m)), so one 16 x 16 accumulator tile of v_mfma_f32_16x16x4_f32 holds 256 consecutive lags and
+ * K = m suffices: m / 4 MFMAs per tile instead of ~2 m LDS reads and m FMAs per lane -- the direct kernel above is
+ * LDS-issue bound (two reads per FMA).  y sits in LDS with 240 + 256 (tiles - 1) zeros in front and 20 behind, and
+ * with one pad word after every 16 (address p + p / 16): the B operand's lanes read addresses 16 apart, which would
+ * otherwise land on two banks.  Means, centred sums of squares and the carried per-wave slab are as above. */
+typedef float mm_f4 __attribute__((ext_vector_type(4)));
+
+template <class T>
+__global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restrict__ sample, unsigned long long C,
+                                                                unsigned int n, unsigned int D, unsigned int m,
+                                                                unsigned int n_tiles, float *__restrict__ means,
+                                                                float *__restrict__ ssq, float *__restrict__ slabs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned int padl = 240u + 256u * (n_tiles - 1u);
+    const unsigned int row_len = padl + m + 20u;            /* logical elements per parameter */
+    const unsigned int row_pitch = row_len + row_len / 16u + 1u; /* with the bank-skew words */
+    float *y = lds;                                          /* [D][row_pitch] */
+    float *acc = lds + (size_t)D * row_pitch;                /* [D][m] lag sums carried over this wave's half-chains */
+    const unsigned int lane = threadIdx.x;
+    const unsigned int li = lane & 15u, kq = lane >> 4;
+    const unsigned long long n_half = 2ull * C;
+    auto at = [](unsigned int p) -> unsigned int { return p + (p >> 4); };
+
+    for (unsigned int i = lane; i < D * m; i += 64)
+        acc[i] = 0.f;
+    for (unsigned int i = lane; i < D * row_pitch; i += 64)
+        y[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const unsigned int k_steps = (m + 3u) / 4u;
+    for (unsigned long long hc = blockIdx.x; hc < n_half; hc += gridDim.x) {
+        const unsigned long long chain = hc < C ? hc : hc - C;
+        const unsigned int row0 = hc < C ? 0u : n - m;
+        const T *src = sample + (chain * n + row0) * D;
+        {
+            /* (t, d) of element e = lane + 64 i without a division per element: advance by 64 = q64 * D + r64 */
+            const unsigned int q64 = 64u / D, r64 = 64u - q64 * D;
+            unsigned int t = lane / D, d = lane - t * D;
+            for (unsigned int e = lane; e < m * D; e += 64) {
+                y[d * row_pitch + at(padl + t)] = (float)src[e];
+                t += q64;
+                d += r64;
+                if (d >= D) {
+                    d -= D;
+                    t += 1;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned int d = 0; d < D; ++d) {
+            float *yd = y + d * row_pitch;
+            float s = 0.f;
+            for (unsigned int t = lane; t < m; t += 64)
+                s += yd[at(padl + t)];
+            const float mean = wave_sum(s) / (float)m;
+            float q = 0.f;
+            for (unsigned int t = lane; t < m; t += 64) {
+                const float v = yd[at(padl + t)] - mean;
+                yd[at(padl + t)] = v;
+                q += v * v;
+            }
+            q = wave_sum(q);
+            if (lane == 0) {
+                means[hc * D + d] = mean;
+                ssq[hc * D + d] = q;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float *accd = acc + d * m;
+            for (unsigned int tau = 0; tau < n_tiles; ++tau) {
+                mm_f4 c0 = {0.f, 0.f, 0.f, 0.f};
+                /* lane (li, kq): A[li][4 s + kq] = y[4 s + kq + li];  B[4 s + kq][li] = y[4 s + kq - 16 li - 256 tau].
+                 * Four k-steps advance the logical index by 16, i.e. the skewed address by 17: four running addresses per
+                 * operand, no index arithmetic in the loop, one accumulator chain (dependent MFMAs issue back to back) */
+                unsigned int aa[4], ba[4];
+#pragma unroll
+                for (unsigned int u = 0; u < 4; ++u) {
+                    aa[u] = at(padl + kq + li + 4u * u);
+                    ba[u] = at(padl + kq - 16u * li - 256u * tau + 4u * u);
+                }
+                unsigned int sidx = 0;
+                for (; sidx + 4 <= k_steps; sidx += 4) {
+#pragma unroll
+                    for (unsigned int u = 0; u < 4; ++u) {
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yd[aa[u]], yd[ba[u]], c0, 0, 0, 0);
+                        aa[u] += 17u;
+                        ba[u] += 17u;
+                    }
+                }
+                for (unsigned int u = 0; sidx < k_steps; ++sidx, ++u)
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yd[aa[u]], yd[ba[u]], c0, 0, 0, 0);
+                /* accumulator element r of lane (li, kq) = tile row 4 kq + r, column li = lag 4 kq + r + 16 li + 256 tau */
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned int lag = 4u * kq + (unsigned int)r + 16u * li + 256u * tau;
+                    if (lag < m)
+                        accd[lag] += c0[r];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float *slab = slabs + (size_t)blockIdx.x * D * m;
+    for (unsigned int i = lane; i < D * m; i += 64)
+        slab[i] = acc[i];
+}
+
 /* out[lag, d] = sum over waves of slabs[w, d, lag].  One wave per group of 64 outputs would serialise n_slabs loads;
  * instead a 256-thread block owns 64 consecutive outputs, its four waves each sum a quarter of the slabs (coalesced
  * 256-byte rows), and the four partial sums are combined in a fixed order -- bitwise reproducible, no atomics. */
@@ -189,7 +307,14 @@ struct DevGuard {
 } // namespace
 
 /* number of waves (= per-wave lag-sum slabs) the half-chain kernel is launched with */
-static unsigned int stats_n_slabs(size_t n_chains) { return (unsigned int)std::min<size_t>(2 * n_chains, 2048); }
+static unsigned int stats_n_slabs(size_t n_chains)
+{
+    /* 4 waves per SIMD hide the LDS / global latencies of the half-chain loop; more only lengthens the slab reduction
+     * (measured at [65536, 400, 3]: 1024 waves 1.65 ms, 2048 0.96, 4096 0.69 + 0.08, 8192 0.82 + 0.21) */
+    const char *e = getenv("MMCMC_STATS_WAVES");
+    const size_t w = e ? (size_t)atoi(e) : 4096;
+    return (unsigned int)std::min<size_t>(2 * n_chains, w ? w : 4096);
+}
 
 extern "C" {
 
@@ -207,26 +332,43 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
         return st;
     DevGuard g(device);
     hipStream_t stream = (hipStream_t)stream_v;
-    const unsigned int m_pad = (unsigned int)(m + 64 + ((m + 64) % 2 == 0 ? 1 : 0)); /* odd row pitch */
-    const size_t lds = ((size_t)dim * m_pad + (size_t)dim * m) * sizeof(float);
-    if (lds > 160 * 1024)
-        return MMCMC_ERR_UNSUPPORTED;
     const unsigned int n_slabs = stats_n_slabs(n_chains);
     float *slabs = nullptr;
-    MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
-    if (lds > 64 * 1024) {
-        const void *fn = dtype == MMCMC_F32 ? (const void *)mm_half_chain_kernel<float>
-                                            : (const void *)mm_half_chain_kernel<double>;
-        MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    /* lag sums on the matrix cores (one 16 x 16 tile per 256 lags) unless the half-chain is too long for LDS */
+    const unsigned int n_tiles = (unsigned int)((m + 255) / 256);
+    const size_t row_len = 240 + 256 * (size_t)(n_tiles - 1) + m + 20, row_pitch = row_len + row_len / 16 + 1;
+    const size_t lds_mfma = ((size_t)dim * row_pitch + (size_t)dim * m) * sizeof(float);
+    const char *force_direct = getenv("MMCMC_STATS_DIRECT"); /* measurement aid: the direct kernel */
+    if (lds_mfma <= 64 * 1024 && !(force_direct && force_direct[0] == '1')) {
+        MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+        if (dtype == MMCMC_F32)
+            hipLaunchKernelGGL(mm_half_chain_mfma_kernel<float>, dim3(n_slabs), dim3(64), lds_mfma, stream,
+                               (const float *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
+                               (unsigned int)m, n_tiles, means, ssq, slabs);
+        else
+            hipLaunchKernelGGL(mm_half_chain_mfma_kernel<double>, dim3(n_slabs), dim3(64), lds_mfma, stream,
+                               (const double *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
+                               (unsigned int)m, n_tiles, means, ssq, slabs);
+    } else {
+        const unsigned int m_pad = (unsigned int)(m + 64 + ((m + 64) % 2 == 0 ? 1 : 0)); /* odd row pitch */
+        const size_t lds = ((size_t)dim * m_pad + (size_t)dim * m) * sizeof(float);
+        if (lds > 160 * 1024)
+            return MMCMC_ERR_UNSUPPORTED;
+        MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+        if (lds > 64 * 1024) {
+            const void *fn = dtype == MMCMC_F32 ? (const void *)mm_half_chain_kernel<float>
+                                                : (const void *)mm_half_chain_kernel<double>;
+            MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (dtype == MMCMC_F32)
+            hipLaunchKernelGGL(mm_half_chain_kernel<float>, dim3(n_slabs), dim3(64), lds, stream, (const float *)sample,
+                               (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, m_pad,
+                               means, ssq, slabs);
+        else
+            hipLaunchKernelGGL(mm_half_chain_kernel<double>, dim3(n_slabs), dim3(64), lds, stream,
+                               (const double *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
+                               (unsigned int)m, m_pad, means, ssq, slabs);
     }
-    if (dtype == MMCMC_F32)
-        hipLaunchKernelGGL(mm_half_chain_kernel<float>, dim3(n_slabs), dim3(64), lds, stream, (const float *)sample,
-                           (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, m_pad,
-                           means, ssq, slabs);
-    else
-        hipLaunchKernelGGL(mm_half_chain_kernel<double>, dim3(n_slabs), dim3(64), lds, stream,
-                           (const double *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
-                           (unsigned int)m, m_pad, means, ssq, slabs);
     MM_HIP(hipGetLastError());
     const unsigned int total = (unsigned int)(dim * m);
     hipLaunchKernelGGL(mm_slab_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, slabs, n_slabs,
