@@ -476,6 +476,18 @@ def test_nuts_lane_group_mfma_bit_exact_vs_host_twin(M, O):
         assert np.array_equal(res[(3, 5)][4], res[key][4]), key
     ref, pos, ad, nlf = O.engine_host_nuts_run(3, O.GAUSSIAN_ND, 32, [], init[:96], 0.8, 6, 14, seed=23, matrix=g.precision)
     assert np.array_equal(res[(3, 5)][0][:96], ref) and np.array_equal(res[(3, 5)][2][:96], nlf)
+    # scheduler corner cases: a depth cap below the first queue level, D = 16, continued runs, run_progress semantics
+    g16 = M.dist.GaussianND.ill_conditioned(16, 50.0, 3)
+    init16 = M.core.init_with_seed(2100, 16, 2) * 0.3
+    outs = []
+    for variant in (3, 1):
+        s = NUTS(g16, init16, 0.8, mode=2).set_seed(9).set_kernel_variant(variant).set_max_depth(3)
+        a = s.run(4, 6)
+        s.set_max_depth(10)
+        b = s.run(3, 0)
+        c = s._run(5, 2, True, "numpy")
+        outs.append((np.concatenate([a, b, c], axis=1), s.leapfrog_counts(), s.depth_histogram()))
+    assert all(np.array_equal(x, y) for x, y in zip(outs[0], outs[1]))
     # sharding: the wave a chain sits in (and its neighbours' tree depths) must not matter
     g = M.dist.GaussianND.ill_conditioned(32, 1e3, 1)
     init = M.core.init_with_seed(50, 32, 8) * 0.3
