@@ -311,7 +311,7 @@ def _ar1(rng, c, n, p, phi=0.6):
 
 
 @pytest.mark.parametrize("c,n,p", [(4, 60, 2), (3, 200, 3), (7, 201, 1), (16, 400, 3), (2, 1000, 2), (5, 2, 2), (1, 50, 4),
-                                   (64, 100, 32)])
+                                   (64, 100, 32), (2, 6000, 3)])  # the last: too long for the MFMA kernel's LDS layout -> direct kernel
 def test_split_rhat_mean_ess_vs_oracle(M, O, c, n, p):
     from mini_mcmc_amd import stats as S
 
