@@ -256,7 +256,7 @@ template <int D> struct mm_lg_lane {
     int lane, q;
     bool active;
 #ifdef MM_LG_PROFILE
-    unsigned long long prof_acc[8], prof_t;
+    unsigned long long prof_acc[16], prof_t;
 #endif
 };
 
@@ -438,7 +438,9 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             }
         }
         double y[NS];
+        MM_LG_TICK(L, 8);
         const double lp = mm_lg_logp_ax<D>(L.Aop, cx, y); /* y = A x */
+        MM_LG_TICK(L, 9);
         if (!done) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -481,6 +483,8 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         MM_LG_TICK(L, 2);
         /* a sibling waits at level k: S is the second child, merge (nuts.rs:900-928) */
         auto merge = [&](const rec &r) {
+            MM_LG_TICK(L, 3);
+            MM_LG_COUNT(L, 12);
             const double u = mm_lg_aux_peek<D>(L, a.seed);
             /* stop criterion on (first leaf of the sibling, current leaf): d = x_cur - x_first */
             double ca = 0.0, cb = 0.0;
@@ -509,10 +513,13 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 S_nalpha += na1;
                 S_s = S_s && crit;
             }
+            MM_LG_TICK(L, 10);
         };
         /* first child at level k: wait for the sibling if still valid; with s' = 0 the parent returns it as it is, so
          * it keeps walking */
         auto push = [&](int k) {
+            MM_LG_TICK(L, 3);
+            MM_LG_COUNT(L, 13);
             if (walking && S_s) {
                 const double cnt =
                     __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
@@ -533,6 +540,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 }
                 walking = false;
             }
+            MM_LG_TICK(L, 11);
         };
         if (j > 0) {
             MM_LG_COUNT(L, 7);
@@ -667,7 +675,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
     }
     unsigned int rows_out = 0;
 #ifdef MM_LG_PROFILE
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 16; ++i)
         L.prof_acc[i] = 0;
     L.prof_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -695,8 +703,8 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
     }
 #ifdef MM_LG_PROFILE
     if (L.lane == 0)
-        for (int i = 0; i < 8; ++i)
-            a.prof[(size_t)blockIdx.x * 8 + i] = L.prof_acc[i];
+        for (int i = 0; i < 16; ++i)
+            a.prof[(size_t)blockIdx.x * 16 + i] = L.prof_acc[i];
 #endif
     if (L.active) {
 #pragma unroll

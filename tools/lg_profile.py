@@ -41,7 +41,7 @@ def main():
     t_adapt = torch.tensor(adapt, device=dev)
     t_scr = torch.empty(waves * lib.lgprof_scratch_doubles_per_wave(), dtype=torch.float64, device=dev)
     t_rec = torch.zeros(waves * 16 * lib.lgprof_rec_doubles_per_chain(), dtype=torch.float64, device=dev)
-    t_prof = torch.zeros((waves, 8), dtype=torch.int64, device=dev)
+    t_prof = torch.zeros((waves, 16), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rc = lib.lgprof_run(C.c_void_p(t_mat.data_ptr()), C.c_void_p(t_state.data_ptr()), C.c_void_p(t_adapt.data_ptr()),
@@ -52,11 +52,16 @@ def main():
     assert rc == 0, rc
     p = t_prof.cpu().numpy().astype(np.float64)
     names = ["transition prologue", "doubling prologue", "leapfrog", "walk", "doubling epilogue", "transition epilogue"]
-    tot = p[:, :6].sum(axis=1)
+    tot = p[:, :6].sum(axis=1) + p[:, 8:12].sum(axis=1)
     print(f"chains {n}  steps {args.steps}  wall {dt * 1e3:.1f} ms  s_memtime ticks per wave: mean {tot.mean():.3e} max {tot.max():.3e}")
     for i, nm in enumerate(names):
         print(f"  {nm:22s} {100 * p[:, i].sum() / tot.sum():6.2f} %")
     leaves, levels = p[:, 6], p[:, 7]
+    L_ = leaves.sum()
+    print(f"  per leaf iteration: records + kick {p[:, 8].sum() / L_:.0f}  MFMA + logp {p[:, 9].sum() / L_:.0f}  leaf bookkeeping {p[:, 2].sum() / L_:.0f}"
+          f"  merges {p[:, 10].sum() / L_:.0f} ({p[:, 12].sum() / L_:.2f} per leaf, {p[:, 10].sum() / max(p[:, 12].sum(), 1):.0f} each)"
+          f"  pushes {p[:, 11].sum() / L_:.0f} ({p[:, 13].sum() / L_:.2f} per leaf, {p[:, 11].sum() / max(p[:, 13].sum(), 1):.0f} each)"
+          f"  walk glue {p[:, 3].sum() / L_:.0f}")
     print(f"  leaf iterations per wave per transition: {leaves.mean() / args.steps:.1f};  walk levels per leaf: {levels.sum() / leaves.sum():.2f}")
     print(f"  ticks per leaf iteration: leapfrog {p[:, 2].sum() / leaves.sum():.1f}  walk {p[:, 3].sum() / leaves.sum():.1f}"
           f"  (s_memtime ticks; the counter ran at ~2.1 GHz in these runs)")
