@@ -63,6 +63,26 @@ int main(int argc, char **argv)
         double f4 = 0;
         for (int32_t k : ks) f4 += (k == 4);
         REQUIRE(std::fabs(f4 / 20000.0 - 0.1954) < 0.05 && dmh.accept_counts()[0] > 0);
+        // NUTS in f64 on a dense 16-D Gaussian (A = tridiagonal 2, -0.5): the lane-group / MFMA kernel behind the facade
+        {
+            const int d = 16;
+            std::vector<double> prec((size_t)d * d, 0.0);
+            for (int i = 0; i < d; ++i) {
+                prec[(size_t)i * d + i] = 2.0;
+                if (i + 1 < d) prec[(size_t)i * d + i + 1] = prec[(size_t)(i + 1) * d + i] = -0.5;
+            }
+            auto init16 = init_with_seed<double>(64, d, 7);
+            NUTS64 n64(GaussianND(d, prec), init16, 64, 0.8);
+            REQUIRE(n64.kernel_variant() == 3);
+            auto s64 = n64.set_seed(3).run(50, 50);
+            REQUIRE(s64.size() == 64u * 50u * (size_t)d);
+            double m = 0, v = 0;
+            for (size_t i = 0; i < s64.size(); i += d) m += s64[i];
+            m /= 3200.0;
+            for (size_t i = 0; i < s64.size(); i += d) v += (s64[i] - m) * (s64[i] - m);
+            v /= 3199.0;
+            REQUIRE(std::fabs(m) < 0.15 && v > 0.3 && v < 0.9); // (A^-1)_00 ~ 0.53
+        }
         // MultiChainTracker over the HMC sample (hmc.rs:242-281)
         MultiChainTracker tr(4, 3);
         tr.step(s3);
