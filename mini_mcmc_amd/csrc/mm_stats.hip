@@ -304,6 +304,45 @@ struct DevGuard {
     }
 };
 
+/* withinvar's cross-chain sums (stats.rs:449-465) on the device: per parameter d the sum of squared deviations of the
+ * half-chain means from their mean, and the sum of the biased half-chain variances.  One block per parameter, f64
+ * accumulators; out[d] = {dsum, wsum}.  Spares the single-GPU path the copy of 2 * 2C * D numbers to the host. */
+__global__ __launch_bounds__(1024) void mm_within_between_kernel(const float *__restrict__ means,
+                                                                 const float *__restrict__ ssq, unsigned long long c2,
+                                                                 unsigned int D, float nf, float *__restrict__ out)
+{
+    __shared__ double red[1024];
+    const unsigned int d = blockIdx.x, tid = threadIdx.x;
+    auto block_sum = [&](double v) -> double {
+        red[tid] = v;
+        __syncthreads();
+        for (unsigned int s = 512; s > 0; s >>= 1) {
+            if (tid < s)
+                red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double s = 0.0;
+    for (unsigned long long c = tid; c < c2; c += 1024)
+        s += (double)means[c * D + d];
+    const float overall = (float)(block_sum(s) / (double)c2);
+    double ds = 0.0, ws = 0.0;
+    for (unsigned long long c = tid; c < c2; c += 1024) {
+        const float df = means[c * D + d] - overall;
+        ds += (double)(df * df);
+        ws += (double)(ssq[c * D + d] / nf); /* biased per-chain variance (quirk Q8) */
+    }
+    ds = block_sum(ds);
+    ws = block_sum(ws);
+    if (tid == 0) {
+        out[2 * d] = (float)ds;
+        out[2 * d + 1] = (float)ws;
+    }
+}
+
 } // namespace
 
 /* number of waves (= per-wave lag-sum slabs) the half-chain kernel is launched with */
@@ -380,6 +419,35 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
 
 /* stats.rs:449-465 (withinvar), :425-427 (rhat), :509-545 (ess) on the gathered sufficient statistics, f32.
  * means, ssq: [c2, dim] in splitcat order (first halves of all chains, then second halves); acov_sum [m, dim]. */
+/* from the cross-chain sums to R-hat and ESS of parameter d (stats.rs:459-465, 425-427, 509-545), f32 */
+static void stats_finish_one(float dsum, float wsum, const float *acov_sum, size_t c2, size_t m, size_t dim, size_t d,
+                             std::vector<float> &rho, float *rhat, float *ess)
+{
+    const float nf = (float)m, cf = (float)c2;
+    const float b = dsum * (nf / (cf - 1.0f));
+    const float w = wsum / cf;
+    const float v = ((nf - 1.0f) / nf) * w + b / nf;
+    rhat[d] = std::sqrt(w / v); /* sqrt(W / var+): the reference's definition (quirk Q7) */
+    for (size_t t = 0; t < m; ++t) {
+        const float avg_rho = (acov_sum[t * dim + d] / nf) / cf; /* mean over chains of autocov_c(t) */
+        const float diff = -avg_rho + w;
+        rho[t] = -(diff / v) + 1.0f;
+    }
+    float mn = (m >= 2) ? rho[0] + rho[1] : 0.0f;
+    float out = 0.0f;
+    for (size_t t = 0; t + 1 < m; t += 2) {
+        float p_t = rho[t] + rho[t + 1];
+        if (p_t <= 0.0f)
+            break;
+        if (p_t > mn)
+            p_t = mn;
+        mn = p_t;
+        out += p_t;
+    }
+    const float tau = -1.0f + 2.0f * out;
+    ess[d] = (1.0f / tau) * cf * nf;
+}
+
 int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_sum, size_t c2, size_t m, size_t dim,
                        float *rhat, float *ess)
 {
@@ -398,28 +466,7 @@ int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_s
             dsum += df * df;
             wsum += ssq[c * dim + d] / nf; /* biased per-chain variance (quirk Q8) */
         }
-        const float b = dsum * (nf / (cf - 1.0f));
-        const float w = wsum / cf;
-        const float v = ((nf - 1.0f) / nf) * w + b / nf;
-        rhat[d] = std::sqrt(w / v); /* sqrt(W / var+): the reference's definition (quirk Q7) */
-        for (size_t t = 0; t < m; ++t) {
-            const float avg_rho = (acov_sum[t * dim + d] / nf) / cf; /* mean over chains of autocov_c(t) */
-            const float diff = -avg_rho + w;
-            rho[t] = -(diff / v) + 1.0f;
-        }
-        float mn = (m >= 2) ? rho[0] + rho[1] : 0.0f;
-        float out = 0.0f;
-        for (size_t t = 0; t + 1 < m; t += 2) {
-            float p_t = rho[t] + rho[t + 1];
-            if (p_t <= 0.0f)
-                break;
-            if (p_t > mn)
-                p_t = mn;
-            mn = p_t;
-            out += p_t;
-        }
-        const float tau = -1.0f + 2.0f * out;
-        ess[d] = (1.0f / tau) * cf * nf;
+        stats_finish_one(dsum, wsum, acov_sum, c2, m, dim, d, rho, rhat, ess);
     }
     return MMCMC_OK;
 }
@@ -441,8 +488,8 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
     const size_t c2 = 2 * n_chains;
     void *d_sample = nullptr;
     float *d_buf = nullptr;
-    const size_t nb = (2 * c2 * dim + m * dim);
-    std::vector<float> h(nb);
+    const size_t nb = (2 * c2 * dim + m * dim + 2 * dim);
+    std::vector<float> h(m * dim + 2 * dim);
     int rc = MMCMC_OK;
     hipError_t e = hipSuccess;
     do {
@@ -453,23 +500,35 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
                 hipSuccess)
                 break;
         }
-        if ((e = hipMalloc((void **)&d_buf, nb * sizeof(float))) != hipSuccess)
+        if ((e = hipMallocAsync((void **)&d_buf, nb * sizeof(float), stream)) != hipSuccess)
             break;
-        float *d_means = d_buf, *d_ssq = d_buf + c2 * dim, *d_acov = d_buf + 2 * c2 * dim;
+        /* layout: means | ssq | acov_sum [m, D] | {dsum, wsum} [D]: the last two blocks are what the host needs */
+        float *d_means = d_buf, *d_ssq = d_buf + c2 * dim, *d_acov = d_buf + 2 * c2 * dim, *d_wb = d_acov + m * dim;
         rc = mmcmc_stats_partials(sample_is_device ? sample : d_sample, dtype, n_chains, n, dim, d_means, d_ssq,
                                   d_acov, device, stream_v);
         if (rc != MMCMC_OK)
             break;
-        if ((e = hipMemcpyAsync(h.data(), d_buf, nb * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+        hipLaunchKernelGGL(mm_within_between_kernel, dim3((unsigned int)dim), dim3(1024), 0, stream, d_means, d_ssq,
+                           (unsigned long long)c2, (unsigned int)dim, (float)m, d_wb);
+        if ((e = hipGetLastError()) != hipSuccess)
+            break;
+        if ((e = hipMemcpyAsync(h.data(), d_acov, h.size() * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
             break;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess)
             break;
-        rc = mmcmc_stats_finish(h.data(), h.data() + c2 * dim, h.data() + 2 * c2 * dim, c2, m, dim, rhat, ess);
+        if (c2 < 2) {
+            rc = MMCMC_ERR_INVALID_ARG;
+            break;
+        }
+        std::vector<float> rho(m);
+        const float *wb = h.data() + m * dim;
+        for (size_t d = 0; d < dim; ++d)
+            stats_finish_one(wb[2 * d], wb[2 * d + 1], h.data(), c2, m, dim, d, rho, rhat, ess);
     } while (0);
     if (d_sample)
         (void)hipFree(d_sample);
     if (d_buf)
-        (void)hipFree(d_buf);
+        (void)hipFreeAsync(d_buf, stream);
     if (e != hipSuccess)
         return (int)e;
     return rc;
