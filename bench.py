@@ -155,12 +155,13 @@ def main() -> None:
     dt_max = float(t.item())
 
     # diagnostics on the last sample (outside the timed region): RCCL all-gather / all-reduce of sufficient statistics
+    def diagnostics():
+        return S.split_rhat_mean_ess_distributed(out) if distributed else S.split_rhat_mean_ess(out)
+
+    diagnostics()  # untimed first call (allocator pools, code objects), like the sampler's warm-up steps
     barrier()
     ts = time.perf_counter()
-    if distributed:
-        rhat, ess = S.split_rhat_mean_ess_distributed(out)
-    else:
-        rhat, ess = S.split_rhat_mean_ess(out)
+    rhat, ess = diagnostics()
     barrier()
     stats_s = time.perf_counter() - ts
 
