@@ -6,10 +6,11 @@
  *   mm_hmc_step  <->  HMC::step + HMC::leapfrog        hmc.rs:304-377, 397-431   (one row of the batch)
  *
  * What is kept from the reference: the accept rules (MH strict `>`, HMC `>=`, NaN rejects), the leapfrog
- * with two separate half-kicks per step, H = -logp + 1/2 |p|^2, positions updated only on accept.
+ * integrator, H = -logp + 1/2 |p|^2, positions updated only on accept.
  * What is consciously different: the random stream (mm_rng.h instead of rand/burn:
  * Q1, Q2, Q6), log-density of the current state carried instead of recomputed (Q3: same value), the
- * symmetric proposal's q-terms dropped from the MH ratio (Q4: they cancel), Sigma^-1 precomputed (Q5),
+ * symmetric proposal's q-terms dropped from the MH ratio (Q4: they cancel), Sigma^-1 precomputed (Q5), the two
+ * half-kicks between consecutive leapfrog steps merged into one (Q6),
  * gradients analytic, and a*b+c written as ONE fused operation where noted -- so values agree with the
  * reference-ordered oracle to rounding, not bit for bit; tests/test_step_parity.py bounds the difference.
  */
@@ -154,24 +155,32 @@ MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x,
     }
     T h_current = ke * T(0.5) - *lp;
     T lpn = *lp;
-    auto leap = [&]() {
-        MM_UNROLL
-        for (int i = 0; i < D; ++i) {
-            p[i] = mm_fma(h, gn[i], p[i]);   /* half kick with the gradient of the previous position */
-            xn[i] = mm_fma(eps, p[i], xn[i]); /* drift */
-        }
-        lpn = Tgt::logp_grad(P, xn, gn);
+    /* hmc.rs:403-429 kicks the momentum by eps/2 at the start and at the end of every leapfrog step; the end kick of one
+     * step and the start kick of the next use the same gradient and are merged here into one kick by eps (SURVEY
+     * App. B Q6: allowed on the GPU, the oracle keeps them apart; the results differ by rounding only) */
+    auto leap = [&](bool last) {
         MM_UNROLL
         for (int i = 0; i < D; ++i)
-            p[i] = mm_fma(h, gn[i], p[i]); /* half kick with the new gradient */
+            xn[i] = mm_fma(eps, p[i], xn[i]); /* drift */
+        lpn = Tgt::logp_grad(P, xn, gn);
+        const T k = last ? h : eps;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            p[i] = mm_fma(k, gn[i], p[i]);
     };
     if constexpr (LCT > 0) {
         MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            p[i] = mm_fma(h, gn[i], p[i]); /* first half kick, with the gradient of the current position */
+        MM_UNROLL
         for (int l = 0; l < LCT; ++l)
-            leap();
-    } else {
+            leap(l + 1 == LCT);
+    } else if (n_leapfrog > 0) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            p[i] = mm_fma(h, gn[i], p[i]);
         for (int l = 0; l < n_leapfrog; ++l)
-            leap();
+            leap(l + 1 == n_leapfrog);
     }
     T kp = 0;
     MM_UNROLL
