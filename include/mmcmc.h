@@ -270,6 +270,22 @@ int mmcmc_mh_discrete_accept_counts(mmcmc_mh_discrete *h, uint64_t *out);       
 int mmcmc_mh_discrete_sync(mmcmc_mh_discrete *h);
 int mmcmc_mh_discrete_destroy(mmcmc_mh_discrete *h);
 
+/* ---- Gibbs sampling with a built-in full conditional --------------------------------------------------------
+ * GibbsSampler / GibbsMarkovChain (gibbs.rs:31-203) take a user-written `Conditional`; the one the reference ships --
+ * the two-component Gaussian mixture over the state [x, z] of gibbs.rs:231-285 and examples/mixture_gibbs.rs:24-76 --
+ * is built in.  params = {mu0, sigma0, mu1, sigma1, pi0}; init: host [n_chains, 2] f64 (the reference starts from
+ * init_det(n, 2)); out: [n_chains, n_collect, 2] f64.  One sweep = x | z then z | x (gibbs.rs:96-101). */
+typedef struct mmcmc_gibbs_mixture mmcmc_gibbs_mixture;
+int mmcmc_gibbs_mixture_create(mmcmc_gibbs_mixture **out, const double *params, const double *init, size_t n_chains,
+                               int device);
+int mmcmc_gibbs_mixture_seed(mmcmc_gibbs_mixture *h, uint64_t seed);            /* GibbsSampler::set_seed gibbs.rs:179-187 */
+int mmcmc_gibbs_mixture_set_chain_offset(mmcmc_gibbs_mixture *h, uint64_t chain_offset);
+int mmcmc_gibbs_mixture_run(mmcmc_gibbs_mixture *h, size_t n_collect, size_t n_discard, double *out, int out_is_device,
+                            void *stream);                                      /* ChainRunner::run core.rs:176-186 */
+int mmcmc_gibbs_mixture_state(mmcmc_gibbs_mixture *h, double *out);             /* host [n_chains, 2] */
+int mmcmc_gibbs_mixture_sync(mmcmc_gibbs_mixture *h);
+int mmcmc_gibbs_mixture_destroy(mmcmc_gibbs_mixture *h);
+
 /* ---- sample sink: io/csv.rs:47-69 save_csv -- header `chain,observation,dim_0,...`, one record per (chain,
  *      observation), values in Rust `Display` formatting (shortest round-trip, no exponent).  sample: HOST
  *      [n_chains, n, dim] of dtype. */

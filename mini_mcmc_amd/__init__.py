@@ -4,7 +4,7 @@ Python here is host plumbing over the C ABI (include/mmcmc.h -> libmmcmc.so, han
 module names and call shapes follow the reference crate (core, distributions, metropolis_hastings, hmc, ...).
 There is no CPU fallback; importing works without a GPU, constructing a sampler does not.
 """
-from . import core, discrete, distributions, hmc, metropolis_hastings, nuts, stats  # noqa: F401
+from . import core, discrete, distributions, gibbs, hmc, metropolis_hastings, nuts, stats  # noqa: F401
 from ._lib import LIB_PATH, MmcmcError, lib  # noqa: F401
 
-__all__ = ["core", "discrete", "distributions", "hmc", "metropolis_hastings", "nuts", "stats", "lib", "LIB_PATH", "MmcmcError"]
+__all__ = ["core", "discrete", "distributions", "gibbs", "hmc", "metropolis_hastings", "nuts", "stats", "lib", "LIB_PATH", "MmcmcError"]

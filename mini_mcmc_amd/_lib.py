@@ -121,6 +121,13 @@ SIGNATURES = {
     "mmcmc_mh_discrete_accept_counts": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "mmcmc_mh_discrete_sync": (C.c_int, [_vp]),
     "mmcmc_mh_discrete_destroy": (C.c_int, [_vp]),
+    "mmcmc_gibbs_mixture_create": (C.c_int, [C.POINTER(_vp), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int]),
+    "mmcmc_gibbs_mixture_seed": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_gibbs_mixture_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_gibbs_mixture_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp]),
+    "mmcmc_gibbs_mixture_state": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "mmcmc_gibbs_mixture_sync": (C.c_int, [_vp]),
+    "mmcmc_gibbs_mixture_destroy": (C.c_int, [_vp]),
     "mmcmc_save_csv": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_char_p]),
     "mmcmc_logp_grad_batch": (C.c_int, [_TP, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int]),
     "mmcmc_draw_noise": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int]),

@@ -1,0 +1,227 @@
+/*
+ * mm_gibbs.hip -- the Gibbs sampler with the built-in mixture conditional on the GPU and its C ABI
+ * (include/mmcmc.h: mmcmc_gibbs_mixture_*).  One chain per lane, the whole run in one launch (GibbsSampler through
+ * ChainRunner::run, gibbs.rs:139-203, core.rs:176-186); the sweep is mm_gibbs_mixture_step (mm_gibbs.h).  Samples
+ * [C, n_collect, 2] f64 are staged per wave in LDS (64 chains x 16 sweeps) and written as 256-byte rows.
+ */
+#include "../../include/mmcmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "mm_gibbs.h"
+
+#define MM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return (int)_e;                                                                                       \
+    } while (0)
+
+namespace {
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        (void)hipSetDevice(d);
+    }
+    ~DevGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+struct run_args {
+    mm_mixture_params P;
+    double *state;  /* [C, 2] */
+    double *out;    /* [C, n_collect, 2] or NULL */
+    unsigned long long n_chains, seed, chain_offset;
+    unsigned int iter0, n_discard, n_collect;
+};
+
+constexpr int TILE = 16;
+
+__global__ __launch_bounds__(64) void mm_gibbs_mixture_kernel(const run_args a)
+{
+    __shared__ double tile[64][2 * TILE + 1];
+    const int lane = threadIdx.x;
+    const unsigned long long c0 = (unsigned long long)blockIdx.x * 64, c = c0 + lane;
+    const bool active = c < a.n_chains;
+    double s[2] = {active ? a.state[2 * c] : 0.0, active ? a.state[2 * c + 1] : 0.0};
+    const unsigned int total = a.n_discard + a.n_collect;
+    unsigned int col = 0, t0 = 0;
+    for (unsigned int t = 0; t < total; ++t) {
+        mm_gibbs_mixture_step(a.P, s, a.seed, a.chain_offset + c, a.iter0 + t);
+        if (t >= a.n_discard && a.out) {
+            tile[lane][2 * col] = s[0];
+            tile[lane][2 * col + 1] = s[1];
+            ++col;
+            if (col == TILE || t + 1 == total) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                /* row r = chain c0 + r: 2 * col consecutive doubles; two chains' rows per pass of 32 lanes each */
+                for (int r = 0; r < 64; r += 2) {
+                    const int rr = r + (lane >> 5), e = lane & 31;
+                    if (c0 + rr < a.n_chains && (unsigned int)e < 2 * col)
+                        a.out[((c0 + rr) * a.n_collect + t0) * 2 + e] = tile[rr][e];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                t0 += col;
+                col = 0;
+            }
+        }
+    }
+    if (active) {
+        a.state[2 * c] = s[0];
+        a.state[2 * c + 1] = s[1];
+    }
+}
+
+} // namespace
+
+struct mmcmc_gibbs_mixture {
+    int device = 0;
+    size_t n_chains = 0;
+    uint64_t seed = 0, chain_offset = 0;
+    uint32_t iter = 0;
+    mm_mixture_params P{};
+    double *d_state = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+extern "C" {
+
+int mmcmc_gibbs_mixture_create(mmcmc_gibbs_mixture **out, const double *params, const double *init, size_t n_chains,
+                               int device)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!params || !init || n_chains == 0 || !(params[1] > 0.0) || !(params[3] > 0.0) ||
+        !(params[4] >= 0.0 && params[4] <= 1.0))
+        return MMCMC_ERR_INVALID_ARG;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= nd)
+        return MMCMC_ERR_INVALID_ARG;
+    mmcmc_gibbs_mixture *h = new (std::nothrow) mmcmc_gibbs_mixture();
+    if (!h)
+        return (int)hipErrorOutOfMemory;
+    h->device = device;
+    h->n_chains = n_chains;
+    h->P = mm_mixture_params{params[0], params[1], params[2], params[3], params[4]};
+    DevGuard g(device);
+    hipError_t e;
+    if ((e = hipMalloc((void **)&h->d_state, n_chains * 2 * sizeof(double))) != hipSuccess ||
+        (e = hipMemcpy(h->d_state, init, n_chains * 2 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->stream, hipStreamDefault)) != hipSuccess) {
+        mmcmc_gibbs_mixture_destroy(h);
+        return (int)e;
+    }
+    *out = h;
+    return MMCMC_OK;
+}
+
+int mmcmc_gibbs_mixture_seed(mmcmc_gibbs_mixture *h, uint64_t seed)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->seed = seed;
+    return MMCMC_OK;
+}
+
+int mmcmc_gibbs_mixture_set_chain_offset(mmcmc_gibbs_mixture *h, uint64_t off)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->chain_offset = off;
+    return MMCMC_OK;
+}
+
+int mmcmc_gibbs_mixture_run(mmcmc_gibbs_mixture *h, size_t n_collect, size_t n_discard, double *out, int out_is_device,
+                            void *stream)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    if ((uint64_t)h->iter + n_collect + n_discard >= (1ull << 32) || n_collect >= (1ull << 30))
+        return MMCMC_ERR_SHAPE;
+    DevGuard g(h->device);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t out_bytes = h->n_chains * n_collect * 2 * sizeof(double);
+    double *d_out = nullptr;
+    bool staged = false;
+    if (out && n_collect > 0) {
+        if (out_is_device) {
+            d_out = out;
+        } else {
+            MM_HIP(hipMalloc((void **)&d_out, out_bytes));
+            staged = true;
+        }
+    }
+    run_args a;
+    a.P = h->P;
+    a.state = h->d_state;
+    a.out = d_out;
+    a.n_chains = h->n_chains;
+    a.seed = h->seed;
+    a.chain_offset = h->chain_offset;
+    a.iter0 = h->iter;
+    a.n_discard = (unsigned int)n_discard;
+    a.n_collect = (unsigned int)n_collect;
+    hipLaunchKernelGGL(mm_gibbs_mixture_kernel, dim3((unsigned int)((h->n_chains + 63) / 64)), dim3(64), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (staged)
+            (void)hipFree(d_out);
+        return (int)e;
+    }
+    h->iter += (uint32_t)(n_collect + n_discard);
+    if (staged) {
+        MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(hipFree(d_out));
+    }
+    return MMCMC_OK;
+}
+
+int mmcmc_gibbs_mixture_state(mmcmc_gibbs_mixture *h, double *out)
+{
+    if (!h || !out)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    MM_HIP(hipDeviceSynchronize());
+    MM_HIP(hipMemcpy(out, h->d_state, h->n_chains * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return MMCMC_OK;
+}
+
+int mmcmc_gibbs_mixture_sync(mmcmc_gibbs_mixture *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    MM_HIP(hipStreamSynchronize(h->stream));
+    return MMCMC_OK;
+}
+
+int mmcmc_gibbs_mixture_destroy(mmcmc_gibbs_mixture *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    DevGuard g(h->device);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_state);
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MMCMC_OK;
+}
+
+} /* extern "C" */

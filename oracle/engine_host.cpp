@@ -364,3 +364,28 @@ extern "C" int eh_discrete_run(int kind, const double *params, const int32_t *in
     }
     return 0;
 }
+
+/* ---- Gibbs with the built-in mixture conditional: the product's mm_gibbs.h compiled for the host ---- */
+#include "../mini_mcmc_amd/csrc/mm_gibbs.h"
+
+extern "C" int eh_gibbs_mixture_run(const double *params, const double *init, size_t n_chains, uint64_t seed,
+                                    uint64_t chain_offset, uint32_t iter0, size_t n_collect, size_t n_discard, double *out,
+                                    double *state_out)
+{
+    const mm_mixture_params P{params[0], params[1], params[2], params[3], params[4]};
+    for (size_t c = 0; c < n_chains; ++c) {
+        double s[2] = {init[2 * c], init[2 * c + 1]};
+        for (size_t t = 0; t < n_collect + n_discard; ++t) {
+            mm_gibbs_mixture_step(P, s, seed, chain_offset + c, iter0 + (uint32_t)t);
+            if (t >= n_discard && out) {
+                out[(c * n_collect + (t - n_discard)) * 2] = s[0];
+                out[(c * n_collect + (t - n_discard)) * 2 + 1] = s[1];
+            }
+        }
+        if (state_out) {
+            state_out[2 * c] = s[0];
+            state_out[2 * c + 1] = s[1];
+        }
+    }
+    return 0;
+}

@@ -129,6 +129,11 @@ def lib() -> C.CDLL:
         "o_discrete_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
         "o_discrete_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), _u64p]),
         "o_discrete_state": (None, [C.c_void_p, C.POINTER(C.c_int32)]),
+        "o_gibbs_create": (C.c_void_p, [_dp, _dp, C.c_int, C.c_uint64]),
+        "o_gibbs_destroy": (None, [C.c_void_p]),
+        "o_gibbs_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_gibbs_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, _dp]),
+        "o_gibbs_state": (None, [C.c_void_p, _dp]),
         "o_split_rhat_mean_ess": (None, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
         "o_autocov_bf": (None, [_fp, C.c_size_t, C.c_size_t, _fp]),
         "o_autocov_fft": (None, [_fp, C.c_size_t, C.c_size_t, _fp]),
@@ -557,6 +562,9 @@ def engine_host_lib() -> C.CDLL:
     E.eh_discrete_run.restype = C.c_int
     E.eh_discrete_run.argtypes = [C.c_int, _dp, C.POINTER(C.c_int32), C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32,
                                   C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u64p]
+    E.eh_gibbs_mixture_run.restype = C.c_int
+    E.eh_gibbs_mixture_run.argtypes = [_dp, _dp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_size_t,
+                                       _dp, _dp]
     E.eh_logp_grad.restype = C.c_int
     E.eh_logp_grad.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     _eh = E
@@ -671,6 +679,50 @@ def engine_host_discrete_run(kind, params, init, n_collect, n_discard, seed=0, c
                            st.ctypes.data_as(_i32p), acc.ctypes.data_as(_u64p))
     assert rc == 0
     return out, st, acc
+
+
+class GibbsMixture:
+    """oracle/gibbs.c: GibbsSampler over the reference's MixtureConditional (state [x, z], f64)."""
+
+    def __init__(self, params, init, conditional_seed=0):
+        self.init = np.ascontiguousarray(init, dtype=np.float64).reshape(-1, 2)
+        self.n_chains = self.init.shape[0]
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        self._h = lib().o_gibbs_create(_d(p), _d(self.init), self.n_chains, int(conditional_seed))
+        if not self._h:
+            raise ValueError("o_gibbs_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().o_gibbs_destroy(self._h)
+            self._h = None
+
+    def use_engine_stream(self, seed, chain_offset=0):
+        lib().o_gibbs_use_engine_stream(self._h, int(seed), int(chain_offset))
+        return self
+
+    def run(self, n_collect, n_discard):
+        out = np.zeros((self.n_chains, n_collect, 2), dtype=np.float64)
+        lib().o_gibbs_run(self._h, n_collect, n_discard, _d(out))
+        return out
+
+    def state(self):
+        out = np.zeros((self.n_chains, 2), dtype=np.float64)
+        lib().o_gibbs_state(self._h, _d(out))
+        return out
+
+
+def engine_host_gibbs_mixture_run(params, init, n_collect, n_discard, seed=0, chain_offset=0, iter0=0):
+    """The product's mm_gibbs.h on the host: (samples [C, n_collect, 2], final states)."""
+    E = engine_host_lib()
+    init = np.ascontiguousarray(init, dtype=np.float64).reshape(-1, 2)
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    out = np.zeros((init.shape[0], n_collect, 2), dtype=np.float64)
+    st = np.zeros_like(init)
+    rc = E.eh_gibbs_mixture_run(_d(p), _d(init), init.shape[0], int(seed), int(chain_offset), int(iter0), n_collect,
+                                n_discard, _d(out), _d(st))
+    assert rc == 0
+    return out, st
 
 
 def engine_host_nuts_run(mode, kind, dim, params, init, target_accept_p, n_collect, n_discard, seed=0, chain_offset=0,
