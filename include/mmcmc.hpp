@@ -332,6 +332,35 @@ class DiscreteMetropolisHastings {
     }
 };
 
+/* GibbsSampler<f64, MixtureConditional> (gibbs.rs:139-203, 231-285); run() -> [n_chains, n_collect, 2] */
+class GibbsMixtureSampler {
+    mmcmc_gibbs_mixture *h_ = nullptr;
+    size_t n_chains_;
+
+  public:
+    GibbsMixtureSampler(double mu0, double sigma0, double mu1, double sigma1, double pi0,
+                        const std::vector<double> &initial_states, int device = 0)
+        : n_chains_(initial_states.size() / 2)
+    {
+        const double p[5] = {mu0, sigma0, mu1, sigma1, pi0};
+        check(mmcmc_gibbs_mixture_create(&h_, p, initial_states.data(), n_chains_, device), "mmcmc_gibbs_mixture_create");
+    }
+    GibbsMixtureSampler(const GibbsMixtureSampler &) = delete;
+    GibbsMixtureSampler &operator=(const GibbsMixtureSampler &) = delete;
+    ~GibbsMixtureSampler() { mmcmc_gibbs_mixture_destroy(h_); }
+    GibbsMixtureSampler &set_seed(uint64_t s)
+    {
+        check(mmcmc_gibbs_mixture_seed(h_, s), "mmcmc_gibbs_mixture_seed");
+        return *this;
+    }
+    std::vector<double> run(size_t n_collect, size_t n_discard)
+    {
+        std::vector<double> out(n_chains_ * n_collect * 2);
+        check(mmcmc_gibbs_mixture_run(h_, n_collect, n_discard, out.data(), 0, nullptr), "mmcmc_gibbs_mixture_run");
+        return out;
+    }
+};
+
 /* MultiChainTracker (stats.rs:189-306): step() takes host states [n_chains, k, dim] */
 class MultiChainTracker {
     mmcmc_tracker *h_ = nullptr;

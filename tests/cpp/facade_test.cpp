@@ -83,6 +83,18 @@ int main(int argc, char **argv)
             v /= 3199.0;
             REQUIRE(std::fabs(m) < 0.15 && v > 0.3 && v < 0.9); // (A^-1)_00 ~ 0.53
         }
+        // examples/mixture_gibbs.rs: 4 chains from init_det(4, 2), mixture (-2, 1, 3, 1.5, pi0 = 0.25)
+        {
+            GibbsMixtureSampler gs(-2.0, 1.0, 3.0, 1.5, 0.25, init);
+            auto sg = gs.set_seed(11).run(1100, 1000);
+            REQUIRE(sg.size() == 4u * 1100u * 2u);
+            double mz = 0;
+            for (size_t i = 1; i < sg.size(); i += 2) {
+                REQUIRE(sg[i] == 0.0 || sg[i] == 1.0);
+                mz += sg[i];
+            }
+            REQUIRE(std::fabs(mz / 4400.0 - 0.75) < 0.15);
+        }
         // MultiChainTracker over the HMC sample (hmc.rs:242-281)
         MultiChainTracker tr(4, 3);
         tr.step(s3);
