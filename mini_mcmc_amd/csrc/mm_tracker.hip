@@ -90,18 +90,42 @@ __global__ void tracker_step_kernel(const T *__restrict__ states, unsigned long 
     }
 }
 
-/* sequential replay of the last `len` flags (time-major, chain-minor order) */
-__global__ void tracker_paccept_kernel(const unsigned char *__restrict__ flags, size_t first, size_t len, int restart,
-                                       float *p_accept)
+/* sequential replay of the last `len` <= kTail flags (time-major, chain-minor order).  One wave: lane l first loads
+ * its contiguous share of the flags into registers (so the dependent chain below never waits for memory), then the
+ * lanes fold their shares one after the other, handing p from lane to lane -- the reference's order exactly. */
+__global__ __launch_bounds__(64) void tracker_paccept_kernel(const unsigned char *__restrict__ flags, size_t first,
+                                                             size_t len, int restart, float *p_accept)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0)
-        return;
-    float p = restart ? 0.5f : *p_accept; /* restart: the sequence before `first` is forgotten anyway */
-    for (size_t i = 0; i < len; ++i) {
-        const float accepted = (float)flags[first + i];
-        p = (1.0f - kAlpha) * p + kAlpha * accepted;
+    constexpr unsigned int per = (unsigned int)(kTail / 64); /* flags per lane */
+    const unsigned int lane = threadIdx.x;
+    unsigned int bits[per / 32];
+    const size_t lo = (size_t)lane * per;
+#pragma unroll
+    for (unsigned int w = 0; w < per / 32; ++w) {
+        unsigned int v = 0;
+        for (unsigned int b = 0; b < 32; ++b) {
+            const size_t i = lo + w * 32 + b;
+            if (i < len && flags[first + i])
+                v |= 1u << b;
+        }
+        bits[w] = v;
     }
-    *p_accept = p;
+    const unsigned int mine = lo < len ? (unsigned int)((len - lo) < per ? (len - lo) : per) : 0u;
+    float p = restart ? 0.5f : *p_accept; /* restart: the sequence before `first` is forgotten anyway */
+    for (unsigned int l = 0; l < 64; ++l) {
+        if (lane == l) {
+#pragma unroll
+            for (unsigned int w = 0; w < per / 32; ++w)
+                for (unsigned int b = 0; b < 32; ++b)
+                    if (w * 32 + b < mine) {
+                        const float accepted = (float)((bits[w] >> b) & 1u);
+                        p = (1.0f - kAlpha) * p + kAlpha * accepted;
+                    }
+        }
+        p = __shfl(p, (int)l, 64);
+    }
+    if (lane == 0)
+        *p_accept = p;
 }
 
 /* within_and_var: out[d] = rhat; one block per parameter */
