@@ -124,6 +124,9 @@ int mmcmc_mh_run(mmcmc_mh *h, size_t n_collect, size_t n_discard, void *out, int
 int mmcmc_mh_state(mmcmc_mh *h, void *out);
 int mmcmc_mh_sync(mmcmc_mh *h);
 int mmcmc_mh_timing(mmcmc_mh *h, mmcmc_timing *t);
+/* run() brackets its launches with two HIP events for mmcmc_*_timing (default on); off = no event packets on the
+ * stream between back-to-back runs (mmcmc_*_timing then returns MMCMC_ERR_STATE) */
+int mmcmc_mh_enable_timing(mmcmc_mh *h, int on);
 int mmcmc_mh_destroy(mmcmc_mh *h);
 
 /* ---- HMC ---------------------------------------------------------------------------------------------
@@ -143,6 +146,7 @@ int mmcmc_hmc_step(mmcmc_hmc *h, void *stream);
 int mmcmc_hmc_state(mmcmc_hmc *h, void *out);
 int mmcmc_hmc_sync(mmcmc_hmc *h);
 int mmcmc_hmc_timing(mmcmc_hmc *h, mmcmc_timing *t);
+int mmcmc_hmc_enable_timing(mmcmc_hmc *h, int on);
 int mmcmc_hmc_destroy(mmcmc_hmc *h);
 
 /* ---- NUTS ------------------------------------------------------------------------------------------------

@@ -112,6 +112,11 @@ class _Sampler:
         stats = S.run_stats(out)
         return (out if to == "torch" else out.cpu().numpy()), stats
 
+    def enable_timing(self, on: bool = True):
+        """HIP-event bracketing of run() for timing() (default on)."""
+        L.check(self._fn("enable_timing")(self._h, 1 if on else 0), "enable_timing")
+        return self
+
     def sync(self):
         L.check(self._fn("sync")(self._h), "sync")
 

@@ -144,6 +144,8 @@ struct Sampler {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool want_accept = true; /* this run(): per-chain accept counts requested */
+    bool timing_enabled = true;
     mmcmc_timing timing{};
     bool alive = true;
 
@@ -267,7 +269,7 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     a.n_leapfrog = s->n_leapfrog;
     a.state = (T *)s->d_state;
     a.out = d_out;
-    a.accept = s->d_accept;
+    a.accept = s->want_accept ? s->d_accept : nullptr;
     a.accept_total = s->d_accept_total;
     a.n_chains = s->n_chains;
     a.seed = s->seed;
@@ -315,13 +317,17 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
             staged = true;
         }
     }
-    MM_HIP(hipMemsetAsync(s->d_accept, 0, s->n_chains * sizeof(unsigned long long), stream));
+    /* per-chain accept counts only when asked for: otherwise neither the clearing fill nor the kernel's stores */
+    s->want_accept = accept_counts != nullptr;
+    if (s->want_accept)
+        MM_HIP(hipMemsetAsync(s->d_accept, 0, s->n_chains * sizeof(unsigned long long), stream));
 
     /* split the run into launches of at most iters_per_launch transitions (0 = one launch) */
     uint64_t remaining_discard = n_discard, remaining_collect = n_collect, t0 = 0;
     const uint64_t cap = s->iters_per_launch ? s->iters_per_launch : (n_discard + n_collect);
     uint32_t launches = 0;
-    MM_HIP(hipEventRecord(s->ev0, stream));
+    if (s->timing_enabled)
+        MM_HIP(hipEventRecord(s->ev0, stream));
     while (remaining_discard + remaining_collect > 0) {
         uint32_t nd = (uint32_t)std::min<uint64_t>(remaining_discard, cap);
         uint32_t nc = (uint32_t)std::min<uint64_t>(remaining_collect, cap - nd);
@@ -340,8 +346,9 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
         t0 += nc;
         ++launches;
     }
-    MM_HIP(hipEventRecord(s->ev1, stream));
-    s->timed = true;
+    if (s->timing_enabled)
+        MM_HIP(hipEventRecord(s->ev1, stream));
+    s->timed = s->timing_enabled;
     s->timing.n_launches = launches;
     s->timing.out_bytes = d_out ? out_bytes : 0;
     s->timing.state_bytes = (uint64_t)launches * 2ull * s->n_chains * s->dim * s->esize();
@@ -584,6 +591,20 @@ int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
     if (!h || variant < 0 || variant > 2)
         return MMCMC_ERR_INVALID_ARG;
     h->s->variant = variant;
+    return MMCMC_OK;
+}
+int mmcmc_mh_enable_timing(mmcmc_mh *h, int on)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->timing_enabled = on != 0;
+    return MMCMC_OK;
+}
+int mmcmc_hmc_enable_timing(mmcmc_hmc *h, int on)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->s->timing_enabled = on != 0;
     return MMCMC_OK;
 }
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters)
