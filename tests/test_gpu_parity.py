@@ -488,6 +488,16 @@ def test_nuts_lane_group_mfma_bit_exact_vs_host_twin(M, O):
         c = s._run(5, 2, True, "numpy")
         outs.append((np.concatenate([a, b, c], axis=1), s.leapfrog_counts(), s.depth_histogram()))
     assert all(np.array_equal(x, y) for x, y in zip(outs[0], outs[1]))
+    # the deepest trees the engine allows (12 doublings: every stack level, the HBM part of the first-leaf table and
+    # the depth cap are exercised) on a cond-1e6 target, all mappings against the host twin
+    g6 = M.dist.GaussianND.ill_conditioned(16, 1e6, 3)
+    init6 = M.core.init_with_seed(20, 16, 5) * 0.3
+    ref6, _, _, nlf6 = O.engine_host_nuts_run(3, O.GAUSSIAN_ND, 16, [], init6, 0.8, 4, 70, seed=7, matrix=g6.precision,
+                                              max_depth=12)
+    for variant in (1, 2, 3):
+        s = NUTS(g6, init6, 0.8, mode=2).set_seed(7).set_max_depth(12).set_kernel_variant(variant)
+        assert np.array_equal(s.run(4, 70), ref6) and np.array_equal(s.leapfrog_counts(), nlf6), variant
+        assert s.depth_histogram()[11:].sum() > 0  # trees of 2048+ leaves did occur
     # sharding: the wave a chain sits in (and its neighbours' tree depths) must not matter
     g = M.dist.GaussianND.ill_conditioned(32, 1e3, 1)
     init = M.core.init_with_seed(50, 32, 8) * 0.3
