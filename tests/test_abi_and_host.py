@@ -36,6 +36,16 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert lib.mmcmc_version() == 100
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/mmcmc.h is the drop-in boundary a `-sys` crate / cgo / JNI stub binds: it must compile as C99, pedantic."""
+    import subprocess
+
+    src = tmp_path / "c99.c"
+    src.write_text('#include "mmcmc.h"\nint main(void) { return MMCMC_OK; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "c99.o")], check=True)
+
+
 def test_product_does_not_link_or_reference_the_oracle():
     import subprocess
 
