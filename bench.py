@@ -75,12 +75,52 @@ def cpu_baseline(seconds_target: float = 15.0) -> dict:
     }
 
 
+def side_configs(dev) -> dict:
+    """BASELINE.json's other single-GPU configurations, measured once each after the headline run and reported as
+    extra keys (they are parity-test cases, not bench lines): config 2 (Gaussian2D MH, 65 536 chains, f32,
+    run(1000, 100)) and config 5 (NUTS, 32-D Gaussian of condition number 1e4, 65 536 chains, f64, 200 + 100,
+    tree-depth compaction).  Kernel time by HIP events on the launch stream.  Never fails the bench."""
+    out = {}
+    try:
+        import numpy as np
+        import torch
+
+        from mini_mcmc_amd.core import init_with_seed
+        from mini_mcmc_amd.distributions import Gaussian2D, GaussianND, IsotropicGaussian
+        from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+        from mini_mcmc_amd.nuts import NUTS
+
+        mh = MetropolisHastings(Gaussian2D([0.0, 0.0], [[1.0, 0.0], [0.0, 1.0]]), IsotropicGaussian(1.0),
+                                init_with_seed(C_PER_GPU, 2, SEED, np.float32), device=dev.index or 0).seed(SEED)
+        ms = []
+        for _ in range(4):
+            mh.run(1000, 100, to="torch", accept_counts=False)
+            ms.append(mh.timing()["kernel_ms"])
+        k = float(np.median(ms[1:]))
+        out["config2_mh"] = {"kernel_ms": k, "samples_per_s": C_PER_GPU * 1000 / (k * 1e-3),
+                             "hbm_frac": C_PER_GPU * 2 * 4 * (1000 + 2) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del mh
+        g = GaussianND.ill_conditioned(32, 1e4, 7)
+        nuts = NUTS(g, init_with_seed(C_PER_GPU, 32, SEED) * 0.1, 0.8, mode=2, device=dev.index or 0).set_seed(SEED).set_max_depth(10)
+        nuts._run(100, 200, True, "torch")
+        torch.cuda.synchronize()
+        k = float(nuts.timing()["kernel_ms"])
+        lf = float(nuts.leapfrog_counts().sum())
+        out["config5_nuts"] = {"kernel_ms": k, "leapfrog_steps_per_s": lf / (k * 1e-3), "draws_per_s": C_PER_GPU * 100 / (k * 1e-3),
+                               "kernel_variant": nuts.kernel_variant,
+                               "f64_mfma_frac": lf * 2 * 32 * 32 / (k * 1e-3) / 78.6e12}
+    except Exception as e:  # pragma: no cover -- side numbers must not take the headline down
+        out["error"] = repr(e)
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements of configs 2 and 5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--variant", type=int, default=2, help="kernel variant: 2 paired+pipelined noise (default), 1 pipelined, 0 plain")
     args = ap.parse_args()
@@ -225,6 +265,8 @@ def main() -> None:
                          "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "flop_per_iteration": FLOP_PER_ITER},
             },
         }
+        if world == 1 and not args.no_side:
+            res["side"] = side_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(res))
