@@ -264,8 +264,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 if ((e = hipStreamSynchronize(st)) != hipSuccess)
                     return e;
                 if (getenv("MMCMC_LGQ_STATS"))
-                    fprintf(stderr, "lgq: units %llu chains %llu (%.2f per unit) idle polls %llu error %u ticks pick %.3g fetch %.3g work %.3g handover %.3g\n", hc.stat_units,
-                            hc.stat_chains, (double)hc.stat_chains / (double)(hc.stat_units ? hc.stat_units : 1), hc.stat_polls,
+                    fprintf(stderr, "lgq: units %llu chains %llu (%.2f per unit) leaf iterations %llu idle polls %llu error %u ticks pick %.3g fetch %.3g work %.3g handover %.3g\n", hc.stat_units,
+                            hc.stat_chains, (double)hc.stat_chains / (double)(hc.stat_units ? hc.stat_units : 1), hc.stat_leaf_iters,
+                            hc.stat_polls,
                             (unsigned int)hc.error, (double)hc.stat_t[0], (double)hc.stat_t[1], (double)hc.stat_t[2], (double)hc.stat_t[3]);
                 return (hc.error != 0ull || hc.remaining != 0ull) ? hipErrorLaunchFailure : hipSuccess;
             }

@@ -97,6 +97,7 @@ struct mm_lgq_ctrl {
     unsigned long long error;     /* != 0 after a watchdog fired: every wave leaves */
     unsigned long long pad[14];
     unsigned long long stat_units, stat_chains, stat_polls; /* work units taken, chains in them, idle polls */
+    unsigned long long stat_leaf_iters;                     /* leaf iterations (of 16 chain slots each) executed */
     unsigned long long stat_t[4];                           /* s_memtime ticks: pick, fetch, work, hand-over */
 };
 
@@ -250,6 +251,7 @@ template <int D> struct mm_lg_lane {
     unsigned int n_alpha;
     int depth;
     unsigned long long n_lf;
+    unsigned long long n_leaf_iters; /* leaf iterations of the wave this lane took part in (wave-uniform) */
     unsigned long long chain; /* global chain index (keys the stream) */
     unsigned long long cl;    /* local chain index (record, state, adaptation state) */
     unsigned int m;
@@ -420,6 +422,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         if (__ballot(!done) == 0ull)
             break;
         MM_LG_COUNT(L, 6);
+        L.n_leaf_iters += 1;
         /* an odd leaf merges with its left neighbour first: request those records now */
         rec r0, r1;
         const bool merge0 = j > 0 && (leaf & 1u);
@@ -657,6 +660,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
     L.active = L.cl < a.n_chains;
     L.chain = a.chain_offset + L.cl;
     L.n_lf = 0;
+    L.n_leaf_iters = 0;
     L.m = a.m0;
     mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
     double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
@@ -778,6 +782,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgc_begin_kernel(
     L.active = L.cl < a.n_chains;
     L.chain = a.chain_offset + L.cl;
     L.n_lf = 0;
+    L.n_leaf_iters = 0;
     L.m = a.m;
     /* the next transition's counters (this parity was last used two transitions ago) */
     if (blockIdx.x == 0 && L.lane <= MM_NUTS_JMAX)
@@ -825,6 +830,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgc_double_kernel
     L.active = valid;
     L.chain = a.chain_offset + L.cl;
     L.n_lf = 0;
+    L.n_leaf_iters = 0;
     L.m = a.m;
     mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
     double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
@@ -893,7 +899,7 @@ template <int D> __global__ void mm_nuts_lgq_init_kernel(const mm_nuts_lg_args a
     if (i == 0) {
         a.ctrl->remaining = a.n_chains;
         a.ctrl->error = 0ull;
-        a.ctrl->stat_units = a.ctrl->stat_chains = a.ctrl->stat_polls = 0ull;
+        a.ctrl->stat_units = a.ctrl->stat_chains = a.ctrl->stat_polls = a.ctrl->stat_leaf_iters = 0ull;
         a.ctrl->stat_t[0] = a.ctrl->stat_t[1] = a.ctrl->stat_t[2] = a.ctrl->stat_t[3] = 0ull;
     }
 }
@@ -937,6 +943,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const 
     L.lane = threadIdx.x & 63;
     L.q = L.lane >> 4;
     L.cl = 0;
+    L.n_leaf_iters = 0;
     mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
     double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
     mm_lg_load_A<D>(L, a.mat);
@@ -1245,6 +1252,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const 
         atomicAdd(&ctrl->stat_units, st_units);
         atomicAdd(&ctrl->stat_chains, st_chains);
         atomicAdd(&ctrl->stat_polls, st_polls);
+        atomicAdd(&ctrl->stat_leaf_iters, L.n_leaf_iters);
     }
 #undef MM_LGQ_T
 }
