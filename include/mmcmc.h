@@ -244,6 +244,13 @@ int mmcmc_tracker_create(mmcmc_tracker **out, size_t n_chains, size_t dim, int d
 int mmcmc_tracker_steps(mmcmc_tracker *h, const void *states, int states_is_device, int dtype, size_t n_rows, size_t t0,
                         size_t k, void *stream);
 int mmcmc_tracker_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *p_accept, void *stream);
+/* The per-chain flavour the generic run_progress uses (core.rs:90-140, 255-300): ChainTracker::new(initial_state) =
+ * mmcmc_tracker_init_last (before any step; states [n_chains, dim]), then mmcmc_tracker_steps as above;
+ * mmcmc_tracker_chain_stats = collect_rhat (stats.rs:150-178, with its chains*params - 1 divisor, quirk Q9), its
+ * NaN-skipping maximum, and the average of the per-chain acceptance EMAs (stats.rs:109-123, started from the first
+ * comparison of coordinate 0: quirk Q12). */
+int mmcmc_tracker_init_last(mmcmc_tracker *h, const void *states, int states_is_device, int dtype, void *stream);
+int mmcmc_tracker_chain_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *avg_p_accept, void *stream);
 int mmcmc_tracker_n(mmcmc_tracker *h, uint64_t *n);
 int mmcmc_tracker_destroy(mmcmc_tracker *h);
 

@@ -113,6 +113,8 @@ SIGNATURES = {
     "mmcmc_tracker_create": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.c_size_t, C.c_int]),
     "mmcmc_tracker_steps": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
     "mmcmc_tracker_stats": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "mmcmc_tracker_init_last": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "mmcmc_tracker_chain_stats": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "mmcmc_tracker_n": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "mmcmc_tracker_destroy": (C.c_int, [_vp]),
     "mmcmc_mh_discrete_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_size_t, C.c_int]),

@@ -92,10 +92,19 @@ class _Sampler:
 
         dev = torch.device("cuda", self.device)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
-        if n_discard:
-            self.run(0, n_discard, to="torch", accept_counts=False, collect=False)
         tracker = S.MultiChainTracker(self.n_chains, self.dim, self.device)
-        tracker.step(torch.as_tensor(self.state(), device=dev))  # the state the sampling starts from (hmc.rs:244-247)
+        # HMC burns in, then feeds one MultiChainTracker the state the sampling starts from and every collected state
+        # (hmc.rs:229-247); the generic runner (MH: core.rs:90-140) keeps one ChainTracker per chain, constructed
+        # with the chain's state before the first step and stepped with EVERY state, burn-in included
+        per_chain = self._prefix != "hmc"
+        if per_chain:
+            tracker.init_last(torch.as_tensor(self.state(), device=dev))
+            if n_discard:
+                tracker.step(self.run(n_discard, 0, to="torch", accept_counts=False))
+        else:
+            if n_discard:
+                self.run(0, n_discard, to="torch", accept_counts=False, collect=False)
+            tracker.step(torch.as_tensor(self.state(), device=dev))
         out = torch.empty((self.n_chains, n_collect, self.dim), dtype=tdt, device=dev)
         every = int(every) if every else max(1, (n_collect + 9) // 10)
         done = 0
@@ -105,8 +114,8 @@ class _Sampler:
             out[:, done:done + k, :] = seg
             tracker.step(out, t0=done, k=k)
             done += k
-            if callback is not None:
-                _, mx, p = tracker._stats()
+            if callback is not None and tracker.n >= 2:
+                _, mx, p = tracker.chain_stats() if per_chain else tracker._stats()
                 callback(done, float(p), float(mx))
         self.tracker = tracker
         stats = S.run_stats(out)

@@ -14,6 +14,10 @@
  *                 (a = 0.01, stats.rs:252-258): one long recurrence.  Its value forgets its start at the rate
  *                 0.99^m, so one lane replays the last 16 384 flags sequentially (0.99^16384 ~ 1e-72): the same f32
  *                 operations in the same order as the reference over the part of the sequence that still matters.
+ *   per chain     ChainTracker (stats.rs:26-141, what the generic run_progress feeds, core.rs:90-140): the same means
+ *                 plus a per-chain acceptance EMA started from the first comparison of coordinate 0 (stats.rs:109-123,
+ *                 quirk Q12); mmcmc_tracker_chain_stats = collect_rhat (stats.rs:150-178, between / (C P - 1): quirk
+ *                 Q9) and the average of the per-chain EMAs (core.rs:268-281).
  *   rhat          within_and_var (stats.rs:288-306) from the per-chain means: block reduction with f64 accumulators
  *                 (the reference sums f32 in ndarray's order; parity to ~1e-6 relative, tests/test_tracker.py).
  */
@@ -58,12 +62,13 @@ template <class T>
 __global__ void tracker_step_kernel(const T *__restrict__ states, unsigned long long C, unsigned long long n_rows,
                                     unsigned long long t0, unsigned int k, unsigned int D, unsigned long long n_before,
                                     float *__restrict__ mean, float *__restrict__ mean_sq, float *__restrict__ last,
-                                    unsigned char *__restrict__ flags /* [k, C] */)
+                                    float *__restrict__ p_chain, unsigned char *__restrict__ flags /* [k, C] */)
 {
     const unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C)
         return;
     float m[kMaxDim], q[kMaxDim], l[kMaxDim];
+    float pc = p_chain[c]; /* ChainTracker::p_accept, -1 before the first step */
     for (unsigned int d = 0; d < D; ++d) {
         m[d] = mean[c * D + d];
         q[d] = mean_sq[c * D + d];
@@ -73,16 +78,23 @@ __global__ void tracker_step_kernel(const T *__restrict__ states, unsigned long 
         const unsigned long long n_i = n_before + t + 1;
         const float n = (float)n_i;
         const T *row = states + (c * n_rows + t0 + t) * D;
-        int ne = 0;
+        int ne = 0, ne0 = 0;
         for (unsigned int d = 0; d < D; ++d) {
             const float x = (float)row[d];
             m[d] = (m[d] * (n - 1.0f) + x) / n;
             q[d] = (n_i == 1) ? x * x : (q[d] * (n - 1.0f) + x * x) / n;
-            ne |= (x != l[d]) ? 1 : 0;
+            const int dif = (x != l[d]) ? 1 : 0;
+            ne |= dif;
+            if (d == 0)
+                ne0 = dif;
             l[d] = x;
         }
         flags[(size_t)t * C + c] = (unsigned char)ne;
+        /* stats.rs:109-123: the first step starts the EMA from the comparison of coordinate 0 alone (Q12) */
+        const float p_start = (pc >= 0.0f) ? pc : (float)ne0;
+        pc = (1.0f - kAlpha) * p_start + kAlpha * (float)ne;
     }
+    p_chain[c] = pc;
     for (unsigned int d = 0; d < D; ++d) {
         mean[c * D + d] = m[d];
         mean_sq[c * D + d] = q[d];
@@ -168,6 +180,58 @@ __global__ __launch_bounds__(1024) void tracker_rhat_kernel(const float *__restr
     }
 }
 
+/* collect_rhat (stats.rs:150-178) over the ChainStats of every chain, and the average per-chain acceptance EMA
+ * (core.rs:268-281); out[d] = rhat, out[D] = mean p_accept.  One block per parameter (+ one for p_accept). */
+__global__ __launch_bounds__(1024) void tracker_chain_stats_kernel(const float *__restrict__ mean,
+                                                                   const float *__restrict__ mean_sq,
+                                                                   const float *__restrict__ p_chain,
+                                                                   unsigned long long C, unsigned int D,
+                                                                   unsigned long long n_i, float *out)
+{
+    __shared__ double red[1024];
+    const unsigned int d = blockIdx.x, tid = threadIdx.x;
+    auto block_sum = [&](double v) -> double {
+        red[tid] = v;
+        __syncthreads();
+        for (unsigned int s = 512; s > 0; s >>= 1) {
+            if (tid < s)
+                red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    if (d == D) {
+        double p = 0.0;
+        for (unsigned long long c = tid; c < C; c += 1024)
+            p += (double)p_chain[c];
+        p = block_sum(p);
+        if (tid == 0)
+            out[D] = (float)(p / (double)C);
+        return;
+    }
+    const float n = (float)n_i, nch = (float)C;
+    double sm = 0.0, sw = 0.0;
+    for (unsigned long long c = tid; c < C; c += 1024) {
+        const float mc = mean[c * D + d];
+        sm += (double)mc;
+        sw += (double)((mean_sq[c * D + d] - mc * mc) * n / (n - 1.0f)); /* ChainTracker::stats sm2 (stats.rs:135-138) */
+    }
+    const float global_mean = (float)(block_sum(sm) / (double)nch);
+    const float within = (float)(block_sum(sw) / (double)nch);
+    double ss = 0.0;
+    for (unsigned long long c = tid; c < C; c += 1024) {
+        const float df = mean[c * D + d] - global_mean;
+        ss += (double)(df * df);
+    }
+    const float between = (float)block_sum(ss) / (float)(C * D - 1); /* diffs.len() - 1: quirk Q9 */
+    if (tid == 0) {
+        const float var = between + within * ((n - 1.0f) / n);
+        out[d] = sqrtf(var / within);
+    }
+}
+
 } // namespace
 
 struct mmcmc_tracker {
@@ -175,6 +239,7 @@ struct mmcmc_tracker {
     size_t n_chains = 0, dim = 0;
     unsigned long long n = 0; /* steps taken */
     float *d_mean = nullptr, *d_mean_sq = nullptr, *d_last = nullptr, *d_p = nullptr, *d_rhat = nullptr;
+    float *d_p_chain = nullptr; /* [C] ChainTracker::p_accept */
     unsigned char *d_flags = nullptr;
     size_t flags_cap = 0;
 };
@@ -213,7 +278,12 @@ int mmcmc_tracker_create(mmcmc_tracker **out, size_t n_chains, size_t dim, int d
     alloc0(&h->d_mean_sq, cd);
     alloc0(&h->d_last, cd);
     alloc0(&h->d_p, sizeof(float));
-    alloc0(&h->d_rhat, dim * sizeof(float));
+    alloc0(&h->d_rhat, (dim + 1) * sizeof(float));
+    alloc0(&h->d_p_chain, n_chains * sizeof(float));
+    if (e == hipSuccess) {
+        std::vector<float> neg(n_chains, -1.0f); /* ChainTracker::new: p_accept = -1 (stats.rs:76) */
+        e = hipMemcpy(h->d_p_chain, neg.data(), n_chains * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         mmcmc_tracker_destroy(h);
         return (int)e;
@@ -253,11 +323,11 @@ int mmcmc_tracker_steps(mmcmc_tracker *h, const void *states, int states_is_devi
     if (dtype == MMCMC_F32)
         hipLaunchKernelGGL(tracker_step_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)d_states,
                            (unsigned long long)h->n_chains, (unsigned long long)n_rows, (unsigned long long)t0,
-                           (unsigned int)k, (unsigned int)h->dim, h->n, h->d_mean, h->d_mean_sq, h->d_last, h->d_flags);
+                           (unsigned int)k, (unsigned int)h->dim, h->n, h->d_mean, h->d_mean_sq, h->d_last, h->d_p_chain, h->d_flags);
     else
         hipLaunchKernelGGL(tracker_step_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)d_states,
                            (unsigned long long)h->n_chains, (unsigned long long)n_rows, (unsigned long long)t0,
-                           (unsigned int)k, (unsigned int)h->dim, h->n, h->d_mean, h->d_mean_sq, h->d_last, h->d_flags);
+                           (unsigned int)k, (unsigned int)h->dim, h->n, h->d_mean, h->d_mean_sq, h->d_last, h->d_p_chain, h->d_flags);
     MM_HIP(hipGetLastError());
     const size_t len = need < kTail ? need : kTail;
     hipLaunchKernelGGL(tracker_paccept_kernel, dim3(1), dim3(64), 0, st, h->d_flags, need - len, len,
@@ -300,6 +370,59 @@ int mmcmc_tracker_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *p
     return MMCMC_OK;
 }
 
+int mmcmc_tracker_init_last(mmcmc_tracker *h, const void *states, int states_is_device, int dtype, void *stream)
+{
+    if (!h || !states || (dtype != MMCMC_F32 && dtype != MMCMC_F64))
+        return MMCMC_ERR_INVALID_ARG;
+    if (h->n != 0)
+        return MMCMC_ERR_STATE;
+    DevGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cd = h->n_chains * h->dim;
+    std::vector<float> f(cd);
+    if (dtype == MMCMC_F32) {
+        MM_HIP(hipMemcpyAsync(f.data(), states, cd * sizeof(float), states_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, st));
+        MM_HIP(hipStreamSynchronize(st));
+    } else {
+        std::vector<double> d(cd);
+        MM_HIP(hipMemcpyAsync(d.data(), states, cd * sizeof(double), states_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, st));
+        MM_HIP(hipStreamSynchronize(st));
+        for (size_t i = 0; i < cd; ++i)
+            f[i] = (float)d[i]; /* to_f32 (stats.rs:66-71) */
+    }
+    MM_HIP(hipMemcpyAsync(h->d_last, f.data(), cd * sizeof(float), hipMemcpyHostToDevice, st));
+    MM_HIP(hipStreamSynchronize(st));
+    return MMCMC_OK;
+}
+
+int mmcmc_tracker_chain_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *avg_p_accept, void *stream)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    if (h->n < 2)
+        return MMCMC_ERR_STATE;
+    DevGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tracker_chain_stats_kernel, dim3((unsigned int)h->dim + 1), dim3(1024), 0, st, h->d_mean,
+                       h->d_mean_sq, h->d_p_chain, (unsigned long long)h->n_chains, (unsigned int)h->dim, h->n, h->d_rhat);
+    MM_HIP(hipGetLastError());
+    std::vector<float> r(h->dim + 1);
+    MM_HIP(hipMemcpyAsync(r.data(), h->d_rhat, (h->dim + 1) * sizeof(float), hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    float mx = r[0];
+    for (size_t d = 0; d < h->dim; ++d) {
+        if (rhat)
+            rhat[d] = r[d];
+        if (!(r[d] != r[d]) && (mx != mx || r[d] > mx))
+            mx = r[d]; /* max_skipnan (core.rs:292) */
+    }
+    if (max_rhat)
+        *max_rhat = mx;
+    if (avg_p_accept)
+        *avg_p_accept = r[h->dim];
+    return MMCMC_OK;
+}
+
 int mmcmc_tracker_n(mmcmc_tracker *h, uint64_t *n)
 {
     if (!h || !n)
@@ -320,6 +443,7 @@ int mmcmc_tracker_destroy(mmcmc_tracker *h)
     (void)hipFree(h->d_p);
     (void)hipFree(h->d_rhat);
     (void)hipFree(h->d_flags);
+    (void)hipFree(h->d_p_chain);
     delete h;
     return MMCMC_OK;
 }

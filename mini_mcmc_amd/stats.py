@@ -194,6 +194,23 @@ class MultiChainTracker:
                 "mmcmc_tracker_steps")
         return self
 
+    def init_last(self, states) -> "MultiChainTracker":
+        """ChainTracker::new(n_params, initial_state) for every chain (stats.rs:60-82): the state the first step is
+        compared with, without taking a step.  Use with `chain_stats()` for the generic run_progress' numbers."""
+        ptr, is_dev, code, shape, dev, stream, keep = _sample_args(states)
+        if tuple(shape) != (self.n_chains, self.n_params):
+            raise ValueError(f"states must be [{self.n_chains}, {self.n_params}]")
+        L.check(L.lib().mmcmc_tracker_init_last(self._h, C.c_void_p(ptr), is_dev, code, stream), "mmcmc_tracker_init_last")
+        return self
+
+    def chain_stats(self):
+        """(collect_rhat over the chains' ChainStats [n_params] (stats.rs:150-178), its maximum, mean per-chain p_accept)"""
+        r = np.zeros(self.n_params, dtype=np.float32)
+        mx, p = C.c_float(), C.c_float()
+        L.check(L.lib().mmcmc_tracker_chain_stats(self._h, r.ctypes.data_as(_fp), C.byref(mx), C.byref(p), None),
+                "mmcmc_tracker_chain_stats")
+        return r, np.float32(mx.value), np.float32(p.value)
+
     def _stats(self):
         r = np.zeros(self.n_params, dtype=np.float32)
         mx, p = C.c_float(), C.c_float()

@@ -8,7 +8,7 @@ def test_tracker_abi_symbols():
     import mini_mcmc_amd
 
     lib = mini_mcmc_amd.lib()
-    for sym in ("create", "steps", "stats", "n", "destroy"):
+    for sym in ("create", "steps", "stats", "init_last", "chain_stats", "n", "destroy"):
         assert hasattr(lib, "mmcmc_tracker_" + sym)
 
 
@@ -48,6 +48,35 @@ def test_tracker_matches_reference_semantics(O):
             else:
                 assert abs(float(tr.p_accept) - float(p_o)) < 1e-6  # start forgotten at rate 0.99^16384
         assert ta.p_accept == tb.p_accept or chains * steps > 16384
+
+
+@pytest.mark.gpu
+def test_per_chain_trackers_match_reference_semantics(O):
+    """ChainTracker + collect_rhat (stats.rs:26-178), what the generic run_progress shows (core.rs:90-140, 255-300)."""
+    import torch
+
+    from mini_mcmc_amd import stats as S
+
+    rng = np.random.default_rng(9)
+    for chains, steps, params in ((4, 40, 2), (257, 33, 3), (5000, 20, 1)):
+        init = rng.standard_normal((chains, params)).astype(np.float32)
+        x = rng.standard_normal((chains, steps, params)).astype(np.float32)
+        keep = rng.random((chains, steps)) < 0.4
+        keep[:, 0] &= rng.random(chains) < 0.5
+        x[:, 0][keep[:, 0]] = init[keep[:, 0]]          # a rejected first step repeats the initial state
+        for t in range(1, steps):
+            x[:, t][keep[:, t]] = x[:, t - 1][keep[:, t]]
+        if params > 1:                                   # first coordinate unchanged but another one moved: Q12
+            x[0, 0, 0] = init[0, 0]
+            x[0, 0, 1] = init[0, 1] + 1.0
+        rhat_o, p_o = O.chain_trackers_rhat(init, x)
+        tr = S.MultiChainTracker(chains, params).init_last(init)
+        tdev = torch.as_tensor(x, device="cuda")
+        tr.step(tdev, t0=0, k=7).step(tdev, t0=7, k=steps - 7)
+        rhat, mx, p = tr.chain_stats()
+        np.testing.assert_allclose(rhat, rhat_o, rtol=2e-5)
+        assert abs(float(mx) - float(np.nanmax(rhat_o))) <= 2e-5 * float(np.nanmax(rhat_o))
+        assert abs(float(p) - float(p_o.astype(np.float64).mean())) < 1e-6  # per-chain EMAs exact, their mean in f64
 
 
 @pytest.mark.gpu
