@@ -60,6 +60,19 @@ class Gaussian2D(Target):
         super().__init__(2, [self.mean[0], self.mean[1], cov[0, 0], cov[0, 1], cov[1, 0], cov[1, 1]])
 
 
+    def logp(self, position) -> float:
+        """`Normalized::logp` (distributions.rs:164-187): the fully normalised log-density, on the host in the
+        reference's order: -ln(2 pi) - 1/2 ln|det| - 1/2 diff^T Sigma^-1 diff (Sigma^-1 = adj / det)."""
+        (a, b), (c, d) = self.cov
+        det = a * d - b * c
+        term_1 = -np.log(2.0 * np.pi)
+        term_2 = -0.5 * np.log(abs(det))
+        diff = np.asarray(position, dtype=np.float64).reshape(2) - self.mean
+        inv_cov = np.array([[d, -b], [-c, a]]) / det
+        term_3 = -0.5 * diff.dot(inv_cov).dot(diff)
+        return float(term_1 + term_2 + term_3)
+
+
 class DiffableGaussian2D(Gaussian2D):
     """distributions.rs:212-316 `DiffableGaussian2D::new(mean, cov)` (gradient target for HMC / NUTS)."""
     kind = L.DIFFABLE_GAUSSIAN2D
@@ -132,3 +145,30 @@ class GaussianND(Target):
         lam = np.logspace(0.0, np.log10(cond), dim)
         a = (q * lam) @ q.T
         return GaussianND((a + a.T) / 2.0)
+
+
+class Categorical:
+    """distributions.rs:421-477 `Categorical::new(probs)` (`Discrete` + `Target<usize>`): host-side utility, not on the
+    GPU path.  Probabilities are normalised on construction; `sample` walks the cumulative sums with `r <= cum` and
+    falls back to the last index; `logp` is ln p_i, -inf out of range.  The generator is numpy's (the reference seeds
+    a SmallRng from the OS)."""
+
+    def __init__(self, probs, seed=None):
+        p = np.asarray(probs, dtype=np.float64)
+        self.probs = p / p.sum()
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self) -> int:
+        r = self._rng.random()
+        cum = 0.0
+        for i, p in enumerate(self.probs):
+            cum += p
+            if r <= cum:
+                return i
+        return len(self.probs) - 1
+
+    def logp(self, index: int) -> float:
+        return float(np.log(self.probs[index])) if 0 <= index < len(self.probs) else float("-inf")
+
+    def unnorm_logp(self, position) -> float:
+        return self.logp(int(position[0]))
