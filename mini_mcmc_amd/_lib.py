@@ -108,6 +108,7 @@ SIGNATURES = {
     "mmcmc_basic_stats_from": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.POINTER(BasicStats)]),
     "mmcmc_run_stats_from": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(RunStats),
                                   C.c_int, _vp]),
+    "mmcmc_hmc_kernel_variant": (C.c_int, [_vp]),
     "mmcmc_mh_enable_timing": (C.c_int, [_vp, C.c_int]),
     "mmcmc_hmc_enable_timing": (C.c_int, [_vp, C.c_int]),
     "mmcmc_tracker_create": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.c_size_t, C.c_int]),

@@ -13,8 +13,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
+#include "mm_hmc_lg.h"
 #include "mm_kernels.h"
 #include "mm_host_rng.h"
 #include "mm_params.h"
@@ -131,7 +133,9 @@ struct Sampler {
     uint64_t iter = 0;
     uint32_t iters_per_launch = 0;
     int variant = 2; /* mm_run_kernel PIPE: 0 plain; 2 (default) noise of two iterations packed + pipelined (PIPE = 1,
-                        noise of t+1 pipelined, measured equal to 2 and is no longer instantiated; 1 selects 2) */
+                        noise of t+1 pipelined, measured equal to 2 and is no longer instantiated; 1 selects 2);
+                        3 = lane-group / MFMA kernel (mm_hmc_lg.h): HMC, f64, GaussianND of dim 16 or 32 */
+    bool lg_ok = false;
     unsigned int block = 64;
     void *d_state = nullptr;
     void *d_mat = nullptr;
@@ -186,6 +190,10 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         delete s;
         return MMCMC_ERR_UNSUPPORTED;
     }
+    /* dense f64 Gaussian at dim 16 / 32 under HMC: the lane-group / MFMA kernel, and the default there */
+    s->lg_ok = sampler == MM_SAMPLER_HMC && dtype == MMCMC_F64 && s->kind == MMCMC_GAUSSIAN_ND && (s->dim == 16 || s->dim == 32);
+    if (s->lg_ok)
+        s->variant = 3;
     DeviceGuard g(device);
     auto fail = [&](int code) {
         if (s->d_state)
@@ -282,7 +290,29 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     unsigned int grid = (unsigned int)((s->n_chains + s->block - 1) / s->block);
     hipError_t e;
     const bool mh = s->sampler == MM_SAMPLER_MH, l10 = s->n_leapfrog == 10;
-    if (s->variant != 0)
+    if (s->variant == 3 && s->lg_ok) {
+        if constexpr (std::is_same<T, double>::value) {
+            mm_hmc_lg_args q;
+            q.mat = (const double *)s->d_mat;
+            q.state = (double *)s->d_state;
+            q.out = (double *)d_out;
+            q.accept = a.accept;
+            q.accept_total = a.accept_total;
+            q.n_chains = a.n_chains;
+            q.seed = a.seed;
+            q.chain_offset = a.chain_offset;
+            q.n_total = n_total;
+            q.iter0 = a.iter0;
+            q.n_discard = n_discard;
+            q.n_collect = n_collect;
+            q.out_t0 = out_t0;
+            q.eps = s->scale;
+            q.n_leapfrog = s->n_leapfrog;
+            e = mm_launch_hmc_lg(s->dim, q, stream);
+        } else {
+            e = hipErrorInvalidValue;
+        }
+    } else if (s->variant != 0)
         e = mh ? k->run_mh_pp(a, grid, s->block, stream)
                : (l10 ? k->run_hmc_pp10(a, grid, s->block, stream) : k->run_hmc_pp(a, grid, s->block, stream));
     else
@@ -588,11 +618,14 @@ int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 }
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
 {
-    if (!h || variant < 0 || variant > 2)
+    if (!h || variant < 0 || variant > 3)
         return MMCMC_ERR_INVALID_ARG;
+    if (variant == 3 && !h->s->lg_ok)
+        return MMCMC_ERR_UNSUPPORTED;
     h->s->variant = variant;
     return MMCMC_OK;
 }
+int mmcmc_hmc_kernel_variant(mmcmc_hmc *h) { return h ? h->s->variant : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_mh_enable_timing(mmcmc_mh *h, int on)
 {
     if (!h)

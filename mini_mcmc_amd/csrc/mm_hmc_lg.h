@@ -1,0 +1,119 @@
+/*
+ * mm_hmc_lg.h -- HMC on the dense Gaussian target in f64 with the lane-group mapping of mm_nuts_lg.h: 16 chains per
+ * wave, four lanes per chain, the gradient -A x on v_mfma_f64_16x16x4 (device only).
+ *
+ * One chain per lane keeps x, p, g, the proposal and its gradient in registers and reads A through the scalar cache:
+ * at D = 32 in f64 that spills and runs at 0.28 G leapfrog-steps/s for 65 536 chains (tools/hmc_dense_gaussian.py).
+ * Here a leapfrog step is 16 MFMAs + ~40 vector instructions for 16 chains.  Transition = HMC::step + leapfrog
+ * (hmc.rs:304-377, 397-431) exactly as mm_hmc_step_noise (mm_samplers.h) states it, with the dot products summed as
+ * four interleaved partial sums: the host build mm_hmc_step_noise<double, mm_target_gnd_grp4<D>, 0, mm_red_grp4<D>>
+ * is this kernel's bit-exact twin (oracle/engine_host.cpp: eh_hmc_grouped_run).
+ * Stream (mm_rng.h, f64 schedule): momentum z[d] = element d & 1 of block d >> 1, accept uniform = u53 of block AUX.
+ */
+#ifndef MM_HMC_LG_H
+#define MM_HMC_LG_H
+
+#include "mm_nuts_lg.h"
+
+struct mm_hmc_lg_args {
+    const double *mat;            /* precision matrix A, row-major [D, D] */
+    double *state;                /* [C, D] */
+    double *out;                  /* [C, n_total, D] or NULL */
+    unsigned long long *accept;   /* [C] += accepted proposals, or NULL */
+    unsigned long long *accept_total; /* += over all chains (wave ballots), or NULL */
+    unsigned long long n_chains, seed, chain_offset, n_total;
+    unsigned int iter0, n_discard, n_collect, out_t0;
+    double eps;
+    int n_leapfrog;
+};
+
+hipError_t mm_launch_hmc_lg(int dim, const mm_hmc_lg_args &a, hipStream_t stream); /* mm_nuts_lg_inst.hip */
+
+#ifdef MM_HMC_LG_KERNELS
+template <int D> __global__ __launch_bounds__(64) void mm_hmc_lg_kernel(const mm_hmc_lg_args a)
+{
+    constexpr int NS = D / 4;
+    mm_lg_lane<D> L; /* only the mapping part (lane, q, Aop) is used */
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    const unsigned long long cl = (unsigned long long)blockIdx.x * 16 + (L.lane & 15);
+    const bool active = cl < a.n_chains;
+    const unsigned long long chain = a.chain_offset + cl;
+    mm_lg_load_A<D>(L, a.mat);
+    double x[NS], y[NS]; /* y = A x = -gradient (mm_lg_logp_ax) */
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        x[s] = active ? a.state[cl * D + 4 * s + L.q] : 0.0;
+    double lp = mm_lg_logp_ax<D>(L.Aop, x, y);
+    const double eps = a.eps, h = eps * 0.5;
+    unsigned long long n_acc = 0, wave_acc = 0;
+    const unsigned int total = a.n_discard + a.n_collect;
+    for (unsigned int t = 0; t < total; ++t) {
+        const unsigned int iter = a.iter0 + t;
+        double p[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int d = 4 * s + L.q;
+            const mm_u32x4 blk = mm_block(a.seed, chain, iter, (uint32_t)(d >> 1));
+            double z0, z1;
+            mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
+            p[s] = (d & 1) ? z1 : z0;
+        }
+        const double u = mm_aux_u53(a.seed, chain, iter, 0u);
+        const double ke = mm_lg_dot<NS>(p, p);
+        const double h_current = ke * 0.5 - lp;
+        double xn[NS], yn[NS], lpn = lp;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            xn[s] = x[s];
+            yn[s] = y[s];
+        }
+        if (a.n_leapfrog > 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                p[s] = fma(-h, yn[s], p[s]); /* first half kick: p + h g, g = -y */
+        }
+        for (int l = 0; l < a.n_leapfrog; ++l) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                xn[s] = fma(eps, p[s], xn[s]);
+            lpn = mm_lg_logp_ax<D>(L.Aop, xn, yn);
+            const double k = (l + 1 == a.n_leapfrog) ? -h : -eps; /* merged half kicks between steps (Q6) */
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                p[s] = fma(k, yn[s], p[s]);
+        }
+        const double kp = mm_lg_dot<NS>(p, p);
+        const double h_proposed = kp * 0.5 - lpn;
+        const double accept_logp = h_current - h_proposed;
+        const bool acc = accept_logp >= mm_log(u); /* hmc.rs:367 `>=`; NaN rejects */
+        if (acc) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                x[s] = xn[s];
+                y[s] = yn[s];
+            }
+            lp = lpn;
+        }
+        n_acc += acc ? 1ull : 0ull;
+        wave_acc += (unsigned long long)__popcll(__ballot(acc && active && L.q == 0));
+        if (t >= a.n_discard && a.out && active) {
+            double *dst = a.out + (cl * a.n_total + a.out_t0 + (t - a.n_discard)) * D;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                dst[4 * s + L.q] = x[s];
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            a.state[cl * D + 4 * s + L.q] = x[s];
+        if (a.accept && L.q == 0)
+            a.accept[cl] += n_acc;
+    }
+    if (a.accept_total && L.lane == 0 && wave_acc)
+        atomicAdd(a.accept_total, wave_acc);
+}
+#endif /* MM_HMC_LG_KERNELS */
+
+#endif /* MM_HMC_LG_H */

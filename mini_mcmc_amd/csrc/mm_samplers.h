@@ -138,18 +138,19 @@ MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t s
 
 /* One HMC transition given its noise: p[D] ~ N(0,1) (momentum; clobbered) and ln_u.  x[D], lp = logp(x),
  * g = grad logp(x) are updated in place; returns 1 on accept. */
-template <class T, class Tgt, int LCT = 0>
+template <class T, class Tgt, int LCT = 0, class Red = mm_red_seq<T, Tgt::dim>>
 MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, T *p, T ln_u)
 {
+    /* Red: summation order of the two kinetic-energy dot products (mm_targets.h): sequential for one chain per lane,
+     * grouped for the lane-group kernel (mm_hmc_lg.h), whose bit-exact host twin this then is */
     /* LCT > 0: the number of leapfrog steps is the compile-time constant LCT (the loop is fully unrolled so the
      * scheduler can overlap it with independent work); LCT == 0: run-time n_leapfrog.  Same arithmetic either way. */
     constexpr int D = Tgt::dim;
     T xn[D], gn[D];
     const T h = eps * T(0.5);
-    T ke = 0;
+    const T ke = Red::dot(p, p);
     MM_UNROLL
     for (int i = 0; i < D; ++i) {
-        ke = mm_fma(p[i], p[i], ke);
         xn[i] = x[i];
         gn[i] = g[i];
     }
@@ -182,10 +183,7 @@ MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x,
         for (int l = 0; l < n_leapfrog; ++l)
             leap(l + 1 == n_leapfrog);
     }
-    T kp = 0;
-    MM_UNROLL
-    for (int i = 0; i < D; ++i)
-        kp = mm_fma(p[i], p[i], kp);
+    const T kp = Red::dot(p, p);
     T h_proposed = kp * T(0.5) - lpn;
     T accept_logp = h_current - h_proposed;
     int acc = accept_logp >= ln_u;

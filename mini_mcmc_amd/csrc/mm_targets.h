@@ -259,4 +259,57 @@ template <class T, int D> struct mm_target<T, MM_GAUSSIAN_ND, D> {
     }
 };
 
+/* Order of the D-term dot products inside a transition (HMC kinetic energy, NUTS criteria, the dense Gaussian's x.y).
+ *   mm_red_seq : one fma chain over i = 0..D-1 (what one lane per chain does).
+ *   mm_red_grp4: four interleaved chains -- chain q sums the terms i = q (mod 4) in ascending order -- combined as
+ *                (c0 + c1) + (c2 + c3).  This is the order the lane-group kernel (mm_nuts_lg.h: four lanes per chain,
+ *                lane q owning the coordinates i = q mod 4, butterfly over the four lanes) produces, so the host build
+ *                of mm_nuts_step with this policy is its bit-exact twin. */
+template <class TT, int D> struct mm_red_seq {
+    MM_HD static TT dot(const TT *a, const TT *b)
+    {
+        TT s = 0;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            s = mm_fma(a[i], b[i], s);
+        return s;
+    }
+};
+template <class TT, int D> struct mm_red_grp4 {
+    MM_HD static TT dot(const TT *a, const TT *b)
+    {
+        TT c[4] = {0, 0, 0, 0};
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            c[i & 3] = mm_fma(a[i], b[i], c[i & 3]);
+        return (c[0] + c[1]) + (c[2] + c[3]);
+    }
+};
+
+/* GaussianND with the grouped reduction for x.y (the matrix-vector product itself stays the in-order fma chain over
+ * the columns, which is exactly what v_mfma_f64_16x16x4_f64 computes -- tools/mfma_f64_check.hip). */
+template <class T, int D> struct mm_target_gnd_grp4 {
+    static constexpr int dim = D;
+    MM_HD static T logp_grad(const mm_tparams<T> &P, const T *x, T *g)
+    {
+        T y[D];
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            T acc = 0;
+            MM_UNROLL
+            for (int j = 0; j < D; ++j)
+                acc = mm_fma(P.mat[i * D + j], x[j], acc);
+            y[i] = acc;
+            g[i] = -acc;
+        }
+        return T(-0.5) * mm_red_grp4<T, D>::dot(x, y);
+    }
+    MM_HD static T logp(const mm_tparams<T> &P, const T *x)
+    {
+        T g[D];
+        return logp_grad(P, x, g);
+    }
+};
+
+
 #endif /* MM_TARGETS_H */

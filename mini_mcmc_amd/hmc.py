@@ -45,6 +45,11 @@ class HMC(_Sampler):
         L.check(L.lib().mmcmc_hmc_seed(self._h, int(seed)), "mmcmc_hmc_seed")
         return self
 
+    @property
+    def kernel_variant(self) -> int:
+        """0 / 2: one chain per lane (plain / paired noise); 3: lane groups + MFMA (f64 GaussianND of dim 16 or 32)."""
+        return int(L.lib().mmcmc_hmc_kernel_variant(self._h))
+
     def step(self) -> None:
         """hmc.rs:304-377: one transition of every chain."""
         L.check(L.lib().mmcmc_hmc_step(self._h, None), "mmcmc_hmc_step")

@@ -565,6 +565,9 @@ def engine_host_lib() -> C.CDLL:
     E.eh_gibbs_mixture_run.restype = C.c_int
     E.eh_gibbs_mixture_run.argtypes = [_dp, _dp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_size_t,
                                        _dp, _dp]
+    E.eh_hmc_grouped_run.restype = C.c_int
+    E.eh_hmc_grouped_run.argtypes = [C.c_int, _dp, C.c_double, C.c_int, _dp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32,
+                                     C.c_size_t, C.c_size_t, _dp, _u64p]
     E.eh_logp_grad.restype = C.c_int
     E.eh_logp_grad.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     _eh = E
@@ -723,6 +726,20 @@ def engine_host_gibbs_mixture_run(params, init, n_collect, n_discard, seed=0, ch
                                 n_discard, _d(out), _d(st))
     assert rc == 0
     return out, st
+
+
+def engine_host_hmc_grouped_run(matrix, init, eps, n_leapfrog, n_collect, n_discard, seed=0, chain_offset=0, iter0=0):
+    """HMC on GaussianND (f64, dim 16 / 32) with the lane-group kernel's reduction order: (samples, states, accepts)."""
+    E = engine_host_lib()
+    m = np.ascontiguousarray(matrix, dtype=np.float64)
+    st = np.ascontiguousarray(init, dtype=np.float64).copy()
+    n, d = st.shape
+    out = np.zeros((n, n_collect, d), dtype=np.float64)
+    acc = np.zeros(n, dtype=np.uint64)
+    rc = E.eh_hmc_grouped_run(d, _d(m), float(eps), int(n_leapfrog), _d(st), n, int(seed), int(chain_offset), int(iter0),
+                              n_collect, n_discard, _d(out), acc.ctypes.data_as(_u64p))
+    assert rc == 0
+    return out, st, acc
 
 
 def engine_host_nuts_run(mode, kind, dim, params, init, target_accept_p, n_collect, n_discard, seed=0, chain_offset=0,

@@ -415,6 +415,39 @@ def test_nuts_bit_exact_vs_host_build(M, O, mode):
         assert s.depth_histogram().sum() == C * (nc + nd - (0 if progress else 1))
 
 
+def test_hmc_lane_group_mfma_bit_exact_vs_host_twin(M, O):
+    """mm_hmc_lg.h (HMC on the dense f64 Gaussian: 16 chains per wave, gradient on v_mfma_f64_16x16x4) against the host
+    build of mm_hmc_step_noise with the grouped reduction order; and against the one-chain-per-lane kernel to rounding."""
+    for dim, cond, C, nc, nd, L, eps, off in ((32, 100.0, 70, 40, 9, 10, 0.05, 0), (32, 1e4, 33, 17, 0, 7, 0.01, 1 << 33),
+                                              (16, 50.0, 100, 25, 5, 10, 0.1, 0), (16, 10.0, 16, 3, 2, 1, 0.2, 5)):
+        g = M.dist.GaussianND.ill_conditioned(dim, cond, 7)
+        init = M.core.init_with_seed(C, dim, 3, np.float64) * 0.3
+        s = M.hmc.HMC(g, init, eps, L).set_seed(19)
+        assert s.kernel_variant == 3  # the default where it exists
+        if off:
+            s.set_chain_offset(off)
+        out = s.run(nc, nd)
+        ref, st, acc = O.engine_host_hmc_grouped_run(g.precision, init, eps, L, nc, nd, seed=19, chain_offset=off)
+        name = f"D={dim} cond={cond} C={C}"
+        assert np.array_equal(out, ref) and np.array_equal(s.state(), st), name
+        assert np.array_equal(s.accept_counts, acc), name
+        out2 = s.run(6, 1)  # continues the chains and the stream
+        ref2, _, acc2 = O.engine_host_hmc_grouped_run(g.precision, st, eps, L, 6, 1, seed=19, chain_offset=off, iter0=nc + nd)
+        assert np.array_equal(out2, ref2) and np.array_equal(s.accept_counts, acc2), name
+        # the one-chain-per-lane kernel computes the same transitions with a different summation order
+        a3 = M.hmc.HMC(g, init, eps, L).set_seed(19).set_chain_offset(off).run(3, 0)
+        a2 = M.hmc.HMC(g, init, eps, L).set_seed(19).set_chain_offset(off).set_kernel_variant(2).run(3, 0)
+        np.testing.assert_allclose(a3, a2, rtol=1e-9, atol=1e-11)
+    with pytest.raises(Exception):
+        M.hmc.HMC(M.dist.StandardNormal(3), M.core.init_with_seed(4, 3, 1, np.float64), 0.1, 5).set_kernel_variant(3)
+    # posterior: whitened draws have unit covariance (32-D, cond 100, 4096 chains)
+    g = M.dist.GaussianND.ill_conditioned(32, 100.0, 5)
+    s = M.hmc.HMC(g, M.core.init_with_seed(4096, 32, 4, np.float64) * 0.1, 0.08, 10).set_seed(6)
+    smp = s.run(50, 150).reshape(-1, 32)
+    w = smp @ np.linalg.cholesky(g.precision)
+    assert np.abs(w.mean(axis=0)).max() < 0.03 and np.abs(np.cov(w.T) - np.eye(32)).max() < 0.05
+
+
 def test_nuts_lane_group_mfma_bit_exact_vs_host_twin(M, O):
     """mm_nuts_lg.h (16 chains per wave, gradient on v_mfma_f64_16x16x4) against the host build of mm_nuts_step with
     the grouped reduction order (engine_host mode 3): samples, positions, adaptation state and tree shapes."""
