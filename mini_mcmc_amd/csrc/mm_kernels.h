@@ -22,6 +22,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mm_samplers.h"
 
 #define MM_SAMPLER_MH 0
@@ -51,6 +53,8 @@ template <class T, int D> struct mm_tile {
     static constexpr int run = tile_t * D;
     static constexpr int stride = run | 1; /* odd => bank-conflict-free both ways */
     static constexpr size_t lds_bytes_per_wave = (size_t)64 * stride * sizeof(T);
+    /* f32 kernels keep the normal draw's table (mm_rng.h) in LDS, once per block, in front of the tiles */
+    static constexpr size_t lds_bytes_table = (sizeof(T) == 4) ? (size_t)MM_ICDF_ROWS * 16 : 0;
 };
 
 /* Write the staged tile of one wave to `out`: for each of the wave's 64 chains one contiguous run of nt*D elements
@@ -152,7 +156,15 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
     using Tile = mm_tile<T, D>;
     constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride;
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
-    T *lds = reinterpret_cast<T *>(mm_lds_raw);
+    T *lds = reinterpret_cast<T *>(mm_lds_raw + Tile::lds_bytes_table);
+    /* where the f32 normals' table is read from: the block's LDS copy (f64 draws do not use a table) */
+    using Tab = typename std::conditional<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
+    Tab tab;
+    if constexpr (sizeof(T) == 4) {
+        mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, blockDim.x);
+        tab.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(mm_lds_raw);
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
     T zc[D], ln_uc = 0; /* PIPE: noise of the current transition, drawn one transition ahead */
     if (PIPE) {
         T u;
-        mm_draw_noise<D>(a.seed, chain, it, zc, &u);
+        mm_draw_noise<D>(a.seed, chain, it, zc, &u, tab);
         ln_uc = mm_logT(u);
     }
 
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         int acc;
         if (PIPE) {
             T zn[D], un;
-            mm_draw_noise<D>(a.seed, chain, it + 1, zn, &un);
+            mm_draw_noise<D>(a.seed, chain, it + 1, zn, &un, tab);
             const T ln_un = mm_logT(un);
             if (SAMPLER == MM_SAMPLER_HMC)
                 acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, zc, ln_uc);
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         /* pairs of transitions; the noise of the next pair is drawn alongside the current pair's transitions */
         const unsigned int total = a.n_discard + a.n_collect;
         T za[D], zb[D], lna, lnb;
-        mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb);
+        mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
         unsigned int tcol = 0, rows_out = 0;
         /* (Staggering the waves' flush phases was measured and bought nothing: the output path is bound by the
          * issue of store instructions per wave, not by HBM bursts -- see mm_flush_tile_raw.) */
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         };
         for (unsigned int t = 0; t < total; t += 2) {
             T zna[D], znb[D], lnna, lnnb;
-            mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb);
+            mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
             transition(za, lna, t);
             if (t + 1 < total)
                 transition(zb, lnb, t + 1);
@@ -324,7 +336,7 @@ __global__ void mm_noise_kernel(unsigned long long seed, unsigned long long chai
 template <class T, class Tgt, int SAMPLER, int PIPE = 0, int LCT = 0>
 hipError_t mm_launch_run(const mm_run_args<T> &a, unsigned int grid, unsigned int block, hipStream_t stream)
 {
-    const size_t lds = (size_t)(block / 64) * mm_tile<T, Tgt::dim>::lds_bytes_per_wave;
+    const size_t lds = mm_tile<T, Tgt::dim>::lds_bytes_table + (size_t)(block / 64) * mm_tile<T, Tgt::dim>::lds_bytes_per_wave;
     hipLaunchKernelGGL((mm_run_kernel<T, Tgt, SAMPLER, PIPE, LCT>), dim3(grid), dim3(block), lds, stream, a);
     return hipGetLastError();
 }

@@ -57,20 +57,14 @@ MM_HD bool mm_is_real(double x) { return x == x && x != (double)INFINITY && x !=
 /* momentum draw: z[0..D) of (chain, iteration) in the element type's schedule (mm_rng.h) */
 template <int D> MM_HD void mm_nuts_momentum(uint64_t seed, uint64_t chain, uint32_t iter, float *z)
 {
+    const mm_icdf_global tab;
     MM_UNROLL
     for (int b = 0; b < (D + 3) / 4; ++b) {
         mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
-        float z0, z1;
-        mm_box_muller_f32(mm_u24(blk.w[0]), mm_u24(blk.w[1]), &z0, &z1);
-        z[4 * b] = z0;
-        if (4 * b + 1 < D)
-            z[4 * b + 1] = z1;
-        if (4 * b + 2 < D) {
-            mm_box_muller_f32(mm_u24(blk.w[2]), mm_u24(blk.w[3]), &z0, &z1);
-            z[4 * b + 2] = z0;
-            if (4 * b + 3 < D)
-                z[4 * b + 3] = z1;
-        }
+        MM_UNROLL
+        for (int i = 0; i < 4; ++i)
+            if (4 * b + i < D)
+                z[4 * b + i] = mm_icdf_f32(blk.w[i], tab);
     }
 }
 template <int D> MM_HD void mm_nuts_momentum(uint64_t seed, uint64_t chain, uint32_t iter, double *z)

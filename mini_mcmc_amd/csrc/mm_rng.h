@@ -15,11 +15,17 @@
  *   u24(w)       = (float)((w >> 8) + 1) * 2^-24                      in (0,1]
  *   u53(hi, lo)  = (double)((((u64)hi << 21) | (lo >> 11)) + 1) * 2^-53   in (0,1]
  *   f32 block b: words w0..w3
- *       normals z[4b+0], z[4b+1] = box_muller(u24(w0), u24(w1));  z[4b+2], z[4b+3] = box_muller(u24(w2), u24(w3))
+ *       normals z[4b+i] = icdf24(w_i), i = 0..3: one normal per word by inversion of the normal CDF on a 2^24-point
+ *                                 lattice, symmetric about 0:  n = (w >> 8) | 1 (odd, 24 bits), sign = bit 8 of w,
+ *                                 z = sign * -Phi^-1(n 2^-25), with -Phi^-1 the piecewise cubic of mm_icdf_table.h
+ *                                 (16 segments per binade of n, |error| <= 1.2e-7 max(1, |z|); |z| <= 5.42)
  *       spare uniform           = u24-style from the low bytes: s = (w0&255) | (w1&255)<<8 | (w2&255)<<16,
  *                                 (float)(s + 1) * 2^-24
  *   f64 block b: z[2b+0], z[2b+1] = box_muller(u53(w0,w1), u53(w2,w3))
  *   box_muller(u1, u2) = ( r cos(2 pi u2), r sin(2 pi u2) ),  r = sqrt(-2 ln u1)
+ *   (f32 normals were Box-Muller pairs too until the inversion table replaced them: ~13 instructions and one 16-byte
+ *    table read per normal instead of ~30 instructions of software log / sqrt / sincos -- the sampling kernels are
+ *    instruction-issue bound and the noise was 60 % of the HMC kernel, tools/hmc_split.hip.)
  *   MH / HMC iteration t of a chain:
  *       noise z[0..D) from blocks 0..;   accept uniform: f32 -> spare of block 0;  f64 -> u53(w0,w1) of block AUX
  *   NUTS iteration: momentum z[0..D) as above; auxiliary draw k (k = 0: Exp(1) = -ln u, then the uniforms in
@@ -29,8 +35,66 @@
 #define MM_RNG_H
 
 #include "mm_math.h"
+#include "mm_icdf_table.h"
 
 #define MM_AUX_BLOCK 0x40000000u
+
+/* ---- the f32 normal: table-driven inverse CDF ----
+ * The table lives in three places with identical contents: a host array, a device array in global memory (default
+ * on the device: 16-byte gathers that hit L1) and, for the kernels that draw noise every iteration, a copy in LDS
+ * (mm_icdf_lds).  `Tab` only says where row r is read from; the arithmetic is the same everywhere. */
+typedef float mm_v4f __attribute__((vector_size(16)));
+static const float mm_icdf_tab_h[MM_ICDF_ROWS * 4] __attribute__((aligned(16))) = MM_ICDF_COEFFS;
+#if defined(__HIPCC__)
+static __device__ const float mm_icdf_tab_d[MM_ICDF_ROWS * 4] __attribute__((aligned(16))) = MM_ICDF_COEFFS;
+#endif
+
+struct mm_icdf_global {
+    MM_HD void row(uint32_t r, float *c) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const mm_v4f v = *reinterpret_cast<const mm_v4f *>(mm_icdf_tab_d + 4 * r);
+#else
+        const mm_v4f v = *reinterpret_cast<const mm_v4f *>(mm_icdf_tab_h + 4 * r);
+#endif
+        c[0] = v[0];
+        c[1] = v[1];
+        c[2] = v[2];
+        c[3] = v[3];
+    }
+};
+
+#if defined(__HIPCC__)
+typedef __attribute__((address_space(3))) const mm_v4f *mm_lds_f4_ptr;
+struct mm_icdf_lds {
+    mm_lds_f4_ptr tab; /* MM_ICDF_ROWS rows, filled by mm_icdf_lds_fill */
+    __device__ __forceinline__ void row(uint32_t r, float *c) const
+    {
+        const mm_v4f v = tab[r];
+        c[0] = v[0];
+        c[1] = v[1];
+        c[2] = v[2];
+        c[3] = v[3];
+    }
+};
+/* every thread of the block copies its share; the caller synchronises the block before the first draw */
+__device__ __forceinline__ void mm_icdf_lds_fill(float *lds_tab, unsigned int tid, unsigned int nthreads)
+{
+    for (unsigned int i = tid; i < MM_ICDF_ROWS; i += nthreads)
+        reinterpret_cast<mm_v4f *>(lds_tab)[i] = *reinterpret_cast<const mm_v4f *>(mm_icdf_tab_d + 4 * i);
+}
+#endif
+
+template <class Tab> MM_HD float mm_icdf_f32(uint32_t w, const Tab &tab)
+{
+    const uint32_t n = (w >> 8) | 1u;           /* odd, < 2^24: exact in f32 */
+    const uint32_t b = mm_f2u((float)n);
+    float c[4];
+    tab.row((b >> 19) & 511u, c);               /* low 5 exponent bits, top 4 mantissa bits */
+    const float t = mm_u2f((b & 0x7ffffu) | 0x3f800000u) - 1.0f; /* [0, 1/16), exact */
+    const float m = fmaf(fmaf(fmaf(c[3], t, c[2]), t, c[1]), t, c[0]);
+    return mm_u2f((mm_f2u(m) & 0x7fffffffu) | ((w << 23) & 0x80000000u)); /* magnitude of m, sign = bit 8 of w */
+}
 
 typedef struct {
     uint32_t w[4];
@@ -90,15 +154,6 @@ MM_HD double mm_u53(uint32_t hi, uint32_t lo)
     return (double)(m + 1ull) * 0x1.0p-53;
 }
 
-MM_HD void mm_box_muller_f32(float u1, float u2, float *z0, float *z1)
-{
-    float r = sqrtf(-2.0f * mm_logf(u1));
-    float s, c;
-    mm_sincos2pif(u2, &s, &c);
-    *z0 = r * c;
-    *z1 = r * s;
-}
-
 MM_HD void mm_box_muller_f64(double u1, double u2, double *z0, double *z1)
 {
     double r = sqrt(-2.0 * mm_log(u1));
@@ -106,13 +161,6 @@ MM_HD void mm_box_muller_f64(double u1, double u2, double *z0, double *z1)
     mm_sincos2pi(u2, &s, &c);
     *z0 = r * c;
     *z1 = r * s;
-}
-
-/* four f32 normals of one block */
-MM_HD void mm_normals4_f32(mm_u32x4 b, float z[4])
-{
-    mm_box_muller_f32(mm_u24(b.w[0]), mm_u24(b.w[1]), &z[0], &z[1]);
-    mm_box_muller_f32(mm_u24(b.w[2]), mm_u24(b.w[3]), &z[2], &z[3]);
 }
 
 /* two f64 normals of one block */
@@ -166,15 +214,6 @@ MM_HD mm_f2 mm_spare_u24x2(mm_u32x4x2 b)
 {
     mm_u2 s = (b.w[0] & 255u) | ((b.w[1] & 255u) << 8) | ((b.w[2] & 255u) << 16);
     return mm_u2_to_f2(s + 1u) * mm_splat2(0x1.0p-24f);
-}
-
-MM_HD void mm_box_muller_f32x2(mm_f2 u1, mm_f2 u2, mm_f2 *z0, mm_f2 *z1)
-{
-    mm_f2 r = mm_sqrt2(mm_splat2(-2.0f) * mm_logf2(u1));
-    mm_f2 s, c;
-    mm_sincos2pif2(u2, &s, &c);
-    *z0 = r * c;
-    *z1 = r * s;
 }
 
 /* auxiliary 53-bit uniform k of an iteration (NUTS; f64 accept uniform uses k = 0) */

@@ -25,29 +25,25 @@ MM_HD double mm_logT(double x) { return mm_log(x); }
 MM_HD float mm_expT(float x) { return mm_expf(x); }
 MM_HD double mm_expT(double x) { return mm_exp(x); }
 
-/* noise of (chain, iteration): z[0..D) ~ N(0,1) and the accept uniform u in (0,1]  (schedule: mm_rng.h) */
-template <int D> MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, float *z, float *u)
+/* noise of (chain, iteration): z[0..D) ~ N(0,1) and the accept uniform u in (0,1]  (schedule: mm_rng.h).
+ * Tab: where the f32 normal's table is read from (mm_icdf_global by default, mm_icdf_lds in the sampling kernel). */
+template <int D, class Tab = mm_icdf_global>
+MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, float *z, float *u, const Tab &tab = Tab())
 {
     MM_UNROLL
     for (int b = 0; b < (D + 3) / 4; ++b) {
         mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
         if (b == 0)
             *u = mm_spare_u24(blk);
-        float z0, z1;
-        mm_box_muller_f32(mm_u24(blk.w[0]), mm_u24(blk.w[1]), &z0, &z1);
-        z[4 * b] = z0;
-        if (4 * b + 1 < D)
-            z[4 * b + 1] = z1;
-        if (4 * b + 2 < D) {
-            mm_box_muller_f32(mm_u24(blk.w[2]), mm_u24(blk.w[3]), &z0, &z1);
-            z[4 * b + 2] = z0;
-            if (4 * b + 3 < D)
-                z[4 * b + 3] = z1;
-        }
+        MM_UNROLL
+        for (int i = 0; i < 4; ++i)
+            if (4 * b + i < D)
+                z[4 * b + i] = mm_icdf_f32(blk.w[i], tab);
     }
 }
 
-template <int D> MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z, double *u)
+template <int D, class Tab = mm_icdf_global>
+MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z, double *u, const Tab & = Tab())
 {
     MM_UNROLL
     for (int b = 0; b < (D + 1) / 2; ++b) {
@@ -62,10 +58,12 @@ template <int D> MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_
 }
 
 /* noise of (chain, iter) AND (chain, iter + 1) in one go: za/lna for iter, zb/lnb for iter + 1, ln* = log of the
- * accept uniform.  f32: both iterations ride in the two lanes of packed instructions; values are bit-identical to
- * mm_draw_noise + mm_logT.  f64: two scalar evaluations (there is no packed f64 arithmetic to gain from). */
-template <int D>
-MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, float *za, float *lna, float *zb, float *lnb)
+ * accept uniform.  f32: the two Philox evaluations are interleaved and the logarithm is packed across the two
+ * iterations (v_pk_*_f32); values are bit-identical to mm_draw_noise + mm_logT.  f64: two scalar evaluations (there
+ * is no packed f64 arithmetic to gain from). */
+template <int D, class Tab = mm_icdf_global>
+MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, float *za, float *lna, float *zb, float *lnb,
+                              const Tab &tab = Tab())
 {
     MM_UNROLL
     for (int b = 0; b < (D + 3) / 4; ++b) {
@@ -75,28 +73,18 @@ MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, floa
             *lna = ln[0];
             *lnb = ln[1];
         }
-        mm_f2 z0, z1;
-        mm_box_muller_f32x2(mm_u24x2(blk.w[0]), mm_u24x2(blk.w[1]), &z0, &z1);
-        za[4 * b] = z0[0];
-        zb[4 * b] = z0[1];
-        if (4 * b + 1 < D) {
-            za[4 * b + 1] = z1[0];
-            zb[4 * b + 1] = z1[1];
-        }
-        if (4 * b + 2 < D) {
-            mm_box_muller_f32x2(mm_u24x2(blk.w[2]), mm_u24x2(blk.w[3]), &z0, &z1);
-            za[4 * b + 2] = z0[0];
-            zb[4 * b + 2] = z0[1];
-            if (4 * b + 3 < D) {
-                za[4 * b + 3] = z1[0];
-                zb[4 * b + 3] = z1[1];
+        MM_UNROLL
+        for (int i = 0; i < 4; ++i)
+            if (4 * b + i < D) {
+                za[4 * b + i] = mm_icdf_f32(blk.w[i][0], tab);
+                zb[4 * b + i] = mm_icdf_f32(blk.w[i][1], tab);
             }
-        }
     }
 }
 
-template <int D>
-MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, double *za, double *lna, double *zb, double *lnb)
+template <int D, class Tab = mm_icdf_global>
+MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, double *za, double *lna, double *zb, double *lnb,
+                              const Tab & = Tab())
 {
     double u;
     mm_draw_noise<D>(seed, chain, iter, za, &u);

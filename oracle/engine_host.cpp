@@ -260,6 +260,15 @@ int eh_nuts_run(int mode, int kind, int dim, const double params[8], const doubl
                                   n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);
 }
 
+/* the product's f32 normal of one Philox word (mm_rng.h: mm_icdf_f32), word by word */
+int eh_icdf24_words(const uint32_t *w, size_t n, float *out)
+{
+    const mm_icdf_global tab;
+    for (size_t i = 0; i < n; ++i)
+        out[i] = mm_icdf_f32(w[i], tab);
+    return 0;
+}
+
 /* noise of (chain, iteration) as the engine draws it: z [n, dim], u [n] */
 int eh_noise(int dtype, uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n, int dim, void *z, void *u)
 {

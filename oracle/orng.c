@@ -5,11 +5,13 @@
  * (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; pinned in
  * tests/test_oracle_rng.py by the Random123 known-answer vectors) and of the draw schedule written
  * down in DESIGN.md / mini_mcmc_amd/csrc/mm_rng.h.  It shares only the elementary functions
- * (mm_logf, mm_sincos2pif, ...) with the product, because those DEFINE the engine's log/sin/cos.
+ * (mm_logf, mm_sincos2pi, ...) and the f32 normal's coefficient table (mm_icdf_table.h, data) with the product,
+ * because those DEFINE the engine's log / sin / cos / inverse normal CDF.
  */
 #include "orng.h"
 
 #include "../mini_mcmc_amd/csrc/mm_math.h"
+#include "../mini_mcmc_amd/csrc/mm_icdf_table.h"
 
 #include <math.h>
 
@@ -89,17 +91,35 @@ static double u53(uint32_t hi, uint32_t lo)
     return (double)(m + 1ull) * 0x1.0p-53;
 }
 
-/* normal #i of (chain, iteration) in the f32 schedule */
+/* normal #i of (chain, iteration) in the f32 schedule: word i % 4 of block i / 4, inverted through the piecewise
+ * cubic of -Phi^-1 (mm_rng.h "icdf24"; the coefficient table is shared DATA, the evaluation below is stated on its
+ * own: frexpf for the binade, arithmetic for segment and offset, where the product manipulates the float's bits) */
+static const float icdf_tab[MM_ICDF_ROWS * 4] = MM_ICDF_COEFFS;
+
+float o_engine_icdf24(uint32_t w)
+{
+    uint32_t n = (w >> 8) | 1u; /* odd 24-bit integer; the normal is sign * -Phi^-1(n 2^-25) */
+    int e;
+    float fr = frexpf((float)n, &e);  /* n = fr 2^e, fr in [1/2, 1) */
+    float m = 2.0f * fr - 1.0f;       /* n = (1 + m) 2^(e-1), m in [0, 1), exact */
+    int j = (int)(m * 16.0f);         /* segment of the binade */
+    float t = (m - (float)j * 0.0625f); /* offset inside the segment, in [0, 1/16), exact */
+    const float *c = icdf_tab + 4 * (((((e - 1) + 127) & 31) << 4) | j);
+    float mag = fabsf(fmaf(fmaf(fmaf(c[3], t, c[2]), t, c[1]), t, c[0]));
+    return ((w >> 8) & 1u) ? -mag : mag;
+}
+
+void o_engine_icdf24_words(const uint32_t *w, size_t n, float *out)
+{
+    for (size_t i = 0; i < n; ++i)
+        out[i] = o_engine_icdf24(w[i]);
+}
+
 float o_engine_normal_f32(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i)
 {
     uint32_t w[4];
     o_engine_block(seed, chain, iteration, i / 4, w);
-    uint32_t pair = (i % 4) / 2;
-    float u1 = u24(w[2 * pair]), u2 = u24(w[2 * pair + 1]);
-    float r = sqrtf(-2.0f * mm_logf(u1));
-    float s, c;
-    mm_sincos2pif(u2, &s, &c);
-    return (i % 2) ? r * s : r * c;
+    return o_engine_icdf24(w[i % 4]);
 }
 
 double o_engine_normal_f64(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i)

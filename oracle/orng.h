@@ -12,6 +12,8 @@
 #ifndef ORACLE_ORNG_H
 #define ORACLE_ORNG_H
 
+#include <stddef.h>
+
 #include "rand_compat.h"
 
 #ifdef __cplusplus
@@ -41,6 +43,8 @@ void o_rng_init_engine_stream(o_rng *r, uint64_t seed, uint64_t chain);
 void o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void o_engine_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t block, uint32_t out[4]);
 float o_engine_normal_f32(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
+float o_engine_icdf24(uint32_t w); /* the f32 normal of one Philox word */
+void o_engine_icdf24_words(const uint32_t *w, size_t n, float *out);
 double o_engine_normal_f64(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
 float o_engine_accept_f32(uint64_t seed, uint64_t chain, uint32_t iteration);
 double o_engine_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t k);

@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
         "o_philox4x32_10": (None, [_u32p, _u32p, _u32p]),
         "o_engine_block": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _u32p]),
         "o_engine_normal_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+        "o_engine_icdf24_words": (None, [_u32p, C.c_size_t, _fp]),
         "o_engine_normal_f64": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "o_engine_accept_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32]),
         "o_engine_aux_u53": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
@@ -205,6 +206,14 @@ def philox4x32_10(ctr, key):
 def engine_normals_f32(seed, chain, iteration, n):
     L = lib()
     return np.array([L.o_engine_normal_f32(seed, chain, iteration, i) for i in range(n)], dtype=np.float32)
+
+
+def engine_icdf24(words):
+    """The oracle's restatement of the engine's f32 normal, one per Philox word."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.empty(w.shape, dtype=np.float32)
+    lib().o_engine_icdf24_words(w.ctypes.data_as(_u32p), w.size, out.ctypes.data_as(_fp))
+    return out
 
 
 def engine_normals_f64(seed, chain, iteration, n):
@@ -559,6 +568,8 @@ def engine_host_lib() -> C.CDLL:
                               C.c_uint32, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp, C.c_void_p, _u64p, C.c_int]
     E.eh_noise.restype = C.c_int
     E.eh_noise.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    E.eh_icdf24_words.restype = C.c_int
+    E.eh_icdf24_words.argtypes = [_u32p, C.c_size_t, _fp]
     E.eh_discrete_run.restype = C.c_int
     E.eh_discrete_run.argtypes = [C.c_int, _dp, C.POINTER(C.c_int32), C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32,
                                   C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u64p]
@@ -609,6 +620,14 @@ def engine_host_noise(seed, chain_offset, iteration, n, dim, dtype=np.float32):
     if rc != 0:
         raise ValueError(f"eh_noise: {rc}")
     return z, u
+
+
+def engine_host_icdf24(words):
+    """The PRODUCT's f32 normal (mm_rng.h: mm_icdf_f32) compiled for the host, one per Philox word."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.empty(w.shape, dtype=np.float32)
+    engine_host_lib().eh_icdf24_words(w.ctypes.data_as(_u32p), w.size, out.ctypes.data_as(_fp))
+    return out
 
 
 def engine_host_logp_grad(kind, dim, params, x, matrix=None, dtype=np.float32, with_grad=True):

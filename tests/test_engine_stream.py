@@ -42,6 +42,37 @@ def test_engine_normals_and_uniforms_distribution(O):
     assert a.min() > 0 and a.max() <= 1 and abs(a.mean() - 0.5) < 0.01
 
 
+def test_f32_normal_is_the_inverse_cdf_on_the_whole_24_bit_lattice(O):
+    """mm_rng.h "icdf24": z = sign * -Phi^-1(n 2^-25), n = (w >> 8) | 1.  EVERY one of the 2^23 magnitudes: the
+    product's evaluation (host build of mm_icdf_f32) equals the oracle's independent restatement bit for bit and is
+    within 1.5e-7 max(1, |z|) of scipy's ndtri; sign = bit 8 gives the exact mirror image; the lattice has the
+    moments of N(0, 1)."""
+    from scipy.special import ndtri
+
+    worst, s2, s4, prev_last = 0.0, 0.0, 0.0, None
+    for k0 in range(0, 1 << 23, 1 << 21):
+        k = np.arange(k0, k0 + (1 << 21), dtype=np.uint32)
+        w = (k << np.uint32(9)) | np.uint32(0xAB)  # low byte is not part of the normal
+        got = O.engine_host_icdf24(w)
+        assert np.array_equal(got.view(np.uint32), O.engine_icdf24(w).view(np.uint32))
+        neg = O.engine_host_icdf24(w | np.uint32(0x100))
+        assert np.array_equal(neg.view(np.uint32), got.view(np.uint32) | np.uint32(0x80000000))
+        want = -ndtri((2.0 * k.astype(np.float64) + 1.0) * 2.0**-25)
+        g = got.astype(np.float64)
+        worst = max(worst, float(np.max(np.abs(g - want) / np.maximum(1.0, want))))
+        assert np.all(g > 0)
+        # decreasing in n up to the approximation error where two cubics meet
+        assert np.all(np.diff(g) <= 2.5e-7 * np.maximum(1.0, g[:-1]))
+        if prev_last is not None:
+            assert g[0] <= prev_last + 1e-6
+        prev_last = g[-1]
+        s2 += float(np.sum(g * g))
+        s4 += float(np.sum(g**4))
+    assert worst < 1.5e-7, worst
+    assert abs(s2 / (1 << 23) - 1.0) < 1e-5 and abs(s4 / (1 << 23) - 3.0) < 1e-3
+    assert O.engine_host_icdf24(np.array([0], dtype=np.uint32))[0] == pytest.approx(5.4201, abs=1e-3)  # the tail ends at Phi^-1(2^-25)
+
+
 @pytest.fixture(scope="module")
 def mmath(tmp_path_factory):
     """Host build of mm_math.h alone (the functions that DEFINE the engine's log/exp/sincos)."""
