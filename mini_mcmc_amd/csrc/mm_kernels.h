@@ -46,12 +46,19 @@ template <class T> struct mm_run_args {
     unsigned long long n_total; /* row count of `out` per chain (n_collect of the whole run) */
 };
 
-/* iterations staged per flush: about 96 f32 (48 f64) elements per chain => 24.8 KB of LDS per wave */
+constexpr int mm_gcd_c(int a, int b) { return b == 0 ? a : mm_gcd_c(b, a % b); }
+
+/* iterations staged per flush: about 96 f32 (48 f64) elements per chain => 25.6 KB of LDS per wave */
 template <class T, int D> struct mm_tile {
     static constexpr int target = (sizeof(T) == 4) ? 96 : 48;
-    static constexpr int tile_t = (target / D) > 0 ? (target / D) : 1;
+    /* even whenever possible: the kernels advance two transitions at a time */
+    static constexpr int tile_t = (target / D) >= 2 ? ((target / D) & ~1) : 1;
     static constexpr int run = tile_t * D;
-    static constexpr int stride = run | 1; /* odd => bank-conflict-free both ways */
+    /* row pitch of the staged tile.  When a chain's run is a whole number of 16-byte pieces the pitch keeps every
+     * piece 16-byte aligned (one ds_read_b128 per piece in the flush; the lane-strided staging writes then meet a
+     * 4-way bank conflict, which costs a few LDS cycles per transition); otherwise odd => conflict-free both ways */
+    static constexpr int epl = 16 / (int)sizeof(T);
+    static constexpr int stride = (run % epl) == 0 ? run + epl : (run | 1);
     static constexpr size_t lds_bytes_per_wave = (size_t)64 * stride * sizeof(T);
     /* f32 kernels keep the normal draw's table (mm_rng.h) in LDS, once per block, in front of the tiles */
     static constexpr size_t lds_bytes_table = (sizeof(T) == 4) ? (size_t)MM_ICDF_ROWS * 16 : 0;
@@ -78,6 +85,9 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
 {
     using Tile = mm_tile<T, D>;
     constexpr int TILE_T = Tile::tile_t, RUN = Tile::run, STRIDE = Tile::stride;
+#ifdef MM_PROBE_SKIP_FLUSH
+    return;
+#endif
     /* LDS operations of one wave execute in order, so the reads below see the rows staged by all 64 lanes and the
      * next tile's writes cannot overtake them: only the compiler has to keep program order (wave_barrier). */
     __builtin_amdgcn_wave_barrier();
@@ -87,7 +97,48 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
     T *const wbase = out + (wave_c0 * n_total + row0) * D;
     const unsigned int n_valid = (unsigned int)min(64ull, n_chains > wave_c0 ? n_chains - wave_c0 : 0ull);
     constexpr int EPL = 16 / (int)sizeof(T); /* elements per 16-byte store: 4 (f32) or 2 (f64) */
-    if (nt == (unsigned int)TILE_T && (RUN % EPL) == 0) {
+    /* piece p = k*64 + lane of the chain-linear image (see below) belongs to chain p / V; because 64 k advances by a
+     * whole number of chains every K0 = V / gcd(64, V) steps (V = 24: K0 = 3 steps = 8 chains), a lane meets only K0
+     * different (chain-in-group, element) pairs: its K0 LDS / global offsets are loop invariants and step a of the
+     * outer loop adds compile-time (LDS) and wave-uniform (global) constants */
+    constexpr int VP = (RUN % EPL) == 0 ? RUN / EPL : 1;
+    constexpr int GC = mm_gcd_c(64, VP), K0 = VP / GC, J0 = 64 / GC;
+    if (nt == (unsigned int)TILE_T && (RUN % EPL) == 0 && K0 <= 4 && n_valid == 64u &&
+        (unsigned long long)chain_stride * 64ull * sizeof(T) < (1ull << 32)) {
+        /* Full tile of a full wave (the common case): all reads of the tile are issued before the first store has
+         * to wait for them, no per-piece address arithmetic, no exec-mask branches. */
+        typedef T mm_vec16 __attribute__((ext_vector_type(EPL), aligned(sizeof(T))));
+        unsigned int src_off[K0], dst_off[K0];
+        MM_UNROLL
+        for (int m = 0; m < K0; ++m) {
+            const int p = m * 64 + lane;
+            const int j = p / VP;
+            const int e = (p - j * VP) * EPL;
+            src_off[m] = (unsigned int)(j * STRIDE + e);
+            dst_off[m] = ((unsigned int)j * chain_stride + (unsigned int)e) * (unsigned int)sizeof(T); /* bytes */
+        }
+        /* every read of the tile is in flight before the first store waits for its data */
+        typedef T mm_vec16a __attribute__((ext_vector_type(EPL))); /* 16-byte aligned: STRIDE % EPL == 0 */
+        mm_vec16a v[GC][K0];
+        MM_UNROLL
+        for (int a = 0; a < GC; ++a) {
+            MM_UNROLL
+            for (int m = 0; m < K0; ++m)
+                v[a][m] = *reinterpret_cast<const mm_vec16a *>(tile + a * J0 * STRIDE + src_off[m]);
+        }
+        MM_UNROLL
+        for (int a = 0; a < GC; ++a) {
+            char *const gbase = reinterpret_cast<char *>(wbase + (unsigned long long)(a * J0) * chain_stride);
+            MM_UNROLL
+            for (int m = 0; m < K0; ++m) {
+#ifdef MM_PROBE_SKIP_STORE
+                asm volatile("" ::"v"(v[a][m]), "v"(gbase + dst_off[m]));
+#else
+                *reinterpret_cast<mm_vec16 *>(gbase + dst_off[m]) = v[a][m];
+#endif
+            }
+        }
+    } else if (nt == (unsigned int)TILE_T && (RUN % EPL) == 0) {
         /* Full tile.  A wave's store instructions are issue-bound (~100 cycles each, whatever their width), so the
          * tile leaves as 16-byte stores: the chain-linear image is cut into 16-byte pieces, piece p = k*64 + lane
          * belongs to chain p / V at element EPL * (p % V) (V = RUN / EPL pieces per chain, compile-time divisor).
@@ -218,41 +269,25 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
     };
 
     if (PIPE == 2) {
-        /* pairs of transitions; the noise of the next pair is drawn alongside the current pair's transitions */
-        const unsigned int total = a.n_discard + a.n_collect;
+        /* Pairs of transitions; the noise of the next pair is drawn alongside the current pair's transitions.
+         * (za, zb) always hold the noise of iterations (it, it + 1).  The loops are kept free of branches other than
+         * their back edges -- burn-in: pairs, then one lone transition if the count is odd; collection: one tile at
+         * a time, TILE_T / 2 pairs with unconditional staging, then the flush -- a taken branch costs a wave more
+         * than the three LDS writes it would skip. */
         T za[D], zb[D], lna, lnb;
         mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
-        unsigned int tcol = 0, rows_out = 0;
-        /* (Staggering the waves' flush phases was measured and bought nothing: the output path is bound by the
-         * issue of store instructions per wave, not by HBM bursts -- see mm_flush_tile_raw.) */
-        const unsigned int cap = (unsigned int)TILE_T;
-        auto transition = [&](T *z, T ln_u, unsigned int t) {
+        unsigned int n_acc32 = 0;
+        auto transition = [&](T *z, T ln_u) {
             int acc;
             if (SAMPLER == MM_SAMPLER_HMC)
                 acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u);
             else
                 acc = mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u);
             acc = acc && active;
-            n_acc += (unsigned long long)acc;
+            n_acc32 += (unsigned int)acc;
             wave_acc += (unsigned long long)__popcll(__ballot(acc));
-            if (t >= a.n_discard && a.out) {
-                MM_UNROLL
-                for (int i = 0; i < D; ++i)
-                    tile[lane * STRIDE + tcol * D + i] = x[i];
-                ++tcol;
-                if (tcol == cap || t + 1 == total) {
-                    mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, tcol);
-                    rows_out += tcol;
-                    tcol = 0;
-                }
-            }
         };
-        for (unsigned int t = 0; t < total; t += 2) {
-            T zna[D], znb[D], lnna, lnnb;
-            mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
-            transition(za, lna, t);
-            if (t + 1 < total)
-                transition(zb, lnb, t + 1);
+        auto shift = [&](const T *zna, const T *znb, T lnna, T lnnb) {
             MM_UNROLL
             for (int i = 0; i < D; ++i) {
                 za[i] = zna[i];
@@ -261,7 +296,58 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
             lna = lnna;
             lnb = lnnb;
             it += 2u;
+        };
+        /* n transitions without output */
+        auto silent = [&](unsigned int n) {
+            for (unsigned int i = 0; i + 1 < n; i += 2) {
+                T zna[D], znb[D], lnna, lnnb;
+                mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
+                transition(za, lna);
+                transition(zb, lnb);
+                shift(zna, znb, lnna, lnnb);
+            }
+            if (n & 1u) {
+                transition(za, lna);
+                it += 1u;
+                mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
+            }
+        };
+        silent(a.n_discard);
+        if (a.out) {
+            T *const row = tile + lane * STRIDE;
+            for (unsigned int rows_out = 0; rows_out < a.n_collect;) {
+                const unsigned int nt = min((unsigned int)TILE_T, a.n_collect - rows_out);
+                T *dst = row;
+                for (unsigned int i = 0; i + 1 < nt; i += 2) {
+                    T zna[D], znb[D], lnna, lnnb;
+                    mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
+                    transition(za, lna);
+                    MM_UNROLL
+                    for (int k = 0; k < D; ++k)
+                        dst[k] = x[k];
+                    transition(zb, lnb);
+                    MM_UNROLL
+                    for (int k = 0; k < D; ++k)
+                        dst[D + k] = x[k];
+                    dst += 2 * D;
+                    shift(zna, znb, lnna, lnnb);
+                }
+                if (nt & 1u) {
+                    transition(za, lna);
+                    MM_UNROLL
+                    for (int k = 0; k < D; ++k)
+                        dst[k] = x[k];
+                    it += 1u;
+                    if (rows_out + nt < a.n_collect)
+                        mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
+                }
+                mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, nt);
+                rows_out += nt;
+            }
+        } else {
+            silent(a.n_collect);
         }
+        n_acc += n_acc32;
     } else {
         for (unsigned int i = 0; i < a.n_discard; ++i)
             step();

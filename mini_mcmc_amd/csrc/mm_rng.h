@@ -176,36 +176,59 @@ typedef struct {
     mm_u2 w[4];
 } mm_u32x4x2;
 
+/* the pair evaluation in three steps, so that a kernel can spread the ten rounds over other work (mm_kernels.h) */
+typedef struct {
+    mm_u2 c0, c1, c2, c3;
+    uint32_t k0, k1;
+} mm_philox_pair;
+
+MM_HD mm_philox_pair mm_philox_pair_init(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t block)
+{
+    mm_philox_pair s;
+    s.c0 = mm_u2{(uint32_t)chain, (uint32_t)chain};
+    s.c1 = mm_u2{(uint32_t)(chain >> 32), (uint32_t)(chain >> 32)};
+    s.c2 = mm_u2{iteration, iteration + 1u};
+    s.c3 = mm_u2{block, block};
+    s.k0 = (uint32_t)seed;
+    s.k1 = (uint32_t)(seed >> 32);
+    return s;
+}
+
+MM_HD void mm_philox_pair_round(mm_philox_pair &s)
+{
+    mm_ul2 p0 = __builtin_convertvector(s.c0, mm_ul2) * 0xD2511F53ull;
+    mm_ul2 p1 = __builtin_convertvector(s.c2, mm_ul2) * 0xCD9E8D57ull;
+    mm_u2 hi0 = __builtin_convertvector(p0 >> 32, mm_u2), lo0 = __builtin_convertvector(p0, mm_u2);
+    mm_u2 hi1 = __builtin_convertvector(p1 >> 32, mm_u2), lo1 = __builtin_convertvector(p1, mm_u2);
+    mm_u2 n0 = hi1 ^ s.c1 ^ s.k0;
+    mm_u2 n2 = hi0 ^ s.c3 ^ s.k1;
+    s.c0 = n0;
+    s.c1 = lo1;
+    s.c2 = n2;
+    s.c3 = lo0;
+    s.k0 += 0x9E3779B9u;
+    s.k1 += 0xBB67AE85u;
+}
+
+MM_HD mm_u32x4x2 mm_philox_pair_words(const mm_philox_pair &s)
+{
+    mm_u32x4x2 o;
+    o.w[0] = s.c0;
+    o.w[1] = s.c1;
+    o.w[2] = s.c2;
+    o.w[3] = s.c3;
+    return o;
+}
+
 MM_HD mm_u32x4x2 mm_block_pair(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t block)
 {
-    mm_u2 c0 = {(uint32_t)chain, (uint32_t)chain};
-    mm_u2 c1 = {(uint32_t)(chain >> 32), (uint32_t)(chain >> 32)};
-    mm_u2 c2 = {iteration, iteration + 1u};
-    mm_u2 c3 = {block, block};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    mm_philox_pair s = mm_philox_pair_init(seed, chain, iteration, block);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int r = 0; r < 10; ++r) {
-        mm_ul2 p0 = __builtin_convertvector(c0, mm_ul2) * 0xD2511F53ull;
-        mm_ul2 p1 = __builtin_convertvector(c2, mm_ul2) * 0xCD9E8D57ull;
-        mm_u2 hi0 = __builtin_convertvector(p0 >> 32, mm_u2), lo0 = __builtin_convertvector(p0, mm_u2);
-        mm_u2 hi1 = __builtin_convertvector(p1 >> 32, mm_u2), lo1 = __builtin_convertvector(p1, mm_u2);
-        mm_u2 n0 = hi1 ^ c1 ^ k0;
-        mm_u2 n2 = hi0 ^ c3 ^ k1;
-        c0 = n0;
-        c1 = lo1;
-        c2 = n2;
-        c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    mm_u32x4x2 o;
-    o.w[0] = c0;
-    o.w[1] = c1;
-    o.w[2] = c2;
-    o.w[3] = c3;
-    return o;
+    for (int r = 0; r < 10; ++r)
+        mm_philox_pair_round(s);
+    return mm_philox_pair_words(s);
 }
 
 MM_HD mm_f2 mm_u24x2(mm_u2 w) { return mm_u2_to_f2((w >> 8) + 1u) * mm_splat2(0x1.0p-24f); }

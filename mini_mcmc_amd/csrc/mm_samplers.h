@@ -126,8 +126,16 @@ MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t s
 
 /* One HMC transition given its noise: p[D] ~ N(0,1) (momentum; clobbered) and ln_u.  x[D], lp = logp(x),
  * g = grad logp(x) are updated in place; returns 1 on accept. */
-template <class T, class Tgt, int LCT = 0, class Red = mm_red_seq<T, Tgt::dim>>
-MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, T *p, T ln_u)
+struct mm_no_hook {
+    MM_HD void operator()(int) const {}
+};
+
+/* Hook: called after leapfrog step l = 0, 1, ... with independent work to be issued alongside the integrator's
+ * dependent chain (the sampling kernel threads the next iterations' Philox rounds through here); it must not touch
+ * the transition's data.  mm_no_hook: nothing. */
+template <class T, class Tgt, int LCT = 0, class Red = mm_red_seq<T, Tgt::dim>, class Hook = mm_no_hook>
+MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, T *p, T ln_u,
+                            Hook &&hook = Hook())
 {
     /* Red: summation order of the two kinetic-energy dot products (mm_targets.h): sequential for one chain per lane,
      * grouped for the lane-group kernel (mm_hmc_lg.h), whose bit-exact host twin this then is */
@@ -162,14 +170,18 @@ MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x,
         for (int i = 0; i < D; ++i)
             p[i] = mm_fma(h, gn[i], p[i]); /* first half kick, with the gradient of the current position */
         MM_UNROLL
-        for (int l = 0; l < LCT; ++l)
+        for (int l = 0; l < LCT; ++l) {
             leap(l + 1 == LCT);
+            hook(l);
+        }
     } else if (n_leapfrog > 0) {
         MM_UNROLL
         for (int i = 0; i < D; ++i)
             p[i] = mm_fma(h, gn[i], p[i]);
-        for (int l = 0; l < n_leapfrog; ++l)
+        for (int l = 0; l < n_leapfrog; ++l) {
             leap(l + 1 == n_leapfrog);
+            hook(l);
+        }
     }
     const T kp = Red::dot(p, p);
     T h_proposed = kp * T(0.5) - lpn;
