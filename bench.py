@@ -259,7 +259,7 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": k_ms,
                 "launches_per_step": 1,
-                "note": "the HMC kernel is f32-VALU/issue bound, not HBM bound (about 600 dependent VALU ops per "
+                "note": "the HMC kernel is f32-VALU/issue bound, not HBM bound (about 270 VALU instructions per "
                         "12 algorithmic bytes); the HBM fraction is reported because BASELINE.json asks for it",
                 "valu": {"achieved_tflops": valu_tflops, "peak_tflops": FP32_VALU_PEAK_TFLOPS,
                          "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "flop_per_iteration": FLOP_PER_ITER},
