@@ -165,7 +165,9 @@ int mmcmc_nuts_set_chain_offset(mmcmc_nuts *h, uint64_t chain_offset);
 /* maximum tree depth (doublings per transition), 1..12, default 10.  The reference's `while s` (nuts.rs:578) is
  * unbounded; a lane that never terminates would stall its whole wave, so the engine caps it. */
 int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
-/* Kernel mapping (not in the reference).  0 = one chain per lane (every target / mode).  1 = lane-group mapping with
+/* Kernel mapping (not in the reference).  0 = one chain per lane, the lanes of a wave taking their transitions in step
+ * (every target / mode); 4 = one chain per lane, every lane advancing through its transitions on its own, one leaf per
+ * tick (dim <= 8; the default there; results identical to 0).  1 = lane-group mapping with
  * the gradient on the matrix cores: 16 chains per wave, four lanes per chain, v_mfma_f64_16x16x4 for A x, the whole
  * run in one launch, every wave keeping its 16 chains.  2 and 3 = the same arithmetic with tree-depth compaction
  * (BASELINE.json config 5): a transition is cut at the doubling boundaries and the chains that still double are
@@ -173,7 +175,7 @@ int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
  * work units from per-level queues, chains advancing independently of each other (the fastest from a few thousand
  * chains on; below 2048 chains it runs as 1).
  * 1..3 exist for mode 2 + MMCMC_GAUSSIAN_ND with dim 16 or 32, where 3 is the default; elsewhere setting them returns
- * MMCMC_ERR_UNSUPPORTED.  1, 2 and 3 give bit-identical results.  They sum the D-term dot products in a different
+ * MMCMC_ERR_UNSUPPORTED (so does 4 above dim 8).  1, 2 and 3 give bit-identical results.  They sum the D-term dot products in a different
  * order than 0 (four interleaved partial sums vs sequential), so their samples differ from 0's in the last bits and,
  * over long trajectories of a stiff target, visibly; each is bit-exact against its own host build
  * (oracle/engine_host.cpp modes 3 and 2).  With variant 3 mmcmc_nuts_run returns after the kernel has finished.

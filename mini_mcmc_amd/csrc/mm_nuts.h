@@ -170,132 +170,186 @@ struct mm_nuts_info {
     uint32_t n_leapfrog; /* gradient evaluations inside the tree */
 };
 
-/* nuts.rs:550-691.  x[D] is updated in place; m is the 1-based global step count (self.m after the increment). */
-template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
-MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST> *ad, uint32_t m, uint32_t n_discard,
-                                ST target_accept_p, int max_depth, uint64_t seed, uint64_t chain,
-                                const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
-{
-    constexpr int D = Tgt::dim;
-    uint32_t aux_k = 0;
-    auto aux = [&]() -> double { return mm_aux_u53(seed, chain, m, aux_k++); };
-
-    TT mom0[D], grad[D];
-    mm_nuts_momentum<D>(seed, chain, m, mom0);
-    const TT ulogp = Tgt::logp_grad(P, x, grad);
-    const ST joint = (ST)(double)(ulogp - Red::dot(mom0, mom0) * TT(0.5));
-    const ST exp1_obs = (ST)(-mm_log(aux())); /* Exp(1) by inversion of the first auxiliary uniform */
-    const ST logu = joint - exp1_obs;
-
+/* One transition (nuts.rs:550-691) as a resumable object: begin() | { double_begin() | leaf_step() until it
+ * returns true | double_end() } while `s` | finish().  mm_nuts_step below runs these back to back (the host build, the
+ * lane-synchronous kernel); the lane-asynchronous kernel (mm_nuts_kernels.h) calls them under masks, one leaf per
+ * tick and lane, so that a lane whose tree is finished starts its next transition instead of idling.  Either way a
+ * chain goes through exactly the same operations in the same order.
+ * The outer edge in direction v is advanced on a copy (cx, cp, cg) and written back when the doubling ends. */
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> struct mm_nuts_tree {
+    static constexpr int D = Tgt::dim;
+    /* of the transition */
     TT xm[D], xp[D], pm[D], pp[D], gm[D], gp[D];
-    MM_UNROLL
-    for (int i = 0; i < D; ++i) {
-        xm[i] = xp[i] = x[i];
-        pm[i] = pp[i] = mom0[i];
-        gm[i] = gp[i] = grad[i];
-    }
-    int j = 0;
-    uint32_t n = 1;
-    bool s = true;
-    ST alpha = 0;
-    uint32_t n_alpha = 0;
+    ST joint, logu, alpha;
+    uint32_t n, n_alpha, aux_k, m;
+    int j;
+    bool s;
     mm_nuts_info info;
-    info.depth = 0;
-    info.n_leapfrog = 0;
+    /* of the doubling in progress */
+    int v, sp;
+    TT cx[D], cp[D], cg[D], eps_signed;
+    /* the most recently completed subtree S */
+    uint32_t S_level, S_n, S_nalpha;
+    bool S_s;
+    ST S_alpha;
+    TT S_first_x[D], S_first_p[D], S_prime[D];
 
-    while (s) {
-        const ST u_run_1 = (ST)aux();
-        const int v = (u_run_1 < ST(0.5)) ? 1 : -1;
-        /* the outer edge in direction v is advanced in place: after the doubling it IS the returned edge */
-        TT *cx = (v == -1) ? xm : xp;
-        TT *cp = (v == -1) ? pm : pp;
-        TT *cg = (v == -1) ? gm : gp;
-        const TT eps_signed = (TT)((ST)v * ad->epsilon);
-        const uint32_t n_leaves = 1u << j;
-        int sp = 0; /* pending first children on the stack */
+    MM_HD double aux(uint64_t seed, uint64_t chain) { return mm_aux_u53(seed, chain, m, aux_k++); }
 
-        /* the most recently completed subtree S */
-        uint32_t S_level = 0, S_n = 0, S_nalpha = 0;
-        bool S_s = true;
-        ST S_alpha = 0;
-        TT S_first_x[D], S_first_p[D], S_prime[D];
+    /* m_: the 1-based global step count (self.m after the increment) */
+    MM_HD void begin(const mm_tparams<TT> &P, const TT *x, uint32_t m_, uint64_t seed, uint64_t chain)
+    {
+        m = m_;
+        aux_k = 0;
+        TT mom0[D], grad[D];
+        mm_nuts_momentum<D>(seed, chain, m, mom0);
+        const TT ulogp = Tgt::logp_grad(P, x, grad);
+        joint = (ST)(double)(ulogp - Red::dot(mom0, mom0) * TT(0.5));
+        const ST exp1_obs = (ST)(-mm_log(aux(seed, chain))); /* Exp(1) by inversion of the first auxiliary uniform */
+        logu = joint - exp1_obs;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            xm[i] = xp[i] = x[i];
+            pm[i] = pp[i] = mom0[i];
+            gm[i] = gp[i] = grad[i];
+        }
+        j = 0;
+        n = 1;
+        s = true;
+        alpha = 0;
+        n_alpha = 0;
+        info.depth = 0;
+        info.n_leapfrog = 0;
+    }
 
-        for (uint32_t leaf = 0; leaf < n_leaves; ++leaf) {
-            const TT lp = mm_nuts_leapfrog<TT, Tgt>(P, cx, cp, cg, eps_signed);
-            info.n_leapfrog += 1;
-            const ST jointp = (ST)(double)(lp - Red::dot(cp, cp) * TT(0.5));
-            S_level = 0;
-            S_n = (logu < jointp) ? 1u : 0u;
-            S_s = (logu - ST(1000)) < jointp;
-            S_alpha = mm_minT(ST(1), mm_expT(jointp - joint));
-            S_nalpha = 1;
+    MM_HD void double_begin(const mm_nuts_adapt<ST> &ad, uint64_t seed, uint64_t chain)
+    {
+        const ST u_run_1 = (ST)aux(seed, chain);
+        v = (u_run_1 < ST(0.5)) ? 1 : -1;
+        const bool neg = v == -1;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            cx[i] = neg ? xm[i] : xp[i];
+            cp[i] = neg ? pm[i] : pp[i];
+            cg[i] = neg ? gm[i] : gp[i];
+        }
+        eps_signed = (TT)((ST)v * ad.epsilon);
+        sp = 0; /* pending first children on the stack */
+        S_level = 0;
+        S_n = 0;
+        S_nalpha = 0;
+        S_s = true;
+        S_alpha = 0;
+    }
+
+    /* one leaf: the leapfrog from the outer edge and the one-leaf subtree S it makes */
+    MM_HD void leaf(const mm_tparams<TT> &P)
+    {
+        const TT lp = mm_nuts_leapfrog<TT, Tgt>(P, cx, cp, cg, eps_signed);
+        info.n_leapfrog += 1;
+        const ST jointp = (ST)(double)(lp - Red::dot(cp, cp) * TT(0.5));
+        S_level = 0;
+        S_n = (logu < jointp) ? 1u : 0u;
+        S_s = (logu - ST(1000)) < jointp;
+        S_alpha = mm_minT(ST(1), mm_expT(jointp - joint));
+        S_nalpha = 1;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            S_first_x[i] = cx[i];
+            S_first_p[i] = cp[i];
+            S_prime[i] = cx[i];
+        }
+    }
+
+    /* one step of handing S up the (implicit) recursion */
+    enum { HAND_MORE = 0, HAND_NEXT_LEAF = 1, HAND_DONE = 2 };
+    MM_HD int hand_up(uint64_t seed, uint64_t chain, const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
+    {
+        if (S_level == (uint32_t)j)
+            return HAND_DONE;
+        if (sp > 0 && stk.c(sp - 1, 0) == S_level) {
+            /* S is the second child: merge with its sibling T1 (nuts.rs:900-928) */
+            const int e = sp - 1;
+            const uint32_t n1 = stk.c(e, 1);
+            const double u = aux(seed, chain); /* always f64 (nuts.rs:910) */
+            uint32_t den = n1 + S_n;
+            if (den < 1)
+                den = 1;
+            const bool take2 = u < ((double)S_n / (double)den);
+            TT fx[D], fp[D];
             MM_UNROLL
             for (int i = 0; i < D; ++i) {
-                S_first_x[i] = cx[i];
-                S_first_p[i] = cp[i];
-                S_prime[i] = cx[i];
+                fx[i] = stk.v(e, 0, i);
+                fp[i] = stk.v(e, 1, i);
+                if (!take2)
+                    S_prime[i] = stk.v(e, 2, i);
             }
-            /* hand S up the (implicit) recursion */
-            for (;;) {
-                if (S_level == (uint32_t)j)
-                    break;
-                if (sp > 0 && stk.c(sp - 1, 0) == S_level) {
-                    /* S is the second child: merge with its sibling T1 (nuts.rs:900-928) */
-                    const int e = sp - 1;
-                    const uint32_t n1 = stk.c(e, 1);
-                    const double u = aux(); /* always f64 (nuts.rs:910) */
-                    uint32_t den = n1 + S_n;
-                    if (den < 1)
-                        den = 1;
-                    const bool take2 = u < ((double)S_n / (double)den);
-                    TT fx[D], fp[D];
-                    MM_UNROLL
-                    for (int i = 0; i < D; ++i) {
-                        fx[i] = stk.v(e, 0, i);
-                        fp[i] = stk.v(e, 1, i);
-                        if (!take2)
-                            S_prime[i] = stk.v(e, 2, i);
-                    }
-                    S_n += n1;
-                    const bool crit = (v == -1) ? mm_stop_criterion<TT, D, Red>(cx, fx, cp, fp)
-                                                : mm_stop_criterion<TT, D, Red>(fx, cx, fp, cp);
-                    S_s = S_s && crit; /* the sibling's s' is 1, or it would not be waiting */
-                    S_alpha = stk.a(e) + S_alpha;
-                    S_nalpha += stk.c(e, 2);
-                    MM_UNROLL
-                    for (int i = 0; i < D; ++i) {
-                        S_first_x[i] = fx[i];
-                        S_first_p[i] = fp[i];
-                    }
-                    S_level += 1;
-                    sp -= 1;
-                } else if (S_s) {
-                    /* first child, still valid: wait for the sibling */
-                    MM_UNROLL
-                    for (int i = 0; i < D; ++i) {
-                        stk.v(sp, 0, i) = S_first_x[i];
-                        stk.v(sp, 1, i) = S_first_p[i];
-                        stk.v(sp, 2, i) = S_prime[i];
-                    }
-                    stk.a(sp) = S_alpha;
-                    stk.c(sp, 0) = S_level;
-                    stk.c(sp, 1) = S_n;
-                    stk.c(sp, 2) = S_nalpha;
-                    sp += 1;
-                    break;
-                } else {
-                    /* first child with s' = 0: the parent returns it as it is (nuts.rs:858 not taken) */
-                    S_level += 1;
-                }
+            S_n += n1;
+            const bool crit = (v == -1) ? mm_stop_criterion<TT, D, Red>(cx, fx, cp, fp)
+                                        : mm_stop_criterion<TT, D, Red>(fx, cx, fp, cp);
+            S_s = S_s && crit; /* the sibling's s' is 1, or it would not be waiting */
+            S_alpha = stk.a(e) + S_alpha;
+            S_nalpha += stk.c(e, 2);
+            MM_UNROLL
+            for (int i = 0; i < D; ++i) {
+                S_first_x[i] = fx[i];
+                S_first_p[i] = fp[i];
             }
-            if (S_level == (uint32_t)j)
-                break; /* the doubling is complete, or was cut short */
+            S_level += 1;
+            sp -= 1;
+        } else if (S_s) {
+            /* first child, still valid: wait for the sibling */
+            MM_UNROLL
+            for (int i = 0; i < D; ++i) {
+                stk.v(sp, 0, i) = S_first_x[i];
+                stk.v(sp, 1, i) = S_first_p[i];
+                stk.v(sp, 2, i) = S_prime[i];
+            }
+            stk.a(sp) = S_alpha;
+            stk.c(sp, 0) = S_level;
+            stk.c(sp, 1) = S_n;
+            stk.c(sp, 2) = S_nalpha;
+            sp += 1;
+            return HAND_NEXT_LEAF;
+        } else {
+            /* first child with s' = 0: the parent returns it as it is (nuts.rs:858 not taken) */
+            S_level += 1;
         }
+        return (S_level == (uint32_t)j) ? HAND_DONE : HAND_MORE;
+    }
 
+    /* one leaf and the merges it completes; true when the doubling is complete (or was cut short) */
+    MM_HD bool leaf_step(const mm_tparams<TT> &P, uint64_t seed, uint64_t chain,
+                         const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
+    {
+        leaf(P);
+        int r;
+        do
+            r = hand_up(seed, chain, stk);
+        while (r == HAND_MORE);
+        return r == HAND_DONE;
+    }
+
+    /* x[D]: the chain's position, replaced by the doubling's proposal when it is accepted */
+    MM_HD void double_end(TT *x, uint64_t seed, uint64_t chain, int max_depth)
+    {
+        const bool neg = v == -1;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            if (neg) {
+                xm[i] = cx[i];
+                pm[i] = cp[i];
+                gm[i] = cg[i];
+            } else {
+                xp[i] = cx[i];
+                pp[i] = cp[i];
+                gp[i] = cg[i];
+            }
+        }
         alpha = S_alpha; /* from the LAST doubling only (nuts.rs:614-615, 649-650) */
         n_alpha = S_nalpha;
         const ST tmp = mm_minT(ST(1), (ST)S_n / (ST)n);
-        const ST u_run_2 = (ST)aux();
+        const ST u_run_2 = (ST)aux(seed, chain);
         if (S_s && (u_run_2 < tmp)) {
             MM_UNROLL
             for (int i = 0; i < D; ++i)
@@ -306,21 +360,41 @@ MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST
         j += 1;
         if (j >= max_depth)
             s = false; /* depth cap: not in the reference */
+        info.depth = j;
     }
-    info.depth = j;
 
     /* dual averaging (nuts.rs:676-690) */
-    ST eta = ST(1) / (ST)(m + MM_NUTS_T0);
-    ad->h_bar = (ST(1) - eta) * ad->h_bar + eta * (target_accept_p - alpha / (ST)n_alpha);
-    if (m <= n_discard) {
-        const ST _m = (ST)m;
-        ad->epsilon = mm_expT(ad->mu - mm_sqrtT(_m) / ST(MM_NUTS_GAMMA) * ad->h_bar);
-        eta = mm_expT(-ST(MM_NUTS_KAPPA) * mm_logT(_m)); /* m^-kappa */
-        ad->epsilon_bar = mm_expT((ST(1) - eta) * mm_logT(ad->epsilon_bar) + eta * mm_logT(ad->epsilon));
-    } else {
-        ad->epsilon = ad->epsilon_bar;
+    MM_HD void finish(mm_nuts_adapt<ST> *ad, uint32_t n_discard, ST target_accept_p) const
+    {
+        ST eta = ST(1) / (ST)(m + MM_NUTS_T0);
+        ad->h_bar = (ST(1) - eta) * ad->h_bar + eta * (target_accept_p - alpha / (ST)n_alpha);
+        if (m <= n_discard) {
+            const ST _m = (ST)m;
+            ad->epsilon = mm_expT(ad->mu - mm_sqrtT(_m) / ST(MM_NUTS_GAMMA) * ad->h_bar);
+            eta = mm_expT(-ST(MM_NUTS_KAPPA) * mm_logT(_m)); /* m^-kappa */
+            ad->epsilon_bar = mm_expT((ST(1) - eta) * mm_logT(ad->epsilon_bar) + eta * mm_logT(ad->epsilon));
+        } else {
+            ad->epsilon = ad->epsilon_bar;
+        }
     }
-    return info;
+};
+
+/* nuts.rs:550-691.  x[D] is updated in place; m is the 1-based global step count (self.m after the increment). */
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
+MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST> *ad, uint32_t m, uint32_t n_discard,
+                                ST target_accept_p, int max_depth, uint64_t seed, uint64_t chain,
+                                const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
+{
+    mm_nuts_tree<TT, ST, Tgt, Red> t;
+    t.begin(P, x, m, seed, chain);
+    while (t.s) {
+        t.double_begin(*ad, seed, chain);
+        while (!t.leaf_step(P, seed, chain, stk)) {
+        }
+        t.double_end(x, seed, chain, max_depth);
+    }
+    t.finish(ad, n_discard, target_accept_p);
+    return t.info;
 }
 
 #endif /* MM_NUTS_H */

@@ -51,7 +51,8 @@ struct NutsBase {
     virtual int leapfrog_counts(uint64_t *out) = 0;
     virtual int depth_histogram(uint32_t *out) = 0;
     virtual int set_variant(int v) = 0;
-    int variant = 0; /* 0: one chain per lane; 1: lane-group / MFMA (mm_nuts_lg.h); 2: + tree-depth compaction, one
+    int variant = 0; /* 0: one chain per lane, lanes in step; 4: one chain per lane, asynchronous lanes (default for
+                      * dim <= 8); 1: lane-group / MFMA (mm_nuts_lg.h); 2: + tree-depth compaction, one
                         launch per level; 3: + compaction by a persistent scheduler */
     int compaction_start = 5; /* variant 2: doublings below this run before the first compaction */
     int compaction_groups = 0; /* variant 2: chain groups with their own launch sequence (0 = choose) */
@@ -165,7 +166,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
         MM_HIP(hipMemset(d_hist, 0, (MM_NUTS_JMAX + 1) * sizeof(unsigned int)));
         /* the pending-subtree stack goes to LDS when tile + stack fit comfortably, else to HBM scratch */
         stack_in_lds = (k->tile_bytes_per_wave + k->stack_bytes_per_wave) <= 40 * 1024;
-        if (!stack_in_lds) {
+        /* the scratch area also serves the asynchronous-lane kernel when ITS stack (max_depth levels, no tile) is over
+         * the LDS limit; max_depth can change after create, so allocate whenever the full stack is */
+        if (!stack_in_lds || k->stack_bytes_per_wave > 40 * 1024) {
             const size_t waves = (n_chains + 63) / 64;
             MM_HIP(hipMalloc((void **)&d_scratch, waves * k->stack_bytes_per_wave));
         }
@@ -190,6 +193,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 variant = 3; /* the default where it exists */
             }
         }
+        if (!lg && k->run_async)
+            variant = 4; /* asynchronous lanes: the default for the one-chain-per-lane kernels */
         MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamDefault));
         MM_HIP(hipEventCreate(&ev0));
         MM_HIP(hipEventCreate(&ev1));
@@ -198,11 +203,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int set_variant(int v) override
     {
-        if (v == 0 || (v >= 1 && v <= 3 && lg)) {
+        if (v == 0 || (v >= 1 && v <= 3 && lg) || (v == 4 && k->run_async)) {
             variant = v;
             return MMCMC_OK;
         }
-        return (v >= 1 && v <= 3) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
+        return (v >= 1 && v <= 4) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
     }
 
     /* the lane-group launch exists for <double, double> only; the other instantiations never reach it */
@@ -354,7 +359,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
             }
         }
         /* init_chain (nuts.rs:528-545) on every run() call */
-        const bool use_lg = variant >= 1 && lg;
+        const bool use_lg = variant >= 1 && variant <= 3 && lg;
         hipError_t e = use_lg ? init_lg(st) : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
         if (e != hipSuccess)
             return (int)e;
@@ -375,6 +380,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
         a.max_depth = max_depth;
         a.target_accept_p = (ST)target_accept_p;
         a.stack_in_lds = stack_in_lds ? 1 : 0;
+        a.async_batch = 0;
+        if (const char *e = getenv("MMCMC_NUTS_ASYNC_BATCH")) /* tuning aid; no result depends on it */
+            a.async_batch = (unsigned int)atoi(e);
         a.scratch = d_scratch;
         const size_t total = n_collect + n_discard;
         if (progress) {
@@ -396,7 +404,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
             a.n_rec = (unsigned int)n_collect;
         }
         MM_HIP(hipEventRecord(ev0, st));
-        e = use_lg ? run_lg(a, st) : k->run(a, st);
+        e = use_lg ? run_lg(a, st) : (variant == 4 && k->run_async) ? k->run_async(a, st) : k->run(a, st);
         if (e != hipSuccess) {
             if (staged)
                 (void)hipFree(d_out);

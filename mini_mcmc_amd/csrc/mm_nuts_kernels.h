@@ -33,6 +33,7 @@ template <class TT, class ST> struct mm_nuts_args {
     int max_depth;
     ST target_accept_p;
     int stack_in_lds;
+    unsigned int async_batch;  /* mm_nuts_async_kernel: lanes between transitions wait for this many (0 = default) */
     unsigned char *scratch;    /* global stack storage when !stack_in_lds: per wave mm_nuts_stack_bytes<>() */
 };
 
@@ -43,6 +44,20 @@ template <class TT, class ST, int D> struct mm_nuts_stack_layout {
     static constexpr size_t alpha_bytes = ((size_t)S::alpha_slots * 64 * sizeof(ST) + 15) / 16 * 16;
     static constexpr size_t cnt_bytes = ((size_t)S::cnt_slots * 64 * sizeof(uint32_t) + 15) / 16 * 16;
     static constexpr size_t bytes = vec_bytes + alpha_bytes + cnt_bytes;
+    /* the same three regions for the first `levels` stack entries only (a run never uses more than max_depth) */
+    __host__ __device__ static constexpr size_t bytes_for(int levels)
+    {
+        return (size_t)levels * 64 * (3 * D * sizeof(TT) + sizeof(ST) + 3 * sizeof(uint32_t));
+    }
+    __device__ static S make_levels(unsigned char *base, int lane, int levels)
+    {
+        S s;
+        s.vec = reinterpret_cast<TT *>(base) + lane;
+        s.alpha = reinterpret_cast<ST *>(base + (size_t)levels * 64 * 3 * D * sizeof(TT)) + lane;
+        s.cnt = reinterpret_cast<uint32_t *>(base + (size_t)levels * 64 * (3 * D * sizeof(TT) + sizeof(ST))) + lane;
+        s.stride = 64;
+        return s;
+    }
     __device__ static S make(unsigned char *base, int lane)
     {
         S s;
@@ -83,6 +98,12 @@ __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, 
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
     TT *tile = reinterpret_cast<TT *>(mm_lds_raw);
     const int lane = threadIdx.x & 63;
+    /* the wave's depth histogram, flushed once (a global atomic per chain and transition, all on a dozen addresses,
+     * serialises in L2: it was 90 % of this kernel's time on small targets) */
+    __shared__ unsigned int hist_lds[MM_NUTS_JMAX + 1];
+    if (lane <= MM_NUTS_JMAX)
+        hist_lds[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
     const unsigned long long wave_c0 = (unsigned long long)blockIdx.x * 64;
     const unsigned long long c = wave_c0 + lane;
     const bool active = c < a.n_chains;
@@ -135,13 +156,16 @@ __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, 
                                                                a.max_depth, a.seed, chain, stk);
             n_lf += inf.n_leapfrog;
             if (a.depth_hist)
-                atomicAdd(&a.depth_hist[inf.depth < MM_NUTS_JMAX ? inf.depth : MM_NUTS_JMAX], 1u);
+                atomicAdd(&hist_lds[inf.depth < MM_NUTS_JMAX ? inf.depth : MM_NUTS_JMAX], 1u);
         }
         __builtin_amdgcn_wave_barrier();
         if (t >= a.n_pre)
             record(t + 1 == total);
     }
 
+    __builtin_amdgcn_wave_barrier();
+    if (a.depth_hist && lane <= MM_NUTS_JMAX && hist_lds[lane] != 0u)
+        atomicAdd(&a.depth_hist[lane], hist_lds[lane]);
     if (active) {
         MM_UNROLL
         for (int i = 0; i < D; ++i)
@@ -150,6 +174,145 @@ __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, 
         if (a.n_leapfrog)
             a.n_leapfrog[c] += n_lf;
     }
+}
+
+#define MM_NUTS_ASYNC_LDS_LIMIT (40u * 1024u) /* four waves per CU must fit 160 KB */
+
+/* The same run with lanes that advance independently ("asynchronous lanes", kernel variant 4).
+ *
+ * In mm_nuts_run_kernel a transition ends for the wave when its deepest tree ends: with trees of 2 .. 1024 leaves the
+ * lanes sit idle most of the time (RosenbrockND(3), 65 536 chains: 22 leaves per transition on average, ~350 for
+ * the deepest of 64 lanes => 6 % of the lane-slots do work).  Here every tick of the wave gives every lane ONE leaf
+ * of ITS tree (mm_nuts_tree::leaf_step); a lane whose doubling or transition completes does the bookkeeping under the
+ * exec mask and begins its next doubling / transition in the same tick.  The noise is a function of (chain, m), so the
+ * results do not depend on when a lane gets there: bit-identical to the synchronous kernel and to the host build.
+ * Samples are written by the owning lane (rows complete at different times, so there is no tile to coalesce). */
+template <class TT, class ST, class Tgt>
+__global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT, ST> a)
+{
+    constexpr int D = Tgt::dim;
+    using Lay = mm_nuts_stack_layout<TT, ST, D>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    const int lane = threadIdx.x & 63;
+    __shared__ unsigned int hist_lds[MM_NUTS_JMAX + 1]; /* see mm_nuts_run_kernel */
+    if (lane <= MM_NUTS_JMAX)
+        hist_lds[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long c = (unsigned long long)blockIdx.x * 64 + lane;
+    const bool active = c < a.n_chains;
+    const unsigned long long chain = a.chain_offset + c;
+    /* no output tile here, so the stack (sized for max_depth levels) fits LDS in more cases than in the kernel above */
+    const bool lds_stack = Lay::bytes_for(a.max_depth) <= MM_NUTS_ASYNC_LDS_LIMIT;
+    const mm_nuts_stack<TT, ST, D> stk = lds_stack ? Lay::make_levels(mm_lds_raw, lane, a.max_depth)
+                                                   : Lay::make(a.scratch + (size_t)blockIdx.x * Lay::bytes, lane);
+
+    TT x[D];
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        x[i] = active ? a.state[c * D + i] : TT(0);
+    mm_nuts_adapt<ST> ad;
+    if (active) {
+        ad = a.adapt[c];
+    } else {
+        ad.epsilon = ST(0.1);
+        ad.epsilon_bar = ST(1);
+        ad.h_bar = ST(0);
+        ad.mu = ST(0);
+    }
+    const unsigned int total = a.n_pre + a.n_rec;
+    TT *const rows = a.out ? a.out + (c * a.n_total + a.out_t0) * D : nullptr; /* this chain's first row */
+    if (a.write_initial && rows && active) {
+        MM_UNROLL
+        for (int k = 0; k < D; ++k)
+            rows[k] = x[k];
+    }
+    const unsigned int first = a.write_initial ? 1u : 0u;
+
+    mm_nuts_tree<TT, ST, Tgt> T;
+    unsigned long long n_lf = 0;
+    unsigned int m = a.m0, done = 0;
+    int phase = 0; /* 0: between transitions, 1: begin a doubling, 2: next leaf, 3: hand the subtree up */
+    bool live = active && total > 0;
+    bool closing = false; /* phase 0 with a finished transition still to be closed (finish + record) */
+    /* measured at 65 536 chains (tools/nuts_small_d.py): 8 is best for D <= 4; at D = 8 waiting does not pay */
+    const unsigned int batch = a.async_batch ? a.async_batch : (D <= 4 ? 8u : 1u);
+    while (__ballot(live) != 0ull) {
+        /* Closing a transition and opening the next (dual averaging: six f64 transcendentals; momentum draw; logp +
+         * gradient) is the longest section and on average only one or two lanes want it per tick: lanes wait in phase
+         * 0 until `batch` of them do, or until nobody has tree work left. */
+        const bool turn = live && phase == 0;
+        const unsigned long long turn_mask = __ballot(turn);
+        if ((unsigned int)__popcll(turn_mask) >= batch || __ballot(live && phase != 0) == 0ull) {
+            if (turn) {
+                if (closing) {
+                    T.finish(&ad, a.n_discard, a.target_accept_p);
+                    n_lf += T.info.n_leapfrog;
+                    if (a.depth_hist)
+                        atomicAdd(&hist_lds[T.info.depth < MM_NUTS_JMAX ? T.info.depth : MM_NUTS_JMAX], 1u);
+                    if (done >= a.n_pre && rows) {
+                        TT *r = rows + (size_t)(first + (done - a.n_pre)) * D;
+                        MM_UNROLL
+                        for (int k = 0; k < D; ++k)
+                            r[k] = x[k];
+                    }
+                    ++done;
+                    closing = false;
+                    live = done < total;
+                }
+                if (live) {
+                    ++m;
+                    T.begin(a.P, x, m, a.seed, chain);
+                    phase = 1;
+                }
+            }
+        }
+        if (live && phase != 0) {
+            if (phase == 1) {
+                T.double_begin(ad, a.seed, chain);
+                phase = 2;
+            }
+            if (phase == 2) {
+                T.leaf(a.P);
+                phase = 3;
+            }
+            /* ONE step up per tick: the number of merges a leaf completes differs from lane to lane (the trailing
+             * ones of its index), and a wave that waited for the longest chain of merges would idle again */
+            const int r = T.hand_up(a.seed, chain, stk);
+            if (r == T.HAND_NEXT_LEAF)
+                phase = 2;
+            if (r == T.HAND_DONE) {
+                T.double_end(x, a.seed, chain, a.max_depth);
+                phase = 1;
+                if (!T.s) {
+                    phase = 0;
+                    closing = true;
+                }
+            }
+        }
+    }
+
+    __builtin_amdgcn_wave_barrier();
+    if (a.depth_hist && lane <= MM_NUTS_JMAX && hist_lds[lane] != 0u)
+        atomicAdd(&a.depth_hist[lane], hist_lds[lane]);
+    if (active) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            a.state[c * D + i] = x[i];
+        a.adapt[c] = ad;
+        if (a.n_leapfrog)
+            a.n_leapfrog[c] += n_lf;
+    }
+}
+
+template <class TT, class ST, class Tgt>
+hipError_t mm_launch_nuts_run_async(const mm_nuts_args<TT, ST> &a, hipStream_t stream)
+{
+    using Lay = mm_nuts_stack_layout<TT, ST, Tgt::dim>;
+    const unsigned int grid = (unsigned int)((a.n_chains + 63) / 64);
+    const size_t need = Lay::bytes_for(a.max_depth);
+    const size_t lds = need <= MM_NUTS_ASYNC_LDS_LIMIT ? need : 0;
+    hipLaunchKernelGGL((mm_nuts_async_kernel<TT, ST, Tgt>), dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError();
 }
 
 template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
@@ -183,6 +346,7 @@ template <class TT, class ST> struct mm_nuts_entry {
     hipError_t (*init)(const mm_tparams<TT> &, const TT *, mm_nuts_adapt<ST> *, unsigned long long,
                        unsigned long long, unsigned long long, hipStream_t);
     hipError_t (*run)(const mm_nuts_args<TT, ST> &, hipStream_t);
+    hipError_t (*run_async)(const mm_nuts_args<TT, ST> &, hipStream_t); /* asynchronous lanes; NULL for dim > 8 */
     size_t stack_bytes_per_wave, tile_bytes_per_wave;
 };
 

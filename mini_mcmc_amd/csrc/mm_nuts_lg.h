@@ -621,7 +621,8 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
 
 /* end of a transition: dual averaging (nuts.rs:676-690), depth histogram */
 template <int D>
-__device__ __forceinline__ void mm_lg_finish(const mm_lg_lane<D> &L, const mm_nuts_lg_args &a, mm_nuts_adapt<double> &ad)
+__device__ __forceinline__ void mm_lg_finish(const mm_lg_lane<D> &L, const mm_nuts_lg_args &a, mm_nuts_adapt<double> &ad,
+                                             unsigned int *hist)
 {
     double eta = 1.0 / (double)(L.m + MM_NUTS_T0);
     ad.h_bar = (1.0 - eta) * ad.h_bar + eta * (a.target_accept_p - L.alpha / (double)L.n_alpha);
@@ -633,8 +634,24 @@ __device__ __forceinline__ void mm_lg_finish(const mm_lg_lane<D> &L, const mm_nu
     } else {
         ad.epsilon = ad.epsilon_bar;
     }
-    if (a.depth_hist && L.q == 0)
-        atomicAdd(&a.depth_hist[L.depth < MM_NUTS_JMAX ? L.depth : MM_NUTS_JMAX], 1u);
+    /* hist: the wave's histogram in LDS where the kernel has one (flushed once: a global atomic per chain and
+     * transition, all on a dozen addresses, serialises in L2), else the global one */
+    if (hist && L.q == 0)
+        atomicAdd(&hist[L.depth < MM_NUTS_JMAX ? L.depth : MM_NUTS_JMAX], 1u);
+}
+
+/* the wave's depth histogram in LDS: zero / flush */
+__device__ __forceinline__ void mm_lg_hist_zero(unsigned int *h, int lane)
+{
+    if (lane <= MM_NUTS_JMAX)
+        h[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void mm_lg_hist_flush(const unsigned int *h, unsigned int *global_hist, int lane)
+{
+    __builtin_amdgcn_wave_barrier();
+    if (global_hist && lane <= MM_NUTS_JMAX && h[lane] != 0u)
+        atomicAdd(&global_hist[lane], h[lane]);
 }
 
 template <int D> __device__ __forceinline__ void mm_lg_write_row(const mm_lg_lane<D> &L, const mm_nuts_lg_args &a, unsigned long long row)
@@ -653,6 +670,8 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
     using Cfg = mm_lg_cfg<D>;
     constexpr int NS = Cfg::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    __shared__ unsigned int hist_lds[MM_NUTS_JMAX + 1];
+    mm_lg_hist_zero(hist_lds, (int)(threadIdx.x & 63));
     mm_lg_lane<D> L;
     L.lane = threadIdx.x & 63;
     L.q = L.lane >> 4;
@@ -697,7 +716,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
         for (int j = 0; __ballot(alive) != 0ull; ++j)
             mm_lg_doubling<D>(L, a, j, alive, ad.epsilon, lds, scr);
         if (L.active)
-            mm_lg_finish<D>(L, a, ad);
+            mm_lg_finish<D>(L, a, ad, a.depth_hist ? hist_lds : nullptr);
         if (t >= a.n_pre) {
             if (a.out && L.active)
                 mm_lg_write_row<D>(L, a, a.out_t0 + rows_out);
@@ -710,6 +729,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lg_kernel(const m
         for (int i = 0; i < 16; ++i)
             a.prof[(size_t)blockIdx.x * 16 + i] = L.prof_acc[i];
 #endif
+    mm_lg_hist_flush(hist_lds, a.depth_hist, L.lane);
     if (L.active) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -757,7 +777,7 @@ __device__ __forceinline__ void mm_lgc_hand_over(mm_lg_lane<D> &L, const mm_nuts
             a.lists[(size_t)j_next * a.c_pad + base + rank] = (unsigned int)L.cl;
         }
     } else if (valid) {
-        mm_lg_finish<D>(L, a, ad);
+        mm_lg_finish<D>(L, a, ad, a.depth_hist);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
             a.state[L.cl * D + 4 * s + L.q] = L.x[s];
@@ -939,6 +959,8 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const 
     using Cfg = mm_lg_cfg<D>;
     constexpr int NS = Cfg::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    __shared__ unsigned int hist_lds[MM_NUTS_JMAX + 1];
+    mm_lg_hist_zero(hist_lds, (int)(threadIdx.x & 63));
     mm_lg_lane<D> L;
     L.lane = threadIdx.x & 63;
     L.q = L.lane >> 4;
@@ -1217,7 +1239,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const 
                                __longlong_as_double((long long)((unsigned long long)L.n | ((unsigned long long)L.aux_k << 32))));
             }
         } else if (valid) {
-            mm_lg_finish<D>(L, a, ad);
+            mm_lg_finish<D>(L, a, ad, a.depth_hist ? hist_lds : nullptr);
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 mm_lg_st<true>(&a.state[L.cl * D + 4 * s + L.q], L.x[s]);
@@ -1246,6 +1268,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const 
             atomicAdd(&ctrl->remaining, 0ull - (unsigned long long)__popcll(fin));
         MM_LGQ_T(3);
     }
+    mm_lg_hist_flush(hist_lds, a.depth_hist, L.lane);
     if (L.lane == 0) {
         for (int i = 0; i < 4; ++i)
             atomicAdd(&ctrl->stat_t[i], st_t[i]);

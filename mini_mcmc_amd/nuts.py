@@ -51,9 +51,10 @@ class NUTS:
         return self
 
     def set_kernel_variant(self, variant: int) -> "NUTS":
-        """0 = one chain per lane; 1 = lane-group / MFMA mapping in one launch; 2 / 3 = the same with tree-depth compaction
-        by one launch per level / by a persistent scheduler (1..3: mode 2, GaussianND, dim 16 or 32, where 3 is the
-        default; all three give bit-identical samples)."""
+        """One chain per lane: 0 = the lanes of a wave take their transitions in step, 4 = every lane advances on its
+        own, one leaf per tick (default for dim <= 8; same results as 0).  1 = lane-group / MFMA mapping in one launch;
+        2 / 3 = the same with tree-depth compaction by one launch per level / by a persistent scheduler (1..3: mode 2,
+        GaussianND, dim 16 or 32, where 3 is the default; all three give bit-identical samples)."""
         L.check(L.lib().mmcmc_nuts_set_kernel_variant(self._h, int(variant)), "mmcmc_nuts_set_kernel_variant")
         return self
 

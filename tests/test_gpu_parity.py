@@ -415,6 +415,45 @@ def test_nuts_bit_exact_vs_host_build(M, O, mode):
         assert s.depth_histogram().sum() == C * (nc + nd - (0 if progress else 1))
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_nuts_asynchronous_lanes_equal_synchronous_lanes(M, O, mode):
+    """Kernel variant 4 (every lane advances through ITS transitions, one leaf per tick; the default for dim <= 8)
+    against variant 0 (the wave waits for its deepest tree) and against the host build: samples, positions, adaptation
+    state, leapfrog counts and the depth histogram are identical, with ragged waves, chain offsets, run / run_progress,
+    a continued handle and a depth cap that bites."""
+    from mini_mcmc_amd.nuts import NUTS
+
+    cases = [
+        (M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], 200, 30, 25, True, 0, 10),
+        (M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], 64, 1, 0, False, 0, 10),   # row 0 only: no transition at all
+        (M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], 70, 2, 0, False, 0, 10),   # initial row + one transition
+        (M.dist.DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), O.DIFFABLE_GAUSSIAN2D, GAUSS, 129, 40, 11, False, 1 << 35, 10),
+        (M.dist.StandardNormal(8), O.STANDARD_NORMAL, [], 65, 12, 7, True, 5, 3),  # max_depth 3 cuts trees short
+    ]
+    for tgt, kind, params, C, nc, nd, progress, off, max_depth in cases:
+        init = M.core.init_with_seed(C, tgt.dim, 17) * 0.7
+        res = {}
+        for variant in (4, 0):
+            s = NUTS(tgt, init, 0.8, mode=mode).set_seed(23).set_max_depth(max_depth)
+            assert s.kernel_variant == 4  # the default
+            s.set_kernel_variant(variant)
+            if off:
+                s.set_chain_offset(off)
+            out = s._run(nc, nd, progress, "numpy")
+            out2 = s._run(5, 0, True, "numpy")  # continue the handle
+            res[variant] = (out, out2, s.positions(), s.leapfrog_counts(), s.depth_histogram(), s.adapt_state())
+        name = f"{type(tgt).__name__} D={tgt.dim} mode={mode} C={C}"
+        for i in range(5):
+            assert np.array_equal(res[4][i], res[0][i]), (name, i)
+        for key in ("epsilon", "epsilon_bar", "h_bar", "mu"):
+            assert np.array_equal(res[4][5][key], res[0][5][key]), (name, key)
+        ref, pos, ad, nlf = O.engine_host_nuts_run(mode, kind, tgt.dim, params, init, 0.8, nc, nd, seed=23,
+                                                   progress=progress, max_depth=max_depth, chain_offset=off)
+        assert np.array_equal(res[4][0], ref), name
+    with pytest.raises(Exception):  # no asynchronous-lane instance above dim 8
+        NUTS(M.dist.GaussianND.ill_conditioned(16, 10.0, 1), M.core.init_with_seed(8, 16, 1), 0.8, mode=1).set_kernel_variant(4)
+
+
 def test_hmc_lane_group_mfma_bit_exact_vs_host_twin(M, O):
     """mm_hmc_lg.h (HMC on the dense f64 Gaussian: 16 chains per wave, gradient on v_mfma_f64_16x16x4) against the host
     build of mm_hmc_step_noise with the grouped reduction order; and against the one-chain-per-lane kernel to rounding."""

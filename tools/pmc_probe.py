@@ -8,6 +8,15 @@ from mini_mcmc_amd.distributions import Gaussian2D, IsotropicGaussian, Rosenbroc
 from mini_mcmc_amd.hmc import HMC
 from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
 what, mode = sys.argv[1], sys.argv[2]
+if what == "nuts3":  # one-chain-per-lane NUTS on RosenbrockND(3): python3 tools/pmc_probe.py nuts3 <scalar mode 0|1|2> [variant]
+    from mini_mcmc_amd.nuts import NUTS
+    s = NUTS(RosenbrockND(3), init_with_seed(65536, 3, 42) * 0.5, 0.8, mode=int(mode)).set_seed(1)
+    if len(sys.argv) > 3:
+        s.set_kernel_variant(int(sys.argv[3]))
+    s._run(100, 100, True, "torch")
+    torch.cuda.synchronize()
+    print("nuts3", mode, s.kernel_variant, s.timing(), int(s.leapfrog_counts().sum()))
+    sys.exit(0)
 if what == "nuts5":
     from mini_mcmc_amd.distributions import GaussianND
     from mini_mcmc_amd.nuts import NUTS
