@@ -12,7 +12,8 @@
  *      half-chain's mean and centred sum of squares per parameter, centred in place, and its biased
  *      autocovariance sum_t y[t] y[t+lag] is accumulated for every lag into a per-wave LDS slab that is carried
  *      across all the half-chains the wave processes; the slab is written out once per wave.
- *   kernel 2 (mm_slab_reduce_kernel): sums the per-wave slabs in a fixed order (bitwise reproducible, no atomics).
+ *   kernel 2 (mm_stats_tail_kernel): sums the per-wave slabs in a fixed order (bitwise reproducible, no atomics) and,
+ *     in other blocks of the same launch, the cross-chain sums of withinvar.
  *   host finish (mm_stats_finish): W, B, var+, the reference's "R-hat" sqrt(W/var+) (quirk Q7), rho_t, Geyer's
  *      initial monotone sequence and ESS exactly as stats.rs:449-465, :509-545 order them, in f32.
  *
@@ -29,6 +30,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <vector>
 
 #define MM_HIP(expr)                                                                                              \
@@ -46,6 +48,23 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_xor(v, off, 64);
     return v;
+}
+
+/* the same total with data-parallel-primitive adds instead of six LDS permutes: pairs, quads, half rows, rows of 16 (every
+ * lane of a row then holds the row's sum), then the four rows */
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+#define MM_DPP_ADD(x, ctrl) ((x) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xf, 0xf, false)))
+    v = MM_DPP_ADD(v, 0xB1);  /* quad_perm [1, 0, 3, 2] */
+    v = MM_DPP_ADD(v, 0x4E);  /* quad_perm [2, 3, 0, 1] */
+    v = MM_DPP_ADD(v, 0x141); /* row_half_mirror */
+    v = MM_DPP_ADD(v, 0x140); /* row_mirror */
+#undef MM_DPP_ADD
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 /* sample [C, n, D] of T (f32 or f64; converted to f32 on load like RunStats::from, stats.rs:365).
@@ -133,10 +152,11 @@ __global__ __launch_bounds__(64) void mm_half_chain_kernel(const T *__restrict__
  *     A[i][t] = y[t + i]  (16 x K),   B[t][j] = y[t - 16 j - 256 tau]  (K x 16)   =>   (A B)[i][j] = c_(i + 16 j + 256 tau)
  * (y = 0 outside [0, m)), so one 16 x 16 accumulator tile of v_mfma_f32_16x16x4_f32 holds 256 consecutive lags and
  * K = m suffices: m / 4 MFMAs per tile instead of ~2 m LDS reads and m FMAs per lane -- the direct kernel above is
- * LDS-issue bound (two reads per FMA).  y sits in LDS with 240 + 256 (tiles - 1) zeros in front and 20 behind, and
+ * LDS-issue bound (two reads per FMA).  y sits in LDS with 240 + 256 (tiles - 1) zeros in front and 36 behind, and
  * with one pad word after every 16 (address p + p / 16): the B operand's lanes read addresses 16 apart, which would
  * otherwise land on two banks.  Means, centred sums of squares and the carried per-wave slab are as above. */
 typedef float mm_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const float *mm_lds_cf;
 
 template <class T>
 __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restrict__ sample, unsigned long long C,
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restr
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned int padl = 240u + 256u * (n_tiles - 1u);
-    const unsigned int row_len = padl + m + 20u;            /* logical elements per parameter */
+    const unsigned int row_len = padl + m + 36u;            /* logical elements per parameter (36 zeros behind) */
     const unsigned int row_pitch = row_len + row_len / 16u + 1u; /* with the bank-skew words */
     float *y = lds;                                          /* [D][row_pitch] */
     float *acc = lds + (size_t)D * row_pitch;                /* [D][m] lag sums carried over this wave's half-chains */
@@ -162,7 +182,15 @@ __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    const unsigned int k_steps = (m + 3u) / 4u;
+    const unsigned int n_groups = (m + 15u) / 16u; /* groups of four k-steps (16 elements of y) */
+    const unsigned int w0 = at(padl + lane);
+    /* operand addresses of k-steps 0..3 in a row, tile 0 (tile tau: B moves back by 256 elements = 272 words) */
+    unsigned int offa[4], offb[4];
+#pragma unroll
+    for (unsigned int u = 0; u < 4; ++u) {
+        offa[u] = at(padl + kq + li + 4u * u);
+        offb[u] = at(padl + kq - 16u * li + 4u * u);
+    }
     for (unsigned long long hc = blockIdx.x; hc < n_half; hc += gridDim.x) {
         const unsigned long long chain = hc < C ? hc : hc - C;
         const unsigned int row0 = hc < C ? 0u : n - m;
@@ -185,17 +213,18 @@ __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restr
         __builtin_amdgcn_wave_barrier();
         for (unsigned int d = 0; d < D; ++d) {
             float *yd = y + d * row_pitch;
+            /* element t = lane + 64 i sits at word at(padl + lane) + 68 i (64 elements = 68 skewed words) */
             float s = 0.f;
-            for (unsigned int t = lane; t < m; t += 64)
-                s += yd[at(padl + t)];
-            const float mean = wave_sum(s) / (float)m;
+            for (unsigned int t = lane, w = w0; t < m; t += 64, w += 68)
+                s += yd[w];
+            const float mean = wave_sum_dpp(s) / (float)m;
             float q = 0.f;
-            for (unsigned int t = lane; t < m; t += 64) {
-                const float v = yd[at(padl + t)] - mean;
-                yd[at(padl + t)] = v;
+            for (unsigned int t = lane, w = w0; t < m; t += 64, w += 68) {
+                const float v = yd[w] - mean;
+                yd[w] = v;
                 q += v * v;
             }
-            q = wave_sum(q);
+            q = wave_sum_dpp(q);
             if (lane == 0) {
                 means[hc * D + d] = mean;
                 ssq[hc * D + d] = q;
@@ -208,23 +237,48 @@ __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restr
                 /* lane (li, kq): A[li][4 s + kq] = y[4 s + kq + li];  B[4 s + kq][li] = y[4 s + kq - 16 li - 256 tau].
                  * Four k-steps advance the logical index by 16, i.e. the skewed address by 17: four running addresses per
                  * operand, no index arithmetic in the loop, one accumulator chain (dependent MFMAs issue back to back) */
-                unsigned int aa[4], ba[4];
+                /* Four running LDS pointers per operand (k-steps 4 g + u, u = 0..3); a group of four k-steps advances the
+                 * logical index by 16 = 17 words, so inside a block of four groups every read is pointer + constant
+                 * (ds_read_b32 with an immediate offset) and the pointers move once per 16 MFMAs.  The row's tail of
+                 * zeros lets the last group run past m. */
+                mm_lds_cf pa[4], pb[4];
 #pragma unroll
                 for (unsigned int u = 0; u < 4; ++u) {
-                    aa[u] = at(padl + kq + li + 4u * u);
-                    ba[u] = at(padl + kq - 16u * li - 256u * tau + 4u * u);
+                    pa[u] = (mm_lds_cf)(yd + offa[u]);
+                    pb[u] = (mm_lds_cf)(yd + offb[u] - 272u * tau);
                 }
-                unsigned int sidx = 0;
-                for (; sidx + 4 <= k_steps; sidx += 4) {
+                unsigned int g = 0;
+                for (; g + 4 <= n_groups; g += 4) {
+                    float av[16], bv[16];
+#pragma unroll
+                    for (unsigned int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (unsigned int u = 0; u < 4; ++u) {
+                            av[4 * q + u] = pa[u][17 * q];
+                            bv[4 * q + u] = pb[u][17 * q];
+                        }
 #pragma unroll
                     for (unsigned int u = 0; u < 4; ++u) {
-                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yd[aa[u]], yd[ba[u]], c0, 0, 0, 0);
-                        aa[u] += 17u;
-                        ba[u] += 17u;
+                        pa[u] += 68;
+                        pb[u] += 68;
                     }
+#pragma unroll
+                    for (unsigned int i = 0; i < 16; ++i)
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], c0, 0, 0, 0);
                 }
-                for (unsigned int u = 0; sidx < k_steps; ++sidx, ++u)
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yd[aa[u]], yd[ba[u]], c0, 0, 0, 0);
+                for (; g < n_groups; ++g) {
+                    float av[4], bv[4];
+#pragma unroll
+                    for (unsigned int u = 0; u < 4; ++u) {
+                        av[u] = pa[u][0];
+                        bv[u] = pb[u][0];
+                        pa[u] += 17;
+                        pb[u] += 17;
+                    }
+#pragma unroll
+                    for (unsigned int u = 0; u < 4; ++u)
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], c0, 0, 0, 0);
+                }
                 /* accumulator element r of lane (li, kq) = tile row 4 kq + r, column li = lag 4 kq + r + 16 li + 256 tau */
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -244,20 +298,69 @@ __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restr
         slab[i] = acc[i];
 }
 
-/* out[lag, d] = sum over waves of slabs[w, d, lag].  One wave per group of 64 outputs would serialise n_slabs loads;
- * instead a 256-thread block owns 64 consecutive outputs, its four waves each sum a quarter of the slabs (coalesced
- * 256-byte rows), and the four partial sums are combined in a fixed order -- bitwise reproducible, no atomics. */
-__global__ __launch_bounds__(256) void mm_slab_reduce_kernel(const float *__restrict__ slabs, unsigned int n_slabs,
-                                                             unsigned int D, unsigned int m, float *__restrict__ out)
+/* The tail of the statistics, one launch, two kinds of blocks.
+ *
+ * Blocks [0, nb_red): out[lag, d] = sum over waves of slabs[w, d, lag].  One wave per group of 64 outputs would
+ * serialise n_slabs loads; instead a 256-thread block owns 64 consecutive outputs, its four waves each sum a quarter
+ * of the slabs (coalesced 256-byte rows), and the four partial sums are combined in a fixed order -- bitwise
+ * reproducible, no atomics.
+ *
+ * Blocks [nb_red, nb_red + D * MM_WB_CHUNKS) (only when wb_part != NULL): withinvar's cross-chain sums
+ * (stats.rs:449-465), per parameter d and chunk of half-chains: sum(mean - s), sum((mean - s)^2), sum(ssq / n) in f64,
+ * s = the first half-chain's mean (any shift near the overall mean avoids the cancellation of the raw moments; the
+ * host turns the three totals into sum((mean - overall)^2) = Sq - Sd^2 / c2 and the sum of the biased variances). */
+#define MM_WB_CHUNKS 32u
+__global__ __launch_bounds__(256) void mm_stats_tail_kernel(const float *__restrict__ slabs, unsigned int n_slabs,
+                                                            unsigned int D, unsigned int m, float *__restrict__ out,
+                                                            unsigned int nb_red, unsigned int n_parts,
+                                                            const float *__restrict__ means,
+                                                            const float *__restrict__ ssq, unsigned long long c2,
+                                                            float nf, double *__restrict__ wb_part)
 {
-    __shared__ float part[4][64];
+    __shared__ float psum[4][64];
+    __shared__ double red[3][256];
+    if (blockIdx.x >= nb_red) {
+        const unsigned int b = blockIdx.x - nb_red, d = b / MM_WB_CHUNKS, ch = b % MM_WB_CHUNKS, tid = threadIdx.x;
+        const float shift = means[d];
+        const unsigned long long per = (c2 + MM_WB_CHUNKS - 1) / MM_WB_CHUNKS;
+        const unsigned long long lo = ch * per, hi = lo + per < c2 ? lo + per : c2;
+        double sd = 0.0, sq = 0.0, ws = 0.0;
+        for (unsigned long long c = lo + tid; c < hi; c += 256) {
+            const double df = (double)(means[c * D + d] - shift);
+            sd += df;
+            sq += df * df;
+            ws += (double)(ssq[c * D + d] / nf); /* biased per-chain variance (quirk Q8) */
+        }
+        red[0][tid] = sd;
+        red[1][tid] = sq;
+        red[2][tid] = ws;
+        __syncthreads();
+        for (unsigned int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                red[0][tid] += red[0][tid + st];
+                red[1][tid] += red[1][tid + st];
+                red[2][tid] += red[2][tid + st];
+            }
+            __syncthreads();
+        }
+        if (tid < 3)
+            wb_part[(size_t)b * 3 + tid] = red[tid][0];
+        return;
+    }
+    /* the slabs are cut into n_parts ranges, block (part, group of 64 outputs) sums one range: with n_parts = 1 `out` is
+     * the total [m, D]; with more (the synchronous entry point) out[part] are partial totals the host adds up in order --
+     * ten blocks walking 4096 slabs each were latency-bound (83 us for 10 MB) */
     const unsigned int lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const unsigned int i = blockIdx.x * 64u + lane; /* over d * m + lag */
     const unsigned int total = D * m;
+    const unsigned int groups = (total + 63u) / 64u;
+    const unsigned int part = blockIdx.x / groups, grp = blockIdx.x - part * groups;
+    const unsigned int i = grp * 64u + lane; /* over d * m + lag */
+    const unsigned int per_part = (n_slabs + n_parts - 1u) / n_parts;
+    const unsigned int p_lo = part * per_part, p_hi = min(n_slabs, p_lo + per_part);
     float s = 0.f;
-    if (i < total) {
-        const unsigned int per = (n_slabs + 3u) / 4u;
-        const unsigned int lo = w * per, hi = min(n_slabs, lo + per);
+    if (i < total && p_lo < p_hi) {
+        const unsigned int per = (p_hi - p_lo + 3u) / 4u;
+        const unsigned int lo = p_lo + w * per, hi = min(p_hi, lo + per);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         unsigned int k = lo;
         for (; k + 3 < hi; k += 4) {
@@ -270,12 +373,12 @@ __global__ __launch_bounds__(256) void mm_slab_reduce_kernel(const float *__rest
             s0 += slabs[(size_t)k * total + i];
         s = (s0 + s1) + (s2 + s3);
     }
-    part[w][lane] = s;
+    psum[w][lane] = s;
     __syncthreads();
     if (w == 0 && i < total) {
-        const float r = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        const float r = (psum[0][lane] + psum[1][lane]) + (psum[2][lane] + psum[3][lane]);
         const unsigned int d = i / m, lag = i - d * m;
-        out[(size_t)lag * D + d] = r;
+        out[(size_t)part * total + (size_t)lag * D + d] = r;
     }
 }
 
@@ -304,45 +407,6 @@ struct DevGuard {
     }
 };
 
-/* withinvar's cross-chain sums (stats.rs:449-465) on the device: per parameter d the sum of squared deviations of the
- * half-chain means from their mean, and the sum of the biased half-chain variances.  One block per parameter, f64
- * accumulators; out[d] = {dsum, wsum}.  Spares the single-GPU path the copy of 2 * 2C * D numbers to the host. */
-__global__ __launch_bounds__(1024) void mm_within_between_kernel(const float *__restrict__ means,
-                                                                 const float *__restrict__ ssq, unsigned long long c2,
-                                                                 unsigned int D, float nf, float *__restrict__ out)
-{
-    __shared__ double red[1024];
-    const unsigned int d = blockIdx.x, tid = threadIdx.x;
-    auto block_sum = [&](double v) -> double {
-        red[tid] = v;
-        __syncthreads();
-        for (unsigned int s = 512; s > 0; s >>= 1) {
-            if (tid < s)
-                red[tid] += red[tid + s];
-            __syncthreads();
-        }
-        const double r = red[0];
-        __syncthreads();
-        return r;
-    };
-    double s = 0.0;
-    for (unsigned long long c = tid; c < c2; c += 1024)
-        s += (double)means[c * D + d];
-    const float overall = (float)(block_sum(s) / (double)c2);
-    double ds = 0.0, ws = 0.0;
-    for (unsigned long long c = tid; c < c2; c += 1024) {
-        const float df = means[c * D + d] - overall;
-        ds += (double)(df * df);
-        ws += (double)(ssq[c * D + d] / nf); /* biased per-chain variance (quirk Q8) */
-    }
-    ds = block_sum(ds);
-    ws = block_sum(ws);
-    if (tid == 0) {
-        out[2 * d] = (float)ds;
-        out[2 * d + 1] = (float)ws;
-    }
-}
-
 } // namespace
 
 /* number of waves (= per-wave lag-sum slabs) the half-chain kernel is launched with */
@@ -355,10 +419,10 @@ static unsigned int stats_n_slabs(size_t n_chains)
     return (unsigned int)std::min<size_t>(2 * n_chains, w ? w : 4096);
 }
 
-extern "C" {
-
-int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
-                         float *ssq, float *acov_sum, int device, void *stream_v)
+/* wb_part: NULL, or [dim][MM_WB_CHUNKS][3] doubles for the cross-chain sums (single-GPU path) */
+static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
+                               float *ssq, float *acov_sum, double *wb_part, float *slabs_ws, unsigned int n_parts,
+                               int device, void *stream_v)
 {
     if (!sample || !means || !ssq || !acov_sum || n_chains == 0 || dim == 0 ||
         (dtype != MMCMC_F32 && dtype != MMCMC_F64))
@@ -372,14 +436,16 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
     DevGuard g(device);
     hipStream_t stream = (hipStream_t)stream_v;
     const unsigned int n_slabs = stats_n_slabs(n_chains);
-    float *slabs = nullptr;
+    /* the per-wave lag sums: the caller's workspace (synchronous path) or a stream-ordered allocation */
+    float *slabs = slabs_ws;
     /* lag sums on the matrix cores (one 16 x 16 tile per 256 lags) unless the half-chain is too long for LDS */
     const unsigned int n_tiles = (unsigned int)((m + 255) / 256);
-    const size_t row_len = 240 + 256 * (size_t)(n_tiles - 1) + m + 20, row_pitch = row_len + row_len / 16 + 1;
+    const size_t row_len = 240 + 256 * (size_t)(n_tiles - 1) + m + 36, row_pitch = row_len + row_len / 16 + 1;
     const size_t lds_mfma = ((size_t)dim * row_pitch + (size_t)dim * m) * sizeof(float);
     const char *force_direct = getenv("MMCMC_STATS_DIRECT"); /* measurement aid: the direct kernel */
     if (lds_mfma <= 64 * 1024 && !(force_direct && force_direct[0] == '1')) {
-        MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+        if (!slabs)
+            MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
         if (dtype == MMCMC_F32)
             hipLaunchKernelGGL(mm_half_chain_mfma_kernel<float>, dim3(n_slabs), dim3(64), lds_mfma, stream,
                                (const float *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
@@ -393,7 +459,8 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
         const size_t lds = ((size_t)dim * m_pad + (size_t)dim * m) * sizeof(float);
         if (lds > 160 * 1024)
             return MMCMC_ERR_UNSUPPORTED;
-        MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+        if (!slabs)
+            MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
         if (lds > 64 * 1024) {
             const void *fn = dtype == MMCMC_F32 ? (const void *)mm_half_chain_kernel<float>
                                                 : (const void *)mm_half_chain_kernel<double>;
@@ -410,11 +477,81 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
     }
     MM_HIP(hipGetLastError());
     const unsigned int total = (unsigned int)(dim * m);
-    hipLaunchKernelGGL(mm_slab_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, slabs, n_slabs,
-                       (unsigned int)dim, (unsigned int)m, acov_sum);
+    /* acov_sum: [n_parts][m, D] partial totals (n_parts = 1: the total) */
+    const unsigned int nb_red = (total + 63) / 64 * n_parts, nb_wb = wb_part ? (unsigned int)dim * MM_WB_CHUNKS : 0u;
+    hipLaunchKernelGGL(mm_stats_tail_kernel, dim3(nb_red + nb_wb), dim3(256), 0, stream, slabs, n_slabs,
+                       (unsigned int)dim, (unsigned int)m, acov_sum, nb_red, n_parts, means, ssq,
+                       (unsigned long long)(2 * n_chains), (float)m, wb_part);
     MM_HIP(hipGetLastError());
-    MM_HIP(hipFreeAsync(slabs, stream));
+    if (!slabs_ws)
+        MM_HIP(hipFreeAsync(slabs, stream));
     return MMCMC_OK;
+}
+
+/* Device workspace of the synchronous entry point (it returns after its kernels have finished, so one buffer per host
+ * thread and device can be reused call after call): grown on demand, never freed. */
+static float *stats_workspace(int device, size_t n_floats)
+{
+    struct Ws {
+        float *p = nullptr;
+        size_t cap = 0;
+    };
+    static thread_local Ws ws[64];
+    Ws &w = ws[device & 63];
+    if (n_floats > w.cap) {
+        if (w.p)
+            (void)hipFree(w.p);
+        w.p = nullptr;
+        w.cap = 0;
+        if (hipMalloc((void **)&w.p, n_floats * sizeof(float)) != hipSuccess)
+            return nullptr;
+        w.cap = n_floats;
+    }
+    return w.p;
+}
+
+/* wait for the work queued so far by polling an event: a blocking hipStreamSynchronize sleeps on an interrupt and
+ * wakes up tens of microseconds after a sub-millisecond reduction has finished */
+static hipError_t stats_wait(hipStream_t stream)
+{
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+        return hipStreamSynchronize(stream);
+    hipError_t e = hipEventRecord(ev, stream);
+    if (e != hipSuccess)
+        return e;
+    for (unsigned int i = 0; i < (1u << 24); ++i) {
+        e = hipEventQuery(ev);
+        if (e != hipErrorNotReady)
+            return e;
+    }
+    return hipEventSynchronize(ev);
+}
+
+/* pinned staging buffer for the few KB that come back, one per host thread, grown on demand, never freed */
+static float *stats_pinned(size_t n_floats)
+{
+    static thread_local float *buf = nullptr;
+    static thread_local size_t cap = 0;
+    if (n_floats > cap) {
+        if (buf)
+            (void)hipHostFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (hipHostMalloc((void **)&buf, n_floats * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return nullptr;
+        cap = n_floats;
+    }
+    return buf;
+}
+
+extern "C" {
+
+int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
+                         float *ssq, float *acov_sum, int device, void *stream_v)
+{
+    return stats_partials_impl(sample, dtype, n_chains, n, dim, means, ssq, acov_sum, nullptr, nullptr, 1u, device,
+                               stream_v);
 }
 
 /* stats.rs:449-465 (withinvar), :425-427 (rhat), :509-545 (ess) on the gathered sufficient statistics, f32.
@@ -488,11 +625,23 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
     const size_t c2 = 2 * n_chains;
     void *d_sample = nullptr;
     float *d_buf = nullptr;
-    const size_t nb = (2 * c2 * dim + m * dim + 2 * dim);
-    std::vector<float> h(m * dim + 2 * dim);
+    /* device layout: means | ssq | acov_sum [m, D] (+ pad to 8 bytes) | cross-chain partial sums [D][CHUNKS][3] f64:
+     * the last two blocks are what the host needs */
+    constexpr unsigned int kParts = 16; /* partial lag-sum totals, added up on the host */
+    const size_t n_acov = (kParts * m * dim + 1) / 2 * 2, n_wb = dim * MM_WB_CHUNKS * 3;
+    const size_t nb = 2 * c2 * dim + n_acov + 2 * n_wb;
     int rc = MMCMC_OK;
     hipError_t e = hipSuccess;
     do {
+        if (c2 < 2) {
+            rc = MMCMC_ERR_INVALID_ARG;
+            break;
+        }
+        float *h = stats_pinned(n_acov + 2 * n_wb);
+        if (!h) {
+            e = hipErrorOutOfMemory;
+            break;
+        }
         if (!sample_is_device) {
             if ((e = hipMalloc(&d_sample, n_chains * n * dim * esz)) != hipSuccess)
                 break;
@@ -500,35 +649,44 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
                 hipSuccess)
                 break;
         }
-        if ((e = hipMallocAsync((void **)&d_buf, nb * sizeof(float), stream)) != hipSuccess)
-            break;
-        /* layout: means | ssq | acov_sum [m, D] | {dsum, wsum} [D]: the last two blocks are what the host needs */
-        float *d_means = d_buf, *d_ssq = d_buf + c2 * dim, *d_acov = d_buf + 2 * c2 * dim, *d_wb = d_acov + m * dim;
-        rc = mmcmc_stats_partials(sample_is_device ? sample : d_sample, dtype, n_chains, n, dim, d_means, d_ssq,
-                                  d_acov, device, stream_v);
-        if (rc != MMCMC_OK)
-            break;
-        hipLaunchKernelGGL(mm_within_between_kernel, dim3((unsigned int)dim), dim3(1024), 0, stream, d_means, d_ssq,
-                           (unsigned long long)c2, (unsigned int)dim, (float)m, d_wb);
-        if ((e = hipGetLastError()) != hipSuccess)
-            break;
-        if ((e = hipMemcpyAsync(h.data(), d_acov, h.size() * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-            break;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess)
-            break;
-        if (c2 < 2) {
-            rc = MMCMC_ERR_INVALID_ARG;
+        const size_t n_slab_floats = (size_t)stats_n_slabs(n_chains) * dim * m;
+        if (!(d_buf = stats_workspace(device, nb + n_slab_floats))) {
+            e = hipErrorOutOfMemory;
             break;
         }
+        float *d_means = d_buf, *d_ssq = d_buf + c2 * dim, *d_acov = d_buf + 2 * c2 * dim;
+        double *d_wb = reinterpret_cast<double *>(d_acov + n_acov);
+        rc = stats_partials_impl(sample_is_device ? sample : d_sample, dtype, n_chains, n, dim, d_means, d_ssq, d_acov,
+                                 d_wb, d_buf + nb, kParts, device, stream_v);
+        if (rc != MMCMC_OK)
+            break;
+        if ((e = hipMemcpyAsync(h, d_acov, (n_acov + 2 * n_wb) * sizeof(float), hipMemcpyDeviceToHost, stream)) !=
+            hipSuccess)
+            break;
+        if ((e = stats_wait(stream)) != hipSuccess)
+            break;
+        for (size_t i = 0; i < m * dim; ++i) { /* lag sums: the partial totals in their fixed order */
+            float t = h[i];
+            for (unsigned int part = 1; part < kParts; ++part)
+                t += h[(size_t)part * m * dim + i];
+            h[i] = t;
+        }
         std::vector<float> rho(m);
-        const float *wb = h.data() + m * dim;
-        for (size_t d = 0; d < dim; ++d)
-            stats_finish_one(wb[2 * d], wb[2 * d + 1], h.data(), c2, m, dim, d, rho, rhat, ess);
+        const double *wb = reinterpret_cast<const double *>(h + n_acov);
+        for (size_t d = 0; d < dim; ++d) {
+            double sd = 0.0, sq = 0.0, ws = 0.0;
+            for (size_t ch = 0; ch < MM_WB_CHUNKS; ++ch) {
+                const double *q = wb + (d * MM_WB_CHUNKS + ch) * 3;
+                sd += q[0];
+                sq += q[1];
+                ws += q[2];
+            }
+            const double dsum = sq - sd * sd / (double)c2; /* sum of (mean - overall mean)^2 */
+            stats_finish_one((float)(dsum > 0.0 ? dsum : 0.0), (float)ws, h, c2, m, dim, d, rho, rhat, ess);
+        }
     } while (0);
     if (d_sample)
         (void)hipFree(d_sample);
-    if (d_buf)
-        (void)hipFreeAsync(d_buf, stream);
     if (e != hipSuccess)
         return (int)e;
     return rc;

@@ -17,6 +17,14 @@ if what == "nuts3":  # one-chain-per-lane NUTS on RosenbrockND(3): python3 tools
     torch.cuda.synchronize()
     print("nuts3", mode, s.kernel_variant, s.timing(), int(s.leapfrog_counts().sum()))
     sys.exit(0)
+if what == "stats":  # split-R-hat / ESS of a [65536, 400, 3] f32 sample in HBM
+    from mini_mcmc_amd import stats as S
+    x = torch.randn(65536, 400, 3, device="cuda")
+    for _ in range(3):
+        S.split_rhat_mean_ess(x)
+    torch.cuda.synchronize()
+    print("stats done")
+    sys.exit(0)
 if what == "nuts5":
     from mini_mcmc_amd.distributions import GaussianND
     from mini_mcmc_amd.nuts import NUTS
