@@ -232,6 +232,12 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
                          float *ssq, float *acov_sum, int device, void *stream);
 int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_sum, size_t n_half_chains, size_t m,
                        size_t dim, float *rhat, float *ess);
+/* finish from the cross-chain SUMS instead of the per-half-chain statistics, for runs where gathering 2 * chains * dim
+ * numbers on every rank is the expensive part: dsum[d] = sum over ALL half-chains of (mean - overall mean)^2,
+ * wsum[d] = sum of the biased half-chain variances ssq / m (two all-reduces: the overall mean first), acov_sum as
+ * above.  Same arithmetic from there on (stats.rs:459-465, :425-427, :509-545). */
+int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float *acov_sum, size_t n_half_chains, size_t m,
+                            size_t dim, float *rhat, float *ess);
 /* basic_stats stats.rs:310-336 (host) and RunStats::from stats.rs:360-371 */
 int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out);
 int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,

@@ -105,6 +105,8 @@ SIGNATURES = {
     "mmcmc_stats_partials": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, _vp]),
     "mmcmc_stats_finish": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
                                      C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mmcmc_stats_finish_sums": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_size_t,
+                                          C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mmcmc_basic_stats_from": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.POINTER(BasicStats)]),
     "mmcmc_run_stats_from": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(RunStats),
                                   C.c_int, _vp]),

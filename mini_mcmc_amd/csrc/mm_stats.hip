@@ -692,6 +692,17 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
     return rc;
 }
 
+int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float *acov_sum, size_t c2, size_t m, size_t dim,
+                            float *rhat, float *ess)
+{
+    if (!dsum || !wsum || !acov_sum || !rhat || !ess || c2 < 2 || m < 1 || dim == 0)
+        return MMCMC_ERR_INVALID_ARG;
+    std::vector<float> rho(m);
+    for (size_t d = 0; d < dim; ++d)
+        stats_finish_one((float)dsum[d], (float)wsum[d], acov_sum, c2, m, dim, d, rho, rhat, ess);
+    return MMCMC_OK;
+}
+
 /* stats.rs:310-336 basic_stats: sorted descending; min = last, median = [len/2], max = first, std with ddof 1 */
 int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out)
 {

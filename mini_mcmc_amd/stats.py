@@ -156,12 +156,51 @@ def gather_partials(means, ssq, acov_sum, group=None):
     return g_means, g_ssq, acov.cpu().numpy()
 
 
+def reduce_partials(means, ssq, acov_sum, group=None):
+    """The exchange of a multi-GPU run without a gather: two all-reduces (RCCL over xGMI with CUDA tensors, gloo with
+    CPU tensors) of D and 2D + m*D numbers.  Inputs are this rank's statistics ([2, C_local, D], [2, C_local, D],
+    [m, D]); returns the global (dsum[D], wsum[D] as float64 numpy, acov_sum [m, D] float32 numpy, number of
+    half-chains): what `stats_finish_sums` needs.  Sums are taken in f64, so the result equals the gathered one
+    (`gather_partials` + `stats_finish`) to f32 rounding whatever the number of ranks."""
+    import torch
+    import torch.distributed as dist
+
+    m, d = acov_sum.shape
+    mu64 = means.reshape(-1, d).double()
+    head = torch.cat([mu64.sum(dim=0), torch.tensor([float(mu64.shape[0])], dtype=torch.float64, device=means.device)])
+    dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group)  # sum of the half-chain means, number of half-chains
+    c2 = int(round(float(head[d].item())))
+    overall = (head[:d] / head[d]).float().double()  # the reference forms the overall mean in f32 (stats.rs:452-455)
+    dev = (mu64.float() - overall.float()).double()  # ... and the deviations too
+    body = torch.cat([(dev * dev).sum(dim=0), (ssq.reshape(-1, d) / float(m)).double().sum(dim=0),
+                      acov_sum.double().reshape(-1)])
+    dist.all_reduce(body, op=dist.ReduceOp.SUM, group=group)
+    body = body.cpu().numpy()
+    return body[:d].copy(), body[d:2 * d].copy(), body[2 * d:].astype(np.float32).reshape(m, d), c2
+
+
+def stats_finish_sums(dsum, wsum, acov_sum, n_half_chains: int):
+    """Host finish (stats.rs:459-465, :425-427, :509-545) from the cross-chain sums of `reduce_partials`."""
+    ds = np.ascontiguousarray(dsum, dtype=np.float64)
+    ws = np.ascontiguousarray(wsum, dtype=np.float64)
+    ac = np.ascontiguousarray(acov_sum, dtype=np.float32)
+    m, d = ac.shape
+    rhat = np.empty(d, dtype=np.float32)
+    ess = np.empty(d, dtype=np.float32)
+    _dp = C.POINTER(C.c_double)
+    st = L.lib().mmcmc_stats_finish_sums(ds.ctypes.data_as(_dp), ws.ctypes.data_as(_dp), ac.ctypes.data_as(_fp),
+                                         int(n_half_chains), m, d, rhat.ctypes.data_as(_fp), ess.ctypes.data_as(_fp))
+    L.check(st, "mmcmc_stats_finish_sums")
+    return rhat, ess
+
+
 def split_rhat_mean_ess_distributed(sample_local, group=None):
     """split_rhat_mean_ess over chains sharded across ranks (rank r holds global chains [r*C_local, (r+1)*C_local)).
-    Every rank returns the same (rhat, ess)."""
+    Every rank returns the same (rhat, ess).  Exchange: `reduce_partials` (two small all-reduces); `gather_partials` +
+    `stats_finish` is the variant that reproduces the single-GPU summation order exactly."""
     means, ssq, acov = stats_partials(sample_local)
-    g_means, g_ssq, g_acov = gather_partials(means, ssq, acov, group)
-    return stats_finish(g_means, g_ssq, g_acov)
+    dsum, wsum, g_acov, c2 = reduce_partials(means, ssq, acov, group)
+    return stats_finish_sums(dsum, wsum, g_acov, c2)
 
 
 class MultiChainTracker:

@@ -54,6 +54,12 @@ def _worker(rank, world, port, q):
     mu, ssq, ac = _host_partials(x[rank * cl:(rank + 1) * cl])
     g_mu, g_ssq, g_ac = S.gather_partials(torch.from_numpy(mu), torch.from_numpy(ssq), torch.from_numpy(ac))
     rhat, ess = S.stats_finish(g_mu, g_ssq, g_ac)
+    # the exchange without a gather (two small all-reduces) must agree with the gathered one
+    dsum, wsum, r_ac, c2 = S.reduce_partials(torch.from_numpy(mu), torch.from_numpy(ssq), torch.from_numpy(ac))
+    rhat2, ess2 = S.stats_finish_sums(dsum, wsum, r_ac, c2)
+    assert c2 == 2 * c_total
+    np.testing.assert_allclose(rhat2, rhat, rtol=2e-6)
+    np.testing.assert_allclose(ess2, ess, rtol=2e-5)
     q.put((rank, rhat, ess, g_mu.shape))
     dist.destroy_process_group()
 

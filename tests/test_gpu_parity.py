@@ -9,10 +9,13 @@ the CPU checker (oracle/).  Run with `-m gpu`.
 Levels A (oracle vs the reference's known answers) and B (engine arithmetic vs reference-ordered arithmetic on
 identical noise) run on the CPU: tests/test_oracle_pins.py, tests/test_step_parity.py.
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -348,6 +351,39 @@ def test_stats_kats_on_gpu(M, O, kats):
         got = acov.cpu().numpy() / 4.0 / 2.0  # /n, mean over the two half-chains
         np.testing.assert_allclose(got, np.array(ka["expected"], dtype=np.float32), atol=ka["atol"])
         np.testing.assert_allclose(means.cpu().numpy()[0, 0], d.mean(axis=0), rtol=1e-6)
+
+
+def test_distributed_diagnostics_over_rccl_one_rank(M, O):
+    """stats.split_rhat_mean_ess_distributed through the real backend ("nccl" = RCCL) on a one-rank group in a child
+    process: device statistics -> two all-reduces of CUDA tensors -> host finish, against the single-GPU entry point.
+    (world_size 2 runs on CPU tensors with gloo in tests/test_distributed_stats.py; 8-GPU runs are the driver's.)"""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MM_ROOT"])
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29583")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from mini_mcmc_amd import stats as S
+from mini_mcmc_amd.core import init_with_seed
+from mini_mcmc_amd.distributions import RosenbrockND
+from mini_mcmc_amd.hmc import HMC
+t = HMC(RosenbrockND(3), init_with_seed(1024, 3, 42, np.float32), 0.032, 10).set_seed(42).run(300, 50, to="torch")
+r1, e1 = S.split_rhat_mean_ess(t)
+r2, e2 = S.split_rhat_mean_ess_distributed(t)
+np.testing.assert_allclose(r2, r1, rtol=2e-6); np.testing.assert_allclose(e2, e1, rtol=1e-4)
+m, q, a = S.stats_partials(t)
+g = S.gather_partials(m, q, a)
+r3, e3 = S.stats_finish(*g)
+np.testing.assert_allclose(r3, r1, rtol=2e-6); np.testing.assert_allclose(e3, e1, rtol=1e-4)
+dist.destroy_process_group()
+print("ok")
+"""
+    env = dict(os.environ, MM_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout.split(), out.stdout + out.stderr  # RCCL prints its banner too
 
 
 def test_stats_on_device_sample_and_sharded_partials(M, O):
