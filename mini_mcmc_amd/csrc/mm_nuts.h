@@ -194,13 +194,48 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
     ST S_alpha;
     TT S_first_x[D], S_first_p[D], S_prime[D];
 
-    MM_HD double aux(uint64_t seed, uint64_t chain) { return mm_aux_u53(seed, chain, m, aux_k++); }
+    /* The auxiliary uniforms (mm_rng.h: draw k = one half of Philox block AUX + (k >> 1)) come from a window of two
+     * consecutive blocks, aux_q[0..3] = draws 2 aux_b .. 2 aux_b + 3, so that every block is evaluated once, not once
+     * per half.  PRE = false: the window follows the draws on demand.  PRE = true: the caller has advanced it
+     * (aux_advance) at a point where all lanes do it together -- the asynchronous-lane kernel, where a Philox
+     * evaluation inside each of the five sections that draw would run five times per tick for a few lanes each. */
+    double aux_q[4];
+    uint32_t aux_b;
+    MM_HD void aux_load(uint64_t seed, uint64_t chain, uint32_t b, double *q) const
+    {
+        const mm_u32x4 blk = mm_block(seed, chain, m, MM_AUX_BLOCK + b);
+        q[0] = mm_u53(blk.w[0], blk.w[1]);
+        q[1] = mm_u53(blk.w[2], blk.w[3]);
+    }
+    MM_HD void aux_advance(uint64_t seed, uint64_t chain)
+    {
+        aux_q[0] = aux_q[2];
+        aux_q[1] = aux_q[3];
+        aux_b += 1;
+        aux_load(seed, chain, aux_b + 1, aux_q + 2);
+    }
+    /* true when the window's first block is used up: at most three draws can follow before the next check */
+    MM_HD bool aux_stale() const { return (aux_k >> 1) > aux_b; }
+    template <bool PRE = false> MM_HD double aux(uint64_t seed, uint64_t chain)
+    {
+        const uint32_t k = aux_k++;
+        if (!PRE) {
+            while ((k >> 1) > aux_b + 1)
+                aux_advance(seed, chain);
+        }
+        const uint32_t r = k - 2u * aux_b;
+        const double lo = (r & 1u) ? aux_q[1] : aux_q[0], hi = (r & 1u) ? aux_q[3] : aux_q[2];
+        return (r & 2u) ? hi : lo;
+    }
 
     /* m_: the 1-based global step count (self.m after the increment) */
     MM_HD void begin(const mm_tparams<TT> &P, const TT *x, uint32_t m_, uint64_t seed, uint64_t chain)
     {
         m = m_;
         aux_k = 0;
+        aux_b = 0;
+        aux_load(seed, chain, 0, aux_q);
+        aux_load(seed, chain, 1, aux_q + 2);
         TT mom0[D], grad[D];
         mm_nuts_momentum<D>(seed, chain, m, mom0);
         const TT ulogp = Tgt::logp_grad(P, x, grad);
@@ -222,9 +257,9 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
         info.n_leapfrog = 0;
     }
 
-    MM_HD void double_begin(const mm_nuts_adapt<ST> &ad, uint64_t seed, uint64_t chain)
+    template <bool PRE = false> MM_HD void double_begin(const mm_nuts_adapt<ST> &ad, uint64_t seed, uint64_t chain)
     {
-        const ST u_run_1 = (ST)aux(seed, chain);
+        const ST u_run_1 = (ST)aux<PRE>(seed, chain);
         v = (u_run_1 < ST(0.5)) ? 1 : -1;
         const bool neg = v == -1;
         MM_UNROLL
@@ -263,6 +298,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
 
     /* one step of handing S up the (implicit) recursion */
     enum { HAND_MORE = 0, HAND_NEXT_LEAF = 1, HAND_DONE = 2 };
+    template <bool PRE = false>
     MM_HD int hand_up(uint64_t seed, uint64_t chain, const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
     {
         if (S_level == (uint32_t)j)
@@ -271,7 +307,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
             /* S is the second child: merge with its sibling T1 (nuts.rs:900-928) */
             const int e = sp - 1;
             const uint32_t n1 = stk.c(e, 1);
-            const double u = aux(seed, chain); /* always f64 (nuts.rs:910) */
+            const double u = aux<PRE>(seed, chain); /* always f64 (nuts.rs:910) */
             uint32_t den = n1 + S_n;
             if (den < 1)
                 den = 1;
@@ -331,7 +367,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
     }
 
     /* x[D]: the chain's position, replaced by the doubling's proposal when it is accepted */
-    MM_HD void double_end(TT *x, uint64_t seed, uint64_t chain, int max_depth)
+    template <bool PRE = false> MM_HD void double_end(TT *x, uint64_t seed, uint64_t chain, int max_depth)
     {
         const bool neg = v == -1;
         MM_UNROLL
@@ -349,7 +385,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
         alpha = S_alpha; /* from the LAST doubling only (nuts.rs:614-615, 649-650) */
         n_alpha = S_nalpha;
         const ST tmp = mm_minT(ST(1), (ST)S_n / (ST)n);
-        const ST u_run_2 = (ST)aux(seed, chain);
+        const ST u_run_2 = (ST)aux<PRE>(seed, chain);
         if (S_s && (u_run_2 < tmp)) {
             MM_UNROLL
             for (int i = 0; i < D; ++i)

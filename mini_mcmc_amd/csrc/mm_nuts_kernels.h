@@ -88,7 +88,9 @@ __global__ void mm_nuts_init_kernel(const mm_tparams<TT> P, const TT *state, mm_
     adapt[c] = ad;
 }
 
-template <class TT, class ST, class Tgt>
+/* LDS_STACK is a template parameter, not a run-time choice: a pointer that may be LDS or HBM is a generic pointer and
+ * every stack access a flat_load / flat_store (which is what these kernels did at first, stack "in LDS" included). */
+template <class TT, class ST, class Tgt, bool LDS_STACK>
 __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, ST> a)
 {
     constexpr int D = Tgt::dim;
@@ -109,9 +111,9 @@ __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, 
     const bool active = c < a.n_chains;
     const unsigned long long chain = a.chain_offset + c;
 
-    unsigned char *stack_base = a.stack_in_lds ? (mm_lds_raw + (Tile::lds_bytes_per_wave + 15) / 16 * 16)
-                                               : (a.scratch + (size_t)blockIdx.x * Lay::bytes);
-    const mm_nuts_stack<TT, ST, D> stk = Lay::make(stack_base, lane);
+    const mm_nuts_stack<TT, ST, D> stk =
+        LDS_STACK ? Lay::make(mm_lds_raw + (Tile::lds_bytes_per_wave + 15) / 16 * 16, lane)
+                  : Lay::make(a.scratch + (size_t)blockIdx.x * Lay::bytes, lane);
 
     TT x[D];
     MM_UNROLL
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, 
  * exec mask and begins its next doubling / transition in the same tick.  The noise is a function of (chain, m), so the
  * results do not depend on when a lane gets there: bit-identical to the synchronous kernel and to the host build.
  * Samples are written by the owning lane (rows complete at different times, so there is no tile to coalesce). */
-template <class TT, class ST, class Tgt>
+template <class TT, class ST, class Tgt, bool LDS_STACK>
 __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT, ST> a)
 {
     constexpr int D = Tgt::dim;
@@ -202,8 +204,7 @@ __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT
     const bool active = c < a.n_chains;
     const unsigned long long chain = a.chain_offset + c;
     /* no output tile here, so the stack (sized for max_depth levels) fits LDS in more cases than in the kernel above */
-    const bool lds_stack = Lay::bytes_for(a.max_depth) <= MM_NUTS_ASYNC_LDS_LIMIT;
-    const mm_nuts_stack<TT, ST, D> stk = lds_stack ? Lay::make_levels(mm_lds_raw, lane, a.max_depth)
+    const mm_nuts_stack<TT, ST, D> stk = LDS_STACK ? Lay::make_levels(mm_lds_raw, lane, a.max_depth)
                                                    : Lay::make(a.scratch + (size_t)blockIdx.x * Lay::bytes, lane);
 
     TT x[D];
@@ -266,9 +267,13 @@ __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT
                 }
             }
         }
+        /* the window of auxiliary uniforms moves here, for all lanes that need it at once (mm_nuts_tree::aux): a lane
+         * draws at most three uniforms per tick (begin / double_begin / one merge / double_end, never all four) */
+        if (live && phase != 0 && T.aux_stale())
+            T.aux_advance(a.seed, chain);
         if (live && phase != 0) {
             if (phase == 1) {
-                T.double_begin(ad, a.seed, chain);
+                T.template double_begin<true>(ad, a.seed, chain);
                 phase = 2;
             }
             if (phase == 2) {
@@ -277,11 +282,11 @@ __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT
             }
             /* ONE step up per tick: the number of merges a leaf completes differs from lane to lane (the trailing
              * ones of its index), and a wave that waited for the longest chain of merges would idle again */
-            const int r = T.hand_up(a.seed, chain, stk);
+            const int r = T.template hand_up<true>(a.seed, chain, stk);
             if (r == T.HAND_NEXT_LEAF)
                 phase = 2;
             if (r == T.HAND_DONE) {
-                T.double_end(x, a.seed, chain, a.max_depth);
+                T.template double_end<true>(x, a.seed, chain, a.max_depth);
                 phase = 1;
                 if (!T.s) {
                     phase = 0;
@@ -310,8 +315,10 @@ hipError_t mm_launch_nuts_run_async(const mm_nuts_args<TT, ST> &a, hipStream_t s
     using Lay = mm_nuts_stack_layout<TT, ST, Tgt::dim>;
     const unsigned int grid = (unsigned int)((a.n_chains + 63) / 64);
     const size_t need = Lay::bytes_for(a.max_depth);
-    const size_t lds = need <= MM_NUTS_ASYNC_LDS_LIMIT ? need : 0;
-    hipLaunchKernelGGL((mm_nuts_async_kernel<TT, ST, Tgt>), dim3(grid), dim3(64), lds, stream, a);
+    if (need <= MM_NUTS_ASYNC_LDS_LIMIT)
+        hipLaunchKernelGGL((mm_nuts_async_kernel<TT, ST, Tgt, true>), dim3(grid), dim3(64), need, stream, a);
+    else
+        hipLaunchKernelGGL((mm_nuts_async_kernel<TT, ST, Tgt, false>), dim3(grid), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -335,8 +342,9 @@ hipError_t mm_launch_nuts_run(const mm_nuts_args<TT, ST> &a, hipStream_t stream)
     const unsigned int grid = (unsigned int)((a.n_chains + 63) / 64);
     size_t lds = (mm_tile<TT, Tgt::dim>::lds_bytes_per_wave + 15) / 16 * 16;
     if (a.stack_in_lds)
-        lds += Lay::bytes;
-    hipLaunchKernelGGL((mm_nuts_run_kernel<TT, ST, Tgt>), dim3(grid), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((mm_nuts_run_kernel<TT, ST, Tgt, true>), dim3(grid), dim3(64), lds + Lay::bytes, stream, a);
+    else
+        hipLaunchKernelGGL((mm_nuts_run_kernel<TT, ST, Tgt, false>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
