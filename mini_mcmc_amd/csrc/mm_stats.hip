@@ -191,15 +191,58 @@ __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restr
         offa[u] = at(padl + kq + li + 4u * u);
         offb[u] = at(padl + kq - 16u * li + 4u * u);
     }
-    for (unsigned long long hc = blockIdx.x; hc < n_half; hc += gridDim.x) {
+    /* The [m, D] block of a half-chain is m D / 64 elements per lane.  When that is at most NPRE they are requested for
+     * the NEXT half-chain before the current one is reduced, and parked in registers: a wave that asked for its block only
+     * when it needed it (ten dependent global loads) spent most of its time waiting, four waves per SIMD or not.
+     * lds_off[i]: where element lane + 64 i goes (word offset into y), the same for every half-chain. */
+    constexpr unsigned int NPRE = 16;
+    const unsigned int mD = m * D;
+    const bool prefetch = mD <= NPRE * 64u;
+    unsigned int lds_off[NPRE];
+    float pre[NPRE];
+    {
+        /* (t, d) of element e = lane + 64 i without a division per element: advance by 64 = q64 * D + r64 */
+        const unsigned int q64 = 64u / D, r64 = 64u - q64 * D;
+        unsigned int t = lane / D, d = lane - t * D;
+#pragma unroll
+        for (unsigned int i = 0; i < NPRE; ++i) {
+            lds_off[i] = d * row_pitch + at(padl + t);
+            t += q64;
+            d += r64;
+            if (d >= D) {
+                d -= D;
+                t += 1;
+            }
+        }
+    }
+    auto block_of = [&](unsigned long long hc) -> const T * {
         const unsigned long long chain = hc < C ? hc : hc - C;
         const unsigned int row0 = hc < C ? 0u : n - m;
-        const T *src = sample + (chain * n + row0) * D;
-        {
-            /* (t, d) of element e = lane + 64 i without a division per element: advance by 64 = q64 * D + r64 */
+        return sample + (chain * n + row0) * D;
+    };
+    auto request = [&](unsigned long long hc) {
+        const T *src = block_of(hc);
+#pragma unroll
+        for (unsigned int i = 0; i < NPRE; ++i) {
+            const unsigned int e = lane + 64u * i;
+            pre[i] = e < mD ? (float)src[e] : 0.f;
+        }
+    };
+    if (prefetch && blockIdx.x < n_half)
+        request(blockIdx.x);
+    for (unsigned long long hc = blockIdx.x; hc < n_half; hc += gridDim.x) {
+        if (prefetch) {
+#pragma unroll
+            for (unsigned int i = 0; i < NPRE; ++i)
+                if (lane + 64u * i < mD)
+                    y[lds_off[i]] = pre[i];
+            if (hc + gridDim.x < n_half)
+                request(hc + gridDim.x);
+        } else {
+            const T *src = block_of(hc);
             const unsigned int q64 = 64u / D, r64 = 64u - q64 * D;
             unsigned int t = lane / D, d = lane - t * D;
-            for (unsigned int e = lane; e < m * D; e += 64) {
+            for (unsigned int e = lane; e < mD; e += 64) {
                 y[d * row_pitch + at(padl + t)] = (float)src[e];
                 t += q64;
                 d += r64;
