@@ -490,6 +490,24 @@ def test_nuts_asynchronous_lanes_equal_synchronous_lanes(M, O, mode):
         NUTS(M.dist.GaussianND.ill_conditioned(16, 10.0, 1), M.core.init_with_seed(8, 16, 1), 0.8, mode=1).set_kernel_variant(4)
 
 
+def test_nuts_asynchronous_lanes_at_full_size(M, O):
+    """65 536 chains (1024 full waves, every lane on its own schedule): variant 4 and variant 0 agree on every sample,
+    every chain's leapfrog count and the depth histogram; the histogram counts every transition once."""
+    from mini_mcmc_amd.nuts import NUTS
+
+    C, nc, nd = 65536, 12, 18
+    init = M.core.init_with_seed(C, 3, 5) * 0.5
+    res = {}
+    for variant in (4, 0):
+        s = NUTS(M.dist.RosenbrockND(3), init, 0.8, mode=1).set_seed(9).set_kernel_variant(variant)
+        out = s._run(nc, nd, True, "numpy")
+        res[variant] = (out, s.leapfrog_counts(), s.depth_histogram())
+    assert np.array_equal(res[4][0], res[0][0])
+    assert np.array_equal(res[4][1], res[0][1]) and np.array_equal(res[4][2], res[0][2])
+    assert int(res[4][2].sum()) == C * (nc + nd)
+    assert np.isfinite(res[4][0]).all()
+
+
 def test_hmc_lane_group_mfma_bit_exact_vs_host_twin(M, O):
     """mm_hmc_lg.h (HMC on the dense f64 Gaussian: 16 chains per wave, gradient on v_mfma_f64_16x16x4) against the host
     build of mm_hmc_step_noise with the grouped reduction order; and against the one-chain-per-lane kernel to rounding."""
