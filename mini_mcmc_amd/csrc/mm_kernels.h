@@ -85,7 +85,7 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
 {
     using Tile = mm_tile<T, D>;
     constexpr int TILE_T = Tile::tile_t, RUN = Tile::run, STRIDE = Tile::stride;
-#ifdef MM_PROBE_SKIP_FLUSH
+#ifdef MM_PROBE_SKIP_FLUSH /* measurement aid of tools/hmc_kernel_probe.hip; never defined in the library build */
     return;
 #endif
     /* LDS operations of one wave execute in order, so the reads below see the rows staged by all 64 lanes and the
@@ -131,7 +131,7 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
             char *const gbase = reinterpret_cast<char *>(wbase + (unsigned long long)(a * J0) * chain_stride);
             MM_UNROLL
             for (int m = 0; m < K0; ++m) {
-#ifdef MM_PROBE_SKIP_STORE
+#ifdef MM_PROBE_SKIP_STORE /* measurement aid (tools/hmc_kernel_probe.hip): the tile is read, not written out */
                 asm volatile("" ::"v"(v[a][m]), "v"(gbase + dst_off[m]));
 #else
                 *reinterpret_cast<mm_vec16 *>(gbase + dst_off[m]) = v[a][m];

@@ -1,6 +1,8 @@
 // Stand-alone driver of the headline kernel (mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>, config 3) for
 // quick A/B experiments on mm_kernels.h: compiles in seconds, no library rebuild.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 [-DMM_PROBE_...] tools/hmc_kernel_probe.hip -o /tmp/probe
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 [-DMM_PROBE_SKIP_STORE | -DMM_PROBE_SKIP_FLUSH] tools/hmc_kernel_probe.hip -o /tmp/probe
+// (-DMM_PROBE_SKIP_STORE: the flush reads the tile but does not store; -DMM_PROBE_SKIP_FLUSH: no flush at all; the
+//  difference between the three builds is the cost of the stores / of the LDS reads / of the staging writes)
 #include "../mini_mcmc_amd/csrc/mm_kernels.h"
 #include <cstdio>
 #include <vector>
