@@ -48,6 +48,11 @@ def test_tracker_matches_reference_semantics(O):
             else:
                 assert abs(float(tr.p_accept) - float(p_o)) < 1e-6  # start forgotten at rate 0.99^16384
         assert ta.p_accept == tb.p_accept or chains * steps > 16384
+        # rows in tiles of 16 through the coalescing kernel (a) or lane by lane in short blocks (b): the same numbers
+        assert np.array_equal(ta.rhat(), tb.rhat())
+        ra, mxa, pa = ta.chain_stats()
+        rb, mxb, pb = tb.chain_stats()
+        assert np.array_equal(ra, rb) and mxa == mxb and pa == pb
 
 
 @pytest.mark.gpu
