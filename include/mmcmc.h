@@ -205,12 +205,14 @@ int mmcmc_nuts_destroy(mmcmc_nuts *h);
 
 /* knobs shared by the samplers:
  * iterations per kernel launch (0 = the whole run in one launch, the default) -- never changes a result;
- * kernel variant: 2 = noise of two iterations packed and software-pipelined (default), 0 = plain -- bit-identical;
+ * kernel variant: 2 = noise of two iterations packed and software-pipelined (default up to dim 16), 0 = plain (default
+ *   at dim 32) -- bit-identical;
  *   HMC only: 3 = the lane-group mapping with the gradient on the matrix cores (16 chains per wave, four lanes per
- *   chain, v_mfma_f64_16x16x4; csrc/mm_hmc_lg.h), for f64 + MMCMC_GAUSSIAN_ND of dim 16 or 32, where it is the default
- *   (elsewhere MMCMC_ERR_UNSUPPORTED).  Like the NUTS mappings it sums the D-term dot products as four interleaved
- *   partial sums, so its samples differ from variants 0 / 2 by rounding; it is bit-exact against its own host build
- *   (oracle/engine_host.cpp: eh_hmc_grouped_run). */
+ *   chain, v_mfma_f64_16x16x4 / v_mfma_f32_16x16x4; csrc/mm_hmc_lg.h), for MMCMC_GAUSSIAN_ND of dim 16 or 32 in f64 and
+ *   f32, where it is the default (elsewhere MMCMC_ERR_UNSUPPORTED).  Like the NUTS mappings it sums the D-term dot
+ *   products as four partial sums (f64: interleaved coordinates, f32: blocks of four), so its samples differ from
+ *   variants 0 / 2 by rounding; it is bit-exact against its own host build (oracle/engine_host.cpp:
+ *   eh_hmc_grouped_run, eh_hmc_grouped_run_f32). */
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters);
 int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters);
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant);

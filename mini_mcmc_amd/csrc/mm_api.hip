@@ -190,8 +190,12 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         delete s;
         return MMCMC_ERR_UNSUPPORTED;
     }
-    /* dense f64 Gaussian at dim 16 / 32 under HMC: the lane-group / MFMA kernel, and the default there */
-    s->lg_ok = sampler == MM_SAMPLER_HMC && dtype == MMCMC_F64 && s->kind == MMCMC_GAUSSIAN_ND && (s->dim == 16 || s->dim == 32);
+    /* dense Gaussian at dim 16 / 32 under HMC (f64 and f32): the lane-group / MFMA kernels, and the default there */
+    s->lg_ok = sampler == MM_SAMPLER_HMC && s->kind == MMCMC_GAUSSIAN_ND && (s->dim == 16 || s->dim == 32);
+    /* at dim 32 the paired / pipelined form holds four noise vectors next to the state and spills: the plain form
+     * is twice as fast there (RosenbrockND(32) f32: 1.0 ms vs 2.2 ms for run(100, 20) of 65 536 chains) */
+    if (s->dim > 16)
+        s->variant = 0;
     if (s->lg_ok)
         s->variant = 3;
     DeviceGuard g(device);
@@ -310,7 +314,23 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
             q.n_leapfrog = s->n_leapfrog;
             e = mm_launch_hmc_lg(s->dim, q, stream);
         } else {
-            e = hipErrorInvalidValue;
+            mm_hmc_lg32_args q;
+            q.mat = (const float *)s->d_mat;
+            q.state = (float *)s->d_state;
+            q.out = (float *)d_out;
+            q.accept = a.accept;
+            q.accept_total = a.accept_total;
+            q.n_chains = a.n_chains;
+            q.seed = a.seed;
+            q.chain_offset = a.chain_offset;
+            q.n_total = n_total;
+            q.iter0 = a.iter0;
+            q.n_discard = n_discard;
+            q.n_collect = n_collect;
+            q.out_t0 = out_t0;
+            q.eps = s->scale;
+            q.n_leapfrog = s->n_leapfrog;
+            e = mm_launch_hmc_lg32(s->dim, q, stream);
         }
     } else if (s->variant != 0)
         e = mh ? k->run_mh_pp(a, grid, s->block, stream)

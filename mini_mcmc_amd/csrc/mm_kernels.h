@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         T za[D], zb[D], lna, lnb;
         mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
         unsigned int n_acc32 = 0;
-        auto transition = [&](T *z, T ln_u) {
+        /* every lambda here MUST be inlined: an out-of-line call that captures x / g / lp by reference pins them (and the
+         * kernel arguments) in scratch memory for the whole kernel -- what the compiler did for the larger targets */
+        auto transition = [&](T *z, T ln_u) __attribute__((always_inline)) {
             int acc;
             if (SAMPLER == MM_SAMPLER_HMC)
                 acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u);
@@ -287,65 +289,68 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
             n_acc32 += (unsigned int)acc;
             wave_acc += (unsigned long long)__popcll(__ballot(acc));
         };
-        auto shift = [&](const T *zna, const T *znb, T lnna, T lnnb) {
-            MM_UNROLL
-            for (int i = 0; i < D; ++i) {
-                za[i] = zna[i];
-                zb[i] = znb[i];
-            }
-            lna = lnna;
-            lnb = lnnb;
-            it += 2u;
-        };
+        /* An odd count ends with half a pair: the second transition of the last pair is handed ln u = NaN, against which
+         * both accept rules (`>`, `>=`) are false, so it leaves state and counters alone; then the noise is drawn afresh
+         * for (it + 1, it + 2).  One pair loop, two inlined transitions, no tail code. */
+        const T never = (T)NAN;
         /* n transitions without output */
-        auto silent = [&](unsigned int n) {
-            for (unsigned int i = 0; i + 1 < n; i += 2) {
+        auto silent = [&](unsigned int n) __attribute__((always_inline)) {
+            for (unsigned int i = 0; i < n; i += 2) {
                 T zna[D], znb[D], lnna, lnnb;
                 mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
                 transition(za, lna);
-                transition(zb, lnb);
-                shift(zna, znb, lnna, lnnb);
+                transition(zb, (i + 1 < n) ? lnb : never);
+                MM_UNROLL
+                for (int k = 0; k < D; ++k) {
+                    za[k] = zna[k];
+                    zb[k] = znb[k];
+                }
+                lna = lnna;
+                lnb = lnnb;
+                it += 2u;
             }
             if (n & 1u) {
-                transition(za, lna);
-                it += 1u;
+                it -= 1u;
                 mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
             }
         };
-        silent(a.n_discard);
+        silent(a.n_discard + (a.out ? 0u : a.n_collect));
         if (a.out) {
             T *const row = tile + lane * STRIDE;
             for (unsigned int rows_out = 0; rows_out < a.n_collect;) {
                 const unsigned int nt = min((unsigned int)TILE_T, a.n_collect - rows_out);
                 T *dst = row;
-                for (unsigned int i = 0; i + 1 < nt; i += 2) {
+                for (unsigned int i = 0; i < nt; i += 2) {
                     T zna[D], znb[D], lnna, lnnb;
                     mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
                     transition(za, lna);
                     MM_UNROLL
                     for (int k = 0; k < D; ++k)
                         dst[k] = x[k];
-                    transition(zb, lnb);
-                    MM_UNROLL
-                    for (int k = 0; k < D; ++k)
-                        dst[D + k] = x[k];
+                    transition(zb, (i + 1 < nt) ? lnb : never);
+                    if (TILE_T % 2 == 0 || i + 1 < nt) { /* row nt of an odd tile: inside an even TILE_T, never flushed */
+                        MM_UNROLL
+                        for (int k = 0; k < D; ++k)
+                            dst[D + k] = x[k];
+                    }
                     dst += 2 * D;
-                    shift(zna, znb, lnna, lnnb);
+                    MM_UNROLL
+                    for (int k = 0; k < D; ++k) {
+                        za[k] = zna[k];
+                        zb[k] = znb[k];
+                    }
+                    lna = lnna;
+                    lnb = lnnb;
+                    it += 2u;
                 }
                 if (nt & 1u) {
-                    transition(za, lna);
-                    MM_UNROLL
-                    for (int k = 0; k < D; ++k)
-                        dst[k] = x[k];
-                    it += 1u;
+                    it -= 1u;
                     if (rows_out + nt < a.n_collect)
                         mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
                 }
                 mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, nt);
                 rows_out += nt;
             }
-        } else {
-            silent(a.n_collect);
         }
         n_acc += n_acc32;
     } else {

@@ -32,3 +32,15 @@ hipError_t mm_launch_hmc_lg(int dim, const mm_hmc_lg_args &a, hipStream_t stream
         return hipErrorInvalidValue;
     return hipGetLastError();
 }
+
+hipError_t mm_launch_hmc_lg32(int dim, const mm_hmc_lg32_args &a, hipStream_t stream)
+{
+    const unsigned int grid = (unsigned int)((a.n_chains + 15) / 16);
+    if (dim == 16)
+        hipLaunchKernelGGL((mm_hmc_lg32_kernel<16>), dim3(grid), dim3(64), 0, stream, a);
+    else if (dim == 32)
+        hipLaunchKernelGGL((mm_hmc_lg32_kernel<32>), dim3(grid), dim3(64), 0, stream, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

@@ -312,4 +312,51 @@ template <class T, int D> struct mm_target_gnd_grp4 {
 };
 
 
+/* The f32 lane-group kernel (mm_hmc_lg.h) on v_mfma_f32_16x16x4_f32: the matrix instruction returns its 16 x 16 result in
+ * row blocks (lane group q holds rows 4 q .. 4 q + 3 of a tile), so lane q of a chain owns the coordinates
+ * coord(q, s) = 16 (s >> 2) + 4 q + (s & 3), s = 0 .. D/4 - 1.  Two consequences for the order of sums, which the host
+ * twin reproduces:
+ *   mm_red_blk4:        partial sum c_q over the coordinates i with (i >> 2) & 3 == q, ascending; total (c0 + c1) + (c2 + c3)
+ *   mm_target_gnd_blk4: row i of A x is the fma chain over the columns in k-step order -- step s takes the columns
+ *                       coord(0, s), coord(1, s), coord(2, s), coord(3, s) (tools/mfma_f32_check.hip: the hardware's
+ *                       accumulation is exactly this chain). */
+MM_HD int mm_blk4_coord(int q, int s) { return 16 * (s >> 2) + 4 * q + (s & 3); }
+template <class TT, int D> struct mm_red_blk4 {
+    MM_HD static TT dot(const TT *a, const TT *b)
+    {
+        TT c[4] = {0, 0, 0, 0};
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            c[(i >> 2) & 3] = mm_fma(a[i], b[i], c[(i >> 2) & 3]);
+        return (c[0] + c[1]) + (c[2] + c[3]);
+    }
+};
+template <class T, int D> struct mm_target_gnd_blk4 {
+    static constexpr int dim = D;
+    MM_HD static T logp_grad(const mm_tparams<T> &P, const T *x, T *g)
+    {
+        T y[D];
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            T acc = 0;
+            MM_UNROLL
+            for (int s = 0; s < D / 4; ++s) {
+                MM_UNROLL
+                for (int k = 0; k < 4; ++k) {
+                    const int j = mm_blk4_coord(k, s);
+                    acc = mm_fma(P.mat[i * D + j], x[j], acc);
+                }
+            }
+            y[i] = acc;
+            g[i] = -acc;
+        }
+        return T(-0.5) * mm_red_blk4<T, D>::dot(x, y);
+    }
+    MM_HD static T logp(const mm_tparams<T> &P, const T *x)
+    {
+        T g[D];
+        return logp_grad(P, x, g);
+    }
+};
+
 #endif /* MM_TARGETS_H */

@@ -429,6 +429,48 @@ static void hmc_grouped(const double *mat, double eps, int L, double *state, siz
     }
 }
 
+/* the f32 twin (mm_hmc_lg32_kernel): blocked ownership of the coordinates, see mm_targets.h */
+template <int D>
+static void hmc_grouped_f32(const float *mat, float eps, int L, float *state, size_t n, uint64_t seed, uint64_t off,
+                            uint32_t it0, size_t nc, size_t nd, float *out, uint64_t *acc)
+{
+    using Tgt = mm_target_gnd_blk4<float, D>;
+    using Red = mm_red_blk4<float, D>;
+    mm_tparams<float> P;
+    P.mat = mat;
+    for (size_t c = 0; c < n; ++c) {
+        float x[D], g[D], p[D], u;
+        for (int i = 0; i < D; ++i)
+            x[i] = state[c * D + i];
+        float lp = Tgt::logp_grad(P, x, g);
+        uint64_t a = 0;
+        for (size_t t = 0; t < nc + nd; ++t) {
+            mm_draw_noise<D>(seed, off + c, it0 + (uint32_t)t, p, &u);
+            a += (uint64_t)mm_hmc_step_noise<float, Tgt, 0, Red>(P, eps, L, x, &lp, g, p, mm_logf(u));
+            if (t >= nd && out)
+                for (int i = 0; i < D; ++i)
+                    out[(c * nc + (t - nd)) * D + i] = x[i];
+        }
+        for (int i = 0; i < D; ++i)
+            state[c * D + i] = x[i];
+        if (acc)
+            acc[c] = a;
+    }
+}
+
+extern "C" int eh_hmc_grouped_run_f32(int dim, const float *matrix, float eps, int n_leapfrog, float *state, size_t n_chains,
+                                      uint64_t seed, uint64_t chain_offset, uint32_t iter0, size_t n_collect,
+                                      size_t n_discard, float *out, uint64_t *accept)
+{
+    if (dim == 16)
+        hmc_grouped_f32<16>(matrix, eps, n_leapfrog, state, n_chains, seed, chain_offset, iter0, n_collect, n_discard, out, accept);
+    else if (dim == 32)
+        hmc_grouped_f32<32>(matrix, eps, n_leapfrog, state, n_chains, seed, chain_offset, iter0, n_collect, n_discard, out, accept);
+    else
+        return -2;
+    return 0;
+}
+
 extern "C" int eh_hmc_grouped_run(int dim, const double *matrix, double eps, int n_leapfrog, double *state, size_t n_chains,
                                   uint64_t seed, uint64_t chain_offset, uint32_t iter0, size_t n_collect, size_t n_discard,
                                   double *out, uint64_t *accept)

@@ -579,6 +579,9 @@ def engine_host_lib() -> C.CDLL:
     E.eh_hmc_grouped_run.restype = C.c_int
     E.eh_hmc_grouped_run.argtypes = [C.c_int, _dp, C.c_double, C.c_int, _dp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32,
                                      C.c_size_t, C.c_size_t, _dp, _u64p]
+    E.eh_hmc_grouped_run_f32.restype = C.c_int
+    E.eh_hmc_grouped_run_f32.argtypes = [C.c_int, _fp, C.c_float, C.c_int, _fp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32,
+                                         C.c_size_t, C.c_size_t, _fp, _u64p]
     E.eh_logp_grad.restype = C.c_int
     E.eh_logp_grad.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     _eh = E
@@ -757,6 +760,21 @@ def engine_host_hmc_grouped_run(matrix, init, eps, n_leapfrog, n_collect, n_disc
     acc = np.zeros(n, dtype=np.uint64)
     rc = E.eh_hmc_grouped_run(d, _d(m), float(eps), int(n_leapfrog), _d(st), n, int(seed), int(chain_offset), int(iter0),
                               n_collect, n_discard, _d(out), acc.ctypes.data_as(_u64p))
+    assert rc == 0
+    return out, st, acc
+
+
+def engine_host_hmc_grouped_run_f32(matrix, init, eps, n_leapfrog, n_collect, n_discard, seed=0, chain_offset=0, iter0=0):
+    """The f32 lane-group kernel's twin (blocked coordinate ownership, mm_targets.h): (samples, states, accepts)."""
+    E = engine_host_lib()
+    m = np.ascontiguousarray(matrix, dtype=np.float32)
+    st = np.ascontiguousarray(init, dtype=np.float32).copy()
+    n, d = st.shape
+    out = np.zeros((n, n_collect, d), dtype=np.float32)
+    acc = np.zeros(n, dtype=np.uint64)
+    rc = E.eh_hmc_grouped_run_f32(d, m.ctypes.data_as(_fp), C.c_float(eps), int(n_leapfrog), st.ctypes.data_as(_fp), n,
+                                  int(seed), int(chain_offset), int(iter0), n_collect, n_discard,
+                                  out.ctypes.data_as(_fp), acc.ctypes.data_as(_u64p))
     assert rc == 0
     return out, st, acc
 

@@ -80,7 +80,7 @@ def test_logp_grad_bit_exact_and_close_to_reference_order(M, O, dtype):
 # ---------------------------------------------------------------- samplers, bit exact
 
 
-def _run_pair(M, O, sampler, tgt, kind, params, init, scale, nc, nd, seed, L=0, mat=None, offset=0, ipl=0):
+def _run_pair(M, O, sampler, tgt, kind, params, init, scale, nc, nd, seed, L=0, mat=None, offset=0, ipl=0, variant=None):
     dtype = init.dtype.type
     if sampler == "mh":
         s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(scale), init).seed(seed)
@@ -90,6 +90,8 @@ def _run_pair(M, O, sampler, tgt, kind, params, init, scale, nc, nd, seed, L=0, 
         s.set_chain_offset(offset)
     if ipl:
         s.set_iters_per_launch(ipl)
+    if variant is not None:
+        s.set_kernel_variant(variant)
     out = s.run(nc, nd)
     ref, ref_state, ref_acc = O.engine_host_run(sampler, kind, tgt.dim, params, init, scale, nc, nd, seed=seed,
                                                 chain_offset=offset, n_leapfrog=L, matrix=mat, dtype=dtype)
@@ -145,7 +147,13 @@ def test_other_targets_and_dims_bit_exact(M, O):
     for sampler, tgt, kind, params, mat, scale, L in cases:
         for dtype in (np.float32, np.float64):
             init = M.core.init_with_seed(70, tgt.dim, 7, dtype)
-            s, out, ref, ref_state, ref_acc = _run_pair(M, O, sampler, tgt, kind, params, init, scale, 37, 4, 99, L=L, mat=mat)
+            # HMC on the dense Gaussian at dim 16 / 32 defaults to the lane-group kernels, which have their own twins
+            # (test_hmc_lane_group_*): here the one-chain-per-lane kernels, both forms
+            variants = (2, 0) if (sampler == "hmc" and kind == O.GAUSSIAN_ND and tgt.dim >= 16) else (None,)
+            for variant in variants:
+                s, out, ref, ref_state, ref_acc = _run_pair(M, O, sampler, tgt, kind, params, init, scale, 37, 4, 99, L=L,
+                                                            mat=mat, variant=variant)
+                assert np.array_equal(out, ref), (sampler, type(tgt).__name__, tgt.dim, dtype.__name__, variant)
             name = f"{sampler} {type(tgt).__name__} D={tgt.dim} {dtype.__name__}"
             assert np.array_equal(out, ref), name
             assert np.array_equal(s.accept_counts, ref_acc), name
@@ -488,6 +496,38 @@ def test_nuts_asynchronous_lanes_equal_synchronous_lanes(M, O, mode):
         assert np.array_equal(res[4][0], ref), name
     with pytest.raises(Exception):  # no asynchronous-lane instance above dim 8
         NUTS(M.dist.GaussianND.ill_conditioned(16, 10.0, 1), M.core.init_with_seed(8, 16, 1), 0.8, mode=1).set_kernel_variant(4)
+
+
+def test_hmc_lane_group_mfma_f32_bit_exact_vs_host_twin(M, O):
+    """The f32 lane-group kernel (mm_hmc_lg.h, second half: v_mfma_f32_16x16x4_f32, lane (c, q) owning the coordinates
+    16 (s >> 2) + 4 q + (s & 3)) against its host twin (blocked reduction order, columns of A x in k-step order), bit for
+    bit: samples, states, accept counts, a continued handle, ragged chain counts, a chain offset beyond 2^32; and
+    against the one-chain-per-lane kernel to rounding."""
+    for dim, cond, C, nc, nd, L, eps, off in ((32, 100.0, 70, 40, 9, 10, 0.05, 0), (32, 1e3, 33, 17, 0, 7, 0.02, 1 << 33),
+                                              (16, 50.0, 100, 25, 5, 10, 0.1, 0), (16, 10.0, 16, 3, 2, 1, 0.2, 5)):
+        g = M.dist.GaussianND.ill_conditioned(dim, cond, 7)
+        init = M.core.init_with_seed(C, dim, 3, np.float32) * np.float32(0.3)
+        s = M.hmc.HMC(g, init, eps, L).set_seed(19)
+        assert s.kernel_variant == 3  # the default where it exists
+        if off:
+            s.set_chain_offset(off)
+        out = s.run(nc, nd)
+        ref, st, acc = O.engine_host_hmc_grouped_run_f32(g.precision, init, eps, L, nc, nd, seed=19, chain_offset=off)
+        name = f"f32 D={dim} cond={cond} C={C}"
+        assert out.dtype == np.float32 and np.array_equal(out, ref) and np.array_equal(s.state(), st), name
+        assert np.array_equal(s.accept_counts, acc), name
+        out2 = s.run(6, 1)  # continues the chains and the stream
+        ref2, _, acc2 = O.engine_host_hmc_grouped_run_f32(g.precision, st, eps, L, 6, 1, seed=19, chain_offset=off, iter0=nc + nd)
+        assert np.array_equal(out2, ref2) and np.array_equal(s.accept_counts, acc2), name
+        a3 = M.hmc.HMC(g, init, eps, L).set_seed(19).set_chain_offset(off).run(2, 0)
+        a2 = M.hmc.HMC(g, init, eps, L).set_seed(19).set_chain_offset(off).set_kernel_variant(2).run(2, 0)
+        np.testing.assert_allclose(a3, a2, rtol=2e-3, atol=2e-4)  # same transitions, other summation order, f32
+    # posterior: whitened draws have unit covariance (32-D, cond 100, 4096 chains)
+    g = M.dist.GaussianND.ill_conditioned(32, 100.0, 5)
+    s = M.hmc.HMC(g, M.core.init_with_seed(4096, 32, 4, np.float32) * np.float32(0.1), 0.08, 10).set_seed(6)
+    smp = s.run(50, 150).reshape(-1, 32).astype(np.float64)
+    w = smp @ np.linalg.cholesky(g.precision)
+    assert np.abs(w.mean(axis=0)).max() < 0.03 and np.abs(np.cov(w.T) - np.eye(32)).max() < 0.05
 
 
 def test_nuts_asynchronous_lanes_at_full_size(M, O):
