@@ -159,6 +159,26 @@ def test_other_targets_and_dims_bit_exact(M, O):
             assert np.array_equal(s.accept_counts, ref_acc), name
 
 
+@pytest.mark.parametrize("nc,nd", [(0, 7), (5, 0), (6, 3), (9, 4), (33, 32), (1, 1)])
+def test_runs_without_output_leave_the_same_state(M, O, nc, nd):
+    """run(collect=False) takes the branch-free burn-in loop for all nc + nd transitions (odd totals end with a half pair
+    whose second transition is masked): final states and accept counts equal the collecting run's and the host build's."""
+    init = M.core.init_with_seed(130, 3, 11, np.float32)
+    for make in (lambda: M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(5),
+                 lambda: M.mh.MetropolisHastings(M.dist.RosenbrockND(3), M.dist.IsotropicGaussian(0.1), init).seed(5)):
+        a = make()
+        a.run(nc, nd, collect=False)
+        b = make()
+        out = b.run(nc, nd)
+        assert np.array_equal(a.state(), b.state()) and np.array_equal(a.accept_counts, b.accept_counts)
+        if nc:
+            assert np.array_equal(out[:, -1, :], b.state())
+    ref, ref_state, ref_acc = O.engine_host_run("hmc", O.ROSENBROCK_ND, 3, [], init, 0.032, nc, nd, seed=5, n_leapfrog=10)
+    h = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(5)
+    h.run(nc, nd, collect=False)
+    assert np.array_equal(h.state(), ref_state) and np.array_equal(h.accept_counts, ref_acc)
+
+
 def test_results_independent_of_launch_partition_and_sharding(M, O):
     # the stream is keyed by (seed, GLOBAL chain id, iteration): splitting the run over launches, continuing a
     # handle, or sharding chains over handles (= GPUs) must not change a single bit
