@@ -172,16 +172,6 @@ MM_HD mm_f2 mm_fma2(mm_f2 a, mm_f2 b, mm_f2 c)
     return r;
 #endif
 }
-MM_HD mm_f2 mm_rint2(mm_f2 a)
-{
-    mm_f2 r = {rintf(a[0]), rintf(a[1])};
-    return r;
-}
-MM_HD mm_f2 mm_sqrt2(mm_f2 a)
-{
-    mm_f2 r = {sqrtf(a[0]), sqrtf(a[1])};
-    return r;
-}
 MM_HD mm_u2 mm_f2_bits(mm_f2 a)
 {
     mm_u2 r;
@@ -196,7 +186,6 @@ MM_HD mm_f2 mm_bits_f2(mm_u2 a)
 }
 MM_HD mm_f2 mm_i2_to_f2(mm_i2 a) { return __builtin_convertvector(a, mm_f2); }
 MM_HD mm_f2 mm_u2_to_f2(mm_u2 a) { return __builtin_convertvector(a, mm_f2); }
-MM_HD mm_i2 mm_f2_to_i2(mm_f2 a) { return __builtin_convertvector(a, mm_i2); }
 /* select on a comparison mask (all-ones / all-zeros lanes) */
 MM_HD mm_f2 mm_sel2(mm_i2 mask, mm_f2 a, mm_f2 b)
 {
@@ -230,35 +219,6 @@ MM_HD mm_f2 mm_logf2(mm_f2 x)
     y = mm_fma2(mm_splat2(-0.5f), z, y);
     mm_f2 r = f + y;
     return mm_fma2(fe, mm_splat2(0.693359375f), r);
-}
-
-/* == mm_sincos2pif, lane by lane */
-MM_HD void mm_sincos2pif2(mm_f2 u, mm_f2 *s, mm_f2 *c)
-{
-    mm_f2 t = u * mm_splat2(4.0f);
-    mm_f2 qf = mm_rint2(t);
-    mm_f2 r = t - qf;
-    mm_f2 y = r * mm_splat2(1.57079632679489662f);
-    mm_f2 y2 = y * y;
-    mm_f2 sp = mm_splat2(2.7557313707e-6f);
-    sp = mm_fma2(sp, y2, mm_splat2(-1.9841269841e-4f));
-    sp = mm_fma2(sp, y2, mm_splat2(8.3333333333e-3f));
-    sp = mm_fma2(sp, y2, mm_splat2(-1.6666666667e-1f));
-    mm_f2 sy = mm_fma2(sp * y2, y, y);
-    mm_f2 cp = mm_splat2(-2.7557319224e-7f);
-    cp = mm_fma2(cp, y2, mm_splat2(2.4801587302e-5f));
-    cp = mm_fma2(cp, y2, mm_splat2(-1.3888888889e-3f));
-    cp = mm_fma2(cp, y2, mm_splat2(4.1666666667e-2f));
-    cp = mm_fma2(cp, y2, mm_splat2(-0.5f));
-    mm_f2 cy = mm_fma2(cp, y2, mm_splat2(1.0f));
-    mm_i2 q = mm_f2_to_i2(qf) & 3;
-    mm_i2 odd = (q & 1) != 0;
-    mm_f2 ss = mm_sel2(odd, cy, sy);
-    mm_f2 cc = mm_sel2(odd, sy, cy);
-    mm_i2 negc = (q == 1) | (q == 2);
-    mm_i2 negs = q >= 2;
-    *c = mm_sel2(negc, -cc, cc);
-    *s = mm_sel2(negs, -ss, ss);
 }
 
 /* ------------------------------------------------------------------ f64 */

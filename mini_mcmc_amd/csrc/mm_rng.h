@@ -12,7 +12,6 @@
  *
  * Draw schedule (normative; oracle/philox_stream.c restates it independently in plain C):
  *   counter = { chain & 0xffffffff, chain >> 32, iteration, block },  key = { seed & 0xffffffff, seed >> 32 }
- *   u24(w)       = (float)((w >> 8) + 1) * 2^-24                      in (0,1]
  *   u53(hi, lo)  = (double)((((u64)hi << 21) | (lo >> 11)) + 1) * 2^-53   in (0,1]
  *   f32 block b: words w0..w3
  *       normals z[4b+i] = icdf24(w_i), i = 0..3: one normal per word by inversion of the normal CDF on a 2^24-point
@@ -140,8 +139,6 @@ MM_HD mm_u32x4 mm_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint3
                             (uint32_t)(seed >> 32));
 }
 
-MM_HD float mm_u24(uint32_t w) { return (float)((w >> 8) + 1u) * 0x1.0p-24f; }
-
 MM_HD float mm_spare_u24(mm_u32x4 b)
 {
     uint32_t s = (b.w[0] & 255u) | ((b.w[1] & 255u) << 8) | ((b.w[2] & 255u) << 16);
@@ -161,12 +158,6 @@ MM_HD void mm_box_muller_f64(double u1, double u2, double *z0, double *z1)
     mm_sincos2pi(u2, &s, &c);
     *z0 = r * c;
     *z1 = r * s;
-}
-
-/* two f64 normals of one block */
-MM_HD void mm_normals2_f64(mm_u32x4 b, double z[2])
-{
-    mm_box_muller_f64(mm_u53(b.w[0], b.w[1]), mm_u53(b.w[2], b.w[3]), &z[0], &z[1]);
 }
 
 /* ---- two iterations at a time (f32): lane 0 = (chain, iteration), lane 1 = (chain, iteration + 1) ----
@@ -230,8 +221,6 @@ MM_HD mm_u32x4x2 mm_block_pair(uint64_t seed, uint64_t chain, uint32_t iteration
         mm_philox_pair_round(s);
     return mm_philox_pair_words(s);
 }
-
-MM_HD mm_f2 mm_u24x2(mm_u2 w) { return mm_u2_to_f2((w >> 8) + 1u) * mm_splat2(0x1.0p-24f); }
 
 MM_HD mm_f2 mm_spare_u24x2(mm_u32x4x2 b)
 {
