@@ -232,7 +232,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_hmc_lg32_kernel(const 
         const float kp = mm_lg32_dot<NS>(p, p);
         const float h_proposed = kp * 0.5f - lpn;
         const float accept_logp = h_current - h_proposed;
-        const bool acc = accept_logp >= mm_logf(u); /* hmc.rs:367 `>=`; NaN rejects */
+        const bool acc = accept_logp >= mm_lnu_f32(u, tab); /* hmc.rs:367 `>=`; NaN rejects */
         if (acc) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {

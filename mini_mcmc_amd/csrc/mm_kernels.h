@@ -60,8 +60,8 @@ template <class T, int D> struct mm_tile {
     static constexpr int epl = 16 / (int)sizeof(T);
     static constexpr int stride = (run % epl) == 0 ? run + epl : (run | 1);
     static constexpr size_t lds_bytes_per_wave = (size_t)64 * stride * sizeof(T);
-    /* f32 kernels keep the normal draw's table (mm_rng.h) in LDS, once per block, in front of the tiles */
-    static constexpr size_t lds_bytes_table = (sizeof(T) == 4) ? (size_t)MM_ICDF_ROWS * 16 : 0;
+    /* f32 kernels keep the tables of the normal draw and of ln u (mm_rng.h) in LDS, once per block, before the tiles */
+    static constexpr size_t lds_bytes_table = (sizeof(T) == 4) ? (size_t)MM_NOISE_TABLE_BYTES : 0;
 };
 
 /* Write the staged tile of one wave to `out`: for each of the wave's 64 chains one contiguous run of nt*D elements
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
     if (PIPE) {
         T u;
         mm_draw_noise<D>(a.seed, chain, it, zc, &u, tab);
-        ln_uc = mm_logT(u);
+        ln_uc = mm_ln_accept(u, tab);
     }
 
     auto step = [&]() {
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         if (PIPE) {
             T zn[D], un;
             mm_draw_noise<D>(a.seed, chain, it + 1, zn, &un, tab);
-            const T ln_un = mm_logT(un);
+            const T ln_un = mm_ln_accept(un, tab);
             if (SAMPLER == MM_SAMPLER_HMC)
                 acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, zc, ln_uc);
             else

@@ -148,11 +148,10 @@ MM_HD void mm_sincos2pif(float u, float *s, float *c)
 /* ------------------------------------------------------------------ f32, two lanes at a time
  *
  * A dependent chain of scalar VALU instructions issues one instruction per ~5 cycles on gfx950, a packed
- * instruction (v_pk_fma_f32, ...) processes two elements in the same time (tools/valu_rate.hip), so functions whose
- * inputs come in independent pairs are also provided on 2-element vectors.  Element k of every result is computed
- * by EXACTLY the operations of the scalar function above (same constants, same order, same fused operations), so
- * mm_logf2(x)[k] == mm_logf(x[k]) bit for bit -- tests/test_engine_stream.py checks this on the host and the GPU
- * parity tests check it on the device.  GCC vector extensions: accepted by g++ (host build) and clang (hipcc). */
+ * instruction (v_pk_fma_f32, ...) processes two elements in the same time (tools/valu_rate.hip): the two-element
+ * vector types and the few helpers on them that the kernels use (Philox pair, RosenbrockND gradient).  Element k of
+ * every result is computed by EXACTLY the scalar operations.  GCC vector extensions: accepted by g++ (host build) and
+ * clang (hipcc). */
 typedef float mm_f2 __attribute__((vector_size(8)));
 typedef int32_t mm_i2 __attribute__((vector_size(8)));
 typedef uint32_t mm_u2 __attribute__((vector_size(8)));
@@ -172,55 +171,7 @@ MM_HD mm_f2 mm_fma2(mm_f2 a, mm_f2 b, mm_f2 c)
     return r;
 #endif
 }
-MM_HD mm_u2 mm_f2_bits(mm_f2 a)
-{
-    mm_u2 r;
-    memcpy(&r, &a, 8);
-    return r;
-}
-MM_HD mm_f2 mm_bits_f2(mm_u2 a)
-{
-    mm_f2 r;
-    memcpy(&r, &a, 8);
-    return r;
-}
-MM_HD mm_f2 mm_i2_to_f2(mm_i2 a) { return __builtin_convertvector(a, mm_f2); }
 MM_HD mm_f2 mm_u2_to_f2(mm_u2 a) { return __builtin_convertvector(a, mm_f2); }
-/* select on a comparison mask (all-ones / all-zeros lanes) */
-MM_HD mm_f2 mm_sel2(mm_i2 mask, mm_f2 a, mm_f2 b)
-{
-    mm_u2 m = (mm_u2)mask;
-    return mm_bits_f2((mm_f2_bits(a) & m) | (mm_f2_bits(b) & ~m));
-}
-
-/* == mm_logf, lane by lane */
-MM_HD mm_f2 mm_logf2(mm_f2 x)
-{
-    mm_u2 ix = mm_f2_bits(x);
-    mm_i2 e = (mm_i2)(ix >> 23) - 127;
-    mm_f2 m = mm_bits_f2((ix & 0x007fffffu) | 0x3f800000u);
-    mm_i2 big = m > mm_splat2(1.41421356237f);
-    m = mm_sel2(big, m * mm_splat2(0.5f), m);
-    e = e - big; /* big lanes are -1 */
-    mm_f2 f = m - mm_splat2(1.0f);
-    mm_f2 z = f * f;
-    mm_f2 p = mm_splat2(7.0376836292e-2f);
-    p = mm_fma2(p, f, mm_splat2(-1.1514610310e-1f));
-    p = mm_fma2(p, f, mm_splat2(1.1676998740e-1f));
-    p = mm_fma2(p, f, mm_splat2(-1.2420140846e-1f));
-    p = mm_fma2(p, f, mm_splat2(1.4249322787e-1f));
-    p = mm_fma2(p, f, mm_splat2(-1.6668057665e-1f));
-    p = mm_fma2(p, f, mm_splat2(2.0000714765e-1f));
-    p = mm_fma2(p, f, mm_splat2(-2.4999993993e-1f));
-    p = mm_fma2(p, f, mm_splat2(3.3333331174e-1f));
-    mm_f2 fe = mm_i2_to_f2(e);
-    mm_f2 y = (p * f) * z;
-    y = mm_fma2(fe, mm_splat2(-2.12194440e-4f), y);
-    y = mm_fma2(mm_splat2(-0.5f), z, y);
-    mm_f2 r = f + y;
-    return mm_fma2(fe, mm_splat2(0.693359375f), r);
-}
-
 /* ------------------------------------------------------------------ f64 */
 
 /* natural log, normal positive finite x. fdlibm-style: s = f/(2+f), odd polynomial in s, ~1 ulp. */

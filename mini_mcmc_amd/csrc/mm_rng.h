@@ -19,7 +19,8 @@
  *                                 z = sign * -Phi^-1(n 2^-25), with -Phi^-1 the piecewise cubic of mm_icdf_table.h
  *                                 (16 segments per binade of n, |error| <= 1.2e-7 max(1, |z|); |z| <= 5.42)
  *       spare uniform           = u24-style from the low bytes: s = (w0&255) | (w1&255)<<8 | (w2&255)<<16,
- *                                 (float)(s + 1) * 2^-24
+ *                                 (float)(s + 1) * 2^-24;  its logarithm (the accept rules compare with ln u) is
+ *                                 mm_lnu_f32: exponent * ln 2 + a cubic in the mantissa on 32 segments
  *   f64 block b: z[2b+0], z[2b+1] = box_muller(u53(w0,w1), u53(w2,w3))
  *   box_muller(u1, u2) = ( r cos(2 pi u2), r sin(2 pi u2) ),  r = sqrt(-2 ln u1)
  *   (f32 normals were Box-Muller pairs too until the inversion table replaced them: ~13 instructions and one 16-byte
@@ -44,8 +45,10 @@
  * (mm_icdf_lds).  `Tab` only says where row r is read from; the arithmetic is the same everywhere. */
 typedef float mm_v4f __attribute__((vector_size(16)));
 static const float mm_icdf_tab_h[MM_ICDF_ROWS * 4] __attribute__((aligned(16))) = MM_ICDF_COEFFS;
+static const float mm_lnm_tab_h[MM_LNM_ROWS * 4] __attribute__((aligned(16))) = MM_LNM_COEFFS;
 #if defined(__HIPCC__)
 static __device__ const float mm_icdf_tab_d[MM_ICDF_ROWS * 4] __attribute__((aligned(16))) = MM_ICDF_COEFFS;
+static __device__ const float mm_lnm_tab_d[MM_LNM_ROWS * 4] __attribute__((aligned(16))) = MM_LNM_COEFFS;
 #endif
 
 struct mm_icdf_global {
@@ -61,15 +64,35 @@ struct mm_icdf_global {
         c[2] = v[2];
         c[3] = v[3];
     }
+    MM_HD void row_ln(uint32_t r, float *c) const /* the logarithm's table (mm_lnu_f32) */
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const mm_v4f v = *reinterpret_cast<const mm_v4f *>(mm_lnm_tab_d + 4 * r);
+#else
+        const mm_v4f v = *reinterpret_cast<const mm_v4f *>(mm_lnm_tab_h + 4 * r);
+#endif
+        c[0] = v[0];
+        c[1] = v[1];
+        c[2] = v[2];
+        c[3] = v[3];
+    }
 };
 
 #if defined(__HIPCC__)
 typedef __attribute__((address_space(3))) const mm_v4f *mm_lds_f4_ptr;
 struct mm_icdf_lds {
-    mm_lds_f4_ptr tab; /* MM_ICDF_ROWS rows, filled by mm_icdf_lds_fill */
+    mm_lds_f4_ptr tab; /* MM_ICDF_ROWS rows of the normal's table, then MM_LNM_ROWS of the logarithm's (mm_icdf_lds_fill) */
     __device__ __forceinline__ void row(uint32_t r, float *c) const
     {
         const mm_v4f v = tab[r];
+        c[0] = v[0];
+        c[1] = v[1];
+        c[2] = v[2];
+        c[3] = v[3];
+    }
+    __device__ __forceinline__ void row_ln(uint32_t r, float *c) const
+    {
+        const mm_v4f v = tab[MM_ICDF_ROWS + r];
         c[0] = v[0];
         c[1] = v[1];
         c[2] = v[2];
@@ -81,8 +104,11 @@ __device__ __forceinline__ void mm_icdf_lds_fill(float *lds_tab, unsigned int ti
 {
     for (unsigned int i = tid; i < MM_ICDF_ROWS; i += nthreads)
         reinterpret_cast<mm_v4f *>(lds_tab)[i] = *reinterpret_cast<const mm_v4f *>(mm_icdf_tab_d + 4 * i);
+    for (unsigned int i = tid; i < MM_LNM_ROWS; i += nthreads)
+        reinterpret_cast<mm_v4f *>(lds_tab)[MM_ICDF_ROWS + i] = *reinterpret_cast<const mm_v4f *>(mm_lnm_tab_d + 4 * i);
 }
 #endif
+#define MM_NOISE_TABLE_BYTES ((MM_ICDF_ROWS + MM_LNM_ROWS) * 16)
 
 template <class Tab> MM_HD float mm_icdf_f32(uint32_t w, const Tab &tab)
 {
@@ -94,6 +120,23 @@ template <class Tab> MM_HD float mm_icdf_f32(uint32_t w, const Tab &tab)
     const float m = fmaf(fmaf(fmaf(c[3], t, c[2]), t, c[1]), t, c[0]);
     return mm_u2f((mm_f2u(m) & 0x7fffffffu) | ((w << 23) & 0x80000000u)); /* magnitude of m, sign = bit 8 of w */
 }
+
+/* ln u of the f32 accept uniform (u = (s + 1) 2^-24, any positive normal f32 works): e ln 2 + ln m with the mantissa's
+ * logarithm a cubic on 32 segments (mm_icdf_table.h); |error| <= 1e-7 max(1, |ln u|) -- far inside the accept rule's own
+ * f32 rounding -- in ~14 instructions and one table read where the polynomial mm_logf takes ~25 */
+template <class Tab> MM_HD float mm_lnu_f32(float u, const Tab &tab)
+{
+    const uint32_t b = mm_f2u(u);
+    const float e = (float)((int32_t)(b >> 23) - 127);
+    float c[4];
+    tab.row_ln((b >> 18) & 31u, c); /* top five mantissa bits */
+    const float t = mm_u2f((b & 0x3ffffu) | 0x3f800000u) - 1.0f; /* [0, 1/32), exact */
+    const float lnm = fmaf(fmaf(fmaf(c[3], t, c[2]), t, c[1]), t, c[0]);
+    return fmaf(e, 0.6931471805599453f, lnm);
+}
+/* the accept uniform's logarithm per element type: f32 the table above, f64 mm_log */
+template <class Tab> MM_HD float mm_ln_accept(float u, const Tab &tab) { return mm_lnu_f32(u, tab); }
+template <class Tab> MM_HD double mm_ln_accept(double u, const Tab &) { return mm_log(u); }
 
 typedef struct {
     uint32_t w[4];

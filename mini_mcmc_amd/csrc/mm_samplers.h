@@ -58,9 +58,8 @@ MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z
 }
 
 /* noise of (chain, iter) AND (chain, iter + 1) in one go: za/lna for iter, zb/lnb for iter + 1, ln* = log of the
- * accept uniform.  f32: the two Philox evaluations are interleaved and the logarithm is packed across the two
- * iterations (v_pk_*_f32); values are bit-identical to mm_draw_noise + mm_logT.  f64: two scalar evaluations (there
- * is no packed f64 arithmetic to gain from). */
+ * accept uniform.  f32: the two Philox evaluations are interleaved; values are bit-identical to mm_draw_noise +
+ * mm_ln_accept.  f64: two scalar evaluations (there is no packed f64 arithmetic to gain from). */
 template <int D, class Tab = mm_icdf_global>
 MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, float *za, float *lna, float *zb, float *lnb,
                               const Tab &tab = Tab())
@@ -69,9 +68,9 @@ MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, floa
     for (int b = 0; b < (D + 3) / 4; ++b) {
         mm_u32x4x2 blk = mm_block_pair(seed, chain, iter, (uint32_t)b);
         if (b == 0) {
-            mm_f2 ln = mm_logf2(mm_spare_u24x2(blk));
-            *lna = ln[0];
-            *lnb = ln[1];
+            const mm_f2 u = mm_spare_u24x2(blk);
+            *lna = mm_lnu_f32(u[0], tab);
+            *lnb = mm_lnu_f32(u[1], tab);
         }
         MM_UNROLL
         for (int i = 0; i < 4; ++i)
@@ -121,7 +120,7 @@ MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t s
     constexpr int D = Tgt::dim;
     T z[D], u;
     mm_draw_noise<D>(seed, chain, iter, z, &u);
-    return mm_mh_step_noise<T, Tgt>(P, prop_std, x, lp, z, mm_logT(u));
+    return mm_mh_step_noise<T, Tgt>(P, prop_std, x, lp, z, mm_ln_accept(u, mm_icdf_global()));
 }
 
 /* One HMC transition given its noise: p[D] ~ N(0,1) (momentum; clobbered) and ln_u.  x[D], lp = logp(x),
@@ -205,7 +204,7 @@ MM_HD int mm_hmc_step(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp
     constexpr int D = Tgt::dim;
     T p[D], u;
     mm_draw_noise<D>(seed, chain, iter, p, &u);
-    return mm_hmc_step_noise<T, Tgt>(P, eps, n_leapfrog, x, lp, g, p, mm_logT(u));
+    return mm_hmc_step_noise<T, Tgt>(P, eps, n_leapfrog, x, lp, g, p, mm_ln_accept(u, mm_icdf_global()));
 }
 
 #endif /* MM_SAMPLERS_H */

@@ -269,6 +269,15 @@ int eh_icdf24_words(const uint32_t *w, size_t n, float *out)
     return 0;
 }
 
+/* the product's logarithm of the f32 accept uniform (mm_rng.h: mm_lnu_f32), value by value */
+int eh_lnu_f32(const float *u, size_t n, float *out)
+{
+    const mm_icdf_global tab;
+    for (size_t i = 0; i < n; ++i)
+        out[i] = mm_lnu_f32(u[i], tab);
+    return 0;
+}
+
 /* noise of (chain, iteration) as the engine draws it: z [n, dim], u [n] */
 int eh_noise(int dtype, uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n, int dim, void *z, void *u)
 {
@@ -446,7 +455,7 @@ static void hmc_grouped_f32(const float *mat, float eps, int L, float *state, si
         uint64_t a = 0;
         for (size_t t = 0; t < nc + nd; ++t) {
             mm_draw_noise<D>(seed, off + c, it0 + (uint32_t)t, p, &u);
-            a += (uint64_t)mm_hmc_step_noise<float, Tgt, 0, Red>(P, eps, L, x, &lp, g, p, mm_logf(u));
+            a += (uint64_t)mm_hmc_step_noise<float, Tgt, 0, Red>(P, eps, L, x, &lp, g, p, mm_lnu_f32(u, mm_icdf_global()));
             if (t >= nd && out)
                 for (int i = 0; i < D; ++i)
                     out[(c * nc + (t - nd)) * D + i] = x[i];

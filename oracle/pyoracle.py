@@ -568,6 +568,8 @@ def engine_host_lib() -> C.CDLL:
                               C.c_uint32, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp, C.c_void_p, _u64p, C.c_int]
     E.eh_noise.restype = C.c_int
     E.eh_noise.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    E.eh_lnu_f32.restype = C.c_int
+    E.eh_lnu_f32.argtypes = [_fp, C.c_size_t, _fp]
     E.eh_icdf24_words.restype = C.c_int
     E.eh_icdf24_words.argtypes = [_u32p, C.c_size_t, _fp]
     E.eh_discrete_run.restype = C.c_int
@@ -623,6 +625,14 @@ def engine_host_noise(seed, chain_offset, iteration, n, dim, dtype=np.float32):
     if rc != 0:
         raise ValueError(f"eh_noise: {rc}")
     return z, u
+
+
+def engine_host_lnu_f32(u):
+    """The PRODUCT's ln u of the f32 accept uniform (mm_rng.h: mm_lnu_f32) compiled for the host."""
+    x = np.ascontiguousarray(u, dtype=np.float32)
+    out = np.empty(x.shape, dtype=np.float32)
+    engine_host_lib().eh_lnu_f32(x.ctypes.data_as(_fp), x.size, out.ctypes.data_as(_fp))
+    return out
 
 
 def engine_host_icdf24(words):

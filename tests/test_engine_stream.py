@@ -73,6 +73,25 @@ def test_f32_normal_is_the_inverse_cdf_on_the_whole_24_bit_lattice(O):
     assert O.engine_host_icdf24(np.array([0], dtype=np.uint32))[0] == pytest.approx(5.4201, abs=1e-3)  # the tail ends at Phi^-1(2^-25)
 
 
+def test_f32_accept_log_is_ln_u_on_all_2_24_uniforms(O):
+    """mm_lnu_f32 (exponent * ln 2 + a cubic in the mantissa on 32 segments) on EVERY accept uniform u = (s + 1) 2^-24:
+    within 1.2e-7 max(1, |ln u|) of ln u, never positive, non-decreasing up to that error, exactly 0 at u = 1."""
+    worst, prev_last = 0.0, None
+    for s0 in range(0, 1 << 24, 1 << 22):
+        s = np.arange(s0, s0 + (1 << 22), dtype=np.float64)
+        u = ((s + 1.0) * 2.0**-24).astype(np.float32)
+        got = O.engine_host_lnu_f32(u).astype(np.float64)
+        want = np.log(u.astype(np.float64))
+        worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want)))))
+        assert np.all(got <= 0.0)
+        assert np.all(np.diff(got) >= -2.5e-7 * np.maximum(1.0, np.abs(got[:-1])))
+        if prev_last is not None:
+            assert got[0] >= prev_last - 1e-6
+        prev_last = got[-1]
+    assert worst < 1.2e-7, worst
+    assert O.engine_host_lnu_f32(np.array([1.0], dtype=np.float32))[0] == 0.0
+
+
 @pytest.fixture(scope="module")
 def mmath(tmp_path_factory):
     """Host build of mm_math.h alone (the functions that DEFINE the engine's log/exp/sincos)."""
@@ -150,7 +169,8 @@ def test_mm_math_f64_accuracy(mmath):
 
 def test_paired_noise_equals_scalar_noise_bit_for_bit(tmp_path):
     """mm_draw_noise_pair (two iterations in the two lanes of packed arithmetic, Philox counters interleaved) must
-    return exactly mm_draw_noise + mm_logf of each iteration -- compiled here with g++ like the host build."""
+    return exactly mm_draw_noise + mm_lnu_f32 (f32) / mm_log (f64) of each iteration -- compiled here with g++ like the host
+    build."""
     src = tmp_path / "pair.cpp"
     src.write_text(r'''
 #include "mm_samplers.h"
@@ -163,7 +183,7 @@ template <int D> int check(uint64_t seed) {
     mm_draw_noise<D>(seed, chain * 7919u, it, z1, &u1);
     mm_draw_noise<D>(seed, chain * 7919u, it + 1, z2, &u2);
     for (int i = 0; i < D; ++i) bad += (za[i] != z1[i]) + (zb[i] != z2[i]);
-    bad += (la != mm_logf(u1)) + (lb != mm_logf(u2));
+    bad += (la != mm_lnu_f32(u1, mm_icdf_global())) + (lb != mm_lnu_f32(u2, mm_icdf_global()));
   }
   return bad;
 }

@@ -36,9 +36,9 @@ template <int SB> __global__ __launch_bounds__(64) void kf(float *o, uint64_t se
                 znb[l] = mm_icdf_f32(blk.w[l][1], tab);
             }
             if (l == D) {
-                mm_f2 ln = mm_logf2(mm_spare_u24x2(blk));
-                lnna = ln[0];
-                lnnb = ln[1];
+                const mm_f2 uu = mm_spare_u24x2(blk);
+                lnna = mm_lnu_f32(uu[0], tab);
+                lnnb = mm_lnu_f32(uu[1], tab);
             }
             if (SB) __builtin_amdgcn_sched_barrier(0);
         });
