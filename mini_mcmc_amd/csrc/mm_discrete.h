@@ -109,7 +109,7 @@ MM_HD int mm_discrete_step(const mm_discrete_params &P, int32_t *x, uint64_t see
     const double proposed_lp = mm_discrete_logp(P, prop);
     const double log_accept_ratio = (proposed_lp + qb) - (current_lp + qf);
     const double u = mm_u53(b.w[2], b.w[3]);
-    if (log_accept_ratio > mm_log(u)) {
+    if (mm_ratio_exceeds_ln_u(log_accept_ratio, u)) { /* log_accept_ratio > ln u (metropolis_hastings.rs:311) */
         *x = prop;
         return 1;
     }

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "mm_discrete.h"
+#include "mm_kernels.h"
 
 #define MM_HIP(expr)                                                                                              \
     do {                                                                                                          \
@@ -46,12 +47,27 @@ struct run_args {
     unsigned int iter0, n_discard, n_collect;
 };
 
-constexpr int TILE = 64;
 
 __global__ __launch_bounds__(64) void mm_discrete_kernel(const run_args a)
 {
-    __shared__ int32_t tile[64][TILE + 1];
+    /* samples are staged and flushed like the continuous samplers' (mm_kernels.h): 96 transitions per tile, 16-byte stores */
+    using Tile = mm_tile<int32_t, 1>;
+    constexpr unsigned int TILE = Tile::tile_t;
+    constexpr int STRIDE = Tile::stride;
+    __shared__ __attribute__((aligned(16))) int32_t tile[64 * STRIDE];
+    /* the log-density table goes to LDS: two dependent per-lane look-ups per transition at HBM / L2 latency, with one
+     * wave per SIMD to hide them, were most of this kernel's time */
+    __shared__ double tab_lds[MM_DISCRETE_POISSON_TABLE];
     const int lane = threadIdx.x;
+    mm_discrete_params P = a.P;
+    /* table_len <= MM_DISCRETE_POISSON_TABLE by construction (mm_discrete_fill_table's cap); unconditional, so that the
+     * pointer is an LDS pointer to the compiler and the look-ups ds_read, not flat_load */
+    for (int i = lane; i < P.table_len && i < MM_DISCRETE_POISSON_TABLE; i += 64)
+        tab_lds[i] = a.P.logp[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    P.logp = tab_lds;
+    P.table_len = P.table_len < MM_DISCRETE_POISSON_TABLE ? P.table_len : MM_DISCRETE_POISSON_TABLE;
     const unsigned long long c0 = (unsigned long long)blockIdx.x * 64, c = c0 + lane;
     const bool active = c < a.n_chains;
     int32_t x = active ? a.state[c] : 0;
@@ -59,18 +75,11 @@ __global__ __launch_bounds__(64) void mm_discrete_kernel(const run_args a)
     const unsigned int total = a.n_discard + a.n_collect;
     unsigned int col = 0, t0 = 0;
     for (unsigned int t = 0; t < total; ++t) {
-        n_acc += (unsigned long long)mm_discrete_step(a.P, &x, a.seed, a.chain_offset + c, a.iter0 + t);
+        n_acc += (unsigned long long)mm_discrete_step(P, &x, a.seed, a.chain_offset + c, a.iter0 + t);
         if (t >= a.n_discard && a.out) {
-            tile[lane][col++] = x;
+            tile[lane * STRIDE + col++] = x;
             if (col == TILE || t + 1 == total) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                /* row r of the tile = chain c0 + r: `col` consecutive samples, one coalesced store per chain */
-                for (int r = 0; r < 64; ++r)
-                    if (c0 + r < a.n_chains && (unsigned int)lane < col)
-                        a.out[(c0 + r) * a.n_collect + t0 + lane] = tile[r][lane];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                mm_flush_tile_raw<int32_t, 1>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
                 t0 += col;
                 col = 0;
             }
@@ -126,6 +135,11 @@ int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *pa
     h->kind = kind;
     h->n_chains = n_chains;
     DevGuard g(device);
+    /* the kernel keeps the log-density table in LDS: at most MM_DISCRETE_POISSON_TABLE states */
+    if (kind == MMCMC_BINOMIAL_CLAMP && !(params[0] >= 0 && params[0] < (double)MM_DISCRETE_POISSON_TABLE)) {
+        delete h;
+        return MMCMC_ERR_UNSUPPORTED;
+    }
     const int cap = kind == MMCMC_BINOMIAL_CLAMP ? (int)params[0] + 1 : MM_DISCRETE_POISSON_TABLE;
     std::vector<double> tab((size_t)cap);
     const int len = mm_discrete_fill_table(kind, params, tab.data(), cap);

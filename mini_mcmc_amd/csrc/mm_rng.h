@@ -138,6 +138,23 @@ template <class Tab> MM_HD float mm_lnu_f32(float u, const Tab &tab)
 template <class Tab> MM_HD float mm_ln_accept(float u, const Tab &tab) { return mm_lnu_f32(u, tab); }
 template <class Tab> MM_HD double mm_ln_accept(double u, const Tab &) { return mm_log(u); }
 
+/* `ratio > ln u` for an f64 uniform, decided without the f64 logarithm whenever possible: the f32 table logarithm of
+ * (float)u is within 1e-6 (1 + |ln u|) of ln u (generous: the conversion moves ln u by 6e-8, the table is good to
+ * ~1e-7 relative; tests/test_engine_stream.py samples the bound), so a ratio outside that band around it is decided
+ * there and only a ratio inside the band -- one proposal in a million -- pays for mm_log.  The DECISION is the one of
+ * the full comparison in every case (NaN falls through to it and rejects), only its cost changes: the f64 logarithm
+ * with its division was a third of the integer-state MH step. */
+MM_HD bool mm_ratio_exceeds_ln_u(double ratio, double u)
+{
+    const float lf = mm_lnu_f32((float)u, mm_icdf_global());
+    const double mid = (double)lf, band = 1e-6 + 1e-6 * (mid < 0 ? -mid : mid);
+    if (ratio > mid + band)
+        return true;
+    if (ratio <= mid - band)
+        return false;
+    return ratio > mm_log(u);
+}
+
 typedef struct {
     uint32_t w[4];
 } mm_u32x4;

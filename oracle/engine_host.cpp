@@ -269,6 +269,15 @@ int eh_icdf24_words(const uint32_t *w, size_t n, float *out)
     return 0;
 }
 
+/* mm_rng.h: mm_ratio_exceeds_ln_u against the plain comparison, pair by pair: the number of disagreements */
+size_t eh_ratio_filter_disagreements(const double *ratio, const double *u, size_t n)
+{
+    size_t bad = 0;
+    for (size_t i = 0; i < n; ++i)
+        bad += mm_ratio_exceeds_ln_u(ratio[i], u[i]) != (ratio[i] > mm_log(u[i]));
+    return bad;
+}
+
 /* the product's logarithm of the f32 accept uniform (mm_rng.h: mm_lnu_f32), value by value */
 int eh_lnu_f32(const float *u, size_t n, float *out)
 {

@@ -568,6 +568,8 @@ def engine_host_lib() -> C.CDLL:
                               C.c_uint32, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp, C.c_void_p, _u64p, C.c_int]
     E.eh_noise.restype = C.c_int
     E.eh_noise.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    E.eh_ratio_filter_disagreements.restype = C.c_size_t
+    E.eh_ratio_filter_disagreements.argtypes = [_dp, _dp, C.c_size_t]
     E.eh_lnu_f32.restype = C.c_int
     E.eh_lnu_f32.argtypes = [_fp, C.c_size_t, _fp]
     E.eh_icdf24_words.restype = C.c_int
@@ -625,6 +627,13 @@ def engine_host_noise(seed, chain_offset, iteration, n, dim, dtype=np.float32):
     if rc != 0:
         raise ValueError(f"eh_noise: {rc}")
     return z, u
+
+
+def engine_host_ratio_filter_disagreements(ratio, u):
+    """How often mm_ratio_exceeds_ln_u (filtered) differs from `ratio > mm_log(u)` (must be never)."""
+    r = np.ascontiguousarray(ratio, dtype=np.float64)
+    uu = np.ascontiguousarray(u, dtype=np.float64)
+    return int(engine_host_lib().eh_ratio_filter_disagreements(_d(r), _d(uu), r.size))
 
 
 def engine_host_lnu_f32(u):

@@ -92,6 +92,28 @@ def test_f32_accept_log_is_ln_u_on_all_2_24_uniforms(O):
     assert O.engine_host_lnu_f32(np.array([1.0], dtype=np.float32))[0] == 0.0
 
 
+def test_filtered_accept_test_equals_the_plain_one(O):
+    """mm_ratio_exceeds_ln_u decides `ratio > ln u` from the f32 table logarithm when the ratio is outside a band around
+    it and from mm_log otherwise.  (a) the band is wide enough: over 53-bit uniforms of every magnitude the table value
+    of (float)u is within a QUARTER of the band of ln u; (b) the decisions agree with the plain comparison on ratios
+    drawn at, just inside, just outside and far from the band, and on NaN / inf."""
+    rng = np.random.default_rng(3)
+    u = np.concatenate([rng.random(2_000_000), np.ldexp(rng.random(2_000_000), -rng.integers(0, 53, 2_000_000)),
+                        (rng.integers(0, 1 << 53, 1_000_000, dtype=np.uint64).astype(np.float64) + 1.0) * 2.0**-53,
+                        np.array([2.0**-53, 1.0, 0.5, 1.0 - 2.0**-53])])
+    u = np.clip(u, 2.0**-53, 1.0)
+    lf = O.engine_host_lnu_f32(u.astype(np.float32)).astype(np.float64)
+    lnu = np.log(u)
+    band = 1e-6 + 1e-6 * np.abs(lf)
+    assert np.max(np.abs(lf - lnu) / band) < 0.25
+    for scale in (0.0, 0.2, 0.9, 1.0, 1.1, 3.0, 1e3, 1e7):
+        for sign in (-1.0, 1.0):
+            ratio = lnu + sign * scale * band * rng.random(u.size)
+            assert O.engine_host_ratio_filter_disagreements(ratio, u) == 0
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0])
+    assert O.engine_host_ratio_filter_disagreements(np.repeat(special, 4), np.tile([2.0**-53, 0.3, 1.0, 0.999], 5)) == 0
+
+
 @pytest.fixture(scope="module")
 def mmath(tmp_path_factory):
     """Host build of mm_math.h alone (the functions that DEFINE the engine's log/exp/sincos)."""
