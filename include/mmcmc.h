@@ -276,6 +276,7 @@ int mmcmc_tracker_destroy(mmcmc_tracker *h);
  * f64 (a table per target, built with the reference's operation order), step = metropolis_hastings.rs:303-315.
  *   MMCMC_POISSON_REFLECT  params {lambda}: PoissonDist + PoissonRandomWalk      tests/metrohast_poisson_test.rs:18-85
  *   MMCMC_BINOMIAL_CLAMP   params {n, p}:   BinomialDist + BinomialRandomWalk    tests/metrohast_poisson_test.rs:150-212
+ *                          (n < 1024: the log-density table lives in LDS; larger n: MMCMC_ERR_UNSUPPORTED)
  *   MMCMC_POISSON_NONNEG   params {lambda}: PoissonTarget + NonnegativeProposal  examples/poisson_mh.rs:8-76
  * (lambda <= 256: states above 1023 have probability zero here.)  init: host [n_chains] i32;
  * out: [n_chains, n_collect] i32 (the reference's Array3<i32>[C, n, 1]).  Integer states and accept counts are
