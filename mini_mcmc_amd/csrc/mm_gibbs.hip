@@ -11,6 +11,7 @@
 #include <new>
 
 #include "mm_gibbs.h"
+#include "mm_kernels.h"
 
 #define MM_HIP(expr)                                                                                              \
     do {                                                                                                          \
@@ -44,11 +45,14 @@ struct run_args {
     unsigned int iter0, n_discard, n_collect;
 };
 
-constexpr int TILE = 16;
 
 __global__ __launch_bounds__(64) void mm_gibbs_mixture_kernel(const run_args a)
 {
-    __shared__ double tile[64][2 * TILE + 1];
+    /* samples are staged and flushed like the continuous samplers' (mm_kernels.h): 24 sweeps per tile, 16-byte stores */
+    using Tile = mm_tile<double, 2>;
+    constexpr unsigned int TILE = Tile::tile_t;
+    constexpr int STRIDE = Tile::stride;
+    __shared__ __attribute__((aligned(16))) double tile[64 * STRIDE];
     const int lane = threadIdx.x;
     const unsigned long long c0 = (unsigned long long)blockIdx.x * 64, c = c0 + lane;
     const bool active = c < a.n_chains;
@@ -58,20 +62,11 @@ __global__ __launch_bounds__(64) void mm_gibbs_mixture_kernel(const run_args a)
     for (unsigned int t = 0; t < total; ++t) {
         mm_gibbs_mixture_step(a.P, s, a.seed, a.chain_offset + c, a.iter0 + t);
         if (t >= a.n_discard && a.out) {
-            tile[lane][2 * col] = s[0];
-            tile[lane][2 * col + 1] = s[1];
+            tile[lane * STRIDE + 2 * col] = s[0];
+            tile[lane * STRIDE + 2 * col + 1] = s[1];
             ++col;
             if (col == TILE || t + 1 == total) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                /* row r = chain c0 + r: 2 * col consecutive doubles; two chains' rows per pass of 32 lanes each */
-                for (int r = 0; r < 64; r += 2) {
-                    const int rr = r + (lane >> 5), e = lane & 31;
-                    if (c0 + rr < a.n_chains && (unsigned int)e < 2 * col)
-                        a.out[((c0 + rr) * a.n_collect + t0) * 2 + e] = tile[rr][e];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                mm_flush_tile_raw<double, 2>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
                 t0 += col;
                 col = 0;
             }
