@@ -130,8 +130,8 @@ struct mm_no_hook {
 };
 
 /* Hook: called after leapfrog step l = 0, 1, ... with independent work to be issued alongside the integrator's
- * dependent chain (the sampling kernel threads the next iterations' Philox rounds through here); it must not touch
- * the transition's data.  mm_no_hook: nothing. */
+ * dependent chain; it must not touch the transition's data.  The kernels pass mm_no_hook (nothing): threading the next
+ * iterations' Philox rounds through here was measured (tools/hmc_split.hip) and is slower, DESIGN.md 5.1. */
 template <class T, class Tgt, int LCT = 0, class Red = mm_red_seq<T, Tgt::dim>, class Hook = mm_no_hook>
 MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, T *p, T ln_u,
                             Hook &&hook = Hook())
