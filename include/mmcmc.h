@@ -180,8 +180,9 @@ int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
  * over long trajectories of a stiff target, visibly; each is bit-exact against its own host build
  * (oracle/engine_host.cpp modes 3 and 2).  With variant 3 mmcmc_nuts_run returns after the kernel has finished.
  * mmcmc_nuts_kernel_variant returns the mapping in use (>= 0) or a negative status.
- * mmcmc_nuts_set_compaction (variants 2, 3): doublings below `first_level` (default 5) run before the first
- * re-packing; variant 2 splits the chains into `n_groups` contiguous groups (1..16; 0 = one per 16 384 chains), each
+ * mmcmc_nuts_set_compaction (variants 2, 3): doublings below `first_level` run before the first re-packing (default 5;
+ * variant 3, until this is called, picks the mode of the depths seen so far minus one, after a 16-transition pilot on a
+ * fresh handle); variant 2 splits the chains into `n_groups` contiguous groups (1..16; 0 = one per 16 384 chains), each
  * with its own launch sequence on its own stream.  Neither setting changes a result. */
 int mmcmc_nuts_set_kernel_variant(mmcmc_nuts *h, int variant);
 int mmcmc_nuts_kernel_variant(mmcmc_nuts *h);

@@ -54,7 +54,8 @@ struct NutsBase {
     int variant = 0; /* 0: one chain per lane, lanes in step; 4: one chain per lane, asynchronous lanes (default for
                       * dim <= 8); 1: lane-group / MFMA (mm_nuts_lg.h); 2: + tree-depth compaction, one
                         launch per level; 3: + compaction by a persistent scheduler */
-    int compaction_start = 5; /* variant 2: doublings below this run before the first compaction */
+    int compaction_start = 5; /* variants 2, 3: doublings below this run before the first compaction */
+    bool compaction_auto = true; /* variant 3: choose it from the depths seen so far (until set_compaction is called) */
     int compaction_groups = 0; /* variant 2: chain groups with their own launch sequence (0 = choose) */
     int device = 0, mode = 0, kind = 0, dim = 0;
     size_t n_chains = 0;
@@ -259,21 +260,75 @@ template <class TT, class ST> struct Nuts : NutsBase {
                     if (w >= 1 && w < nw)
                         nw = w;
                 }
-                hipError_t e = lg->run_queue(g, nw, st);
-                if (e != hipSuccess)
-                    return e;
-                /* the kernel reports a stuck queue instead of hanging */
-                mm_lgq_ctrl hc;
-                if ((e = hipMemcpyAsync(&hc, d_lg_ctrl, sizeof(hc), hipMemcpyDeviceToHost, st)) != hipSuccess)
-                    return e;
-                if ((e = hipStreamSynchronize(st)) != hipSuccess)
-                    return e;
-                if (getenv("MMCMC_LGQ_STATS"))
-                    fprintf(stderr, "lgq: units %llu chains %llu (%.2f per unit) leaf iterations %llu idle polls %llu error %u ticks pick %.3g fetch %.3g work %.3g handover %.3g\n", hc.stat_units,
-                            hc.stat_chains, (double)hc.stat_chains / (double)(hc.stat_units ? hc.stat_units : 1), hc.stat_leaf_iters,
-                            hc.stat_polls,
-                            (unsigned int)hc.error, (double)hc.stat_t[0], (double)hc.stat_t[1], (double)hc.stat_t[2], (double)hc.stat_t[3]);
-                return (hc.error != 0ull || hc.remaining != 0ull) ? hipErrorLaunchFailure : hipSuccess;
+                /* one launch of the scheduler; the kernel reports a stuck queue instead of hanging */
+                auto launch = [&](const mm_nuts_lg_args &gq) -> hipError_t {
+                    hipError_t e = lg->run_queue(gq, nw, st);
+                    if (e != hipSuccess)
+                        return e;
+                    mm_lgq_ctrl hc;
+                    if ((e = hipMemcpyAsync(&hc, d_lg_ctrl, sizeof(hc), hipMemcpyDeviceToHost, st)) != hipSuccess)
+                        return e;
+                    if ((e = hipStreamSynchronize(st)) != hipSuccess)
+                        return e;
+                    if (getenv("MMCMC_LGQ_STATS"))
+                        fprintf(stderr, "lgq: first level %d units %llu chains %llu (%.2f per unit) leaf iterations %llu idle polls %llu error %u ticks pick %.3g fetch %.3g work %.3g handover %.3g\n",
+                                gq.j0, hc.stat_units, hc.stat_chains,
+                                (double)hc.stat_chains / (double)(hc.stat_units ? hc.stat_units : 1), hc.stat_leaf_iters,
+                                hc.stat_polls, (unsigned int)hc.error, (double)hc.stat_t[0], (double)hc.stat_t[1],
+                                (double)hc.stat_t[2], (double)hc.stat_t[3]);
+                    return (hc.error != 0ull || hc.remaining != 0ull) ? hipErrorLaunchFailure : hipSuccess;
+                };
+                /* The first compaction level pays when it sits just below the depth most trees reach (config 5, trees
+                 * 7 - 8 deep: level 5 660 ms, 7 648 ms, 8 782 ms at 65 536 chains; 234 -> 203 ms at 16 384).  Unless the
+                 * caller fixed it, it is the mode of the handle's depth histogram minus one; a fresh handle runs its
+                 * first 16 transitions as a pilot with the default to have a histogram.  Splitting a run never changes a
+                 * result (the stream is keyed by chain and step). */
+                auto level_from_history = [&](int *level) -> hipError_t {
+                    unsigned int hh[MM_NUTS_JMAX + 1];
+                    hipError_t e = hipMemcpyAsync(hh, d_hist, sizeof(hh), hipMemcpyDeviceToHost, st);
+                    if (e != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
+                        return e;
+                    unsigned long long sum = 0;
+                    int mode = 0;
+                    for (int i = 0; i <= MM_NUTS_JMAX; ++i) {
+                        sum += hh[i];
+                        if (hh[i] > hh[mode])
+                            mode = i;
+                    }
+                    if (sum >= 8ull * n_chains) {
+                        int l = mode - 1;
+                        l = l < 3 ? 3 : l;
+                        *level = l < max_depth ? l : max_depth;
+                    }
+                    return hipSuccess;
+                };
+                if (compaction_auto) {
+                    int level = -1;
+                    hipError_t e = level_from_history(&level);
+                    if (e != hipSuccess)
+                        return e;
+                    const unsigned int pilot = 16;
+                    if (level < 0 && total >= 4 * pilot) {
+                        mm_nuts_lg_args g1 = g, g2 = g;
+                        g1.n_pre = a.n_pre < pilot ? a.n_pre : pilot;
+                        g1.n_rec = pilot - g1.n_pre;
+                        if ((e = launch(g1)) != hipSuccess)
+                            return e;
+                        if ((e = level_from_history(&level)) != hipSuccess)
+                            return e;
+                        g2.m0 = a.m0 + pilot;
+                        g2.n_pre = a.n_pre - g1.n_pre;
+                        g2.n_rec = a.n_rec - g1.n_rec;
+                        g2.write_initial = 0;
+                        g2.out_t0 = a.out_t0 + (a.write_initial ? 1u : 0u) + g1.n_rec;
+                        if (level >= 0)
+                            g2.j0 = level;
+                        return launch(g2);
+                    }
+                    if (level >= 0)
+                        g.j0 = level;
+                }
+                return launch(g);
             }
             /* Tree-depth compaction: 1 + (max_depth - j0) launches per transition.  The late launches of a
              * transition hold few chains (a few per cent reach the deepest level), so the chains are split into
@@ -556,6 +611,7 @@ int mmcmc_nuts_set_compaction(mmcmc_nuts *h, int first_level, int n_groups)
     if (!h || first_level < 0 || first_level > MM_NUTS_JMAX || n_groups < 0 || n_groups > 16)
         return MMCMC_ERR_INVALID_ARG;
     h->p->compaction_start = first_level;
+    h->p->compaction_auto = false;
     h->p->compaction_groups = n_groups;
     return MMCMC_OK;
 }
