@@ -43,6 +43,18 @@ struct mm_hmc_lg32_args {
 hipError_t mm_launch_hmc_lg32(int dim, const mm_hmc_lg32_args &a, hipStream_t stream);
 
 #ifdef MM_HMC_LG_KERNELS
+/* the value held by the partner lane group q ^ 1 (lanes 16 apart in the pairs (0,1) and (2,3)): v_permlane16_swap with both
+ * operands = x returns {rows (0,0,2,2), rows (1,1,3,3)} of x, so an even row reads the second, an odd row the first */
+__device__ __forceinline__ double mm_lg_from_partner(double x, int q)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const unsigned int lo = (unsigned int)__double2loint(x), hi = (unsigned int)__double2hiint(x);
+    const u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double from_even = __hiloint2double((int)h[0], (int)l[0]), from_odd = __hiloint2double((int)h[1], (int)l[1]);
+    return (q & 1) ? from_even : from_odd;
+}
+
 template <int D> __global__ __launch_bounds__(64) void mm_hmc_lg_kernel(const mm_hmc_lg_args a)
 {
     constexpr int NS = D / 4;
@@ -64,13 +76,20 @@ template <int D> __global__ __launch_bounds__(64) void mm_hmc_lg_kernel(const mm
     for (unsigned int t = 0; t < total; ++t) {
         const unsigned int iter = a.iter0 + t;
         double p[NS];
+        /* Coordinates 4 s + q and 4 s + (q ^ 1) are the two normals of ONE Box-Muller block (f64 schedule: z[d] = element
+         * d & 1 of block d >> 1), held by lane groups q and q ^ 1.  Each of the two evaluates every other block and hands
+         * the partner its half (v_permlane16_swap: rows q <-> q ^ 1), instead of both evaluating all of them and throwing
+         * one normal away: half the Philox + Box-Muller work, the same values. */
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int d = 4 * s + L.q;
+        for (int j = 0; j < NS / 2; ++j) {
+            const int s_mine = 2 * j + (L.q & 1), d = 4 * s_mine + L.q;
             const mm_u32x4 blk = mm_block(a.seed, chain, iter, (uint32_t)(d >> 1));
             double z0, z1;
             mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
-            p[s] = (d & 1) ? z1 : z0;
+            const double own = (d & 1) ? z1 : z0, other = (d & 1) ? z0 : z1; /* other: the partner's coordinate d ^ 1 */
+            const double recv = mm_lg_from_partner(other, L.q);
+            p[2 * j] = (L.q & 1) ? recv : own;
+            p[2 * j + 1] = (L.q & 1) ? own : recv;
         }
         const double u = mm_aux_u53(a.seed, chain, iter, 0u);
         const double ke = mm_lg_dot<NS>(p, p);
