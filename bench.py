@@ -122,7 +122,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements of configs 2 and 5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--variant", type=int, default=2, help="kernel variant: 2 paired+pipelined noise (default), 1 pipelined, 0 plain")
+    ap.add_argument("--variant", type=int, default=5, help="kernel variant: 5 noise waves + transition waves, two waves per SIMD (default), 2 one wave per SIMD with paired + pipelined noise, 0 plain")
     args = ap.parse_args()
 
     import numpy as np
@@ -251,7 +251,8 @@ def main() -> None:
             "roofline": {
                 "kernel": {0: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=0, L=0>",
                            1: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>",
-                           2: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>"}[args.variant],
+                           2: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>",
+                           5: "mm_run_split_kernel<float, RosenbrockND<3>, HMC, L=10>"}[args.variant],
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

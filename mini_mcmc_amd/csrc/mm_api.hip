@@ -134,7 +134,8 @@ struct Sampler {
     uint32_t iters_per_launch = 0;
     int variant = 2; /* mm_run_kernel PIPE: 0 plain; 2 (default) noise of two iterations packed + pipelined (PIPE = 1,
                         noise of t+1 pipelined, measured equal to 2 and is no longer instantiated; 1 selects 2);
-                        3 = lane-group / MFMA kernel (mm_hmc_lg.h): HMC, f64, GaussianND of dim 16 or 32 */
+                        3 = lane-group / MFMA kernel (mm_hmc_lg.h): HMC, f64, GaussianND of dim 16 or 32;
+                        5 = noise waves + transition waves (mm_split_kernels.h), the default for f32 up to dim 8 */
     bool lg_ok = false;
     unsigned int block = 64;
     void *d_state = nullptr;
@@ -196,6 +197,10 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
      * is twice as fast there (RosenbrockND(32) f32: 1.0 ms vs 2.2 ms for run(100, 20) of 65 536 chains) */
     if (s->dim > 16)
         s->variant = 0;
+    /* f32 up to dim 8: noise waves + transition waves, two waves per SIMD (mm_split_kernels.h; config 3: 0.225 ms
+     * against 0.268 ms for variant 2) */
+    if (dtype == MMCMC_F32 && s->kf->run_mh_split)
+        s->variant = 5;
     if (s->lg_ok)
         s->variant = 3;
     DeviceGuard g(device);
@@ -332,6 +337,9 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
             q.n_leapfrog = s->n_leapfrog;
             e = mm_launch_hmc_lg32(s->dim, q, stream);
         }
+    } else if (s->variant == 5) {
+        /* noise waves + transition waves (mm_split_kernels.h); the setter has checked that the instance exists */
+        e = mh ? k->run_mh_split(a, stream) : (l10 ? k->run_hmc_split10(a, stream) : k->run_hmc_split(a, stream));
     } else if (s->variant != 0)
         e = mh ? k->run_mh_pp(a, grid, s->block, stream)
                : (l10 ? k->run_hmc_pp10(a, grid, s->block, stream) : k->run_hmc_pp(a, grid, s->block, stream));
@@ -629,18 +637,28 @@ int mmcmc_mh_set_chain_offset(mmcmc_mh *h, uint64_t off)
     h->s->chain_offset = off;
     return MMCMC_OK;
 }
+/* variant 5 (two waves per SIMD: noise waves + transition waves) exists up to dim 8 */
+static bool split_ok(const Sampler *s)
+{
+    return s->dtype == MMCMC_F32 ? (s->kf && s->kf->run_mh_split) : (s->kd && s->kd->run_mh_split);
+}
+
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 {
-    if (!h || variant < 0 || variant > 2)
+    if (!h || variant < 0 || (variant > 2 && variant != 5))
         return MMCMC_ERR_INVALID_ARG;
+    if (variant == 5 && !split_ok(h->s))
+        return MMCMC_ERR_UNSUPPORTED;
     h->s->variant = variant;
     return MMCMC_OK;
 }
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
 {
-    if (!h || variant < 0 || variant > 3)
+    if (!h || variant < 0 || (variant > 3 && variant != 5))
         return MMCMC_ERR_INVALID_ARG;
     if (variant == 3 && !h->s->lg_ok)
+        return MMCMC_ERR_UNSUPPORTED;
+    if (variant == 5 && !split_ok(h->s))
         return MMCMC_ERR_UNSUPPORTED;
     h->s->variant = variant;
     return MMCMC_OK;

@@ -48,11 +48,9 @@ template <class T> struct mm_run_args {
 
 constexpr int mm_gcd_c(int a, int b) { return b == 0 ? a : mm_gcd_c(b, a % b); }
 
-/* iterations staged per flush: about 96 f32 (48 f64) elements per chain => 25.6 KB of LDS per wave */
-template <class T, int D> struct mm_tile {
-    static constexpr int target = (sizeof(T) == 4) ? 96 : 48;
-    /* even whenever possible: the kernels advance two transitions at a time */
-    static constexpr int tile_t = (target / D) >= 2 ? ((target / D) & ~1) : 1;
+/* TILE_T iterations of 64 chains staged per flush */
+template <class T, int D, int TILE_T> struct mm_tile_t {
+    static constexpr int tile_t = TILE_T;
     static constexpr int run = tile_t * D;
     /* row pitch of the staged tile.  When a chain's run is a whole number of 16-byte pieces the pitch keeps every
      * piece 16-byte aligned (one ds_read_b128 per piece in the flush; the lane-strided staging writes then meet a
@@ -63,10 +61,17 @@ template <class T, int D> struct mm_tile {
     /* f32 kernels keep the tables of the normal draw and of ln u (mm_rng.h) in LDS, once per block, before the tiles */
     static constexpr size_t lds_bytes_table = (sizeof(T) == 4) ? (size_t)MM_NOISE_TABLE_BYTES : 0;
 };
+/* about 96 f32 (48 f64) elements per chain => 25.6 KB of LDS per wave; even whenever possible: the kernels advance
+ * two transitions at a time */
+template <class T, int D> struct mm_tile_default {
+    static constexpr int target = (sizeof(T) == 4) ? 96 : 48;
+    static constexpr int tile_t = (target / D) >= 2 ? ((target / D) & ~1) : 1;
+};
+template <class T, int D> struct mm_tile : mm_tile_t<T, D, mm_tile_default<T, D>::tile_t> {};
 
 /* Write the staged tile of one wave to `out`: for each of the wave's 64 chains one contiguous run of nt*D elements
  * starting at row `row0` of that chain.  Whole-wave stores of 64 consecutive elements of the chain-linear image. */
-template <class T, int D>
+template <class T, int D, class Tile = mm_tile<T, D>>
 __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_total, unsigned long long n_chains,
                                                   const T *tile, int lane, unsigned long long wave_c0,
                                                   unsigned long long row0, unsigned int nt);
@@ -78,12 +83,11 @@ __device__ __forceinline__ void mm_flush_tile(const mm_run_args<T> &a, const T *
     mm_flush_tile_raw<T, D>(a.out, a.n_total, a.n_chains, tile, lane, wave_c0, row0, nt);
 }
 
-template <class T, int D>
+template <class T, int D, class Tile>
 __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_total, unsigned long long n_chains,
                                                   const T *tile, int lane, unsigned long long wave_c0,
                                                   unsigned long long row0, unsigned int nt)
 {
-    using Tile = mm_tile<T, D>;
     constexpr int TILE_T = Tile::tile_t, RUN = Tile::run, STRIDE = Tile::stride;
 #ifdef MM_PROBE_SKIP_FLUSH /* measurement aid of tools/hmc_kernel_probe.hip; never defined in the library build */
     return;
@@ -462,6 +466,10 @@ template <class T> struct mm_kernel_entry {
     hipError_t (*run_hmc_pp10)(const mm_run_args<T> &, unsigned int, unsigned int, hipStream_t); /* PIPE = 2, L = 10 */
     hipError_t (*logp_grad)(const mm_tparams<T> &, const T *, T *, T *, unsigned long long, hipStream_t);
     size_t lds_bytes_per_wave;
+    /* noise waves + transition waves, two waves per SIMD (mm_split_kernels.h); null above dim 8 */
+    hipError_t (*run_mh_split)(const mm_run_args<T> &, hipStream_t);
+    hipError_t (*run_hmc_split)(const mm_run_args<T> &, hipStream_t);
+    hipError_t (*run_hmc_split10)(const mm_run_args<T> &, hipStream_t); /* L = 10 unrolled */
 };
 
 template <class T> struct mm_noise_entry {

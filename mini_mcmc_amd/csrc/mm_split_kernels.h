@@ -1,0 +1,326 @@
+/*
+ * mm_split_kernels.h -- the many-chain MH / HMC kernel with TWO waves per SIMD: noise waves and transition waves.
+ *
+ * Why.  One chain per lane makes a transition a long dependent stream of f32 VALU instructions.  On gfx950 a wave
+ * issues at most one VALU instruction per ~4.4 cycles, whatever its instruction-level parallelism, while a SIMD
+ * issues one per ~2.2 cycles when TWO waves feed it (tools/issue_rate.hip: plain FMA / integer streams 4.4 -> 2.2
+ * cycles per instruction per SIMD from one wave to two; 32 x 32 multiplies stay at ~4.3).  BASELINE's chain counts
+ * (65 536 = 1024 waves = ONE per SIMD) leave half of every SIMD's issue slots empty in mm_run_kernel, and more chains
+ * per GPU is not what configs 2 / 3 ask for.  So a chain is given two lanes in two waves of one SIMD:
+ *
+ *   workgroup = 512 threads = 8 waves for 256 chains; waves w and w + 4 sit on the same SIMD (a workgroup's waves
+ *   are dealt to the SIMDs cyclically) and share 64 chains:
+ *     wave w     ("transition wave"): state in registers, runs mm_hmc_step_noise / mm_mh_step_noise -- exactly the
+ *                arithmetic of mm_run_kernel, bit for bit -- and stages the collected states in an LDS tile;
+ *     wave w + 4 ("noise wave"): draws the transitions' noise -- a pure function of (seed, chain, iteration), so it
+ *                needs nothing from its partner -- two iterations at a time (mm_draw_noise_pair) into an LDS ring, and
+ *                writes the full tiles to HBM (the stores' issue latency costs the transition wave nothing).
+ *   The ring has two halves of RB transitions, there are two tiles per pair; one s_barrier per RB transitions hands a
+ *   filled ring half and a full tile over and the drained / flushed ones back.  Where the noise outweighs the
+ *   transition (MH: ~115 of ~140 instructions) the transition wave draws QP of the RB / 2 noise pairs of a batch
+ *   itself, so that both waves carry about the same load.
+ *
+ * Same functions of (seed, chain, iteration) as every other variant: samples, states and accept counts are
+ * bit-identical to mm_run_kernel and to the host build (tests/test_gpu_parity.py::test_kernel_variants_agree).
+ *
+ * Replaces (like mm_kernels.h): run_chain core.rs:55-73, ChainRunner::run core.rs:176-186, HMC::run hmc.rs:137-158.
+ */
+#ifndef MM_SPLIT_KERNELS_H
+#define MM_SPLIT_KERNELS_H
+
+#include "mm_kernels.h"
+
+/* LDS plan of one workgroup (4 wave pairs): [f32 tables][4 x 2 tiles][4 rings of 2 x RB transitions].
+ * Who writes the tiles out is decided by the balance of the two roles.  HMC: the transition wave is the busy one either
+ * way and flushes its own (single) tile -- measured faster than handing it over (config 3: 0.225 vs 0.233 ms).  MH: the
+ * noise dominates, the transition wave takes a share of it and the noise wave the flushing; two tiles per pair.
+ * Candidates (ring half RB, elements per chain and tile) in order of preference, the first that fits 160 KB wins: HMC wants
+ * large tiles (few, long store bursts), MH wants RB = 8 (short transitions: barriers dearer than stores). */
+template <class T, int D, int RB, int WANT, int NTILE> struct mm_split_try {
+    static constexpr int epl = 16 / (int)sizeof(T);
+    static constexpr int nw = (D + 1 + epl - 1) / epl * epl; /* noise row of one chain: z[D], ln u, padded to 16 bytes */
+    static constexpr size_t row_bytes = (size_t)64 * nw * sizeof(T); /* one transition of one wave pair */
+    static constexpr size_t ring_bytes = 2 * (size_t)RB * row_bytes;
+    static constexpr int tile_want = WANT / (int)(sizeof(T) / 4) / D;
+    static constexpr int tile_t = tile_want / RB * RB; /* a whole number of batches, so that full tiles take the fast flush */
+    using Tile = mm_tile_t<T, D, (tile_t > 0 ? tile_t : RB)>;
+    static constexpr size_t tile_bytes = (Tile::lds_bytes_per_wave + 15) / 16 * 16;
+    static constexpr size_t table_bytes = (Tile::lds_bytes_table + 15) / 16 * 16;
+    static constexpr size_t lds_bytes = table_bytes + 4 * NTILE * tile_bytes + 4 * ring_bytes;
+    static constexpr int ntile = NTILE;
+    static constexpr bool ok = tile_t >= RB && lds_bytes <= 160 * 1024;
+};
+template <class T, int D, bool MH, int I = 0> struct mm_split_pick {
+    static constexpr int rb_hmc[12] = {8, 4, 8, 4, 2, 8, 4, 2, 2, 8, 4, 2}, want_hmc[12] = {48, 48, 32, 32, 48, 24, 24, 32, 24, 16, 16, 16};
+    static constexpr int rb_mh[12] = {8, 8, 8, 4, 4, 4, 8, 2, 2, 2, 4, 2}, want_mh[12] = {48, 32, 24, 48, 32, 24, 16, 48, 32, 24, 16, 16};
+    static constexpr int rb = MH ? rb_mh[I] : rb_hmc[I], want = MH ? want_mh[I] : want_hmc[I];
+    using Try = mm_split_try<T, D, rb, want, (MH ? 2 : 1)>;
+    using type = typename std::conditional<Try::ok, Try, typename mm_split_pick<T, D, MH, I + 1>::type>::type;
+};
+template <class T, int D, bool MH> struct mm_split_pick<T, D, MH, 12> {
+    using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, (MH ? 2 : 1)>; /* RB = TILE_T = 2: always fits up to dim 8 */
+};
+template <class T, int D, bool MH> struct mm_split_plan : mm_split_pick<T, D, MH>::type {
+    using Base = typename mm_split_pick<T, D, MH>::type;
+    static constexpr int rb = (int)(Base::ring_bytes / 2 / Base::row_bytes);
+    static_assert(Base::tile_t >= rb && Base::lds_bytes <= 160 * 1024, "LDS plan of the split kernel");
+};
+
+/* share of the noise the transition wave draws itself (pairs per batch): MH two of the four pairs of a batch of 8 */
+#ifndef MM_SPLIT_MH_QP
+#define MM_SPLIT_MH_QP 2 /* config 2: 0.312 / 0.298 / 0.275 ms with 0 / 1 / 2 pairs */
+#endif
+template <class T, int D> struct mm_split_mh_qp {
+    static constexpr int rb = mm_split_plan<T, D, true>::rb;
+    static constexpr int value = rb >= 8 ? MM_SPLIT_MH_QP : (rb >= 4 && MM_SPLIT_MH_QP ? 1 : 0);
+};
+
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0>
+__global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> a)
+{
+    constexpr int D = Tgt::dim;
+    using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH>;
+    using Tile = typename Plan::Tile;
+    constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride, NW = Plan::nw, RB = Plan::rb, EPL = Plan::epl;
+    constexpr int QN = 2 * QP; /* transitions per batch whose noise the transition wave draws itself */
+    constexpr bool PFLUSH = Plan::ntile == 2; /* the noise wave writes the tiles out */
+    static_assert(QN <= RB, "QP");
+    typedef T mm_vrow __attribute__((ext_vector_type(EPL)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6; /* 0..3 transition waves, 4..7 noise waves */
+    const int pair = wave & 3;
+    const bool noise_wave = wave >= 4;
+    T *const tiles = reinterpret_cast<T *>(mm_lds_raw + Plan::table_bytes + (size_t)pair * Plan::ntile * Plan::tile_bytes);
+    constexpr size_t TILE_ELEMS = Plan::tile_bytes / sizeof(T);
+    T *const ring = reinterpret_cast<T *>(mm_lds_raw + Plan::table_bytes + 4 * Plan::ntile * Plan::tile_bytes + (size_t)pair * Plan::ring_bytes);
+    const unsigned long long c = (unsigned long long)blockIdx.x * 256ull + (unsigned long long)(pair * 64 + lane);
+    const unsigned long long wave_c0 = c - lane;
+    const unsigned long long chain = a.chain_offset + c;
+    const unsigned int n_silent = a.n_discard + (a.out ? 0u : a.n_collect);
+    const unsigned int n_loud = a.out ? a.n_collect : 0u;
+    /* both roles walk the same schedule: silent transitions in batches of RB (the last one short), then the collected
+     * ones in batches of RB (the last one short), one barrier before each batch and one after the last; a tile is
+     * complete after TILE_T collected transitions, or with the last one */
+    using Tab = typename std::conditional<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
+    Tab tab;
+    if constexpr (sizeof(T) == 4) {
+        mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, 512u);
+        tab.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(mm_lds_raw);
+    }
+#ifdef MM_SPLIT_PRIO_Q /* experiment hook of tools/split_probe.hip */
+    if (!noise_wave)
+        __builtin_amdgcn_s_setprio(MM_SPLIT_PRIO_Q);
+#endif
+
+    if (noise_wave) {
+        __syncthreads(); /* the table is complete */
+        unsigned int it = a.iter0;
+        int half = 0;
+        /* noise of iterations [it + QN, it + nb) of a batch into rows QN.. of the current ring half */
+        auto fill = [&](unsigned int nb) __attribute__((always_inline)) {
+            T *dst = ring + ((size_t)half * RB + QN) * 64 * NW + (size_t)lane * NW;
+            for (unsigned int j = QN; j < nb; j += 2) {
+                T row_a[NW], row_b[NW];
+                mm_draw_noise_pair<D>(a.seed, chain, it + j, row_a, &row_a[D], row_b, &row_b[D], tab);
+                MM_UNROLL
+                for (int k = D + 1; k < NW; ++k) {
+                    row_a[k] = T(0);
+                    row_b[k] = T(0);
+                }
+                MM_UNROLL
+                for (int k = 0; k < NW; k += EPL) {
+                    mm_vrow va, vb;
+                    MM_UNROLL
+                    for (int e = 0; e < EPL; ++e) {
+                        va[e] = row_a[k + e];
+                        vb[e] = row_b[k + e];
+                    }
+                    *reinterpret_cast<mm_vrow *>(dst + k) = va;
+                    *reinterpret_cast<mm_vrow *>(dst + 64 * NW + k) = vb; /* row j + 1 (RB is even: always inside the half) */
+                }
+                dst += 2 * 64 * NW;
+            }
+            it += nb;
+            half ^= 1;
+        };
+        for (unsigned int done = 0; done < n_silent; done += RB) {
+            fill(min((unsigned int)RB, n_silent - done));
+            __syncthreads();
+        }
+        /* collected transitions: after the barrier that hands batch b over, the partner has finished batch b - 1; a tile
+         * that batch completed is written out while the partner stages into the other one */
+        unsigned int tcol = 0, rows_out = 0, pend = 0; /* pend: rows of the completed tile waiting to be flushed */
+        int tb = 0, pend_tb = 0;
+        for (unsigned int done = 0; done < n_loud; done += RB) {
+            const unsigned int nb = min((unsigned int)RB, n_loud - done);
+            fill(nb);
+            __syncthreads();
+            if (PFLUSH && pend) {
+                mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
+                                              (unsigned long long)a.out_t0 + rows_out, pend);
+                rows_out += pend;
+                pend = 0;
+            }
+            tcol += nb; /* what the partner is staging now */
+            if (tcol == (unsigned int)TILE_T || done + nb >= n_loud) {
+                pend = tcol;
+                pend_tb = tb;
+                tb ^= 1;
+                tcol = 0;
+            }
+        }
+        __syncthreads(); /* the partner has finished its last batch */
+        if (PFLUSH && pend)
+            mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
+                                          (unsigned long long)a.out_t0 + rows_out, pend);
+        return;
+    }
+
+    /* ---- transition wave ---- */
+    const bool active = c < a.n_chains;
+    T x[D], g[D], lp;
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        x[i] = active ? a.state[c * D + i] : T(0);
+    if (SAMPLER == MM_SAMPLER_HMC)
+        lp = Tgt::logp_grad(a.P, x, g);
+    else
+        lp = Tgt::logp(a.P, x);
+    __syncthreads(); /* the table is complete */
+
+    unsigned int n_acc32 = 0;
+    unsigned long long wave_acc = 0;
+    unsigned int it = a.iter0;
+    int half = 0;
+    auto load_row = [&](const T *src, T *z, T *ln_u) __attribute__((always_inline)) {
+        T row[NW];
+        MM_UNROLL
+        for (int k = 0; k < NW; k += EPL) {
+            const mm_vrow v = *reinterpret_cast<const mm_vrow *>(src + k);
+            MM_UNROLL
+            for (int e = 0; e < EPL; ++e)
+                row[k + e] = v[e];
+        }
+        MM_UNROLL
+        for (int k = 0; k < D; ++k)
+            z[k] = row[k];
+        *ln_u = row[D];
+    };
+    auto transition = [&](T *z, T ln_u) __attribute__((always_inline)) {
+        int acc;
+        if (SAMPLER == MM_SAMPLER_HMC)
+            acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u);
+        else
+            acc = mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u);
+        acc = acc && active;
+        n_acc32 += (unsigned int)acc;
+        wave_acc += (unsigned long long)__popcll(__ballot(acc));
+    };
+    /* one batch: nb transitions; `stage` (null: silent) receives the states.  The first QN take noise drawn here, in
+     * registers; the others the partner's rows, each requested one transition ahead */
+    T zq[QN > 0 ? QN : 1][D], lnq[QN > 0 ? QN : 1]; /* own noise of the NEXT batch, drawn after this batch's barrier */
+    auto draw_own = [&](unsigned int it_batch) __attribute__((always_inline)) {
+        MM_UNROLL
+        for (int q = 0; q < QN; q += 2)
+            mm_draw_noise_pair<D>(a.seed, chain, it_batch + q, zq[q], &lnq[q], zq[q + 1], &lnq[q + 1], tab);
+    };
+    auto batch = [&](unsigned int nb, T *stage) __attribute__((always_inline)) {
+        const T *src = ring + (size_t)half * RB * 64 * NW + (size_t)lane * NW;
+        T zc[D], lnc;
+        if (QN < RB)
+            load_row(src + (size_t)QN * 64 * NW, zc, &lnc);
+        MM_UNROLL
+        for (int q = 0; q < QN; ++q) {
+            if ((unsigned int)q < nb) {
+                transition(zq[q], lnq[q]);
+                if (stage) {
+                    MM_UNROLL
+                    for (int k = 0; k < D; ++k)
+                        stage[q * D + k] = x[k];
+                }
+            }
+        }
+        for (unsigned int j = QN; j < nb; ++j) {
+            T zn[D], lnn; /* rows past nb hold stale data: requested, never used */
+            load_row(src + (size_t)min(j + 1u, (unsigned int)RB - 1u) * 64 * NW, zn, &lnn);
+            transition(zc, lnc);
+            if (stage) {
+                MM_UNROLL
+                for (int k = 0; k < D; ++k)
+                    stage[j * D + k] = x[k];
+            }
+            MM_UNROLL
+            for (int k = 0; k < D; ++k)
+                zc[k] = zn[k];
+            lnc = lnn;
+        }
+        it += nb;
+        half ^= 1;
+    };
+
+    if (QN)
+        draw_own(it);
+    for (unsigned int done = 0; done < n_silent; done += RB) {
+        __syncthreads(); /* ring half `half` is full; the other one is free again */
+        batch(min((unsigned int)RB, n_silent - done), nullptr);
+        if (QN)
+            draw_own(it); /* for the next batch (a batch past the end of the run: drawn, never used) */
+    }
+    unsigned int tcol = 0, rows_out = 0;
+    int tb = 0;
+    for (unsigned int done = 0; done < n_loud; done += RB) {
+        const unsigned int nb = min((unsigned int)RB, n_loud - done);
+        __syncthreads(); /* ... and (PFLUSH) the tile this batch may be the first to write into has been flushed */
+        batch(nb, tiles + (size_t)tb * TILE_ELEMS + lane * STRIDE + tcol * D);
+        if (QN)
+            draw_own(it);
+        tcol += nb;
+        if (PFLUSH) {
+            if (tcol == (unsigned int)TILE_T) {
+                tb ^= 1;
+                tcol = 0;
+            }
+        } else if (tcol == (unsigned int)TILE_T || done + nb >= n_loud) {
+            mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles, lane, wave_c0,
+                                          (unsigned long long)a.out_t0 + rows_out, tcol);
+            rows_out += tcol;
+            tcol = 0;
+        }
+    }
+    __syncthreads(); /* hands the last tile over */
+
+    if (active) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            a.state[c * D + i] = x[i];
+        if (a.accept)
+            a.accept[c] += (unsigned long long)n_acc32;
+    }
+    if (a.accept_total && lane == 0 && wave_acc)
+        atomicAdd(a.accept_total, wave_acc);
+}
+
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0>
+hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
+{
+    using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH>;
+    static unsigned long long attr_set = 0; /* > 64 KB of dynamic LDS has to be allowed once per kernel and device */
+    auto kern = mm_run_split_kernel<T, Tgt, SAMPLER, LCT, QP>;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)Plan::lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        if (dev < 64)
+            attr_set |= 1ull << dev;
+    }
+    const unsigned int grid = (unsigned int)((a.n_chains + 255ull) / 256ull);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Plan::lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+#endif /* MM_SPLIT_KERNELS_H */

@@ -219,7 +219,7 @@ def test_kernel_variants_agree_bit_for_bit(M, O):
         for sampler, tgt, scale, L, C, nc, nd in cases:
             init = M.core.init_with_seed(C, tgt.dim, 21, dtype)
             outs = []
-            for variant in (0, 2):
+            for variant in (0, 2) + ((5,) if tgt.dim <= 8 else ()):  # 5: noise waves + transition waves (dim <= 8)
                 if sampler == "mh":
                     s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(scale), init).seed(77)
                 else:
@@ -229,6 +229,54 @@ def test_kernel_variants_agree_bit_for_bit(M, O):
             for other in outs[1:]:
                 for a, b in zip(outs[0], other):
                     assert np.array_equal(a, b), (sampler, type(tgt).__name__, dtype.__name__)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_split_role_kernel_bit_exact_vs_host_build(M, O, dtype):
+    """Kernel variant 5 (mm_split_kernels.h: 512-thread workgroups, four transition waves fed by four noise waves through
+    an LDS ring, two waves per SIMD) against the host build: every target it is instantiated for (dim <= 8), ragged
+    chain counts around the 64 / 256 boundaries, collected counts around the ring-half and tile sizes, odd burn-in,
+    runs without output, continued handles, chain offsets beyond 2^32, split launches."""
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((8, 8))
+    A = A @ A.T / 8 + np.eye(8)
+    cases = [
+        ("hmc", M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], None, 0.032, 10),
+        ("hmc", M.dist.RosenbrockND(3), O.ROSENBROCK_ND, [], None, 0.05, 7),
+        ("hmc", M.dist.DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), O.DIFFABLE_GAUSSIAN2D, GAUSS, None, 0.1, 10),
+        ("hmc", M.dist.Rosenbrock2D(1.0, 100.0), O.ROSENBROCK2D, [1.0, 100.0], None, 0.01, 10),
+        ("hmc", M.dist.StandardNormal(1), O.STANDARD_NORMAL, [], None, 0.3, 4),
+        ("hmc", M.dist.StandardNormal(5), O.STANDARD_NORMAL, [], None, 0.3, 4),
+        ("hmc", M.dist.IsotropicGaussian(2.0, 7), O.ISOTROPIC_GAUSSIAN, [2.0], None, 0.5, 3),
+        ("hmc", M.dist.GaussianND(A), O.GAUSSIAN_ND, [], A, 0.2, 5),
+        ("mh", M.dist.Gaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), O.GAUSSIAN2D, GAUSS, None, 1.0, 0),
+        ("mh", M.dist.RosenbrockND(4), O.ROSENBROCK_ND, [], None, 0.1, 0),
+        ("mh", M.dist.StandardNormal(6), O.STANDARD_NORMAL, [], None, 0.4, 0),
+        ("mh", M.dist.GaussianND(A), O.GAUSSIAN_ND, [], A, 0.15, 0),
+    ]
+    shapes = [(300, 37, 4, 0), (1, 1, 0, 0), (64, 16, 1, 0), (65, 17, 8, 1 << 33), (257, 8, 0, 0), (256, 49, 3, 5), (70, 0, 9, 0)]
+    for ci, (sampler, tgt, kind, params, mat, scale, L) in enumerate(cases):
+        for C, nc, nd, off in (shapes if ci in (0, 8) else shapes[ci % len(shapes):][:2]):
+            init = M.core.init_with_seed(C, tgt.dim, 7, dtype)
+            s, out, ref, ref_state, ref_acc = _run_pair(M, O, sampler, tgt, kind, params, init, scale, nc, nd, 99, L=L,
+                                                        mat=mat, offset=off, variant=5)
+            name = f"{sampler} {type(tgt).__name__} D={tgt.dim} {dtype.__name__} C={C} run({nc}, {nd})"
+            assert np.array_equal(out, ref), name
+            assert np.array_equal(s.accept_counts, ref_acc) and np.array_equal(s.state(), ref_state), name
+    # continued handle, launch partition, run without output
+    init = M.core.init_with_seed(333, 3, 42, dtype)
+    whole = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1).set_kernel_variant(2).run(60, 9)
+    h = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1).set_kernel_variant(5)
+    a = h.run(25, 9)
+    b = h.run(35, 0)
+    assert np.array_equal(np.concatenate([a, b], axis=1), whole)
+    split = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1).set_kernel_variant(5).set_iters_per_launch(13).run(60, 9)
+    assert np.array_equal(split, whole)
+    q = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(1).set_kernel_variant(5)
+    q.run(60, 9, collect=False)
+    assert np.array_equal(q.state(), whole[:, -1, :])
+    with pytest.raises(Exception):  # no instance above dim 8
+        M.hmc.HMC(M.dist.StandardNormal(16), M.core.init_with_seed(8, 16, 1, dtype), 0.1, 5).set_kernel_variant(5)
 
 
 def test_torch_device_output_matches_host_output(M, O):

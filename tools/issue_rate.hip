@@ -21,6 +21,9 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(unsigned long long
     float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
     unsigned u0 = threadIdx.x + 1, u1 = u0 * 3, u2 = u0 * 5, u3 = u0 * 7;
     unsigned long long m0 = u0, m1 = u1;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    double d0 = x0, d1 = x1, d2 = x2, d3 = x3, e0 = x4, e1 = x5, e2 = x6, e3 = x7, da = a, db = b;
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {1, 1, 1, 1};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
@@ -52,6 +55,31 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(unsigned long long
         } else if (MODE == 5) { // v_mad_u64_u32 independent (two accumulators)
             asm volatile(REP16("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %2, %1\n") REP16("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %2, %1\n")
                          REP4(REP4("v_mad_u64_u32 %0, vcc, %2, %3, %0\n")) : "+v"(m0), "+v"(m1) : "v"(u0), "v"(u1) : "vcc");
+        } else if (MODE == 7) { // dependent plain FMAs with only the low 32 lanes enabled: does a half-empty wave issue in one pass?
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0xffffffff\n" REP64("v_fma_f32 %0, %0, %1, %2\n") REP16("v_fma_f32 %0, %0, %1, %2\n")
+                         "s_mov_b64 exec, s[20:21]\n" : "+v"(x0) : "v"(a), "v"(b) : "s20", "s21");
+        } else if (MODE == 8) { // f64 FMAs, independent (4 registers)
+            asm volatile(REP16("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n")
+                         REP4("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n")
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(da), "v"(db));
+        } else if (MODE == 9) { // f64 FMAs, dependent chain
+            asm volatile(REP64("v_fma_f64 %0, %0, %1, %2\n") REP16("v_fma_f64 %0, %0, %1, %2\n") : "+v"(d0) : "v"(da), "v"(db));
+        } else if (MODE == 10) { // f64 MFMA 16x16x4, two accumulators, back to back (16 per iteration)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, d1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d2, d3, acc1, 0, 0, 0);
+            }
+        } else if (MODE == 11) { // 16 f64 MFMAs with 4 independent f64 FMAs after each (64 FMAs): do the two pipes overlap?
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, d1, acc0, 0, 0, 0);
+                asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                             : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(da), "v"(db));
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d2, d3, acc1, 0, 0, 0);
+                asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                             : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(da), "v"(db));
+            }
         } else if (MODE == 6) { // integer xor / add, independent
             asm volatile(REP16("v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n")
                          REP4("v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n")
@@ -61,7 +89,8 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(unsigned long long
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0)
         cyc[(size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
-    sink[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (float)(u0 ^ u1 ^ u2 ^ u3) + (float)(m0 ^ m1) + lds[0];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (float)(u0 ^ u1 ^ u2 ^ u3) + (float)(m0 ^ m1) + lds[0] +
+        (float)(d0 + d1 + d2 + d3 + e0 + e1 + e2 + e3 + acc0[0] + acc0[1] + acc0[2] + acc0[3] + acc1[0] + acc1[1] + acc1[2] + acc1[3]);
 }
 
 template <int MODE> void run(const char *name, int inst_per_iter, int waves_per_simd)
@@ -97,13 +126,18 @@ template <int MODE> void run(const char *name, int inst_per_iter, int waves_per_
 int main()
 {
     for (int w : {1, 2, 4}) {
-        run<0>("v_fma_f32 independent (8 regs)", 80, w);
+        run<0>("v_fma_f32 independent (8 regs)", 192, w);
         run<1>("v_fma_f32 dependent chain", 80, w);
         run<2>("v_fma_f32 two chains interleaved", 80, w);
         run<3>("v_pk_fma_f32 independent", 80, w);
         run<4>("v_mul_hi/lo_u32 independent", 80, w);
         run<5>("v_mad_u64_u32 (2 accumulators)", 80, w);
         run<6>("v_xor/v_add_u32 independent", 80, w);
+        run<7>("v_fma_f32 dependent, 32 lanes on", 80, w);
+        run<8>("v_fma_f64 independent", 80, w);
+        run<9>("v_fma_f64 dependent chain", 80, w);
+        run<10>("v_mfma_f64_16x16x4 back to back", 16, w);
+        run<11>("16 MFMA f64 + 64 v_fma_f64 (per MFMA)", 16, w);
     }
     return 0;
 }

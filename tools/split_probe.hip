@@ -1,0 +1,69 @@
+// Stand-alone driver of the split-role kernel (mm_split_kernels.h) next to mm_run_kernel for quick A/B experiments:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 [-DMM_SPLIT_PRIO_Q=3]
+//         [-DMM_SPLIT_MH_QP=0|1|2] tools/split_probe.hip -o /tmp/split_probe
+// config 3 (HMC RosenbrockND(3), 65 536 chains, run(400, 50)) and config 2 (MH Gaussian2D, run(1000, 100)).
+#include "../mini_mcmc_amd/csrc/mm_split_kernels.h"
+#include "../mini_mcmc_amd/csrc/mm_params.h"
+#include <cstdio>
+#include <vector>
+
+template <class Tgt, int SAMPLER, int LCT> static void bench(const char *name, int D, unsigned NC, unsigned ND, float scale, mm_tparams<float> P)
+{
+    const unsigned long long C = 65536;
+    std::vector<float> h(C * D);
+    for (size_t i = 0; i < h.size(); ++i)
+        h[i] = 0.01f * (float)(i % 97) - 0.3f;
+    float *state, *out;
+    (void)hipMalloc(&state, C * D * 4);
+    (void)hipMalloc(&out, C * NC * D * 4);
+    mm_run_args<float> a{};
+    a.P = P;
+    a.scale = scale; a.n_leapfrog = 10; a.state = state; a.out = out; a.n_chains = C; a.seed = 42;
+    a.n_discard = ND; a.n_collect = NC; a.n_total = NC;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int kern = 0; kern < 2; ++kern) {
+        for (int mode = 0; mode < 2; ++mode) {
+            a.out = mode ? nullptr : out;
+            float best = 1e9;
+            for (int r = 0; r < 8; ++r) {
+                (void)hipMemcpy(state, h.data(), C * D * 4, hipMemcpyHostToDevice);
+                (void)hipEventRecord(e0);
+                if (kern == 0)
+                    (void)mm_launch_run<float, Tgt, SAMPLER, 2, LCT>(a, 1024, 64, 0);
+                else
+                    (void)mm_launch_run_split<float, Tgt, SAMPLER, LCT, (SAMPLER == MM_SAMPLER_MH ? mm_split_mh_qp<float, Tgt::dim>::value : 0)>(a, 0);
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                float ms;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best)
+                    best = ms;
+            }
+            double s = 0;
+            std::vector<float> ho(C * D), hs(1 << 18);
+            (void)hipMemcpy(ho.data(), state, C * D * 4, hipMemcpyDeviceToHost);
+            for (float v : ho)
+                s += v;
+            if (!mode) {
+                (void)hipMemcpy(hs.data(), out + (size_t)12345 * NC * D, hs.size() * 4, hipMemcpyDeviceToHost);
+                for (float v : hs)
+                    s += v;
+            }
+            printf("%-10s %-14s %s: %.4f ms   checksum %.6f\n", name, kern ? "split" : "mm_run_kernel", mode ? "no output " : "with output", best, s);
+        }
+    }
+    (void)hipFree(state);
+    (void)hipFree(out);
+}
+
+int main()
+{
+    mm_tparams<float> P{};
+    bench<mm_target<float, MM_ROSENBROCK_ND, 3>, MM_SAMPLER_HMC, 10>("hmc cfg3", 3, 400, 50, 0.032f, P);
+    const double g[6] = {0.0, 0.0, 1.0, 0.0, 0.0, 1.0};
+    mm_fill_params<float>(MM_GAUSSIAN2D, g, &P);
+    bench<mm_target<float, MM_GAUSSIAN2D, 2>, MM_SAMPLER_MH, 0>("mh cfg2", 2, 1000, 100, 1.0f, P);
+    return 0;
+}
