@@ -16,6 +16,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "mm_generic.h"
 #include "mm_hmc_lg.h"
 #include "mm_kernels.h"
 #include "mm_host_rng.h"
@@ -137,6 +138,10 @@ struct Sampler {
                         3 = lane-group / MFMA kernel (mm_hmc_lg.h): HMC, f64, GaussianND of dim 16 or 32;
                         5 = noise waves + transition waves (mm_split_kernels.h), the default for f32 up to dim 8 */
     bool lg_ok = false;
+    bool generic = false;      /* no fixed-dimension kernel: the run-time-dimension path (mm_generic.h), variant 6 */
+    bool generic_ok = false;   /* the target kind has a run-time-dimension form */
+    void *d_gscratch = nullptr; /* its HBM store when the chain vectors do not fit LDS */
+    size_t c_pad = 0;
     unsigned int block = 64;
     void *d_state = nullptr;
     void *d_mat = nullptr;
@@ -187,19 +192,25 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         s->kf = find_kernel<float>(s->kind, s->dim);
     else
         s->kd = find_kernel<double>(s->kind, s->dim);
+    s->generic_ok = mm_generic_kind_ok(s->kind);
     if (!s->kf && !s->kd) {
-        delete s;
-        return MMCMC_ERR_UNSUPPORTED;
+        /* a dimension without a register-resident kernel: the run-time-dimension path */
+        if (!s->generic_ok) {
+            delete s;
+            return MMCMC_ERR_UNSUPPORTED;
+        }
+        s->generic = true;
+        s->variant = 6;
     }
     /* dense Gaussian at dim 16 / 32 under HMC (f64 and f32): the lane-group / MFMA kernels, and the default there */
     s->lg_ok = sampler == MM_SAMPLER_HMC && s->kind == MMCMC_GAUSSIAN_ND && (s->dim == 16 || s->dim == 32);
     /* at dim 32 the paired / pipelined form holds four noise vectors next to the state and spills: the plain form
      * is twice as fast there (RosenbrockND(32) f32: 1.0 ms vs 2.2 ms for run(100, 20) of 65 536 chains) */
-    if (s->dim > 16)
+    if (s->dim > 16 && !s->generic)
         s->variant = 0;
     /* f32 up to dim 8: noise waves + transition waves, two waves per SIMD (mm_split_kernels.h; config 3: 0.225 ms
      * against 0.268 ms for variant 2) */
-    if (dtype == MMCMC_F32 && s->kf->run_mh_split)
+    if (dtype == MMCMC_F32 && s->kf && s->kf->run_mh_split)
         s->variant = 5;
     if (s->lg_ok)
         s->variant = 3;
@@ -213,6 +224,8 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
             (void)hipFree(s->d_accept);
         if (s->d_accept_total)
             (void)hipFree(s->d_accept_total);
+        if (s->d_gscratch)
+            (void)hipFree(s->d_gscratch);
         if (s->stream)
             (void)hipStreamDestroy(s->stream);
         if (s->ev0)
@@ -239,6 +252,17 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         return fail((int)e);
     if ((e = hipMemcpy(s->d_state, init, bytes, hipMemcpyHostToDevice)) != hipSuccess)
         return fail((int)e);
+    s->c_pad = (n_chains + 63) / 64 * 64;
+    if (s->generic_ok) {
+        /* the run-time-dimension path (default without a fixed-dimension kernel, selectable as variant 6 otherwise)
+         * keeps a chain's vectors in LDS when they fit, else in this lane-interleaved HBM store */
+        const size_t lds = dtype == MMCMC_F32 ? mm_generic_store_bytes<float>(sampler, s->dim) : mm_generic_store_bytes<double>(sampler, s->dim);
+        if (lds > MM_GENERIC_LDS_MAX && s->generic) {
+            const size_t nvec = sampler == MM_SAMPLER_HMC ? MM_GV_HMC : MM_GV_MH;
+            if ((e = hipMalloc(&s->d_gscratch, nvec * (size_t)s->dim * s->c_pad * s->esize())) != hipSuccess)
+                return fail((int)e);
+        }
+    }
     if ((e = hipMalloc((void **)&s->d_accept, n_chains * sizeof(unsigned long long))) != hipSuccess)
         return fail((int)e);
     if ((e = hipMalloc((void **)&s->d_accept_total, sizeof(unsigned long long))) != hipSuccess)
@@ -268,6 +292,8 @@ int sampler_destroy(Sampler *s)
         (void)hipFree(s->d_mat);
     (void)hipFree(s->d_accept);
     (void)hipFree(s->d_accept_total);
+    if (s->d_gscratch)
+        (void)hipFree(s->d_gscratch);
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
     (void)hipStreamDestroy(s->stream);
@@ -299,7 +325,33 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     unsigned int grid = (unsigned int)((s->n_chains + s->block - 1) / s->block);
     hipError_t e;
     const bool mh = s->sampler == MM_SAMPLER_MH, l10 = s->n_leapfrog == 10;
-    if (s->variant == 3 && s->lg_ok) {
+    if (s->variant == 6) {
+        mm_gen_args<T> q;
+        q.P = P;
+        q.kind = s->kind;
+        q.dim = s->dim;
+        q.sampler = mh ? 0 : 1;
+        q.scale = (T)s->scale;
+        q.n_leapfrog = s->n_leapfrog;
+        q.state = (T *)s->d_state;
+        q.out = d_out;
+        q.accept = a.accept;
+        q.accept_total = a.accept_total;
+        q.scratch = (T *)s->d_gscratch;
+        q.n_chains = a.n_chains;
+        q.c_pad = s->c_pad;
+        q.seed = a.seed;
+        q.chain_offset = a.chain_offset;
+        q.n_total = n_total;
+        q.iter0 = a.iter0;
+        q.n_discard = n_discard;
+        q.n_collect = n_collect;
+        q.out_t0 = out_t0;
+        if constexpr (std::is_same<T, float>::value)
+            e = mm_launch_run_generic_f32(q, stream);
+        else
+            e = mm_launch_run_generic_f64(q, stream);
+    } else if (s->variant == 3 && s->lg_ok) {
         if constexpr (std::is_same<T, double>::value) {
             mm_hmc_lg_args q;
             q.mat = (const double *)s->d_mat;
@@ -471,7 +523,7 @@ template <class T>
 int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, void *logp, void *grad)
 {
     const mm_kernel_entry<T> *k = find_kernel<T>(target->kind, target->dim);
-    if (!k)
+    if (!k && !mm_generic_kind_ok(target->kind))
         return MMCMC_ERR_UNSUPPORTED;
     mm_tparams<T> P;
     T *d_mat = nullptr;
@@ -479,7 +531,7 @@ int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, 
     if (st != MMCMC_OK)
         return st;
     size_t d = (size_t)target->dim;
-    T *dx = nullptr, *dl = nullptr, *dg = nullptr;
+    T *dx = nullptr, *dl = nullptr, *dg = nullptr, *dscr = nullptr;
     int rc = MMCMC_OK;
     hipError_t e;
     do {
@@ -491,8 +543,21 @@ int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, 
             break;
         if ((e = hipMemcpy(dx, x, n * d * sizeof(T), hipMemcpyHostToDevice)) != hipSuccess)
             break;
-        if ((e = k->logp_grad(P, dx, dl, dg, (unsigned long long)n, nullptr)) != hipSuccess)
-            break;
+        if (k) {
+            if ((e = k->logp_grad(P, dx, dl, dg, (unsigned long long)n, nullptr)) != hipSuccess)
+                break;
+        } else {
+            /* run-time dimension: position and gradient of row i in a lane-interleaved scratch store */
+            const unsigned long long n_pad = (n + 63) / 64 * 64;
+            if ((e = hipMalloc((void **)&dscr, 2 * d * n_pad * sizeof(T))) != hipSuccess)
+                break;
+            if constexpr (std::is_same<T, float>::value)
+                e = mm_launch_logp_grad_generic_f32(P, target->kind, target->dim, dx, dl, dg, dscr, n, n_pad, nullptr);
+            else
+                e = mm_launch_logp_grad_generic_f64(P, target->kind, target->dim, dx, dl, dg, dscr, n, n_pad, nullptr);
+            if (e != hipSuccess)
+                break;
+        }
         if ((e = hipDeviceSynchronize()) != hipSuccess)
             break;
         if ((e = hipMemcpy(logp, dl, n * sizeof(T), hipMemcpyDeviceToHost)) != hipSuccess)
@@ -506,6 +571,8 @@ int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, 
     (void)hipFree(dl);
     if (dg)
         (void)hipFree(dg);
+    if (dscr)
+        (void)hipFree(dscr);
     if (d_mat)
         (void)hipFree(d_mat);
     return rc;
@@ -520,8 +587,8 @@ int draw_noise_t(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_
     for (int i = 0; i < nn; ++i)
         if (t[i].dim == dim)
             k = &t[i];
-    if (!k)
-        return MMCMC_ERR_UNSUPPORTED;
+    if (!k && dim <= 0)
+        return MMCMC_ERR_INVALID_ARG;
     T *dz = nullptr, *du = nullptr;
     hipError_t e;
     do {
@@ -529,7 +596,13 @@ int draw_noise_t(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_
             break;
         if ((e = hipMalloc((void **)&du, n * sizeof(T))) != hipSuccess)
             break;
-        if ((e = k->noise(seed, chain_offset, iteration, (unsigned long long)n, dz, du, nullptr)) != hipSuccess)
+        if (k)
+            e = k->noise(seed, chain_offset, iteration, (unsigned long long)n, dz, du, nullptr);
+        else if constexpr (std::is_same<T, float>::value)
+            e = mm_launch_noise_generic_f32(seed, chain_offset, iteration, dim, (unsigned long long)n, dz, du, nullptr);
+        else
+            e = mm_launch_noise_generic_f64(seed, chain_offset, iteration, dim, (unsigned long long)n, dz, du, nullptr);
+        if (e != hipSuccess)
             break;
         if ((e = hipDeviceSynchronize()) != hipSuccess)
             break;
@@ -642,11 +715,29 @@ static bool split_ok(const Sampler *s)
 {
     return s->dtype == MMCMC_F32 ? (s->kf && s->kf->run_mh_split) : (s->kd && s->kd->run_mh_split);
 }
+/* variant 6 = the run-time-dimension path: always for dimensions without a fixed kernel (then the only variant); on
+ * request wherever the target kind has one and the chain vectors fit LDS (what the bit-identity tests use) */
+static int set_variant_common(Sampler *s, int variant)
+{
+    if (s->generic)
+        return variant == 6 ? MMCMC_OK : MMCMC_ERR_UNSUPPORTED;
+    if (variant == 6) {
+        const size_t lds = s->dtype == MMCMC_F32 ? mm_generic_store_bytes<float>(s->sampler, s->dim)
+                                                 : mm_generic_store_bytes<double>(s->sampler, s->dim);
+        if (!s->generic_ok || lds > MM_GENERIC_LDS_MAX)
+            return MMCMC_ERR_UNSUPPORTED;
+        s->variant = 6;
+        return MMCMC_OK;
+    }
+    return 1; /* not handled here */
+}
 
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 {
-    if (!h || variant < 0 || (variant > 2 && variant != 5))
+    if (!h || variant < 0 || (variant > 2 && variant != 5 && variant != 6))
         return MMCMC_ERR_INVALID_ARG;
+    if (const int st = set_variant_common(h->s, variant); st <= 0)
+        return st;
     if (variant == 5 && !split_ok(h->s))
         return MMCMC_ERR_UNSUPPORTED;
     h->s->variant = variant;
@@ -654,8 +745,10 @@ int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 }
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
 {
-    if (!h || variant < 0 || (variant > 3 && variant != 5))
+    if (!h || variant < 0 || (variant > 3 && variant != 5 && variant != 6))
         return MMCMC_ERR_INVALID_ARG;
+    if (const int st = set_variant_common(h->s, variant); st <= 0)
+        return st;
     if (variant == 3 && !h->s->lg_ok)
         return MMCMC_ERR_UNSUPPORTED;
     if (variant == 5 && !split_ok(h->s))

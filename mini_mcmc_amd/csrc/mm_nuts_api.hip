@@ -88,6 +88,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
     unsigned int *d_lg_lists = nullptr, *d_lg_counts = nullptr;
     mm_lgq_ctrl *d_lg_ctrl = nullptr;
     unsigned int n_resident_waves = 1024;
+    int lgq_occ = 1; /* waves per SIMD of the persistent scheduler (MMCMC_LGQ_OCC overrides) */
     size_t c_pad = 0;
     static constexpr int kMaxGroups = 16;
     hipStream_t lg_streams[kMaxGroups] = {};
@@ -254,7 +255,14 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 g.ctrl = d_lg_ctrl;
                 g.slots = d_lg_lists;
                 const unsigned int groups16 = (unsigned int)(c_pad / 16);
-                unsigned int nw = groups16 < n_resident_waves ? groups16 : n_resident_waves;
+                /* waves per SIMD the scheduler is built for (mm_lg_cfg): 2 wherever two per SIMD can be filled */
+                int occ = lgq_occ;
+                if (const char *ev = getenv("MMCMC_LGQ_OCC"))
+                    occ = atoi(ev) == 2 ? 2 : 1;
+                if (groups16 < 2u * n_resident_waves)
+                    occ = 1;
+                const unsigned int resident = n_resident_waves * (unsigned int)occ;
+                unsigned int nw = groups16 < resident ? groups16 : resident;
                 if (const char *ev = getenv("MMCMC_LGQ_WAVES")) {
                     const unsigned int w = (unsigned int)atoi(ev);
                     if (w >= 1 && w < nw)
@@ -262,7 +270,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 }
                 /* one launch of the scheduler; the kernel reports a stuck queue instead of hanging */
                 auto launch = [&](const mm_nuts_lg_args &gq) -> hipError_t {
-                    hipError_t e = lg->run_queue(gq, nw, st);
+                    hipError_t e = lg->run_queue(gq, nw, occ, st);
                     if (e != hipSuccess)
                         return e;
                     mm_lgq_ctrl hc;

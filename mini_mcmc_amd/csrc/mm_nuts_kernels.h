@@ -370,7 +370,7 @@ struct mm_nuts_lg_entry {
                        unsigned long long, unsigned long long, hipStream_t);
     hipError_t (*run)(const mm_nuts_lg_args &, hipStream_t);            /* all transitions, one launch */
     hipError_t (*run_transition)(mm_nuts_lg_args, hipStream_t);         /* one transition, tree-depth compaction */
-    hipError_t (*run_queue)(const mm_nuts_lg_args &, unsigned int, hipStream_t); /* persistent scheduler */
+    hipError_t (*run_queue)(const mm_nuts_lg_args &, unsigned int, int, hipStream_t); /* persistent scheduler (waves, waves per SIMD) */
     size_t scratch_doubles_per_wave;
     size_t rec_doubles_per_chain;
 };

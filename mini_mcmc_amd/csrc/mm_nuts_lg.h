@@ -130,14 +130,19 @@ struct mm_nuts_lg_args {
 #endif
 };
 
-template <int D> struct mm_lg_cfg {
+/* OCC = waves per SIMD the kernel is built for: 1 = the 512-register budget and 40 KB of LDS per wave (levels 0..2 of
+ * the pending entries and first-leaf records 1..3 in LDS); 2 = 256 registers and 20 KB (levels 0..1, record 1), the
+ * records of a merge requested when the merge needs them instead of before the leapfrog -- a second wave hides the
+ * latency (persistent scheduler only) */
+template <int D, int OCC = 1> struct mm_lg_cfg {
     static_assert(D % 16 == 0, "lane-group kernel: D must be a multiple of 16");
     static constexpr int NS = D / 4;           /* coordinates per lane */
     static constexpr int NT = D / 16;          /* 16-row result tiles */
     static constexpr int ES = NS + 2;          /* pending entry: proposal[NS], alpha, (n | n_alpha << 32) */
     static constexpr int FS = 2 * NS;          /* first-leaf record: x[NS], p[NS] */
-    static constexpr int LE = 3;               /* entry(k), k < LE, in LDS */
-    static constexpr int LF = 3;               /* first(c), 1 <= c <= LF, in LDS */
+    static constexpr int LE = OCC == 1 ? 3 : 2; /* entry(k), k < LE, in LDS */
+    static constexpr int LF = OCC == 1 ? 3 : 1; /* first(c), 1 <= c <= LF, in LDS */
+    static constexpr bool prefetch = OCC == 1;  /* records of the level-0 / 1 merges requested before the leapfrog */
     static constexpr int lds_E = 0, lds_F = LE * ES, lds_slots = LE * ES + LF * FS;
     static constexpr size_t lds_bytes = (size_t)lds_slots * 64 * sizeof(double);
     /* HBM slots per wave: entry(k), k = LE..JMAX-1 | first(c), c = LF+1..JMAX */
@@ -334,11 +339,11 @@ template <int D, bool COH = false> __device__ __forceinline__ void mm_lg_begin(m
 
 /* doubling j of the wave's chains (one iteration of `while s`, nuts.rs:578-671); `alive` in: the chain takes part,
  * out: it wants another doubling */
-template <int D, bool COH = false>
+template <int D, bool COH = false, int OCC = 1>
 __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, int j, bool &alive,
                                                double epsilon, mm_lds_double *lds, double *scr)
 {
-    using Cfg = mm_lg_cfg<D>;
+    using Cfg = mm_lg_cfg<D, OCC>;
     constexpr int NS = Cfg::NS, ES = Cfg::ES;
     const size_t st = (size_t)a.c_pad * 4;
 
@@ -427,9 +432,9 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         rec r0, r1;
         const bool merge0 = j > 0 && (leaf & 1u);
         const bool merge1 = j > 1 && (leaf & 3u) == 3u; /* ... and then with the pair before it */
-        if (merge0)
+        if (Cfg::prefetch && merge0)
             load_rec(0, first_slot(leaf, 0), r0);
-        if (merge1)
+        if (Cfg::prefetch && merge1)
             load_rec(1, first_slot(leaf, 1), r1);
         /* leapfrog of the outer edge (nuts.rs:979-996), in place; chains that are done keep their edge (the
          * matrix product runs for all 64 lanes: MFMA has no per-lane mask, their columns are recomputed) */
@@ -547,15 +552,20 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         };
         if (j > 0) {
             MM_LG_COUNT(L, 7);
-            if (merge0)
-                merge(r0); /* level 0, records requested before the leapfrog */
+            if (merge0) {
+                if (!Cfg::prefetch)
+                    load_rec(0, first_slot(leaf, 0), r0);
+                merge(r0); /* level 0; OCC 1: records requested before the leapfrog */
+            }
             else
                 push(0);
             if (j > 1 && __ballot(walking) != 0ull) {
                 MM_LG_COUNT(L, 7);
-                if (merge1)
+                if (merge1) {
+                    if (!Cfg::prefetch)
+                        load_rec(1, first_slot(leaf, 1), r1);
                     merge(r1);
-                else if ((leaf >> 1) & 1u) {
+                } else if ((leaf >> 1) & 1u) {
                     /* bit 1 set but bit 0 clear: the level-0 child was first, a failing one was handed up */
                     rec rk;
                     load_rec(1, first_slot(leaf, 1), rk);
@@ -954,9 +964,9 @@ __device__ __forceinline__ void mm_lgq_append(const mm_lg_lane<D> &L, const mm_n
     }
 }
 
-template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const mm_nuts_lg_args a)
+template <int D, int OCC = 1> __global__ __launch_bounds__(64, OCC) void mm_nuts_lgq_kernel(const mm_nuts_lg_args a)
 {
-    using Cfg = mm_lg_cfg<D>;
+    using Cfg = mm_lg_cfg<D, OCC>;
     constexpr int NS = Cfg::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
     __shared__ unsigned int hist_lds[MM_NUTS_JMAX + 1];
@@ -1222,7 +1232,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const 
         }
         /* one copy of the doubling code for both kinds of unit (the kernel's hot loop should stay small) */
         for (int j = j_first; j < j_next && __ballot(alive) != 0ull; ++j)
-            mm_lg_doubling<D, true>(L, a, j, alive, ad.epsilon, lds, scr);
+            mm_lg_doubling<D, true, OCC>(L, a, j, alive, ad.epsilon, lds, scr);
 
         MM_LGQ_T(2);
         /* ---- hand the chains on ---- */
@@ -1280,12 +1290,18 @@ template <int D> __global__ __launch_bounds__(64) void mm_nuts_lgq_kernel(const 
 #undef MM_LGQ_T
 }
 
-template <int D> hipError_t mm_launch_nuts_lgq(const mm_nuts_lg_args &a, unsigned int n_waves, hipStream_t stream)
+/* occ: waves per SIMD the scheduler kernel is built for (1 or 2); the caller sizes n_waves and the scratch accordingly */
+template <int D> hipError_t mm_launch_nuts_lgq(const mm_nuts_lg_args &a, unsigned int n_waves, int occ, hipStream_t stream)
 {
     const size_t n_slots = (size_t)MM_LGQ_SHARDS * MM_LGQ_NQ * a.c_pad;
     const size_t scalar_base = (size_t)mm_lg_cfg<D>::n_vec * D * a.c_pad;
     hipLaunchKernelGGL((mm_nuts_lgq_init_kernel<D>), dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0, stream, a, scalar_base);
-    hipLaunchKernelGGL((mm_nuts_lgq_kernel<D>), dim3(n_waves), dim3(64), mm_lg_cfg<D>::lds_bytes, stream, a);
+    using Cfg1 = mm_lg_cfg<D, 1>;
+    using Cfg2 = mm_lg_cfg<D, 2>;
+    if (occ == 2)
+        hipLaunchKernelGGL((mm_nuts_lgq_kernel<D, 2>), dim3(n_waves), dim3(64), Cfg2::lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL((mm_nuts_lgq_kernel<D, 1>), dim3(n_waves), dim3(64), Cfg1::lds_bytes, stream, a);
     return hipGetLastError();
 }
 

@@ -9,7 +9,8 @@
         DIM, &mm_launch_nuts_init<double, double, mm_target_gnd_grp4<double, DIM>, mm_red_grp4<double, DIM>>,     \
             &mm_launch_nuts_lg<DIM>, &mm_launch_nuts_lgc_transition<DIM>,                                         \
             &mm_launch_nuts_lgq<DIM>,                                                                             \
-            mm_lg_cfg<DIM>::scratch_doubles_per_wave, mm_lg_cfg<DIM>::rec_doubles(1)                              \
+            /* sized for either build of the scheduler */                                                         \
+            (mm_lg_cfg<DIM, 2>::scratch_doubles_per_wave > mm_lg_cfg<DIM, 1>::scratch_doubles_per_wave ? mm_lg_cfg<DIM, 2>::scratch_doubles_per_wave : mm_lg_cfg<DIM, 1>::scratch_doubles_per_wave), mm_lg_cfg<DIM>::rec_doubles(1)                              \
     }
 
 static const mm_nuts_lg_entry g_lg_table[] = {MM_LGENTRY(16), MM_LGENTRY(32)};

@@ -17,6 +17,7 @@
 #include "../mini_mcmc_amd/csrc/mm_params.h"
 #include "../mini_mcmc_amd/csrc/mm_nuts.h"
 #include "../mini_mcmc_amd/csrc/mm_samplers.h"
+#include "../mini_mcmc_amd/csrc/mm_generic.h"
 
 namespace {
 
@@ -60,6 +61,52 @@ void run_chains(const mm_tparams<T> &P, T scale, int n_leapfrog, T *state, size_
         t.join();
 }
 
+/* the run-time-dimension path (mm_generic.h) on the host: the store is a plain array per chain */
+template <class T>
+int run_generic(int hmc, int kind, int dim, const mm_tparams<T> &P, T scale, int L, T *state, size_t n, uint64_t seed,
+                uint64_t off, uint32_t it0, size_t nc, size_t nd, T *out, uint64_t *acc, int nth)
+{
+    if (!mm_generic_kind_ok(kind) || dim < 1)
+        return -2;
+    auto work = [&](size_t lo, size_t hi) {
+        std::vector<T> buf((size_t)MM_GV_HMC * dim);
+        mm_gstore<T, T *> s;
+        s.base = buf.data();
+        s.stride = 1;
+        s.dim = dim;
+        for (size_t c = lo; c < hi; ++c) {
+            for (int i = 0; i < dim; ++i)
+                s.st(MM_GV_X, i, state[c * dim + i]);
+            T lp = mm_gen_logp_grad<T>(kind, P, s, MM_GV_X, hmc ? MM_GV_G : -1);
+            uint64_t n_acc = 0;
+            uint32_t it = it0;
+            for (size_t t = 0; t < nd + nc; ++t, ++it) {
+                const int a = hmc ? mm_gen_hmc_step<T>(kind, P, scale, L, s, &lp, seed, off + c, it)
+                                  : mm_gen_mh_step<T>(kind, P, scale, s, &lp, seed, off + c, it);
+                n_acc += (uint64_t)a;
+                if (t >= nd && out)
+                    for (int i = 0; i < dim; ++i)
+                        out[(c * nc + (t - nd)) * dim + i] = s.ld(MM_GV_X, i);
+            }
+            for (int i = 0; i < dim; ++i)
+                state[c * dim + i] = s.ld(MM_GV_X, i);
+            if (acc)
+                acc[c] = n_acc;
+        }
+    };
+    if (nth <= 1 || n < 2) {
+        work(0, n);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    size_t nt = std::min<size_t>((size_t)nth, n);
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto &t : th)
+        t.join();
+    return 0;
+}
+
 template <class T, int KIND, int D>
 int run_kd(int hmc, const mm_tparams<T> &P, T scale, int L, T *state, size_t n, uint64_t seed, uint64_t off,
            uint32_t it0, size_t nc, size_t nd, T *out, uint64_t *acc, int nth)
@@ -84,7 +131,7 @@ int run_kd(int hmc, const mm_tparams<T> &P, T scale, int L, T *state, size_t n, 
     case 8: return run_kd<T, KIND, 8>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);          \
     case 16: return run_kd<T, KIND, 16>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);        \
     case 32: return run_kd<T, KIND, 32>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);        \
-    default: return -2;                                                                                           \
+    default: return run_generic<T>(hmc, KIND, dim, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);   \
     }
 
 template <class T>
@@ -104,6 +151,8 @@ int run_t(int hmc, int kind, int dim, const double params[8], const double *matr
         P.mat = mat.data();
     }
     T scale = (T)scale_d;
+    if (hmc >= 2) /* samplers 2 / 3: MH / HMC through the run-time-dimension path whatever the dimension */
+        return run_generic<T>(hmc - 2, kind, dim, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth);
     switch (kind) {
     case MM_GAUSSIAN2D:
         return dim == 2 ? run_kd<T, MM_GAUSSIAN2D, 2>(hmc, P, scale, L, state, n, seed, off, it0, nc, nd, out, acc, nth) : -3;
@@ -129,7 +178,8 @@ int run_t(int hmc, int kind, int dim, const double params[8], const double *matr
 extern "C" {
 
 /* Run n_chains chains for n_discard + n_collect transitions on the host with the engine's own arithmetic.
- * sampler: 0 = MH (scale = proposal std), 1 = HMC (scale = step size).  dtype: 0 = f32, 1 = f64.
+ * sampler: 0 = MH (scale = proposal std), 1 = HMC (scale = step size); 2 / 3 = the same through the run-time-dimension
+ * path (mm_generic.h), which dimensions without a fixed-size instance take anyway.  dtype: 0 = f32, 1 = f64.
  * state [n, dim] in/out; out [n, n_collect, dim] or NULL; accept [n] or NULL.  Returns 0, or <0 if unsupported. */
 int eh_run(int sampler, int dtype, int kind, int dim, const double params[8], const double *matrix, double scale,
            int n_leapfrog, void *state, size_t n_chains, uint64_t seed, uint64_t chain_offset, uint32_t iter0,
@@ -311,8 +361,22 @@ int eh_noise(int dtype, uint64_t seed, uint64_t chain_offset, uint32_t iteration
         NOISE_CASE(16)
         NOISE_CASE(32)
     default:
-        return -2;
+        break;
     }
+    if (dim < 1)
+        return -2;
+    for (size_t i = 0; i < n; ++i) {
+        if (dtype == 0) {
+            float *zz = (float *)z + i * dim;
+            mm_gen_noise(seed, chain_offset + i, iteration, dim, 0.0f, [&](int k, float v) { zz[k] = v; });
+            ((float *)u)[i] = mm_spare_u24(mm_block(seed, chain_offset + i, iteration, 0u));
+        } else {
+            double *zz = (double *)z + i * dim;
+            mm_gen_noise(seed, chain_offset + i, iteration, dim, 0.0, [&](int k, double v) { zz[k] = v; });
+            ((double *)u)[i] = mm_aux_u53(seed, chain_offset + i, iteration, 0);
+        }
+    }
+    return 0;
 }
 
 /* log-density (and gradient if g != NULL) of n rows with the engine's arithmetic */
@@ -354,6 +418,22 @@ int eh_logp_grad(int dtype, int kind, int dim, const double params[8], const dou
         EV_ND(MM_ROSENBROCK_ND)
         EV_ND(MM_STANDARD_NORMAL)
         EV_ND(MM_GAUSSIAN_ND)
+        if (mm_generic_kind_ok(kind) && dim >= 1) {
+            std::vector<T> buf((size_t)2 * dim);
+            mm_gstore<T, T *> s;
+            s.base = buf.data();
+            s.stride = 1;
+            s.dim = dim;
+            for (size_t i = 0; i < n; ++i) {
+                for (int k = 0; k < dim; ++k)
+                    s.st(0, k, xx[i * dim + k]);
+                lp[i] = mm_gen_logp_grad<T>(kind, P, s, 0, gg ? 1 : -1);
+                if (gg)
+                    for (int k = 0; k < dim; ++k)
+                        gg[i * dim + k] = s.ld(1, k);
+            }
+            return 0;
+        }
         return -2;
     };
     return dtype == 0 ? eval(float{}) : eval(double{});

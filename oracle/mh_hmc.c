@@ -21,7 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXD 64
+#define MAXD 512 /* the reference has no limit; the GPU parity tests go up to 257 */
 
 /* ------------------------------------------------------------------ init */
 

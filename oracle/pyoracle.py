@@ -610,7 +610,8 @@ def engine_host_run(sampler, kind, dim, params, init, scale, n_collect, n_discar
     out = np.empty((n, n_collect, dim), dtype=dtype) if want_out else None
     acc = np.zeros(n, dtype=np.uint64)
     p, m = _eh_target_args(kind, params, matrix)
-    rc = E.eh_run(0 if sampler == "mh" else 1, 0 if dtype == np.float32 else 1, kind, dim, _d(p),
+    code = {"mh": 0, "hmc": 1, "mh_generic": 2, "hmc_generic": 3}[sampler]  # *_generic: mm_generic.h whatever the dimension
+    rc = E.eh_run(code, 0 if dtype == np.float32 else 1, kind, dim, _d(p),
                   _d(m) if m is not None else None, float(scale), int(n_leapfrog), state.ctypes.data, n, seed,
                   chain_offset, iter0, n_collect, n_discard, out.ctypes.data if want_out else None,
                   acc.ctypes.data_as(_u64p), n_threads or default_threads())
