@@ -222,6 +222,37 @@ int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant);
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant);
 int mmcmc_hmc_kernel_variant(mmcmc_hmc *h); /* the variant in use (>= 0) or a negative status */
 
+/* ---- device groups: one call runs every chain on N GPUs (csrc/mm_group.hip) ------------------------------------
+ * `run` of the reference executes ALL chains of the sampler (ChainRunner::run core.rs:176-186, HMC::run hmc.rs:137-158).
+ * A group shards n_chains contiguously over `devices` (device i: global chains [first_i, first_i + n_i), stream keyed by
+ * the global index, so the sample does not depend on the number of devices), runs the shards from one host thread per
+ * device with no data-path collective, and reduces split-R-hat / ESS (stats.rs:416-546) over all chains: per-device
+ * sufficient statistics, RCCL ncclAllGather of the per-half-chain means / sums of squares + ncclAllReduce of the lag
+ * sums over xGMI, host finish in the single-GPU summation order.  (RCCL is bound at run time; if it is missing, or a
+ * device is listed twice -- several shards on one GPU --, the statistics travel through the host; *used_rccl says which.)
+ *   init: host [n_chains, dim] of dtype.  run: the sample stays on the devices (mmcmc_hmc_group_shard gives each shard's
+ *   device pointer [n_i, n_collect, dim]); out_host, if not NULL, also receives [n_chains, n_collect, dim];
+ *   accept_counts: host [n_chains] or NULL.  A second run continues the chains. */
+typedef struct mmcmc_hmc_group mmcmc_hmc_group;
+int mmcmc_hmc_group_create(mmcmc_hmc_group **out, const mmcmc_target_desc *target, const void *init, size_t n_chains,
+                           double step_size, int n_leapfrog, int dtype, const int *devices, int n_devices);
+int mmcmc_hmc_group_seed(mmcmc_hmc_group *g, uint64_t seed);
+int mmcmc_hmc_group_set_chain_offset(mmcmc_hmc_group *g, uint64_t first_global_chain);
+int mmcmc_hmc_group_run(mmcmc_hmc_group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts);
+int mmcmc_hmc_group_state(mmcmc_hmc_group *g, void *out); /* host [n_chains, dim] */
+int mmcmc_hmc_group_split_rhat_mean_ess(mmcmc_hmc_group *g, float *rhat, float *ess, int *used_rccl); /* of the last run */
+int mmcmc_hmc_group_shard(mmcmc_hmc_group *g, int i, int *device, size_t *first_chain, size_t *n_chains, void **sample_dev);
+int mmcmc_hmc_group_destroy(mmcmc_hmc_group *g);
+typedef struct mmcmc_mh_group mmcmc_mh_group;
+int mmcmc_mh_group_create(mmcmc_mh_group **out, const mmcmc_target_desc *target, const mmcmc_proposal_desc *proposal,
+                          const void *init, size_t n_chains, int dtype, const int *devices, int n_devices);
+int mmcmc_mh_group_seed(mmcmc_mh_group *g, uint64_t seed);
+int mmcmc_mh_group_set_chain_offset(mmcmc_mh_group *g, uint64_t first_global_chain);
+int mmcmc_mh_group_run(mmcmc_mh_group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts);
+int mmcmc_mh_group_state(mmcmc_mh_group *g, void *out);
+int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *g, float *rhat, float *ess, int *used_rccl);
+int mmcmc_mh_group_destroy(mmcmc_mh_group *g);
+
 /* ---- diagnostics: stats.rs ------------------------------------------------------------------------------
  * split_rhat_mean_ess(sample[chains, n, params]) -> (rhat[params], ess[params])   stats.rs:416-423
  * (splitcat :396-402, withinvar :429-477, rhat :425-427 = sqrt(W/var+) as the reference defines it, ess :496-546).

@@ -138,6 +138,21 @@ SIGNATURES = {
     "mmcmc_save_csv": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_char_p]),
     "mmcmc_logp_grad_batch": (C.c_int, [_TP, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int]),
     "mmcmc_draw_noise": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int]),
+    "mmcmc_hmc_group_create": (C.c_int, [C.POINTER(_vp), _TP, _vp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "mmcmc_hmc_group_seed": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_hmc_group_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_hmc_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint64)]),
+    "mmcmc_hmc_group_state": (C.c_int, [_vp, _vp]),
+    "mmcmc_hmc_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mmcmc_hmc_group_shard": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
+    "mmcmc_hmc_group_destroy": (C.c_int, [_vp]),
+    "mmcmc_mh_group_create": (C.c_int, [C.POINTER(_vp), _TP, _PP, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "mmcmc_mh_group_seed": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_mh_group_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_mh_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint64)]),
+    "mmcmc_mh_group_state": (C.c_int, [_vp, _vp]),
+    "mmcmc_mh_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mmcmc_mh_group_destroy": (C.c_int, [_vp]),
 }
 
 

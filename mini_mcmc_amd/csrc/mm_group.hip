@@ -1,0 +1,522 @@
+/*
+ * mm_group.hip -- device groups behind the C ABI: ONE call runs every chain on N GPUs of the process.
+ *
+ * The reference's contract is "run() executes all chains" (ChainRunner::run core.rs:176-186, HMC::run hmc.rs:137-158);
+ * with one sampler handle per device the caller of the C ABI would have to write the sharding and the exchange of the
+ * diagnostics itself.  A group owns one handle per device -- device i holds the contiguous block of global chains
+ * [first_i, first_i + n_i), keyed into the random stream by their GLOBAL index, so the samples do not depend on the
+ * number of devices -- and runs them from one host thread per device (every call into the per-device ABI blocks only
+ * its own thread).  Chains never talk to each other while sampling: no data-path collective.  The one exchange is
+ * the split-R-hat / ESS reduction (stats.rs:416-546): every device reduces its own sample to the per-half-chain
+ * statistics (mmcmc_stats_partials), RCCL all-gathers means / sums of squares over xGMI (ncclAllGather) and
+ * all-reduces the lag sums (ncclAllReduce), and the host finish (mmcmc_stats_finish) runs on the gathered statistics
+ * in the single-GPU order.  RCCL is loaded at run time (librccl.so.1: the copy PyTorch has already mapped, if any);
+ * without it, or when a device appears twice in the list (several shards on one GPU: what a one-GPU test box can
+ * exercise), the few KB of statistics are exchanged through the host instead.
+ */
+#include "../../include/mmcmc.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+namespace {
+
+/* ---- RCCL, bound at run time ---- */
+typedef void *ncclComm_t;
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    bool ok() const { return CommInitAll && CommDestroy && AllGather && AllReduce; }
+};
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib)
+                break;
+        }
+        if (!r.lib)
+            return;
+        r.CommInitAll = (int (*)(ncclComm_t *, int, const int *))dlsym(r.lib, "ncclCommInitAll");
+        r.CommDestroy = (int (*)(ncclComm_t))dlsym(r.lib, "ncclCommDestroy");
+        r.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t, hipStream_t))dlsym(r.lib, "ncclAllGather");
+        r.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t))dlsym(r.lib, "ncclAllReduce");
+    });
+    return r;
+}
+
+/* one host thread per device for the life of the group: calls into the per-device ABI block only their own thread,
+ * and per-thread state of that ABI (the statistics' work buffers) stays with its device */
+class Worker {
+  public:
+    Worker() : th_([this] { loop(); }) {}
+    ~Worker()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<int()> job)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            job_ = std::move(job);
+            has_job_ = true;
+            done_ = false;
+        }
+        cv_.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return done_; });
+        return rc_;
+    }
+
+  private:
+    void loop()
+    {
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return has_job_ || quit_; });
+                if (quit_ && !has_job_)
+                    return;
+                job = std::move(job_);
+                has_job_ = false;
+            }
+            const int rc = job();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                rc_ = rc;
+                done_ = true;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    bool has_job_ = false, done_ = true, quit_ = false;
+    int rc_ = 0;
+    std::thread th_;
+};
+
+struct Shard {
+    int device = 0;
+    size_t first = 0, n = 0; /* global chains [first, first + n) */
+    mmcmc_hmc *hmc = nullptr;
+    mmcmc_mh *mh = nullptr;
+    void *d_sample = nullptr; /* [n, n_collect, dim] of the last run, on the device */
+    size_t sample_cap = 0;
+    hipStream_t stream = nullptr;
+    float *d_stats = nullptr; /* means [2 cmax, dim] | ssq [2 cmax, dim] | acov [m, dim] | gathered [N][2][2 cmax dim] */
+    size_t stats_cap = 0;
+    ncclComm_t comm = nullptr;
+    std::unique_ptr<Worker> worker;
+};
+
+struct Group {
+    int sampler = 0; /* 0 MH, 1 HMC */
+    int dtype = MMCMC_F32, dim = 0;
+    size_t n_chains = 0, cmax = 0;
+    size_t last_collect = 0;
+    bool use_rccl = false, comm_ready = false;
+    uint64_t user_offset = 0;
+    std::vector<Shard> sh;
+    size_t esize() const { return dtype == MMCMC_F32 ? 4 : 8; }
+};
+
+template <class F> int for_each_shard(Group *g, F &&f)
+{
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        if (!g->sh[i].worker)
+            g->sh[i].worker.reset(new Worker());
+        g->sh[i].worker->post([&f, g, i]() -> int { return f(g->sh[i], (int)i); });
+    }
+    int st = MMCMC_OK;
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        const int rc = g->sh[i].worker->wait();
+        if (rc != MMCMC_OK && st == MMCMC_OK)
+            st = rc;
+    }
+    return st;
+}
+
+int group_destroy(Group *g)
+{
+    if (!g)
+        return MMCMC_ERR_INVALID_ARG;
+    for (Shard &s : g->sh) {
+        s.worker.reset();
+        (void)hipSetDevice(s.device);
+        if (s.comm && rccl().ok())
+            (void)rccl().CommDestroy(s.comm);
+        if (s.hmc)
+            (void)mmcmc_hmc_destroy(s.hmc);
+        if (s.mh)
+            (void)mmcmc_mh_destroy(s.mh);
+        if (s.d_sample)
+            (void)hipFree(s.d_sample);
+        if (s.d_stats)
+            (void)hipFree(s.d_stats);
+        if (s.stream)
+            (void)hipStreamDestroy(s.stream);
+    }
+    delete g;
+    return MMCMC_OK;
+}
+
+int group_create(Group **out, int sampler, const mmcmc_target_desc *target, const mmcmc_proposal_desc *proposal, const void *init,
+                 size_t n_chains, double scale, int n_leapfrog, int dtype, const int *devices, int n_devices)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!target || !init || !devices || n_devices < 1 || n_devices > 64 || n_chains < (size_t)n_devices ||
+        (dtype != MMCMC_F32 && dtype != MMCMC_F64))
+        return MMCMC_ERR_INVALID_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    bool dup = false;
+    for (int i = 0; i < n_devices; ++i) {
+        if (devices[i] < 0 || devices[i] >= n_dev)
+            return MMCMC_ERR_INVALID_ARG;
+        for (int j = 0; j < i; ++j)
+            dup = dup || devices[j] == devices[i];
+    }
+    Group *g = new (std::nothrow) Group();
+    if (!g)
+        return (int)hipErrorOutOfMemory;
+    g->sampler = sampler;
+    g->dtype = dtype;
+    g->dim = target->dim;
+    g->n_chains = n_chains;
+    g->use_rccl = !dup && rccl().ok();
+    g->sh.resize((size_t)n_devices);
+    const size_t esz = g->esize(), base = n_chains / (size_t)n_devices, rem = n_chains % (size_t)n_devices;
+    size_t first = 0;
+    for (int i = 0; i < n_devices; ++i) {
+        Shard &s = g->sh[(size_t)i];
+        s.device = devices[i];
+        s.first = first;
+        s.n = base + ((size_t)i < rem ? 1 : 0);
+        first += s.n;
+        g->cmax = s.n > g->cmax ? s.n : g->cmax;
+    }
+    const int st = for_each_shard(g, [&](Shard &s, int) -> int {
+        const char *p = (const char *)init + s.first * (size_t)g->dim * esz;
+        int rc = sampler ? mmcmc_hmc_create(&s.hmc, target, p, s.n, scale, n_leapfrog, dtype, s.device)
+                         : mmcmc_mh_create(&s.mh, target, proposal, p, s.n, dtype, s.device);
+        if (rc != MMCMC_OK)
+            return rc;
+        rc = sampler ? mmcmc_hmc_set_chain_offset(s.hmc, s.first) : mmcmc_mh_set_chain_offset(s.mh, s.first);
+        if (rc != MMCMC_OK)
+            return rc;
+        if (hipSetDevice(s.device) != hipSuccess)
+            return MMCMC_ERR_NO_DEVICE;
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        return e == hipSuccess ? MMCMC_OK : (int)e;
+    });
+    if (st != MMCMC_OK) {
+        group_destroy(g);
+        return st;
+    }
+    *out = g;
+    return MMCMC_OK;
+}
+
+int group_seed(Group *g, uint64_t seed)
+{
+    if (!g)
+        return MMCMC_ERR_INVALID_ARG;
+    for (Shard &s : g->sh) {
+        const int rc = g->sampler ? mmcmc_hmc_seed(s.hmc, seed) : mmcmc_mh_seed(s.mh, seed);
+        if (rc != MMCMC_OK)
+            return rc;
+    }
+    return MMCMC_OK;
+}
+
+int group_set_chain_offset(Group *g, uint64_t off)
+{
+    if (!g)
+        return MMCMC_ERR_INVALID_ARG;
+    g->user_offset = off;
+    for (Shard &s : g->sh) {
+        const int rc = g->sampler ? mmcmc_hmc_set_chain_offset(s.hmc, off + s.first) : mmcmc_mh_set_chain_offset(s.mh, off + s.first);
+        if (rc != MMCMC_OK)
+            return rc;
+    }
+    return MMCMC_OK;
+}
+
+/* run(n_collect, n_discard) of every chain; the sample stays on the devices (one shard each) and, when out_host is
+ * given, is also copied into the caller's [n_chains, n_collect, dim] array; accept_counts [n_chains] or NULL */
+int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts)
+{
+    if (!g)
+        return MMCMC_ERR_INVALID_ARG;
+    const size_t esz = g->esize(), row = n_collect * (size_t)g->dim * esz;
+    const int st = for_each_shard(g, [&](Shard &s, int) -> int {
+        if (hipSetDevice(s.device) != hipSuccess)
+            return MMCMC_ERR_NO_DEVICE;
+        const size_t bytes = s.n * row;
+        if (bytes > s.sample_cap) {
+            if (s.d_sample)
+                (void)hipFree(s.d_sample);
+            s.d_sample = nullptr;
+            s.sample_cap = 0;
+            hipError_t e = hipMalloc(&s.d_sample, bytes);
+            if (e != hipSuccess)
+                return (int)e;
+            s.sample_cap = bytes;
+        }
+        uint64_t *acc = accept_counts ? accept_counts + s.first : nullptr;
+        void *d_out = n_collect ? s.d_sample : nullptr;
+        int rc = g->sampler ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, acc, s.stream)
+                            : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, acc, s.stream);
+        if (rc != MMCMC_OK)
+            return rc;
+        hipError_t e = hipSuccess;
+        if (out_host && n_collect)
+            e = hipMemcpyAsync((char *)out_host + s.first * row, s.d_sample, bytes, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s.stream);
+        return e == hipSuccess ? MMCMC_OK : (int)e;
+    });
+    if (st == MMCMC_OK)
+        g->last_collect = n_collect;
+    return st;
+}
+
+int group_state(Group *g, void *out)
+{
+    if (!g || !out)
+        return MMCMC_ERR_INVALID_ARG;
+    const size_t esz = g->esize();
+    return for_each_shard(g, [&](Shard &s, int) -> int {
+        void *p = (char *)out + s.first * (size_t)g->dim * esz;
+        return g->sampler ? mmcmc_hmc_state(s.hmc, p) : mmcmc_mh_state(s.mh, p);
+    });
+}
+
+/* split-R-hat / ESS of the last run's sample (stats.rs:416-423) over ALL devices' chains */
+int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
+{
+    if (!g || !rhat || !ess)
+        return MMCMC_ERR_INVALID_ARG;
+    const size_t n = g->last_collect, m = n / 2, D = (size_t)g->dim, N = g->sh.size();
+    if (m < 1)
+        return MMCMC_ERR_SHAPE;
+    const size_t part = 2 * g->cmax * D;             /* per-device means (or ssq), padded to the largest shard */
+    const size_t own = 2 * part + m * D;             /* means | ssq | acov */
+    const size_t total = own + N * 2 * part + m * D; /* + gathered [N][means | ssq] + reduced acov */
+    if (g->use_rccl && !g->comm_ready) {
+        std::vector<ncclComm_t> comms(N);
+        std::vector<int> devs(N);
+        for (size_t i = 0; i < N; ++i)
+            devs[i] = g->sh[i].device;
+        if (rccl().CommInitAll(comms.data(), (int)N, devs.data()) != 0) {
+            g->use_rccl = false; /* e.g. no peer access: exchange through the host */
+        } else {
+            for (size_t i = 0; i < N; ++i)
+                g->sh[i].comm = comms[i];
+            g->comm_ready = true;
+        }
+    }
+    if (used_rccl)
+        *used_rccl = g->use_rccl ? 1 : 0;
+    std::vector<float> h_own(g->use_rccl ? 0 : N * own);
+    int st = for_each_shard(g, [&](Shard &s, int i) -> int {
+        if (hipSetDevice(s.device) != hipSuccess)
+            return MMCMC_ERR_NO_DEVICE;
+        hipError_t e;
+        if (total > s.stats_cap) {
+            if (s.d_stats)
+                (void)hipFree(s.d_stats);
+            s.d_stats = nullptr;
+            s.stats_cap = 0;
+            if ((e = hipMalloc((void **)&s.d_stats, total * sizeof(float))) != hipSuccess)
+                return (int)e;
+            s.stats_cap = total;
+        }
+        float *means = s.d_stats, *ssq = means + part, *acov = ssq + part, *gathered = acov + m * D, *acov_all = gathered + N * 2 * part;
+        if ((e = hipMemsetAsync(s.d_stats, 0, own * sizeof(float), s.stream)) != hipSuccess)
+            return (int)e;
+        /* the local statistics are [2][n_i][D] (first halves of the local chains, then their second halves); every
+         * rank sends a slot of 2 * cmax * D floats (all-gather wants equal counts), the tail past 2 n_i D stays zero */
+        int rc = mmcmc_stats_partials(s.d_sample, g->dtype, s.n, n, D, means, ssq, acov, s.device, s.stream);
+        if (rc != MMCMC_OK)
+            return rc;
+        if (g->use_rccl) {
+            /* means and ssq are adjacent: one all-gather of 2 * part floats per rank; lag sums: one all-reduce */
+            if (rccl().AllGather(means, gathered, 2 * part, kNcclFloat32, s.comm, s.stream) != 0)
+                return (int)hipErrorUnknown;
+            if (rccl().AllReduce(acov, acov_all, m * D, kNcclFloat32, kNcclSum, s.comm, s.stream) != 0)
+                return (int)hipErrorUnknown;
+        } else {
+            if ((e = hipMemcpyAsync(h_own.data() + (size_t)i * own, s.d_stats, own * sizeof(float), hipMemcpyDeviceToHost, s.stream)) != hipSuccess)
+                return (int)e;
+        }
+        e = hipStreamSynchronize(s.stream);
+        return e == hipSuccess ? MMCMC_OK : (int)e;
+    });
+    if (st != MMCMC_OK)
+        return st;
+    /* host finish on the global statistics in splitcat order: first halves of all chains, then second halves */
+    std::vector<float> g_all(N * 2 * part), acov(m * D, 0.f);
+    if (g->use_rccl) {
+        Shard &s0 = g->sh[0];
+        (void)hipSetDevice(s0.device);
+        const float *gathered = s0.d_stats + own, *acov_all = gathered + N * 2 * part;
+        hipError_t e = hipMemcpy(g_all.data(), gathered, g_all.size() * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(acov.data(), acov_all, acov.size() * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return (int)e;
+    } else {
+        for (size_t i = 0; i < N; ++i) {
+            std::memcpy(g_all.data() + i * 2 * part, h_own.data() + i * own, 2 * part * sizeof(float));
+            const float *a = h_own.data() + i * own + 2 * part;
+            for (size_t k = 0; k < m * D; ++k)
+                acov[k] += a[k];
+        }
+    }
+    const size_t C = g->n_chains;
+    std::vector<float> means(2 * C * D), ssq(2 * C * D);
+    for (size_t i = 0; i < N; ++i) {
+        const Shard &s = g->sh[i];
+        const float *mi = g_all.data() + i * 2 * part, *qi = mi + part;
+        for (int half = 0; half < 2; ++half) {
+            std::memcpy(means.data() + ((size_t)half * C + s.first) * D, mi + (size_t)half * s.n * D, s.n * D * sizeof(float));
+            std::memcpy(ssq.data() + ((size_t)half * C + s.first) * D, qi + (size_t)half * s.n * D, s.n * D * sizeof(float));
+        }
+    }
+    return mmcmc_stats_finish(means.data(), ssq.data(), acov.data(), 2 * C, m, D, rhat, ess);
+}
+
+} // namespace
+
+struct mmcmc_hmc_group {
+    Group *g;
+};
+struct mmcmc_mh_group {
+    Group *g;
+};
+
+extern "C" {
+
+int mmcmc_hmc_group_create(mmcmc_hmc_group **out, const mmcmc_target_desc *target, const void *init, size_t n_chains,
+                           double step_size, int n_leapfrog, int dtype, const int *devices, int n_devices)
+{
+    if (!out)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    Group *g = nullptr;
+    const int st = group_create(&g, 1, target, nullptr, init, n_chains, step_size, n_leapfrog, dtype, devices, n_devices);
+    if (st != MMCMC_OK)
+        return st;
+    *out = new (std::nothrow) mmcmc_hmc_group{g};
+    if (!*out) {
+        group_destroy(g);
+        return (int)hipErrorOutOfMemory;
+    }
+    return MMCMC_OK;
+}
+int mmcmc_hmc_group_seed(mmcmc_hmc_group *h, uint64_t seed) { return h ? group_seed(h->g, seed) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_hmc_group_set_chain_offset(mmcmc_hmc_group *h, uint64_t off) { return h ? group_set_chain_offset(h->g, off) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_hmc_group_run(mmcmc_hmc_group *h, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts)
+{
+    return h ? group_run(h->g, n_collect, n_discard, out_host, accept_counts) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_group_state(mmcmc_hmc_group *h, void *out) { return h ? group_state(h->g, out) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_hmc_group_split_rhat_mean_ess(mmcmc_hmc_group *h, float *rhat, float *ess, int *used_rccl)
+{
+    return h ? group_split_rhat_ess(h->g, rhat, ess, used_rccl) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_group_shard(mmcmc_hmc_group *h, int i, int *device, size_t *first_chain, size_t *n_chains, void **sample_dev)
+{
+    if (!h || i < 0 || (size_t)i >= h->g->sh.size())
+        return MMCMC_ERR_INVALID_ARG;
+    const Shard &s = h->g->sh[(size_t)i];
+    if (device)
+        *device = s.device;
+    if (first_chain)
+        *first_chain = s.first;
+    if (n_chains)
+        *n_chains = s.n;
+    if (sample_dev)
+        *sample_dev = s.d_sample;
+    return MMCMC_OK;
+}
+int mmcmc_hmc_group_destroy(mmcmc_hmc_group *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    const int st = group_destroy(h->g);
+    delete h;
+    return st;
+}
+
+int mmcmc_mh_group_create(mmcmc_mh_group **out, const mmcmc_target_desc *target, const mmcmc_proposal_desc *proposal,
+                          const void *init, size_t n_chains, int dtype, const int *devices, int n_devices)
+{
+    if (!out || !proposal)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    Group *g = nullptr;
+    const int st = group_create(&g, 0, target, proposal, init, n_chains, proposal->std, 0, dtype, devices, n_devices);
+    if (st != MMCMC_OK)
+        return st;
+    *out = new (std::nothrow) mmcmc_mh_group{g};
+    if (!*out) {
+        group_destroy(g);
+        return (int)hipErrorOutOfMemory;
+    }
+    return MMCMC_OK;
+}
+int mmcmc_mh_group_seed(mmcmc_mh_group *h, uint64_t seed) { return h ? group_seed(h->g, seed) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_mh_group_set_chain_offset(mmcmc_mh_group *h, uint64_t off) { return h ? group_set_chain_offset(h->g, off) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_mh_group_run(mmcmc_mh_group *h, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts)
+{
+    return h ? group_run(h->g, n_collect, n_discard, out_host, accept_counts) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_mh_group_state(mmcmc_mh_group *h, void *out) { return h ? group_state(h->g, out) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *h, float *rhat, float *ess, int *used_rccl)
+{
+    return h ? group_split_rhat_ess(h->g, rhat, ess, used_rccl) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_mh_group_destroy(mmcmc_mh_group *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    const int st = group_destroy(h->g);
+    delete h;
+    return st;
+}
+
+} /* extern "C" */

@@ -1,0 +1,121 @@
+"""Device groups: one `run` for every chain on N GPUs of this process (include/mmcmc.h: mmcmc_*_group_*).
+
+The reference's `run` executes ALL chains of a sampler (ChainRunner::run core.rs:176-186, HMC::run hmc.rs:137-158); a
+group keeps that contract across GPUs: contiguous shards, the stream keyed by the global chain index (the sample does
+not depend on the number of devices), no collective while sampling, split-R-hat / ESS reduced over RCCL inside the
+library.  (One process per GPU with torch.distributed -- bench.py, stats.split_rhat_mean_ess_distributed -- is the other
+way to use several GPUs; this one needs no launcher.)"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .distributions import IsotropicGaussian, Target
+
+
+class _Group:
+    _prefix = ""
+
+    def _fn(self, name):
+        return getattr(L.lib(), f"mmcmc_{self._prefix}_group_{name}")
+
+    def set_chain_offset(self, first_global_chain: int):
+        L.check(self._fn("set_chain_offset")(self._h, int(first_global_chain)), "group_set_chain_offset")
+        return self
+
+    def run(self, n_collect: int, n_discard: int = 0, to_host: bool = True):
+        """sample [n_chains, n_collect, dim] on the host (to_host=False: it stays on the devices, see `shards`)."""
+        out = np.empty((self.n_chains, n_collect, self.dim), dtype=self.dtype) if to_host else None
+        acc = np.zeros(self.n_chains, dtype=np.uint64)
+        st = self._fn("run")(self._h, n_collect, n_discard, out.ctypes.data if to_host else None,
+                             acc.ctypes.data_as(C.POINTER(C.c_uint64)))
+        L.check(st, f"mmcmc_{self._prefix}_group_run")
+        self.accept_counts = acc
+        return out
+
+    def state(self) -> np.ndarray:
+        out = np.empty((self.n_chains, self.dim), dtype=self.dtype)
+        L.check(self._fn("state")(self._h, out.ctypes.data), "group_state")
+        return out
+
+    def split_rhat_mean_ess(self):
+        """(rhat[dim], ess[dim]) of the last run's sample over the chains of ALL devices (stats.rs:416-423);
+        `self.used_rccl` tells whether the statistics were exchanged by RCCL or through the host."""
+        rhat = np.empty(self.dim, dtype=np.float32)
+        ess = np.empty(self.dim, dtype=np.float32)
+        used = C.c_int(0)
+        st = self._fn("split_rhat_mean_ess")(self._h, rhat.ctypes.data_as(C.POINTER(C.c_float)),
+                                             ess.ctypes.data_as(C.POINTER(C.c_float)), C.byref(used))
+        L.check(st, "group_split_rhat_mean_ess")
+        self.used_rccl = bool(used.value)
+        return rhat, ess
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._fn("destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HMCGroup(_Group):
+    """HMC::new(target, initial_positions, step_size, n_leapfrog) (hmc.rs:87-109) over `devices`."""
+
+    _prefix = "hmc"
+
+    def __init__(self, target: Target, initial_positions, step_size: float, n_leapfrog: int, devices=(0,)):
+        init = np.ascontiguousarray(initial_positions)
+        if init.dtype not in (np.float32, np.float64):
+            init = init.astype(np.float32)
+        self.n_chains, self.dim = init.shape
+        self.dtype = init.dtype.type
+        self.devices = [int(d) for d in devices]
+        dev = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        d = target.desc()
+        st = L.lib().mmcmc_hmc_group_create(C.byref(self._h), C.byref(d), init.ctypes.data, self.n_chains, float(step_size),
+                                            int(n_leapfrog), L.F32 if self.dtype == np.float32 else L.F64, dev, len(self.devices))
+        L.check(st, "mmcmc_hmc_group_create")
+
+    def set_seed(self, seed: int) -> "HMCGroup":
+        L.check(L.lib().mmcmc_hmc_group_seed(self._h, int(seed)), "mmcmc_hmc_group_seed")
+        return self
+
+    def shards(self):
+        """[(device, first_chain, n_chains, device pointer of the shard's sample [n_i, n_collect, dim])]"""
+        out = []
+        for i in range(len(self.devices)):
+            dev, first, n, ptr = C.c_int(), C.c_size_t(), C.c_size_t(), C.c_void_p()
+            L.check(L.lib().mmcmc_hmc_group_shard(self._h, i, C.byref(dev), C.byref(first), C.byref(n), C.byref(ptr)), "group_shard")
+            out.append((dev.value, first.value, n.value, ptr.value))
+        return out
+
+
+class MetropolisHastingsGroup(_Group):
+    """MetropolisHastings::new(target, proposal, initial_states) (metropolis_hastings.rs:149-193) over `devices`."""
+
+    _prefix = "mh"
+
+    def __init__(self, target: Target, proposal: IsotropicGaussian, initial_states, devices=(0,)):
+        init = np.ascontiguousarray(initial_states)
+        if init.dtype not in (np.float32, np.float64):
+            init = init.astype(np.float32)
+        self.n_chains, self.dim = init.shape
+        self.dtype = init.dtype.type
+        self.devices = [int(d) for d in devices]
+        dev = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        d, p = target.desc(), proposal.proposal_desc()
+        st = L.lib().mmcmc_mh_group_create(C.byref(self._h), C.byref(d), C.byref(p), init.ctypes.data, self.n_chains,
+                                           L.F32 if self.dtype == np.float32 else L.F64, dev, len(self.devices))
+        L.check(st, "mmcmc_mh_group_create")
+
+    def seed(self, seed: int) -> "MetropolisHastingsGroup":
+        L.check(L.lib().mmcmc_mh_group_seed(self._h, int(seed)), "mmcmc_mh_group_seed")
+        return self

@@ -16,6 +16,7 @@
 
 #include "../mini_mcmc_amd/csrc/mm_params.h"
 #include "../mini_mcmc_amd/csrc/mm_nuts.h"
+#include "../mini_mcmc_amd/csrc/mm_nuts_dims.h"
 #include "../mini_mcmc_amd/csrc/mm_samplers.h"
 #include "../mini_mcmc_amd/csrc/mm_generic.h"
 
@@ -268,11 +269,7 @@ static int nuts_t(int kind, int dim, const double params[8], const double *matri
                                                      adapt, (TT *)out, nlf, nth);                                 \
         return 0;                                                                                                 \
     }
-    NT(MM_DIFFABLE_GAUSSIAN2D, 2) NT(MM_GAUSSIAN2D, 2) NT(MM_ROSENBROCK2D, 2)
-    NT(MM_STANDARD_NORMAL, 1) NT(MM_STANDARD_NORMAL, 2) NT(MM_STANDARD_NORMAL, 3) NT(MM_STANDARD_NORMAL, 4) NT(MM_STANDARD_NORMAL, 8)
-    NT(MM_ISOTROPIC_GAUSSIAN, 2) NT(MM_ISOTROPIC_GAUSSIAN, 3)
-    NT(MM_ROSENBROCK_ND, 2) NT(MM_ROSENBROCK_ND, 3) NT(MM_ROSENBROCK_ND, 4) NT(MM_ROSENBROCK_ND, 8)
-    NT(MM_GAUSSIAN_ND, 2) NT(MM_GAUSSIAN_ND, 4) NT(MM_GAUSSIAN_ND, 8) NT(MM_GAUSSIAN_ND, 16) NT(MM_GAUSSIAN_ND, 32)
+    MM_NUTS_INSTANCES(NT)
 #undef NT
     return -2;
 }

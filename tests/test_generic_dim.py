@@ -175,3 +175,41 @@ def test_gpu_any_dimension_vs_reference_order_and_posterior(M, O):
     x = s.run(60, 40).reshape(-1, 20).astype(np.float64)
     assert np.abs(x.mean(axis=0)).max() < 0.02 and np.abs(x.var(axis=0) / 4.0 - 1.0).max() < 0.01
     assert 0.5 < s.accept_counts.mean() / 100 <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gpu_nuts_more_dimensions_bit_exact_vs_host_build(M, O, mode):
+    """NUTS keeps its vectors in registers, so its dimensions are compile-time instances (csrc/mm_nuts_dims.h): every
+    dimension up to 8 and 10, 16, 20 for the N-dimensional built-ins (24 / 32 for the dense Gaussian).  The added ones
+    against the host build: samples, tree shapes, adaptation state."""
+    from mini_mcmc_amd.nuts import NUTS
+
+    rng = np.random.default_rng(8)
+
+    def spd(d):
+        A = rng.standard_normal((d, d))
+        return A @ A.T / d + np.eye(d)
+
+    A24, A5 = spd(24), spd(5)
+    cases = [
+        (M.dist.RosenbrockND(10), O.ROSENBROCK_ND, [], None),
+        (M.dist.RosenbrockND(5), O.ROSENBROCK_ND, [], None),
+        (M.dist.IsotropicGaussian(1.5, 20), O.ISOTROPIC_GAUSSIAN, [1.5], None),
+        (M.dist.IsotropicGaussian(0.7, 6), O.ISOTROPIC_GAUSSIAN, [0.7], None),
+        (M.dist.StandardNormal(16), O.STANDARD_NORMAL, [], None),
+        (M.dist.GaussianND(A24), O.GAUSSIAN_ND, [], A24),
+        (M.dist.GaussianND(A5), O.GAUSSIAN_ND, [], A5),
+    ]
+    for tgt, kind, params, mat in cases:
+        init = M.core.init_with_seed(70, tgt.dim, 31) * 0.6
+        s = NUTS(tgt, init, 0.8, mode=mode).set_seed(77)
+        out = s._run(7, 6, False, "numpy")
+        ref, pos, ad, nlf = O.engine_host_nuts_run(mode, kind, tgt.dim, params, init, 0.8, 7, 6, seed=77, matrix=mat)
+        name = f"{type(tgt).__name__} D={tgt.dim} mode={mode}"
+        assert np.array_equal(out, ref) and np.array_equal(s.positions(), pos), name
+        assert np.array_equal(s.leapfrog_counts(), nlf), name
+        a = s.adapt_state()
+        assert np.array_equal(a["epsilon"], ad[:, 0]) and np.array_equal(a["h_bar"], ad[:, 2]), name
+    with pytest.raises(Exception):  # not every dimension: NUTS has no run-time-D path
+        NUTS(M.dist.RosenbrockND(11), M.core.init_with_seed(4, 11, 1), 0.8, mode=mode)
