@@ -75,40 +75,104 @@ def cpu_baseline(seconds_target: float = 15.0) -> dict:
     }
 
 
-def side_configs(dev) -> dict:
+def _cpu_side_baselines(seconds_each: float) -> dict:
+    """BASELINE.md section 3's other CPU rows, on bounded samples: config 2 = the reference-faithful MH restatement
+    (oracle/mh_hmc.c with the reference's own stream: xoshiro256++ / ziggurat, every chain holding a clone of the
+    proposal generator (quirk Q1), D + 1 normals per proposal (Q2), logp recomputed, q-terms kept --
+    metropolis_hastings.rs:150-153, 303-315; distributions.rs:364-372), chains block-partitioned over all cores;
+    config 5 = the recursive NUTS restatement (oracle/nuts.c, nuts.rs:550-946) on the same 32-D target, scaled down to
+    4 chains per core and 30 + 10 transitions."""
+    import numpy as np
+
+    import oracle as O
+
+    cores = os.cpu_count() or 1
+    out = {}
+    n_chains = 64 * cores
+    init = O.init_with_seed(n_chains, 2, SEED, np.float32)
+    mh = O.MetropolisHastings(O.gaussian2d([0.0, 0.0], [[1.0, 0.0], [0.0, 1.0]]), 1.0, init, np.float32, proposal_seed=SEED).seed(SEED)
+    mh.run(50, 10, n_threads=cores, want_out=False)
+    t0, reps = time.perf_counter(), 0
+    while True:
+        mh.run(1000, 100, n_threads=cores, want_out=True)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_each:
+            break
+    out["config2_mh"] = {"value": reps * n_chains * 1000 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+                         "sample": f"{reps} x run(1000,100) of {n_chains} chains in {dt:.1f} s, reference-faithful MH (Q1, Q2 kept)"}
+    from mini_mcmc_amd.distributions import GaussianND
+
+    g = GaussianND.ill_conditioned(32, 1e4, 7)
+    n5 = 4 * cores
+    nuts = O.NUTS(O.gaussian_nd(g.precision), O.init_with_seed(n5, 32, SEED) * 0.1, 0.8, mode=2).set_seed(SEED).set_max_depth(10)
+    t0 = time.perf_counter()
+    nuts.run(10, 30, progress=True, n_threads=cores)
+    dt = time.perf_counter() - t0
+    lf = sum(nuts.chain_state(i)["n_leapfrog_total"] for i in range(n5))
+    out["config5_nuts"] = {"value": lf / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+                           "draws_per_s": n5 * 10 / dt,
+                           "sample": f"{n5} chains x (30 warm-up + 10 draws) in {dt:.1f} s, recursive NUTS restatement, f64, max depth 10"}
+    return out
+
+
+def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
     """BASELINE.json's other single-GPU configurations, measured once each after the headline run and reported as
     extra keys (they are parity-test cases, not bench lines): config 2 (Gaussian2D MH, 65 536 chains, f32,
-    run(1000, 100)) and config 5 (NUTS, 32-D Gaussian of condition number 1e4, 65 536 chains, f64, 200 + 100,
-    tree-depth compaction).  Kernel time by HIP events on the launch stream.  Never fails the bench."""
+    run(1000, 100)), config 5 (NUTS, 32-D Gaussian of condition number 1e4, 65 536 chains, f64, 200 + 100,
+    tree-depth compaction), and config 3's long run (run(1000, 200): the ESS of a longer sample).  Kernel
+    time by HIP events on the launch stream.  With cpu_seconds > 0 the CPU restatements of configs 2 and 5 are timed
+    too.  Never fails the bench."""
     out = {}
     try:
         import numpy as np
         import torch
 
+        from mini_mcmc_amd import stats as S
         from mini_mcmc_amd.core import init_with_seed
-        from mini_mcmc_amd.distributions import Gaussian2D, GaussianND, IsotropicGaussian
+        from mini_mcmc_amd.distributions import Gaussian2D, GaussianND, IsotropicGaussian, RosenbrockND
+        from mini_mcmc_amd.hmc import HMC
         from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
         from mini_mcmc_amd.nuts import NUTS
 
         mh = MetropolisHastings(Gaussian2D([0.0, 0.0], [[1.0, 0.0], [0.0, 1.0]]), IsotropicGaussian(1.0),
                                 init_with_seed(C_PER_GPU, 2, SEED, np.float32), device=dev.index or 0).seed(SEED)
         ms = []
-        for _ in range(4):
+        for _ in range(6):
             mh.run(1000, 100, to="torch", accept_counts=False)
             ms.append(mh.timing()["kernel_ms"])
         k = float(np.median(ms[1:]))
         out["config2_mh"] = {"kernel_ms": k, "samples_per_s": C_PER_GPU * 1000 / (k * 1e-3),
                              "hbm_frac": C_PER_GPU * 2 * 4 * (1000 + 2) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del mh
+        # config 3, long run: 1000 collected after 200 (SURVEY 8d); ESS / R-hat of that sample
+        h = HMC(RosenbrockND(DIM), init_with_seed(C_PER_GPU, DIM, SEED, np.float32), STEP_SIZE, N_LEAPFROG,
+                device=dev.index or 0).set_seed(SEED)
+        t = h.run(1000, 200, to="torch", accept_counts=False)
+        torch.cuda.synchronize()
+        k = float(h.timing()["kernel_ms"])
+        S.split_rhat_mean_ess(t)  # first call at this shape: work buffers
+        t0 = time.perf_counter()
+        rhat, ess = S.split_rhat_mean_ess(t)
+        st_ms = (time.perf_counter() - t0) * 1e3
+        out["config3_long"] = {"run": "run(1000, 200)", "kernel_ms": k, "stats_ms": st_ms, "ess_min": float(ess.min()),
+                               "split_rhat_max_conventional": float((1.0 / rhat).max()),
+                               "ess_per_s": float(ess.min()) / ((k + st_ms) * 1e-3),
+                               "samples_per_s": C_PER_GPU * 1000 / (k * 1e-3)}
+        del h, t
         g = GaussianND.ill_conditioned(32, 1e4, 7)
         nuts = NUTS(g, init_with_seed(C_PER_GPU, 32, SEED) * 0.1, 0.8, mode=2, device=dev.index or 0).set_seed(SEED).set_max_depth(10)
         nuts._run(100, 200, True, "torch")
         torch.cuda.synchronize()
-        k = float(nuts.timing()["kernel_ms"])
+        tm = nuts.timing()
+        k = float(tm["kernel_ms"])
         lf = float(nuts.leapfrog_counts().sum())
-        out["config5_nuts"] = {"kernel_ms": k, "leapfrog_steps_per_s": lf / (k * 1e-3), "draws_per_s": C_PER_GPU * 100 / (k * 1e-3),
-                               "kernel_variant": nuts.kernel_variant,
+        out["config5_nuts"] = {"kernel_ms": k, "n_launches": int(tm["n_launches"]), "leapfrog_steps_per_s": lf / (k * 1e-3),
+                               "draws_per_s": C_PER_GPU * 100 / (k * 1e-3), "kernel_variant": nuts.kernel_variant,
                                "f64_mfma_frac": lf * 2 * 32 * 32 / (k * 1e-3) / 78.6e12}
+        del nuts
+        if cpu_seconds > 0:
+            out["cpu_baselines"] = _cpu_side_baselines(cpu_seconds)
     except Exception as e:  # pragma: no cover -- side numbers must not take the headline down
         out["error"] = repr(e)
     return out
@@ -209,6 +273,39 @@ def main() -> None:
     barrier()
     stats_s = (time.perf_counter() - ts) / N_DIAG
 
+    # the same work as a pipeline (N = 1): while the sampler writes run k + 1 into one buffer, the statistics of run k are
+    # reduced from the other one on a second stream -- the diagnostics leave the critical path
+    pipe_ms = None
+    if not distributed:
+        out2 = torch.empty_like(out)
+        bufs = (out, out2)
+        s_stats = torch.cuda.Stream(dev)
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def step_into(buf):
+            st = lib.mmcmc_hmc_run(sampler._h, N_COLLECT, N_DISCARD, buf.data_ptr(), 1, None, C.c_void_p(stream))
+            L.check(st, "mmcmc_hmc_run")
+
+        sampler.enable_timing(False)
+        n_pipe = min(args.steps, 50)
+        for timed in (False, True):
+            barrier()
+            tp = time.perf_counter()
+            for k in range(n_pipe if timed else 3):
+                step_into(bufs[k % 2])
+                done[k % 2].record()
+                if k > 0:
+                    with torch.cuda.stream(s_stats):
+                        s_stats.wait_event(done[(k - 1) % 2])
+                        S.split_rhat_mean_ess(bufs[(k - 1) % 2])  # returns when the statistics of run k - 1 are on the host
+            with torch.cuda.stream(s_stats):
+                s_stats.wait_event(done[(n_pipe - 1) % 2 if timed else 0])
+                rhat_p, ess_p = S.split_rhat_mean_ess(bufs[(n_pipe - 1) % 2 if timed else 0])
+            barrier()
+            if timed:
+                pipe_ms = (time.perf_counter() - tp) / n_pipe * 1e3
+        sampler.enable_timing(True)
+
     if rank == 0:
         samples = float(args.steps) * C_PER_GPU * world * N_COLLECT
         ms_per_step = dt_max / args.steps * 1e3
@@ -217,13 +314,27 @@ def main() -> None:
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         iters = C_PER_GPU * (N_COLLECT + N_DISCARD)
         valu_tflops = iters * FLOP_PER_ITER / (k_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes and issue slots of the dominant kernel come from separate rocprofv3 --pmc passes over the same kernel
+        # (tools/pmc_hmc_traffic.sh, tools/pmc_sq.sh; summaries committed under profiles/): counters cannot be collected
+        # inside an un-profiled run, so they are labelled with their source instead of being passed off as live
+        traffic, traffic_src, issue = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hmc_kernel_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("variant", 2) == args.variant:
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/hmc_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, not this run)"
             except Exception:
                 traffic = None
+        cpath = os.path.join(ROOT, "profiles", "hmc_kernel_counters.json")
+        if os.path.exists(cpath):
+            try:
+                cj = json.load(open(cpath))
+                if cj.get("variant", 2) == args.variant:
+                    issue = cj
+            except Exception:
+                issue = None
         res = {
             "metric": "samples/sec (all chains), 3D Rosenbrock HMC",
             "value": samples / dt_max,
@@ -247,29 +358,37 @@ def main() -> None:
             "ess_per_s": float(ess.min()) * args.steps / (dt_max + stats_s * args.steps),
             "ess_min": float(ess.min()),
             "split_rhat_max_conventional": float((1.0 / rhat).max()),
+            "ess_note": "ESS of ONE run(400, 50) from init_with_seed: split R-hat ~1.9, the Rosenbrock chains have not "
+                        "converged in 450 transitions (nor has the reference's example); side.config3_long is run(1000, 200)",
             "stats_ms": stats_s * 1e3,
+            "pipelined_ms_per_step": pipe_ms,
+            "ess_per_s_pipelined": (float(ess.min()) / (pipe_ms * 1e-3)) if pipe_ms else None,
             "roofline": {
                 "kernel": {0: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=0, L=0>",
                            1: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>",
                            2: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>",
                            5: "mm_run_split_kernel<float, RosenbrockND<3>, HMC, L=10>"}[args.variant],
-                "bound": "hbm",
+                "bound": "hbm",  # the roofline BASELINE.json names; what actually limits the kernel: "limiter" below
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
+                "limiter": "valu_issue",
+                "valu_issue": issue,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": k_ms,
                 "launches_per_step": 1,
-                "note": "the HMC kernel is f32-VALU/issue bound, not HBM bound (about 270 VALU instructions per "
-                        "12 algorithmic bytes); the HBM fraction is reported because BASELINE.json asks for it",
+                "note": "the kernel is bound by VALU instruction issue, not by HBM (about 270 VALU instructions per 12 "
+                        "algorithmic bytes; tools/issue_rate.hip: 4.4 cycles per instruction for one wave, 2.2 per SIMD "
+                        "with two): `frac` is the HBM fraction BASELINE.json asks for, `valu_issue` the SQ-counter view",
                 "valu": {"achieved_tflops": valu_tflops, "peak_tflops": FP32_VALU_PEAK_TFLOPS,
                          "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "flop_per_iteration": FLOP_PER_ITER},
             },
         }
         if world == 1 and not args.no_side:
-            res["side"] = side_configs(dev)
+            res["side"] = side_configs(dev, 0.0 if args.no_cpu_baseline else max(3.0, args.cpu_seconds / 3))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(res))

@@ -38,7 +38,7 @@ extern "C" {
 #define MMCMC_ERR_UNSUPPORTED (-2)  /* target kind / dim / dtype combination has no kernel        */
 #define MMCMC_ERR_SHAPE (-3)        /* the analogue of ndarray::ShapeError from core.rs:184       */
 #define MMCMC_ERR_NO_DEVICE (-4)    /* no HIP device: the engine never falls back to the CPU      */
-#define MMCMC_ERR_STATE (-5)        /* handle used in the wrong state (e.g. destroyed)            */
+#define MMCMC_ERR_STATE (-5)        /* call made in the wrong state (e.g. timing before any run)  */
 
 /* ---- element types ---- */
 #define MMCMC_F32 0

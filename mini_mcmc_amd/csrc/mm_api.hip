@@ -157,7 +157,6 @@ struct Sampler {
     bool want_accept = true; /* this run(): per-chain accept counts requested */
     bool timing_enabled = true;
     mmcmc_timing timing{};
-    bool alive = true;
 
     size_t esize() const { return dtype == MMCMC_F32 ? 4 : 8; }
 };
@@ -283,8 +282,6 @@ int sampler_destroy(Sampler *s)
 {
     if (!s)
         return MMCMC_ERR_INVALID_ARG;
-    if (!s->alive)
-        return MMCMC_ERR_STATE;
     DeviceGuard g(s->device);
     (void)hipStreamSynchronize(s->stream);
     (void)hipFree(s->d_state);
@@ -297,7 +294,6 @@ int sampler_destroy(Sampler *s)
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
     (void)hipStreamDestroy(s->stream);
-    s->alive = false;
     delete s;
     return MMCMC_OK;
 }
@@ -408,8 +404,6 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
 {
     if (!s)
         return MMCMC_ERR_INVALID_ARG;
-    if (!s->alive)
-        return MMCMC_ERR_STATE;
     if (n_collect + n_discard == 0)
         return MMCMC_OK;
     if ((uint64_t)n_collect * (uint64_t)s->dim >= (1ull << 30) || s->iter + n_collect + n_discard >= (1ull << 32))
@@ -418,12 +412,22 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : s->stream;
     const size_t out_bytes = s->n_chains * n_collect * (size_t)s->dim * s->esize();
     void *d_out = nullptr;
+    /* host output: a device staging buffer, released on every path out of this function */
+    struct Staging {
+        void *p = nullptr;
+        ~Staging()
+        {
+            if (p)
+                (void)hipFree(p);
+        }
+    } staging;
     bool staged = false;
     if (out && n_collect > 0) {
         if (out_is_device) {
             d_out = out;
         } else {
-            MM_HIP(hipMalloc(&d_out, out_bytes));
+            MM_HIP(hipMalloc(&staging.p, out_bytes));
+            d_out = staging.p;
             staged = true;
         }
     }
@@ -446,11 +450,8 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
             st = launch_range<float>(s, s->kf, s->Pf, (float *)d_out, n_collect, nd, nc, (uint32_t)t0, stream);
         else
             st = launch_range<double>(s, s->kd, s->Pd, (double *)d_out, n_collect, nd, nc, (uint32_t)t0, stream);
-        if (st != MMCMC_OK) {
-            if (staged)
-                (void)hipFree(d_out);
+        if (st != MMCMC_OK)
             return st;
-        }
         remaining_discard -= nd;
         remaining_collect -= nc;
         t0 += nc;
@@ -467,7 +468,6 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
     if (staged) {
         MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
         MM_HIP(hipStreamSynchronize(stream));
-        MM_HIP(hipFree(d_out));
     }
     if (accept_counts) {
         static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
@@ -482,8 +482,6 @@ int sampler_state(Sampler *s, void *out)
 {
     if (!s || !out)
         return MMCMC_ERR_INVALID_ARG;
-    if (!s->alive)
-        return MMCMC_ERR_STATE;
     DeviceGuard g(s->device);
     MM_HIP(hipStreamSynchronize(s->stream));
     MM_HIP(hipDeviceSynchronize());
@@ -495,8 +493,6 @@ int sampler_sync(Sampler *s)
 {
     if (!s)
         return MMCMC_ERR_INVALID_ARG;
-    if (!s->alive)
-        return MMCMC_ERR_STATE;
     DeviceGuard g(s->device);
     if (s->timed)
         MM_HIP(hipEventSynchronize(s->ev1));
@@ -508,8 +504,8 @@ int sampler_timing(Sampler *s, mmcmc_timing *t)
 {
     if (!s || !t)
         return MMCMC_ERR_INVALID_ARG;
-    if (!s->alive || !s->timed)
-        return MMCMC_ERR_STATE;
+    if (!s->timed)
+        return MMCMC_ERR_STATE; /* no timed run yet */
     DeviceGuard g(s->device);
     MM_HIP(hipEventSynchronize(s->ev1));
     float ms = 0.f;

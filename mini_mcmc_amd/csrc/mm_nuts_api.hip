@@ -89,6 +89,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
     mm_lgq_ctrl *d_lg_ctrl = nullptr;
     unsigned int n_resident_waves = 1024;
     int lgq_occ = 1; /* waves per SIMD of the persistent scheduler (MMCMC_LGQ_OCC overrides) */
+    unsigned int n_launches_run = 0; /* sampling launches of the current run() (reported by timing()) */
+    int auto_level = -1;             /* first compaction level chosen from the depth histogram, once it is known */
     size_t c_pad = 0;
     static constexpr int kMaxGroups = 16;
     hipStream_t lg_streams[kMaxGroups] = {};
@@ -270,6 +272,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 }
                 /* one launch of the scheduler; the kernel reports a stuck queue instead of hanging */
                 auto launch = [&](const mm_nuts_lg_args &gq) -> hipError_t {
+                    ++n_launches_run;
                     hipError_t e = lg->run_queue(gq, nw, occ, st);
                     if (e != hipSuccess)
                         return e;
@@ -311,10 +314,14 @@ template <class TT, class ST> struct Nuts : NutsBase {
                     return hipSuccess;
                 };
                 if (compaction_auto) {
-                    int level = -1;
-                    hipError_t e = level_from_history(&level);
+                    /* once the histogram has fixed the level it is kept: no device-to-host copy and no stream
+                     * synchronisation per run() after that */
+                    int level = auto_level;
+                    hipError_t e = level < 0 ? level_from_history(&level) : hipSuccess;
                     if (e != hipSuccess)
                         return e;
+                    if (level >= 0)
+                        auto_level = level;
                     const unsigned int pilot = 16;
                     if (level < 0 && total >= 4 * pilot) {
                         mm_nuts_lg_args g1 = g, g2 = g;
@@ -324,17 +331,19 @@ template <class TT, class ST> struct Nuts : NutsBase {
                             return e;
                         if ((e = level_from_history(&level)) != hipSuccess)
                             return e;
+                        if (level >= 0)
+                            auto_level = level;
                         g2.m0 = a.m0 + pilot;
                         g2.n_pre = a.n_pre - g1.n_pre;
                         g2.n_rec = a.n_rec - g1.n_rec;
                         g2.write_initial = 0;
                         g2.out_t0 = a.out_t0 + (a.write_initial ? 1u : 0u) + g1.n_rec;
                         if (level >= 0)
-                            g2.j0 = level;
+                            g2.j0 = level < max_depth ? level : max_depth;
                         return launch(g2);
                     }
                     if (level >= 0)
-                        g.j0 = level;
+                        g.j0 = level < max_depth ? level : max_depth;
                 }
                 return launch(g);
             }
@@ -412,15 +421,26 @@ template <class TT, class ST> struct Nuts : NutsBase {
         hipStream_t st = stream_v ? (hipStream_t)stream_v : stream;
         const size_t out_bytes = n_chains * n_collect * (size_t)dim * sizeof(TT);
         TT *d_out = nullptr;
+        /* host output: a device staging buffer, released on every path out of this function */
+        struct Staging {
+            void *p = nullptr;
+            ~Staging()
+            {
+                if (p)
+                    (void)hipFree(p);
+            }
+        } staging;
         bool staged = false;
         if (out && n_collect > 0) {
             if (out_is_device) {
                 d_out = (TT *)out;
             } else {
-                MM_HIP(hipMalloc((void **)&d_out, out_bytes));
+                MM_HIP(hipMalloc(&staging.p, out_bytes));
+                d_out = (TT *)staging.p;
                 staged = true;
             }
         }
+        n_launches_run = 0;
         /* init_chain (nuts.rs:528-545) on every run() call */
         const bool use_lg = variant >= 1 && variant <= 3 && lg;
         hipError_t e = use_lg ? init_lg(st) : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
@@ -468,22 +488,21 @@ template <class TT, class ST> struct Nuts : NutsBase {
         }
         MM_HIP(hipEventRecord(ev0, st));
         e = use_lg ? run_lg(a, st) : (variant == 4 && k->run_async) ? k->run_async(a, st) : k->run(a, st);
-        if (e != hipSuccess) {
-            if (staged)
-                (void)hipFree(d_out);
+        if (e != hipSuccess)
             return (int)e;
-        }
         MM_HIP(hipEventRecord(ev1, st));
         m += a.n_pre + a.n_rec;
         timed = true;
-        timing.n_launches = 1;
+        /* sampling launches of this run (the persistent scheduler of a fresh handle: a 16-transition pilot plus the
+         * rest; compaction by launches: one per level and transition); kernel_ms is the time on the stream between the
+         * first and the last, host gaps of multi-launch runs included */
+        timing.n_launches = n_launches_run ? n_launches_run : 1;
         timing.out_bytes = d_out ? out_bytes : 0;
         timing.state_bytes = 2ull * n_chains * dim * sizeof(TT);
         timing.kernel_ms = -1.f;
         if (staged) {
             MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
             MM_HIP(hipStreamSynchronize(st));
-            MM_HIP(hipFree(d_out));
         }
         return MMCMC_OK;
     }

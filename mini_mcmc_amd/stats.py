@@ -107,6 +107,8 @@ def stats_partials(sample):
 
     assert sample.is_cuda and sample.dim() == 3
     t = sample.contiguous()
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.float()  # like _sample_args: the kernels read 4- or 8-byte floats only (RunStats::from casts to f32, stats.rs:365)
     code = L.F32 if t.dtype == torch.float32 else L.F64
     c, n, d = t.shape
     m = n // 2

@@ -1,0 +1,271 @@
+//! Safe wrappers over the C ABI (`mini-mcmc-hip-sys`) with the call shapes of mini-mcmc 0.8.3:
+//!
+//! | mini-mcmc | here |
+//! |---|---|
+//! | `MetropolisHastings::new(target, proposal, init).seed(s).run(n, d)` (metropolis_hastings.rs:149-193, core.rs:176-186) | `GpuMetropolisHastings::new(..).seed(s).run(n, d)` |
+//! | `HMC::new(target, init, eps, L).set_seed(s).run(n, d)` / `.step()` (hmc.rs:87-158, 304-377) | `GpuHmc::new(..).set_seed(s).run(n, d)` / `.step()` |
+//! | `NUTS::new(target, init, p).set_seed(s).run(n, d)` (nuts.rs:123-170, 347-353) | `GpuNuts::new(..).set_seed(s).run(n, d)` |
+//! | `stats::split_rhat_mean_ess(view)` (stats.rs:416-423) | `split_rhat_mean_ess(view)` |
+//! | `core::init_det(n, d)` (core.rs:404-409) | `init_det(n, d)` |
+//!
+//! Targets: user closures cannot run on the GPU, so the samplers take a [`GpuTarget`] -- a description of one of the
+//! built-in densities (the reference's `Gaussian2D`, `DiffableGaussian2D`, `IsotropicGaussian`, `Rosenbrock2D`,
+//! `RosenbrockND` plus a dense `GaussianND`).  `run` returns `Result<Array3<T>, ShapeError>` like `ChainRunner::run`;
+//! every other failure of the engine (no device, unsupported kind) is an [`MmcmcError`].
+//!
+//! NOT compiled in the build image (no Rust toolchain there); `tests/c/abi_call_sequence.c` performs the same calls.
+
+use mini_mcmc_hip_sys as sys;
+use ndarray::{Array1, Array2, Array3, ArrayView3, ErrorKind, ShapeError};
+use std::ffi::CStr;
+use std::marker::PhantomData;
+use std::os::raw::{c_int, c_void};
+use std::ptr::{null, null_mut};
+
+/// A status of the engine that is not a shape error.
+#[derive(Debug, Clone)]
+pub struct MmcmcError {
+    pub status: i32,
+    pub message: String,
+}
+impl std::fmt::Display for MmcmcError {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "mmcmc status {}: {}", self.status, self.message)
+    }
+}
+impl std::error::Error for MmcmcError {}
+
+fn check(status: c_int) -> Result<(), MmcmcError> {
+    if status == sys::MMCMC_OK {
+        return Ok(());
+    }
+    let message = unsafe { CStr::from_ptr(sys::mmcmc_status_string(status)) }.to_string_lossy().into_owned();
+    Err(MmcmcError { status, message })
+}
+
+/// `ChainRunner::run` can only fail with a `ShapeError` (core.rs:184); the engine's MMCMC_ERR_SHAPE maps onto it, and so
+/// does anything else `run` reports (the trait's signature has no other channel).
+fn shape_error(status: c_int) -> ShapeError {
+    ShapeError::from_kind(if status == sys::MMCMC_ERR_SHAPE { ErrorKind::IncompatibleShape } else { ErrorKind::Unsupported })
+}
+
+/// f32 / f64: the element types the kernels exist for.
+pub trait GpuFloat: Copy + Default + 'static {
+    const DTYPE: c_int;
+}
+impl GpuFloat for f32 {
+    const DTYPE: c_int = sys::MMCMC_F32;
+}
+impl GpuFloat for f64 {
+    const DTYPE: c_int = sys::MMCMC_F64;
+}
+
+/// One of the built-in targets (`Target` / `GradientTarget` of distributions.rs:65-108 for the GPU path).
+#[derive(Clone, Debug)]
+pub enum GpuTarget {
+    /// `Gaussian2D { mean, cov }` (distributions.rs:158-206)
+    Gaussian2D { mean: [f64; 2], cov: [[f64; 2]; 2] },
+    /// `DiffableGaussian2D::new(mean, cov)` (distributions.rs:212-316)
+    DiffableGaussian2D { mean: [f64; 2], cov: [[f64; 2]; 2] },
+    /// `IsotropicGaussian::new(std)` as a target (distributions.rs:394-402)
+    IsotropicGaussian { std: f64 },
+    /// `Rosenbrock2D { a, b }` (distributions.rs:490-524)
+    Rosenbrock2D { a: f64, b: f64 },
+    /// `RosenbrockND {}` (distributions.rs:528-547); the dimension comes from the initial positions
+    RosenbrockND,
+    /// zero-mean Gaussian with a dense precision matrix, row-major `[dim, dim]` (not in the reference)
+    GaussianND { precision: Vec<f64> },
+}
+impl GpuTarget {
+    fn desc(&self, dim: usize) -> sys::mmcmc_target_desc {
+        let mut d = sys::mmcmc_target_desc { kind: 0, dim: dim as i32, params: [0.0; 8], matrix: null() };
+        match self {
+            GpuTarget::Gaussian2D { mean, cov } | GpuTarget::DiffableGaussian2D { mean, cov } => {
+                d.kind = if matches!(self, GpuTarget::Gaussian2D { .. }) { sys::MMCMC_GAUSSIAN2D } else { sys::MMCMC_DIFFABLE_GAUSSIAN2D };
+                d.params[..6].copy_from_slice(&[mean[0], mean[1], cov[0][0], cov[0][1], cov[1][0], cov[1][1]]);
+            }
+            GpuTarget::IsotropicGaussian { std } => {
+                d.kind = sys::MMCMC_ISOTROPIC_GAUSSIAN;
+                d.params[0] = *std;
+            }
+            GpuTarget::Rosenbrock2D { a, b } => {
+                d.kind = sys::MMCMC_ROSENBROCK2D;
+                d.params[0] = *a;
+                d.params[1] = *b;
+            }
+            GpuTarget::RosenbrockND => d.kind = sys::MMCMC_ROSENBROCK_ND,
+            GpuTarget::GaussianND { precision } => {
+                d.kind = sys::MMCMC_GAUSSIAN_ND;
+                d.matrix = precision.as_ptr(); // copied to the device by *_create
+            }
+        }
+        d
+    }
+}
+
+fn flatten<T: Copy>(init: &[Vec<T>]) -> (Vec<T>, usize, usize) {
+    let n = init.len();
+    let d = init.first().map(|r| r.len()).unwrap_or(0);
+    let mut flat = Vec::with_capacity(n * d);
+    for row in init {
+        assert_eq!(row.len(), d, "every chain needs a starting point of the same dimension");
+        flat.extend_from_slice(row);
+    }
+    (flat, n, d)
+}
+
+/// `core::init_det(n, d)` (core.rs:404-409): the reference's own seeded stream, bit for bit.
+pub fn init_det<T: GpuFloat + From<f32>>(n: usize, d: usize) -> Vec<Vec<f64>> {
+    init_with_seed(n, d, 42)
+}
+/// `core::init_with_seed(n, d, seed)` (core.rs:413-419).
+pub fn init_with_seed(n: usize, d: usize, seed: u64) -> Vec<Vec<f64>> {
+    let mut flat = vec![0f64; n * d];
+    unsafe { sys::mmcmc_init_with_seed(n, d, seed, flat.as_mut_ptr()) };
+    flat.chunks(d.max(1)).map(|c| c.to_vec()).collect()
+}
+
+/// `MetropolisHastings<T, _, _, IsotropicGaussian<T>>` on the GPU: one chain per lane.
+pub struct GpuMetropolisHastings<T: GpuFloat> {
+    h: *mut sys::mmcmc_mh,
+    n_chains: usize,
+    dim: usize,
+    /// accept counts of the last `run`, one per chain
+    pub accept_counts: Vec<u64>,
+    _t: PhantomData<T>,
+}
+unsafe impl<T: GpuFloat> Send for GpuMetropolisHastings<T> {}
+impl<T: GpuFloat> GpuMetropolisHastings<T> {
+    /// `MetropolisHastings::new(target, proposal, initial_states)` (metropolis_hastings.rs:149-159);
+    /// `proposal_std` = `IsotropicGaussian::new(std)`.
+    pub fn new(target: GpuTarget, proposal_std: f64, initial_states: Vec<Vec<T>>) -> Result<Self, MmcmcError> {
+        let (flat, n, d) = flatten(&initial_states);
+        let desc = target.desc(d);
+        let prop = sys::mmcmc_proposal_desc { kind: sys::MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN, reserved: 0, std: proposal_std };
+        let mut h = null_mut();
+        check(unsafe { sys::mmcmc_mh_create(&mut h, &desc, &prop, flat.as_ptr() as *const c_void, n, T::DTYPE, 0) })?;
+        Ok(Self { h, n_chains: n, dim: d, accept_counts: vec![0; n], _t: PhantomData })
+    }
+    /// `.seed(seed)` (metropolis_hastings.rs:187-193)
+    pub fn seed(self, seed: u64) -> Self {
+        unsafe { sys::mmcmc_mh_seed(self.h, seed) };
+        self
+    }
+    /// `ChainRunner::run` (core.rs:176-186): `[n_chains, n_collect, dim]`.
+    pub fn run(&mut self, n_collect: usize, n_discard: usize) -> Result<Array3<T>, ShapeError> {
+        let mut out = Array3::<T>::default((self.n_chains, n_collect, self.dim));
+        let st = unsafe {
+            sys::mmcmc_mh_run(self.h, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, 0, self.accept_counts.as_mut_ptr(), null_mut())
+        };
+        if st == sys::MMCMC_OK { Ok(out) } else { Err(shape_error(st)) }
+    }
+    /// current states `[n_chains, dim]` (`MarkovChain::current_state` of every chain, core.rs:39-45)
+    pub fn current_states(&self) -> Result<Array2<T>, MmcmcError> {
+        let mut out = Array2::<T>::default((self.n_chains, self.dim));
+        check(unsafe { sys::mmcmc_mh_state(self.h, out.as_mut_ptr() as *mut c_void) })?;
+        Ok(out)
+    }
+}
+impl<T: GpuFloat> Drop for GpuMetropolisHastings<T> {
+    fn drop(&mut self) {
+        unsafe { sys::mmcmc_mh_destroy(self.h) };
+    }
+}
+
+/// `HMC<T, B, GTarget>` on the GPU (hmc.rs:44-158): the leapfrog runs in registers, one chain per lane.
+pub struct GpuHmc<T: GpuFloat> {
+    h: *mut sys::mmcmc_hmc,
+    n_chains: usize,
+    dim: usize,
+    pub accept_counts: Vec<u64>,
+    _t: PhantomData<T>,
+}
+unsafe impl<T: GpuFloat> Send for GpuHmc<T> {}
+impl<T: GpuFloat> GpuHmc<T> {
+    /// `HMC::new(target, initial_positions, step_size, n_leapfrog)` (hmc.rs:87-109)
+    pub fn new(target: GpuTarget, initial_positions: Vec<Vec<T>>, step_size: f64, n_leapfrog: usize) -> Result<Self, MmcmcError> {
+        let (flat, n, d) = flatten(&initial_positions);
+        let desc = target.desc(d);
+        let mut h = null_mut();
+        check(unsafe { sys::mmcmc_hmc_create(&mut h, &desc, flat.as_ptr() as *const c_void, n, step_size, n_leapfrog as c_int, T::DTYPE, 0) })?;
+        Ok(Self { h, n_chains: n, dim: d, accept_counts: vec![0; n], _t: PhantomData })
+    }
+    /// `.set_seed(seed)` (hmc.rs:118-121; inert in the reference -- quirk Q6 -- effective here)
+    pub fn set_seed(self, seed: u64) -> Self {
+        unsafe { sys::mmcmc_hmc_seed(self.h, seed) };
+        self
+    }
+    /// `HMC::run(n_collect, n_discard)` (hmc.rs:137-158): `[n_chains, n_collect, dim]`
+    pub fn run(&mut self, n_collect: usize, n_discard: usize) -> Result<Array3<T>, ShapeError> {
+        let mut out = Array3::<T>::default((self.n_chains, n_collect, self.dim));
+        let st = unsafe {
+            sys::mmcmc_hmc_run(self.h, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, 0, self.accept_counts.as_mut_ptr(), null_mut())
+        };
+        if st == sys::MMCMC_OK { Ok(out) } else { Err(shape_error(st)) }
+    }
+    /// `HMC::step()` (hmc.rs:304-377): one transition of every chain
+    pub fn step(&mut self) -> Result<(), MmcmcError> {
+        check(unsafe { sys::mmcmc_hmc_step(self.h, null_mut()) })?;
+        check(unsafe { sys::mmcmc_hmc_sync(self.h) })
+    }
+    /// `positions` (hmc.rs:49): `[n_chains, dim]`
+    pub fn positions(&self) -> Result<Array2<T>, MmcmcError> {
+        let mut out = Array2::<T>::default((self.n_chains, self.dim));
+        check(unsafe { sys::mmcmc_hmc_state(self.h, out.as_mut_ptr() as *mut c_void) })?;
+        Ok(out)
+    }
+}
+impl<T: GpuFloat> Drop for GpuHmc<T> {
+    fn drop(&mut self) {
+        unsafe { sys::mmcmc_hmc_destroy(self.h) };
+    }
+}
+
+/// `NUTS<T, B, GTarget>` on the GPU (nuts.rs:100-353).  `T = f64`: f32 tensors + f64 scalars like the reference's
+/// `NUTS<f64, Autodiff<NdArray>, _>` (samples come back as f32); `T = f32`: f32 / f32.
+pub struct GpuNuts {
+    h: *mut sys::mmcmc_nuts,
+    n_chains: usize,
+    dim: usize,
+}
+unsafe impl Send for GpuNuts {}
+impl GpuNuts {
+    /// `NUTS::new(target, initial_positions, target_accept_p)` (nuts.rs:123-129); `scalars_f64` picks the reference's `T`.
+    pub fn new(target: GpuTarget, initial_positions: Vec<Vec<f64>>, target_accept_p: f64, scalars_f64: bool) -> Result<Self, MmcmcError> {
+        let (flat, n, d) = flatten(&initial_positions);
+        let desc = target.desc(d);
+        let mut h = null_mut();
+        check(unsafe { sys::mmcmc_nuts_create(&mut h, &desc, flat.as_ptr(), n, target_accept_p, if scalars_f64 { 0 } else { 1 }, 0) })?;
+        Ok(Self { h, n_chains: n, dim: d })
+    }
+    /// `.set_seed(seed)` (nuts.rs:347-353)
+    pub fn set_seed(self, seed: u64) -> Self {
+        unsafe { sys::mmcmc_nuts_seed(self.h, seed) };
+        self
+    }
+    /// `NUTS::run(n_collect, n_discard)` (nuts.rs:163-170): N - 1 transitions, row 0 may be the initial point (quirk Q11)
+    pub fn run(&mut self, n_collect: usize, n_discard: usize) -> Result<Array3<f32>, ShapeError> {
+        let mut out = Array3::<f32>::default((self.n_chains, n_collect, self.dim));
+        let mut st = unsafe { sys::mmcmc_nuts_run(self.h, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, 0, 0, null_mut()) };
+        if st == sys::MMCMC_OK {
+            st = unsafe { sys::mmcmc_nuts_sync(self.h) };
+        }
+        if st == sys::MMCMC_OK { Ok(out) } else { Err(shape_error(st)) }
+    }
+}
+impl Drop for GpuNuts {
+    fn drop(&mut self) {
+        unsafe { sys::mmcmc_nuts_destroy(self.h) };
+    }
+}
+
+/// `stats::split_rhat_mean_ess(sample)` (stats.rs:416-423): `(rhat, ess)`, rhat = sqrt(W / var+) as the crate defines it.
+pub fn split_rhat_mean_ess(sample: ArrayView3<f32>) -> Result<(Array1<f32>, Array1<f32>), MmcmcError> {
+    let (c, n, p) = sample.dim();
+    let owned = sample.as_standard_layout();
+    let (mut rhat, mut ess) = (Array1::<f32>::zeros(p), Array1::<f32>::zeros(p));
+    check(unsafe {
+        sys::mmcmc_split_rhat_mean_ess(owned.as_ptr() as *const c_void, 0, sys::MMCMC_F32, c, n, p, rhat.as_mut_ptr(), ess.as_mut_ptr(), 0, null_mut())
+    })?;
+    Ok((rhat, ess))
+}

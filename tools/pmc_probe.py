@@ -38,13 +38,17 @@ if what == "nuts5":
     torch.cuda.synchronize()
     print("nuts5", n, s.timing(), int(s.leapfrog_counts().sum()))
     sys.exit(0)
-variant = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+variant = int(sys.argv[3]) if len(sys.argv) > 3 else None  # None: the sampler's default
 C = 65536
 if what == "hmc":
-    s = HMC(RosenbrockND(3), init_with_seed(C, 3, 42, np.float32), 0.032, 10).set_seed(42).set_kernel_variant(variant)
+    s = HMC(RosenbrockND(3), init_with_seed(C, 3, 42, np.float32), 0.032, 10).set_seed(42)
+    if variant is not None:
+        s.set_kernel_variant(variant)
     nc, nd = (400, 50) if mode == "collect" else (0, 450)
 else:
-    s = MetropolisHastings(Gaussian2D([0, 0], [[1, 0], [0, 1]]), IsotropicGaussian(1.0), init_with_seed(C, 2, 42, np.float32)).seed(42).set_kernel_variant(variant)
+    s = MetropolisHastings(Gaussian2D([0, 0], [[1, 0], [0, 1]]), IsotropicGaussian(1.0), init_with_seed(C, 2, 42, np.float32)).seed(42)
+    if variant is not None:
+        s.set_kernel_variant(variant)
     nc, nd = (1000, 100) if mode == "collect" else (0, 1100)
 for _ in range(3):
     s.run(nc, nd, to="torch", accept_counts=False, collect=(mode == "collect"))
