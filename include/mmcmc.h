@@ -222,6 +222,23 @@ int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant);
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant);
 int mmcmc_hmc_kernel_variant(mmcmc_hmc *h); /* the variant in use (>= 0) or a negative status */
 
+/* ---- user-defined targets (csrc/mm_rtc.hip) ------------------------------------------------------------------
+ * The reference's `Target` / `GradientTarget` (distributions.rs:65-108) are open traits.  The GPU analogue of
+ * `impl GradientTarget for MyDensity`: the HIP source of
+ *     template <class T> struct mmcmc_user_target {
+ *         static constexpr int dim = <dim>;
+ *         MM_HD static T logp(const mm_tparams<T> &P, const T *x);                // unnorm_logp
+ *         MM_HD static T logp_grad(const mm_tparams<T> &P, const T *x, T *g);     // unnorm_logp_and_grad, returns logp
+ *     };
+ * (P.p[0..8) = `params` of the mmcmc_target_desc a sampler is later created with, P.mat = its `matrix` [dim, dim] or
+ * NULL; everything in csrc/mm_math.h / mm_targets.h -- mm_fma, mm_logf, mm_exp, ... -- is in scope) is compiled with
+ * hipRTC into the engine's own MH / HMC kernel skeleton for f32 and f64 and registered under a new target kind
+ * (>= MMCMC_USER_KIND_BASE), which mmcmc_mh_create, mmcmc_hmc_create, mmcmc_*_group_create and mmcmc_logp_grad_batch
+ * then accept like a built-in kind (dim 1..32).  `log` (may be NULL) receives the compiler's diagnostics.
+ * MMCMC_ERR_INVALID_ARG: the source does not compile (see log); MMCMC_ERR_UNSUPPORTED: no libhiprtc on this machine. */
+#define MMCMC_USER_KIND_BASE 1000
+int mmcmc_target_register_source(const char *name, int dim, const char *hip_source, int *kind_out, char *log, size_t log_len);
+
 /* ---- device groups: one call runs every chain on N GPUs (csrc/mm_group.hip) ------------------------------------
  * `run` of the reference executes ALL chains of the sampler (ChainRunner::run core.rs:176-186, HMC::run hmc.rs:137-158).
  * A group shards n_chains contiguously over `devices` (device i: global chains [first_i, first_i + n_i), stream keyed by

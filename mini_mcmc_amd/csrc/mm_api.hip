@@ -21,6 +21,7 @@
 #include "mm_kernels.h"
 #include "mm_host_rng.h"
 #include "mm_params.h"
+#include "mm_rtc.h"
 
 #define MM_HIP(expr)                                                                                              \
     do {                                                                                                          \
@@ -97,8 +98,15 @@ int validate_target(const mmcmc_target_desc *t)
         if (!t->matrix)
             return MMCMC_ERR_INVALID_ARG;
         break;
-    default:
-        return MMCMC_ERR_UNSUPPORTED;
+    default: {
+        /* a kind handed out by mmcmc_target_register_source (mm_rtc.hip) */
+        const mm_user_target *u = mm_rtc_find(t->kind);
+        if (!u)
+            return MMCMC_ERR_UNSUPPORTED;
+        if (mm_rtc_dim(u) != t->dim)
+            return MMCMC_ERR_SHAPE;
+        break;
+    }
     }
     return MMCMC_OK;
 }
@@ -107,9 +115,14 @@ int validate_target(const mmcmc_target_desc *t)
 template <class T> int make_params(const mmcmc_target_desc *t, mm_tparams<T> *P, T **d_mat)
 {
     *d_mat = nullptr;
-    if (mm_fill_params<T>(t->kind, t->params, P) != 0)
+    if (t->kind >= MM_USER_KIND_BASE) {
+        /* user target: the description's parameters as they are; `matrix`, if given, is dim x dim */
+        std::memset(P, 0, sizeof *P);
+        for (int i = 0; i < 8; ++i)
+            P->p[i] = (T)t->params[i];
+    } else if (mm_fill_params<T>(t->kind, t->params, P) != 0)
         return MMCMC_ERR_INVALID_ARG;
-    if (t->kind == MMCMC_GAUSSIAN_ND) {
+    if (t->kind == MMCMC_GAUSSIAN_ND || (t->kind >= MM_USER_KIND_BASE && t->matrix)) {
         size_t n = (size_t)t->dim * t->dim;
         std::vector<T> h(n);
         for (size_t i = 0; i < n; ++i)
@@ -138,6 +151,7 @@ struct Sampler {
                         3 = lane-group / MFMA kernel (mm_hmc_lg.h): HMC, f64, GaussianND of dim 16 or 32;
                         5 = noise waves + transition waves (mm_split_kernels.h), the default for f32 up to dim 8 */
     bool lg_ok = false;
+    const mm_user_target *user = nullptr; /* run-time compiled target (mm_rtc.hip), variant 7 */
     bool generic = false;      /* no fixed-dimension kernel: the run-time-dimension path (mm_generic.h), variant 6 */
     bool generic_ok = false;   /* the target kind has a run-time-dimension form */
     void *d_gscratch = nullptr; /* its HBM store when the chain vectors do not fit LDS */
@@ -192,7 +206,10 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
     else
         s->kd = find_kernel<double>(s->kind, s->dim);
     s->generic_ok = mm_generic_kind_ok(s->kind);
-    if (!s->kf && !s->kd) {
+    s->user = s->kind >= MM_USER_KIND_BASE ? mm_rtc_find(s->kind) : nullptr;
+    if (s->user) {
+        s->variant = 7;
+    } else if (!s->kf && !s->kd) {
         /* a dimension without a register-resident kernel: the run-time-dimension path */
         if (!s->generic_ok) {
             delete s;
@@ -205,7 +222,7 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
     s->lg_ok = sampler == MM_SAMPLER_HMC && s->kind == MMCMC_GAUSSIAN_ND && (s->dim == 16 || s->dim == 32);
     /* at dim 32 the paired / pipelined form holds four noise vectors next to the state and spills: the plain form
      * is twice as fast there (RosenbrockND(32) f32: 1.0 ms vs 2.2 ms for run(100, 20) of 65 536 chains) */
-    if (s->dim > 16 && !s->generic)
+    if (s->dim > 16 && !s->generic && !s->user)
         s->variant = 0;
     /* f32 up to dim 8: noise waves + transition waves, two waves per SIMD (mm_split_kernels.h; config 3: 0.225 ms
      * against 0.268 ms for variant 2) */
@@ -213,6 +230,8 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         s->variant = 5;
     if (s->lg_ok)
         s->variant = 3;
+    if (s->user)
+        s->variant = 7;
     DeviceGuard g(device);
     auto fail = [&](int code) {
         if (s->d_state)
@@ -298,6 +317,17 @@ int sampler_destroy(Sampler *s)
     return MMCMC_OK;
 }
 
+/* mm_tile<T, D>::lds_bytes_table + lds_bytes_per_wave for a dimension known only at run time (one wave per workgroup):
+ * must mirror mm_kernels.h (mm_tile_default / mm_tile_t) */
+static size_t mm_tile_lds_bytes_rt(size_t esz, int D)
+{
+    const int target = esz == 4 ? 96 : 48;
+    const int tile_t = (target / D) >= 2 ? ((target / D) & ~1) : 1;
+    const int run = tile_t * D, epl = (int)(16 / esz);
+    const int stride = (run % epl) == 0 ? run + epl : (run | 1);
+    return (esz == 4 ? (size_t)MM_NOISE_TABLE_BYTES : 0) + (size_t)64 * stride * esz;
+}
+
 template <class T>
 int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P, T *d_out, size_t n_total,
                  uint32_t n_discard, uint32_t n_collect, uint32_t out_t0, hipStream_t stream)
@@ -321,7 +351,11 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     unsigned int grid = (unsigned int)((s->n_chains + s->block - 1) / s->block);
     hipError_t e;
     const bool mh = s->sampler == MM_SAMPLER_MH, l10 = s->n_leapfrog == 10;
-    if (s->variant == 6) {
+    if (s->variant == 7 && s->user) {
+        /* the same skeleton (mm_run_kernel_body, PIPE = 2) around the user's functor, from the run-time compiled module */
+        const size_t lds = mm_tile_lds_bytes_rt(sizeof(T), s->dim);
+        e = mm_rtc_launch_run(s->user, mh ? 0 : 1, std::is_same<T, float>::value ? 0 : 1, &a, sizeof(a), grid, s->block, lds, stream);
+    } else if (s->variant == 6) {
         mm_gen_args<T> q;
         q.P = P;
         q.kind = s->kind;
@@ -518,8 +552,9 @@ int sampler_timing(Sampler *s, mmcmc_timing *t)
 template <class T>
 int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, void *logp, void *grad)
 {
-    const mm_kernel_entry<T> *k = find_kernel<T>(target->kind, target->dim);
-    if (!k && !mm_generic_kind_ok(target->kind))
+    const mm_user_target *user = target->kind >= MM_USER_KIND_BASE ? mm_rtc_find(target->kind) : nullptr;
+    const mm_kernel_entry<T> *k = user ? nullptr : find_kernel<T>(target->kind, target->dim);
+    if (!k && !user && !mm_generic_kind_ok(target->kind))
         return MMCMC_ERR_UNSUPPORTED;
     mm_tparams<T> P;
     T *d_mat = nullptr;
@@ -539,7 +574,16 @@ int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, 
             break;
         if ((e = hipMemcpy(dx, x, n * d * sizeof(T), hipMemcpyHostToDevice)) != hipSuccess)
             break;
-        if (k) {
+        if (user) {
+            struct {
+                mm_tparams<T> P;
+                const T *x;
+                T *logp, *grad;
+                unsigned long long n;
+            } ua{P, dx, dl, dg, (unsigned long long)n};
+            if ((e = mm_rtc_launch_logp_grad(user, std::is_same<T, float>::value ? 0 : 1, &ua, sizeof(ua), n, nullptr)) != hipSuccess)
+                break;
+        } else if (k) {
             if ((e = k->logp_grad(P, dx, dl, dg, (unsigned long long)n, nullptr)) != hipSuccess)
                 break;
         } else {
@@ -715,6 +759,8 @@ static bool split_ok(const Sampler *s)
  * request wherever the target kind has one and the chain vectors fit LDS (what the bit-identity tests use) */
 static int set_variant_common(Sampler *s, int variant)
 {
+    if (s->user)
+        return variant == 7 ? MMCMC_OK : MMCMC_ERR_UNSUPPORTED;
     if (s->generic)
         return variant == 6 ? MMCMC_OK : MMCMC_ERR_UNSUPPORTED;
     if (variant == 6) {
@@ -730,7 +776,7 @@ static int set_variant_common(Sampler *s, int variant)
 
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 {
-    if (!h || variant < 0 || (variant > 2 && variant != 5 && variant != 6))
+    if (!h || variant < 0 || (variant > 2 && variant != 5 && variant != 6 && variant != 7))
         return MMCMC_ERR_INVALID_ARG;
     if (const int st = set_variant_common(h->s, variant); st <= 0)
         return st;
@@ -741,7 +787,7 @@ int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 }
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
 {
-    if (!h || variant < 0 || (variant > 3 && variant != 5 && variant != 6))
+    if (!h || variant < 0 || (variant > 3 && variant != 5 && variant != 6 && variant != 7))
         return MMCMC_ERR_INVALID_ARG;
     if (const int st = set_variant_common(h->s, variant); st <= 0)
         return st;

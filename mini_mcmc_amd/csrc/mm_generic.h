@@ -94,7 +94,7 @@ template <class T, class S> MM_HD T mm_gen_logp_grad(int kind, const mm_tparams<
         return T(-0.5) * q;
     }
     default:
-        return T(NAN);
+        return T(MM_NAN_F);
     }
 }
 
@@ -220,7 +220,7 @@ template <class T, bool LDS> __global__ __launch_bounds__(64) void mm_run_generi
     const unsigned long long c = (unsigned long long)blockIdx.x * 64ull + lane;
     const bool active = c < a.n_chains;
     const unsigned long long chain = a.chain_offset + c;
-    using Ptr = typename std::conditional<LDS, typename mm_lds_ptr<T>::type, T *>::type;
+    using Ptr = typename mm_cond<LDS, typename mm_lds_ptr<T>::type, T *>::type;
     mm_gstore<T, Ptr> s;
     if constexpr (LDS) {
         s.base = (Ptr)reinterpret_cast<T *>(mm_lds_raw) + lane;

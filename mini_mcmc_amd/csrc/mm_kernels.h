@@ -20,11 +20,12 @@
 #ifndef MM_KERNELS_H
 #define MM_KERNELS_H
 
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
-
-#include <type_traits>
+#endif
 
 #include "mm_samplers.h"
+
 
 #define MM_SAMPLER_MH 0
 #define MM_SAMPLER_HMC 1
@@ -205,7 +206,7 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
  * LCT > 0: compile-time leapfrog count (the loop is unrolled into that block).  Results are bit-identical for
  * every (PIPE, LCT): all variants evaluate the same functions (mm_rng.h, mm_samplers.h). */
 template <class T, class Tgt, int SAMPLER, int PIPE = 0, int LCT = 0>
-__global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
+__device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
 {
     constexpr int D = Tgt::dim;
     using Tile = mm_tile<T, D>;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
     T *lds = reinterpret_cast<T *>(mm_lds_raw + Tile::lds_bytes_table);
     /* where the f32 normals' table is read from: the block's LDS copy (f64 draws do not use a table) */
-    using Tab = typename std::conditional<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
+    using Tab = typename mm_cond<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
     Tab tab;
     if constexpr (sizeof(T) == 4) {
         mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, blockDim.x);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         /* An odd count ends with half a pair: the second transition of the last pair is handed ln u = NaN, against which
          * both accept rules (`>`, `>=`) are false, so it leaves state and counters alone; then the noise is drawn afresh
          * for (it + 1, it + 2).  One pair loop, two inlined transitions, no tail code. */
-        const T never = (T)NAN;
+        const T never = (T)MM_NAN_F;
         /* n transitions without output */
         auto silent = [&](unsigned int n) __attribute__((always_inline)) {
             for (unsigned int i = 0; i < n; i += 2) {
@@ -389,6 +390,14 @@ __global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
         atomicAdd(a.accept_total, wave_acc);
 }
 
+/* the kernel proper; the body is a device function so that a run-time compiled translation unit (user targets,
+ * mm_rtc.hip) can wrap it in an extern "C" kernel of its own */
+template <class T, class Tgt, int SAMPLER, int PIPE = 0, int LCT = 0>
+__global__ __launch_bounds__(256) void mm_run_kernel(const mm_run_args<T> a)
+{
+    mm_run_kernel_body<T, Tgt, SAMPLER, PIPE, LCT>(a);
+}
+
 /* BatchedGradientTarget::unnorm_logp_batch / unnorm_logp_and_grad for n rows (parity tests) */
 template <class T, class Tgt>
 __global__ void mm_logp_grad_kernel(const mm_tparams<T> P, const T *x, T *logp, T *grad, unsigned long long n)
@@ -427,6 +436,7 @@ __global__ void mm_noise_kernel(unsigned long long seed, unsigned long long chai
     u[i] = uu;
 }
 
+#if !defined(__HIPCC_RTC__)
 /* host-side launchers + dispatch record for one (sampler, dtype, kind, dim) instance */
 template <class T, class Tgt, int SAMPLER, int PIPE = 0, int LCT = 0>
 hipError_t mm_launch_run(const mm_run_args<T> &a, unsigned int grid, unsigned int block, hipStream_t stream)
@@ -483,5 +493,7 @@ const mm_kernel_entry<float> *mm_kernel_table_f32(int *n);
 const mm_kernel_entry<double> *mm_kernel_table_f64(int *n);
 const mm_noise_entry<float> *mm_noise_table_f32(int *n);
 const mm_noise_entry<double> *mm_noise_table_f64(int *n);
+
+#endif /* !__HIPCC_RTC__ */
 
 #endif /* MM_KERNELS_H */

@@ -12,9 +12,29 @@
 #ifndef MM_MATH_H
 #define MM_MATH_H
 
+#if defined(__HIPCC_RTC__)
+/* hipRTC (run-time compiled user targets, mm_rtc.hip): no host headers; the compiler's built-in runtime header declares
+ * the device math functions, these are the fixed-width types this code uses */
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef __SIZE_TYPE__ size_t;
+#else
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#endif
+/* spelled as builtins so that the header needs no libc declarations */
+#define MM_INFINITY_F (__builtin_huge_valf())
+#define MM_NAN_F (__builtin_nanf(""))
+
+#if defined(__cplusplus)
+/* std::conditional without <type_traits> (the header also compiles under hipRTC, which has no host headers) */
+template <bool C, class A, class B> struct mm_cond { typedef A type; };
+template <class A, class B> struct mm_cond<false, A, B> { typedef B type; };
+#endif
 
 #if defined(__HIPCC__)
 #define MM_HD __host__ __device__ __forceinline__
@@ -33,25 +53,25 @@
 MM_HD uint32_t mm_f2u(float f)
 {
     uint32_t u;
-    memcpy(&u, &f, 4);
+    __builtin_memcpy(&u, &f, 4);
     return u;
 }
 MM_HD float mm_u2f(uint32_t u)
 {
     float f;
-    memcpy(&f, &u, 4);
+    __builtin_memcpy(&f, &u, 4);
     return f;
 }
 MM_HD uint64_t mm_d2u(double f)
 {
     uint64_t u;
-    memcpy(&u, &f, 8);
+    __builtin_memcpy(&u, &f, 8);
     return u;
 }
 MM_HD double mm_u2d(uint64_t u)
 {
     double f;
-    memcpy(&f, &u, 8);
+    __builtin_memcpy(&f, &u, 8);
     return f;
 }
 
@@ -93,7 +113,7 @@ MM_HD float mm_expf(float x)
     if (!(x == x))
         return x;
     if (x > 88.72283905206835f)
-        return INFINITY;
+        return MM_INFINITY_F;
     if (x < -103.97208f)
         return 0.0f;
     float kf = rintf(x * 1.44269504088896341f);
@@ -206,7 +226,7 @@ MM_HD double mm_exp(double x)
     if (!(x == x))
         return x;
     if (x > 709.782712893384)
-        return (double)INFINITY;
+        return (double)MM_INFINITY_F;
     if (x < -745.1332191019411)
         return 0.0;
     double kf = rint(x * 1.44269504088896338700e+00);

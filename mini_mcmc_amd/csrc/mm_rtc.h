@@ -1,0 +1,19 @@
+/* mm_rtc.h -- run-time compiled user targets (mm_rtc.hip): what the rest of the library sees */
+#ifndef MM_RTC_H
+#define MM_RTC_H
+
+#include <hip/hip_runtime.h>
+
+#define MM_USER_KIND_BASE 1000 /* = MMCMC_USER_KIND_BASE: kinds handed out by mmcmc_target_register_source */
+
+struct mm_user_target; /* opaque */
+const mm_user_target *mm_rtc_find(int kind);
+int mm_rtc_dim(const mm_user_target *t);
+/* kernels of a registered target: sampler 0 MH / 1 HMC, dtype 0 f32 / 1 f64; `args` = the mm_run_args<T> block */
+hipError_t mm_rtc_launch_run(const mm_user_target *t, int sampler, int dtype, void *args, size_t args_bytes, unsigned int grid,
+                             unsigned int block, size_t lds, hipStream_t stream);
+/* unnorm_logp / unnorm_logp_and_grad of n rows; `args` = {mm_tparams<T> P, const T *x, T *logp, T *grad, u64 n} packed */
+hipError_t mm_rtc_launch_logp_grad(const mm_user_target *t, int dtype, void *args, size_t args_bytes, unsigned long long n,
+                                   hipStream_t stream);
+
+#endif /* MM_RTC_H */

@@ -55,7 +55,7 @@ template <class T, int D, bool MH, int I = 0> struct mm_split_pick {
     static constexpr int rb_mh[12] = {8, 8, 8, 4, 4, 4, 8, 2, 2, 2, 4, 2}, want_mh[12] = {48, 32, 24, 48, 32, 24, 16, 48, 32, 24, 16, 16};
     static constexpr int rb = MH ? rb_mh[I] : rb_hmc[I], want = MH ? want_mh[I] : want_hmc[I];
     using Try = mm_split_try<T, D, rb, want, (MH ? 2 : 1)>;
-    using type = typename std::conditional<Try::ok, Try, typename mm_split_pick<T, D, MH, I + 1>::type>::type;
+    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick<T, D, MH, I + 1>::type>::type;
 };
 template <class T, int D, bool MH> struct mm_split_pick<T, D, MH, 12> {
     using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, (MH ? 2 : 1)>; /* RB = TILE_T = 2: always fits up to dim 8 */
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
     /* both roles walk the same schedule: silent transitions in batches of RB (the last one short), then the collected
      * ones in batches of RB (the last one short), one barrier before each batch and one after the last; a tile is
      * complete after TILE_T collected transitions, or with the last one */
-    using Tab = typename std::conditional<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
+    using Tab = typename mm_cond<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
     Tab tab;
     if constexpr (sizeof(T) == 4) {
         mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, 512u);

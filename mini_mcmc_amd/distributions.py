@@ -147,6 +147,26 @@ class GaussianND(Target):
         return GaussianND((a + a.T) / 2.0)
 
 
+class UserTarget(Target):
+    """A target of the user's own: the GPU analogue of `impl GradientTarget for MyDensity` (distributions.rs:65-108).
+
+    `source` is HIP C++ defining `template <class T> struct mmcmc_user_target` with `static constexpr int dim`,
+    `logp(P, x)` and `logp_grad(P, x, g)` (include/mmcmc.h: mmcmc_target_register_source); it is compiled at run time
+    (hipRTC) into the engine's MH / HMC kernels for f32 and f64.  `params` (up to 8 numbers) arrive as `P.p[i]`,
+    `matrix` ([dim, dim]) as `P.mat`.  `UserTarget.compile_log` holds the compiler's diagnostics."""
+
+    def __init__(self, name: str, dim: int, source: str, params=(), matrix=None):
+        super().__init__(dim, params, matrix)
+        kind = C.c_int(0)
+        log = C.create_string_buffer(1 << 16)
+        st = L.lib().mmcmc_target_register_source(name.encode(), int(dim), source.encode(), C.byref(kind), log, len(log))
+        self.compile_log = log.value.decode(errors="replace")
+        if st != L.OK:
+            raise L.MmcmcError(st, "mmcmc_target_register_source" + (": " + self.compile_log[-2000:] if self.compile_log else ""))
+        self.kind = kind.value
+        self.name = name
+
+
 class Categorical:
     """distributions.rs:421-477 `Categorical::new(probs)` (`Discrete` + `Target<usize>`): host-side utility, not on the
     GPU path.  Probabilities are normalised on construction; `sample` walks the cumulative sums with `r <= cum` and
