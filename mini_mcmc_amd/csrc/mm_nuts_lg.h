@@ -130,23 +130,23 @@ struct mm_nuts_lg_args {
 #endif
 };
 
-/* OCC = waves per SIMD the kernel is built for: 1 = the 512-register budget and 40 KB of LDS per wave (levels 0..2 of
- * the pending entries and first-leaf records 1..3 in LDS); 2 = 256 registers and 20 KB (levels 0..1, record 1), the
- * records of a merge requested when the merge needs them instead of before the leapfrog -- a second wave hides the
- * latency (persistent scheduler only) */
+/* OCC = waves per SIMD the kernel is built for: 1 = the 512-register budget and 40 KB of LDS per wave; 2 = 256 registers
+ * and 20 KB (persistent scheduler only).  Level 0 of the pending-subtree stack never reaches memory: leaves are taken
+ * in pairs and the first leaf's subtree waits for its sibling in registers (so does its (x, p) for the stop criterion).
+ * Memory holds entry(k) for k >= 1 -- k <= LE in LDS, deeper levels in HBM -- and the first-leaf records c >= 2 (c = 1
+ * would serve level-0 merges only) -- c <= 1 + LF in LDS */
 template <int D, int OCC = 1> struct mm_lg_cfg {
     static_assert(D % 16 == 0, "lane-group kernel: D must be a multiple of 16");
     static constexpr int NS = D / 4;           /* coordinates per lane */
     static constexpr int NT = D / 16;          /* 16-row result tiles */
     static constexpr int ES = NS + 2;          /* pending entry: proposal[NS], alpha, (n | n_alpha << 32) */
     static constexpr int FS = 2 * NS;          /* first-leaf record: x[NS], p[NS] */
-    static constexpr int LE = OCC == 1 ? 3 : 2; /* entry(k), k < LE, in LDS */
-    static constexpr int LF = OCC == 1 ? 3 : 1; /* first(c), 1 <= c <= LF, in LDS */
-    static constexpr bool prefetch = OCC == 1;  /* records of the level-0 / 1 merges requested before the leapfrog */
+    static constexpr int LE = OCC == 1 ? 3 : 2; /* entry(k), 1 <= k <= LE, in LDS */
+    static constexpr int LF = OCC == 1 ? 3 : 1; /* first(c), 2 <= c <= 1 + LF, in LDS */
     static constexpr int lds_E = 0, lds_F = LE * ES, lds_slots = LE * ES + LF * FS;
     static constexpr size_t lds_bytes = (size_t)lds_slots * 64 * sizeof(double);
-    /* HBM slots per wave: entry(k), k = LE..JMAX-1 | first(c), c = LF+1..JMAX */
-    static constexpr int hbm_E = 0, hbm_F = (MM_NUTS_JMAX - LE) * ES, hbm_slots = hbm_F + (MM_NUTS_JMAX - LF) * FS;
+    /* HBM slots per wave: entry(k), k = LE + 1 .. JMAX - 1 | first(c), c = LF + 2 .. JMAX */
+    static constexpr int hbm_E = 0, hbm_F = (MM_NUTS_JMAX - 1 - LE) * ES, hbm_slots = hbm_F + (MM_NUTS_JMAX - 1 - LF) * FS;
     static constexpr size_t scratch_doubles_per_wave = (size_t)hbm_slots * 64;
     /* per-chain record, structure of arrays over the (padded) chains: vector v, coordinate 4 s + q of chain c at
      * rec[((v * NS + s) * c_pad + c) * 4 + q] -- a wave of 16 consecutive chains reads 512 contiguous bytes, a wave of
@@ -347,35 +347,35 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     constexpr int NS = Cfg::NS, ES = Cfg::ES;
     const size_t st = (size_t)a.c_pad * 4;
 
-    /* records of the merge at level k (wave-uniform k, cc): the sibling's entry and its first leaf */
+    /* records of the merge at level k >= 1 (wave-uniform k, cc >= 2): the sibling's entry and its first leaf */
     struct rec {
         double fx[NS], fp[NS], prime[NS], alpha, cnt;
     };
     auto load_rec = [&](int k, int cc, rec &r) {
-        if (cc <= Cfg::LF) {
-            const mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 1) * Cfg::FS) * 64;
+        if (cc <= 1 + Cfg::LF) {
+            const mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 r.fx[s] = f[s * 64];
                 r.fp[s] = f[(NS + s) * 64];
             }
         } else {
-            const double *f = scr + (size_t)(Cfg::hbm_F + (cc - Cfg::LF - 1) * Cfg::FS) * 64;
+            const double *f = scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 r.fx[s] = f[s * 64];
                 r.fp[s] = f[(NS + s) * 64];
             }
         }
-        if (k < Cfg::LE) {
-            const mm_lds_double *e = lds + (size_t)(Cfg::lds_E + k * ES) * 64;
+        if (k <= Cfg::LE) {
+            const mm_lds_double *e = lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 r.prime[s] = e[s * 64];
             r.alpha = e[NS * 64];
             r.cnt = e[(NS + 1) * 64];
         } else {
-            const double *e = scr + (size_t)(Cfg::hbm_E + (k - Cfg::LE) * ES) * 64;
+            const double *e = scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 r.prime[s] = e[s * 64];
@@ -410,7 +410,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     const double h = epsv * 0.5, nh = -h; /* cg holds A x = -gradient */
     const unsigned int n_leaves = 1u << j;
     /* nothing in flight when the leaf loop starts: otherwise every use of these loop-carried registers gets a
-     * conservative vmcnt wait that also drains the records requested ahead of the leapfrog */
+     * conservative vmcnt wait */
     __builtin_amdgcn_s_waitcnt(0);
 
     bool done = !alive;
@@ -421,23 +421,14 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         S_prime[s] = 0.0;
+    bool walking = false;
 
-    MM_LG_TICK(L, 1);
-    for (unsigned int leaf = 0; leaf < n_leaves; ++leaf) {
-        if (__ballot(!done) == 0ull)
-            break;
+    /* one leaf: leapfrog of the outer edge (nuts.rs:979-996), in place, and the base case of build_tree
+     * (nuts.rs:782-856); chains that are done keep their edge (the matrix product runs for all 64 lanes: MFMA has no
+     * per-lane mask, their columns are recomputed) */
+    auto leaf_eval = [&](unsigned int leaf) {
         MM_LG_COUNT(L, 6);
         L.n_leaf_iters += 1;
-        /* an odd leaf merges with its left neighbour first: request those records now */
-        rec r0, r1;
-        const bool merge0 = j > 0 && (leaf & 1u);
-        const bool merge1 = j > 1 && (leaf & 3u) == 3u; /* ... and then with the pair before it */
-        if (Cfg::prefetch && merge0)
-            load_rec(0, first_slot(leaf, 0), r0);
-        if (Cfg::prefetch && merge1)
-            load_rec(1, first_slot(leaf, 1), r1);
-        /* leapfrog of the outer edge (nuts.rs:979-996), in place; chains that are done keep their edge (the
-         * matrix product runs for all 64 lanes: MFMA has no per-lane mask, their columns are recomputed) */
         if (!done) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -466,18 +457,19 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             S_s = (L.logu - 1000.0) < jointp;
             S_alpha = fmin(1.0, mm_exp(jointp - L.joint));
             S_nalpha = 1;
-            /* an even leaf starts subtrees: file its (x, p) under the highest level it starts */
-            if (j > 0 && (leaf & 1u) == 0u) {
+            /* a leaf that starts a subtree of level >= 2 files its (x, p) under the highest level it starts (the first
+             * leaf of a level-1 subtree waits in registers, below) */
+            if (j > 1 && (leaf & 3u) == 0u) {
                 const int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
-                if (cc <= Cfg::LF) {
-                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 1) * Cfg::FS) * 64;
+                if (cc <= 1 + Cfg::LF) {
+                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         f[s * 64] = cx[s];
                         f[(NS + s) * 64] = cp[s];
                     }
                 } else {
-                    double *f = scr + (size_t)(Cfg::hbm_F + (cc - Cfg::LF - 1) * Cfg::FS) * 64;
+                    double *f = scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         f[s * 64] = cx[s];
@@ -486,109 +478,124 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 }
             }
         }
-        /* hand S up the implicit recursion; walking lanes have S at level k at the top of iteration k */
-        bool walking = !done;
+        walking = !done;
         MM_LG_TICK(L, 2);
-        /* a sibling waits at level k: S is the second child, merge (nuts.rs:900-928) */
-        auto merge = [&](const rec &r) {
-            MM_LG_TICK(L, 3);
-            MM_LG_COUNT(L, 12);
-            const double u = mm_lg_aux_peek<D>(L, a.seed);
-            /* stop criterion on (first leaf of the sibling, current leaf): d = x_cur - x_first */
-            double ca = 0.0, cb = 0.0;
+    };
+    /* a sibling waits: S is the second child, merge (nuts.rs:900-928); (fx, fp) = the sibling's first leaf */
+    auto merge = [&](const double *fx, const double *fp, const double *prime, double alpha, double cnt_d) {
+        MM_LG_TICK(L, 3);
+        MM_LG_COUNT(L, 12);
+        const double u = mm_lg_aux_peek<D>(L, a.seed);
+        /* stop criterion on (first leaf of the sibling, current leaf): d = x_cur - x_first */
+        double ca = 0.0, cb = 0.0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double d = cx[s] - r.fx[s];
-                ca = fma(d, r.fp[s], ca);
-                cb = fma(d, cp[s], cb);
-            }
-            ca = mm_lg_group_sum(ca);
-            cb = mm_lg_group_sum(cb);
-            const bool crit = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
-            if (walking) {
-                L.aux_k += 1;
-                const unsigned long long cnt = (unsigned long long)__double_as_longlong(r.cnt);
-                const unsigned int n1 = (unsigned int)cnt, na1 = (unsigned int)(cnt >> 32);
-                unsigned int den = n1 + S_n;
-                if (den < 1)
-                    den = 1;
-                const bool take2 = u < ((double)S_n / (double)den);
+        for (int s = 0; s < NS; ++s) {
+            const double d = cx[s] - fx[s];
+            ca = fma(d, fp[s], ca);
+            cb = fma(d, cp[s], cb);
+        }
+        ca = mm_lg_group_sum(ca);
+        cb = mm_lg_group_sum(cb);
+        const bool crit = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
+        if (walking) {
+            L.aux_k += 1;
+            const unsigned long long cnt = (unsigned long long)__double_as_longlong(cnt_d);
+            const unsigned int n1 = (unsigned int)cnt, na1 = (unsigned int)(cnt >> 32);
+            unsigned int den = n1 + S_n;
+            if (den < 1)
+                den = 1;
+            const bool take2 = u < ((double)S_n / (double)den);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                S_prime[s] = take2 ? S_prime[s] : prime[s];
+            S_n += n1;
+            S_alpha = alpha + S_alpha;
+            S_nalpha += na1;
+            S_s = S_s && crit;
+        }
+        MM_LG_TICK(L, 10);
+    };
+    /* first child at level k >= 1: wait for the sibling if still valid; with s' = 0 the parent returns it as it is, so
+     * it keeps walking */
+    auto push = [&](int k) {
+        MM_LG_TICK(L, 3);
+        MM_LG_COUNT(L, 13);
+        if (walking && S_s) {
+            const double cnt =
+                __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
+            if (k <= Cfg::LE) {
+                mm_lds_double *e = lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64;
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    S_prime[s] = take2 ? S_prime[s] : r.prime[s];
-                S_n += n1;
-                S_alpha = r.alpha + S_alpha;
-                S_nalpha += na1;
-                S_s = S_s && crit;
-            }
-            MM_LG_TICK(L, 10);
-        };
-        /* first child at level k: wait for the sibling if still valid; with s' = 0 the parent returns it as it is, so
-         * it keeps walking */
-        auto push = [&](int k) {
-            MM_LG_TICK(L, 3);
-            MM_LG_COUNT(L, 13);
-            if (walking && S_s) {
-                const double cnt =
-                    __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
-                if (k < Cfg::LE) {
-                    mm_lds_double *e = lds + (size_t)(Cfg::lds_E + k * ES) * 64;
+                    e[s * 64] = S_prime[s];
+                e[NS * 64] = S_alpha;
+                e[(NS + 1) * 64] = cnt;
+            } else {
+                double *e = scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        e[s * 64] = S_prime[s];
-                    e[NS * 64] = S_alpha;
-                    e[(NS + 1) * 64] = cnt;
-                } else {
-                    double *e = scr + (size_t)(Cfg::hbm_E + (k - Cfg::LE) * ES) * 64;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        e[s * 64] = S_prime[s];
-                    e[NS * 64] = S_alpha;
-                    e[(NS + 1) * 64] = cnt;
-                }
-                walking = false;
+                for (int s = 0; s < NS; ++s)
+                    e[s * 64] = S_prime[s];
+                e[NS * 64] = S_alpha;
+                e[(NS + 1) * 64] = cnt;
             }
-            MM_LG_TICK(L, 11);
-        };
-        if (j > 0) {
+            walking = false;
+        }
+        MM_LG_TICK(L, 11);
+    };
+    /* hand S up the implicit recursion from level 1: walking lanes have S at level k at the top of iteration k */
+    auto walk_up = [&](unsigned int leaf) {
+        for (int k = 1; k < j; ++k) {
+            if (__ballot(walking) == 0ull)
+                break;
             MM_LG_COUNT(L, 7);
-            if (merge0) {
-                if (!Cfg::prefetch)
-                    load_rec(0, first_slot(leaf, 0), r0);
-                merge(r0); /* level 0; OCC 1: records requested before the leapfrog */
-            }
-            else
-                push(0);
-            if (j > 1 && __ballot(walking) != 0ull) {
-                MM_LG_COUNT(L, 7);
-                if (merge1) {
-                    if (!Cfg::prefetch)
-                        load_rec(1, first_slot(leaf, 1), r1);
-                    merge(r1);
-                } else if ((leaf >> 1) & 1u) {
-                    /* bit 1 set but bit 0 clear: the level-0 child was first, a failing one was handed up */
-                    rec rk;
-                    load_rec(1, first_slot(leaf, 1), rk);
-                    merge(rk);
-                } else {
-                    push(1);
-                }
-            }
-            for (int k = 2; k < j; ++k) {
-                if (__ballot(walking) == 0ull)
-                    break;
-                MM_LG_COUNT(L, 7);
-                if ((leaf >> k) & 1u) {
-                    rec rk;
-                    load_rec(k, first_slot(leaf, k), rk);
-                    merge(rk);
-                } else {
-                    push(k);
-                }
+            if ((leaf >> k) & 1u) {
+                rec rk;
+                load_rec(k, first_slot(leaf, k), rk);
+                merge(rk.fx, rk.fp, rk.prime, rk.alpha, rk.cnt);
+            } else {
+                push(k);
             }
         }
         done = done || walking; /* reached level j: the doubling is complete, or was cut short */
         MM_LG_TICK(L, 3);
+    };
+
+    MM_LG_TICK(L, 1);
+    if (j == 0) {
+        if (__ballot(!done) != 0ull) {
+            leaf_eval(0u);
+            done = done || walking;
+        }
+    } else {
+        for (unsigned int leaf = 0; leaf < n_leaves; leaf += 2) {
+            if (__ballot(!done) == 0ull)
+                break;
+            /* ---- the first leaf of a level-1 subtree: its one-leaf subtree (level 0) waits for the sibling in registers */
+            leaf_eval(leaf);
+            double fx[NS], fp[NS], P_prime[NS], P_alpha;
+            unsigned int P_n, P_nalpha;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                fx[s] = cx[s];
+                fp[s] = cp[s];
+                P_prime[s] = S_prime[s];
+            }
+            P_alpha = S_alpha;
+            P_n = S_n;
+            P_nalpha = S_nalpha;
+            MM_LG_COUNT(L, 7);
+            MM_LG_COUNT(L, 13);
+            walking = walking && !S_s; /* valid: it waits (nuts.rs:858-899); not valid: handed up as it is */
+            walk_up(leaf);
+            if (__ballot(!done) == 0ull)
+                break;
+            /* ---- its sibling: merge at level 0 with the waiting subtree, then hand the pair up */
+            leaf_eval(leaf + 1u);
+            MM_LG_COUNT(L, 7);
+            merge(fx, fp, P_prime, P_alpha,
+                  __longlong_as_double((long long)((unsigned long long)P_n | ((unsigned long long)P_nalpha << 32))));
+            walk_up(leaf + 1u);
+        }
     }
 
     /* write the advanced edge back; whole-trajectory criterion against the other edge (d = x_cur - x_other) */

@@ -119,28 +119,35 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
         unsigned int it = a.iter0;
         int half = 0;
         /* noise of iterations [it + QN, it + nb) of a batch into rows QN.. of the current ring half */
+        /* PAIRS noise pairs are drawn back to back before any of them is stored: their Philox rounds and table reads
+         * overlap (a lone pair waits out every LDS table read: the noise wave has no other work to cover it) */
+#ifndef MM_SPLIT_FILL_PAIRS
+#define MM_SPLIT_FILL_PAIRS 1 /* 2 and 4 measured: no difference (config 2: 0.273 / 0.280 / 0.272 ms) */
+#endif
+        constexpr int PAIRS = ((RB - QN) % (2 * MM_SPLIT_FILL_PAIRS) == 0 && RB > QN) ? MM_SPLIT_FILL_PAIRS : 1;
         auto fill = [&](unsigned int nb) __attribute__((always_inline)) {
             T *dst = ring + ((size_t)half * RB + QN) * 64 * NW + (size_t)lane * NW;
-            for (unsigned int j = QN; j < nb; j += 2) {
-                T row_a[NW], row_b[NW];
-                mm_draw_noise_pair<D>(a.seed, chain, it + j, row_a, &row_a[D], row_b, &row_b[D], tab);
+            for (unsigned int j = QN; j < nb; j += 2 * PAIRS) {
+                T rows[2 * PAIRS][NW];
                 MM_UNROLL
-                for (int k = D + 1; k < NW; ++k) {
-                    row_a[k] = T(0);
-                    row_b[k] = T(0);
-                }
+                for (int q = 0; q < PAIRS; ++q)
+                    mm_draw_noise_pair<D>(a.seed, chain, it + j + 2 * q, rows[2 * q], &rows[2 * q][D], rows[2 * q + 1], &rows[2 * q + 1][D], tab);
                 MM_UNROLL
-                for (int k = 0; k < NW; k += EPL) {
-                    mm_vrow va, vb;
+                for (int r = 0; r < 2 * PAIRS; ++r) {
                     MM_UNROLL
-                    for (int e = 0; e < EPL; ++e) {
-                        va[e] = row_a[k + e];
-                        vb[e] = row_b[k + e];
+                    for (int k = D + 1; k < NW; ++k)
+                        rows[r][k] = T(0);
+                    MM_UNROLL
+                    for (int k = 0; k < NW; k += EPL) {
+                        mm_vrow v;
+                        MM_UNROLL
+                        for (int e = 0; e < EPL; ++e)
+                            v[e] = rows[r][k + e];
+                        /* rows past nb (an odd or short batch) land inside the half: RB - QN is a multiple of 2 PAIRS */
+                        *reinterpret_cast<mm_vrow *>(dst + (size_t)r * 64 * NW + k) = v;
                     }
-                    *reinterpret_cast<mm_vrow *>(dst + k) = va;
-                    *reinterpret_cast<mm_vrow *>(dst + 64 * NW + k) = vb; /* row j + 1 (RB is even: always inside the half) */
                 }
-                dst += 2 * 64 * NW;
+                dst += 2 * PAIRS * 64 * NW;
             }
             it += nb;
             half ^= 1;

@@ -28,6 +28,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
@@ -341,6 +343,302 @@ __global__ __launch_bounds__(64) void mm_half_chain_mfma_kernel(const T *__restr
         slab[i] = acc[i];
 }
 
+/* The same half-chain statistics with the lag sums as REGISTER TILES on the vector ALU -- the default where it fits.
+ *
+ * Why not the matrix cores: v_mfma_f32_16x16x4_f32 has exactly the f32 vector rate (64 FLOP / clock / SIMD), and the
+ * Hankel x Toeplitz product above spends 256 x m multiply-adds on the m (m + 1) / 2 products a half-chain's lag sums
+ * need (2.5x at m = 200); its floor for [65 536, 400, 3] is 0.26 ms, the kernel took 0.45 ms.  Only the SUM over the
+ * wave's half-chains of every lag sum is wanted, so nothing has to be reduced across lanes per half-chain: the
+ * (t, lag) triangle of a parameter is cut into tiles of 8 time steps x 16 lags, every lane owns TPL of the
+ * D x tiles(m) tiles for the whole launch and keeps its tiles' 16 lag sums in registers across all the half-chains of
+ * the wave.  Per tile and half-chain: y[T0 .. T0 + 8) and y[T0 + K0 .. T0 + K0 + 24) come from LDS as eight
+ * 16-byte reads, then 128 FMAs run from registers -- 16 multiply-adds per LDS instruction where the direct kernel did
+ * one.  (y is zero past m, so tiles on the diagonal need no masks.)  At the end the lanes' tiles are folded into the
+ * per-wave slab in a fixed order (bitwise reproducible, no atomics).  Lanes used: D tiles(m) / (64 TPL) = 99 % at
+ * [., 400, 3]; executed multiply-adds 1.09 x the useful ones. */
+template <class T, int TPL, bool VEC>
+__global__ __launch_bounds__(64) void mm_half_chain_tile_kernel(const T *__restrict__ sample, unsigned long long C,
+                                                                unsigned int n, unsigned int D, unsigned int m,
+                                                                float *__restrict__ means, float *__restrict__ ssq,
+                                                                float *__restrict__ slabs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr unsigned int RT = 8, SK = 16; /* tile: RT time steps x SK lags */
+    const unsigned int nbt = (m + RT - 1) / RT, nbk = (m + SK - 1) / SK;
+    /* a row of y: blocks of 8 elements, 12 words apart (element t at word 12 (t / 8) + t % 8), zeros behind (reads reach
+     * element T0 + K0 + RT + SK).  The lanes of a 16-byte read are in consecutive time blocks: 48 bytes apart they cover
+     * the 64 banks once per 16 lanes, 32 bytes apart (no pad) every read was a 2-way bank conflict */
+    auto at = [](unsigned int t) -> unsigned int { return 12u * (t >> 3) + (t & 7u); };
+    const unsigned int pitch = 12u * ((m + RT + SK + 8 + 7) / 8) + 4u;
+    float *y = lds;                              /* [D][pitch] */
+    float *slab = lds + (size_t)D * pitch;       /* [D][m] */
+    float *scratch = slab + (size_t)D * m;       /* [64][SK] one tile slot of every lane (final fold) */
+    const unsigned int lane = threadIdx.x;
+    const unsigned long long n_half = 2ull * C;
+    /* tiles of one parameter, lag block kb = 0 .. nbk-1: time blocks tb with RT tb + SK kb < m, i.e. cnt(kb) of them;
+     * enumerated kb-major; tile e of the launch = d * n_tiles + first(kb) + tb */
+    auto cnt = [&](unsigned int kb) -> unsigned int { return (m - SK * kb + RT - 1) / RT; };
+    unsigned int n_tiles = 0;
+    for (unsigned int kb = 0; kb < nbk; ++kb)
+        n_tiles += cnt(kb);
+    /* this lane's tiles: LDS word offsets of y[T0] and y[T0 + K0] in the row of the tile's parameter */
+    unsigned int off_t[TPL], off_w[TPL];
+#pragma unroll
+    for (int sl = 0; sl < TPL; ++sl) {
+        const unsigned int e = lane + 64u * (unsigned int)sl;
+        /* no tile in this slot: both operands from the zero tail of row 0 (element m + 8 onwards) */
+        off_t[sl] = 12u * ((m + 15) / 8);
+        off_w[sl] = 12u * ((m + 15) / 8);
+        if (e < D * n_tiles) {
+            const unsigned int d = e / n_tiles;
+            unsigned int r = e - d * n_tiles, kb = 0;
+            while (r >= cnt(kb)) {
+                r -= cnt(kb);
+                ++kb;
+            }
+            off_t[sl] = d * pitch + 12u * r;
+            off_w[sl] = d * pitch + 12u * (r + 2u * kb);
+        }
+    }
+    float acc[TPL][SK];
+#pragma unroll
+    for (int sl = 0; sl < TPL; ++sl)
+#pragma unroll
+        for (unsigned int j = 0; j < SK; ++j)
+            acc[sl][j] = 0.f;
+    for (unsigned int i = lane; i < D * pitch; i += 64)
+        y[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    /* the [m, D] block of the NEXT half-chain is requested before the current one is reduced (as in the MFMA kernel).
+     * VEC (f32, every block 16-byte aligned: the host checks n D, (n - m) D and m D for multiples of 4): 16-byte loads,
+     * three per lane at [., 400, 3] where 4-byte loads take ten -- the block arrives in a quarter of the instructions */
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned int NPRE = VEC ? 4 : 16;
+    const unsigned int mD = m * D;
+    const bool prefetch = mD <= NPRE * 64u * (VEC ? 4u : 1u);
+    unsigned int lds_off[VEC ? 4 * NPRE : NPRE];
+    float pre[VEC ? 1 : NPRE];
+    f4 pre4[VEC ? NPRE : 1];
+    if (VEC) {
+#pragma unroll
+        for (unsigned int i = 0; i < NPRE; ++i)
+#pragma unroll
+            for (unsigned int c = 0; c < 4; ++c) {
+                const unsigned int e = 4u * (lane + 64u * i) + c, t = e / D, d = e - t * D;
+                lds_off[4 * i + c] = e < mD ? d * pitch + at(t) : 0u;
+            }
+    } else {
+        const unsigned int q64 = 64u / D, r64 = 64u - q64 * D;
+        unsigned int t = lane / D, d = lane - t * D;
+#pragma unroll
+        for (unsigned int i = 0; i < NPRE; ++i) {
+            lds_off[i] = d * pitch + at(t);
+            t += q64;
+            d += r64;
+            if (d >= D) {
+                d -= D;
+                t += 1;
+            }
+        }
+    }
+    auto block_of = [&](unsigned long long hc) -> const T * {
+        const unsigned long long chain = hc < C ? hc : hc - C;
+        const unsigned int row0 = hc < C ? 0u : n - m;
+        return sample + (chain * n + row0) * D;
+    };
+    auto request = [&](unsigned long long hc) {
+        const T *src = block_of(hc);
+        if constexpr (VEC) {
+            const f4 *src4 = reinterpret_cast<const f4 *>(src);
+#pragma unroll
+            for (unsigned int i = 0; i < NPRE; ++i) {
+                const unsigned int v = lane + 64u * i;
+                pre4[i] = 4u * v < mD ? src4[v] : f4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (unsigned int i = 0; i < NPRE; ++i) {
+                const unsigned int e = lane + 64u * i;
+                pre[i] = e < mD ? (float)src[e] : 0.f;
+            }
+        }
+    };
+    if (prefetch && blockIdx.x < n_half)
+        request(blockIdx.x);
+    for (unsigned long long hc = blockIdx.x; hc < n_half; hc += gridDim.x) {
+        if (prefetch) {
+            if constexpr (VEC) {
+#pragma unroll
+                for (unsigned int i = 0; i < NPRE; ++i)
+                    if (4u * (lane + 64u * i) < mD) { /* m D is a multiple of 4: whole vectors */
+#pragma unroll
+                        for (unsigned int c = 0; c < 4; ++c)
+                            y[lds_off[4 * i + c]] = pre4[i][c];
+                    }
+            } else {
+#pragma unroll
+                for (unsigned int i = 0; i < NPRE; ++i)
+                    if (lane + 64u * i < mD)
+                        y[lds_off[i]] = pre[i];
+            }
+            if (hc + gridDim.x < n_half)
+                request(hc + gridDim.x);
+        } else {
+            const T *src = block_of(hc);
+            const unsigned int q64 = 64u / D, r64 = 64u - q64 * D;
+            unsigned int t = lane / D, d = lane - t * D;
+            for (unsigned int e = lane; e < mD; e += 64) {
+                y[d * pitch + at(t)] = (float)src[e];
+                t += q64;
+                d += r64;
+                if (d >= D) {
+                    d -= D;
+                    t += 1;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        /* mean, centred sum of squares, centring in place, up to four parameters at a time in one basic block: their LDS
+         * reads and wave reductions are independent chains the scheduler interleaves (one parameter after the other, two
+         * waves per SIMD, every DPP / readlane / LDS latency was exposed: 0.10 of the kernel's 0.39 ms) */
+#ifndef MM_STATS_PROBE_SKIP_CENTER
+        auto centre = [&](unsigned int d0, auto nu_tag) __attribute__((always_inline)) {
+            constexpr unsigned int NU = decltype(nu_tag)::value;
+            float s0[NU], mean[NU], q[NU];
+#pragma unroll
+            for (unsigned int u = 0; u < NU; ++u)
+                s0[u] = 0.f;
+            for (unsigned int t = lane; t < m; t += 64) {
+                const unsigned int w = at(t);
+#pragma unroll
+                for (unsigned int u = 0; u < NU; ++u)
+                    s0[u] += y[(d0 + u) * pitch + w];
+            }
+#pragma unroll
+            for (unsigned int u = 0; u < NU; ++u) {
+                mean[u] = wave_sum_dpp(s0[u]) / (float)m;
+                q[u] = 0.f;
+            }
+            for (unsigned int t = lane; t < m; t += 64) {
+                const unsigned int w = at(t);
+#pragma unroll
+                for (unsigned int u = 0; u < NU; ++u) {
+                    const float v = y[(d0 + u) * pitch + w] - mean[u];
+                    y[(d0 + u) * pitch + w] = v;
+                    q[u] += v * v;
+                }
+            }
+#pragma unroll
+            for (unsigned int u = 0; u < NU; ++u)
+                q[u] = wave_sum_dpp(q[u]);
+            if (lane == 0) {
+#pragma unroll
+                for (unsigned int u = 0; u < NU; ++u) {
+                    means[hc * D + d0 + u] = mean[u];
+                    ssq[hc * D + d0 + u] = q[u];
+                }
+            }
+        };
+        for (unsigned int d0 = 0; d0 < D; d0 += 4) {
+            const unsigned int left = D - d0;
+            if (left >= 4)
+                centre(d0, std::integral_constant<unsigned int, 4>());
+            else if (left == 3)
+                centre(d0, std::integral_constant<unsigned int, 3>());
+            else if (left == 2)
+                centre(d0, std::integral_constant<unsigned int, 2>());
+            else
+                centre(d0, std::integral_constant<unsigned int, 1>());
+        }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        /* the tiles, software-pipelined: the operands of tile sl + 1 are requested before the 128 multiply-adds of tile
+         * sl (no branches in here: a lane without a tile in some slot reads zeros) */
+        float yt[2][RT], yw[2][RT + SK];
+        auto fetch = [&](int sl, int b) __attribute__((always_inline)) {
+            const f4 *pt = reinterpret_cast<const f4 *>(y + off_t[sl]);
+            const f4 *pw = reinterpret_cast<const f4 *>(y + off_w[sl]);
+#pragma unroll
+            for (unsigned int i = 0; i < RT / 4; ++i) {
+                const f4 v = pt[3 * (i >> 1) + (i & 1u)];
+                yt[b][4 * i] = v[0];
+                yt[b][4 * i + 1] = v[1];
+                yt[b][4 * i + 2] = v[2];
+                yt[b][4 * i + 3] = v[3];
+            }
+#pragma unroll
+            for (unsigned int i = 0; i < (RT + SK) / 4; ++i) {
+                const f4 v = pw[3 * (i >> 1) + (i & 1u)]; /* block i / 2 at word 12 (i / 2), half i % 2 */
+                yw[b][4 * i] = v[0];
+                yw[b][4 * i + 1] = v[1];
+                yw[b][4 * i + 2] = v[2];
+                yw[b][4 * i + 3] = v[3];
+            }
+        };
+#ifndef MM_STATS_PROBE_SKIP_TILES /* measurement aid of tools/stats_probe.hip; never defined in the library build */
+        fetch(0, 0);
+#pragma unroll
+        for (int sl = 0; sl < TPL; ++sl) {
+            const int b = sl & 1;
+            if (sl + 1 < TPL)
+                fetch(sl + 1, b ^ 1);
+#pragma unroll
+            for (unsigned int r = 0; r < RT; ++r)
+#pragma unroll
+                for (unsigned int j = 0; j < SK; ++j)
+                    acc[sl][j] = fmaf(yt[b][r], yw[b][r + j], acc[sl][j]);
+        }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    /* fold the lanes' tiles into the slab, slot by slot, in a fixed order: output (d, lag) takes, from the lanes whose
+     * tile of this slot covers it (same d, kb = lag / SK: a run of consecutive tiles), their sums in ascending tb */
+    for (unsigned int i = lane; i < D * m; i += 64)
+        slab[i] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < TPL; ++sl) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (unsigned int j = 0; j < SK; ++j)
+            scratch[lane * SK + j] = acc[sl][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned int e_lo = 64u * (unsigned int)sl, e_hi = e_lo + 64u;
+        for (unsigned int o = lane; o < D * m; o += 64) {
+            const unsigned int d = o / m, lag = o - d * m, kb = lag / SK, j = lag - kb * SK;
+            unsigned int first = d * n_tiles;
+            for (unsigned int q = 0; q < kb; ++q)
+                first += cnt(q);
+            const unsigned int last = first + cnt(kb); /* tiles [first, last) cover (d, kb) */
+            const unsigned int lo = first > e_lo ? first : e_lo, hi = last < e_hi ? last : e_hi;
+            float sum = slab[o];
+            for (unsigned int e = lo; e < hi; ++e)
+                sum += scratch[(e - e_lo) * SK + j];
+            slab[o] = sum;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float *out = slabs + (size_t)blockIdx.x * D * m;
+    for (unsigned int i = lane; i < D * m; i += 64)
+        out[i] = slab[i];
+}
+
+/* tiles of 8 time steps x 16 lags of one parameter's (t, lag) triangle (the kernel's own count) */
+static unsigned int stats_tile_count(size_t m)
+{
+    unsigned int n = 0;
+    for (size_t kb = 0; 16 * kb < m; ++kb)
+        n += (unsigned int)((m - 16 * kb + 7) / 8);
+    return n;
+}
+
 /* The tail of the statistics, one launch, two kinds of blocks.
  *
  * Blocks [0, nb_red): out[lag, d] = sum over waves of slabs[w, d, lag].  One wave per group of 64 outputs would
@@ -491,7 +789,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         return st;
     DevGuard g(device);
     hipStream_t stream = (hipStream_t)stream_v;
-    const unsigned int n_slabs = stats_n_slabs(n_chains);
+    unsigned int n_slabs = stats_n_slabs(n_chains);
     /* the per-wave lag sums: the caller's workspace (synchronous path) or a stream-ordered allocation */
     float *slabs = slabs_ws;
     /* lag sums on the matrix cores (one 16 x 16 tile per 256 lags) unless the half-chain is too long for LDS */
@@ -499,7 +797,52 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
     const size_t row_len = 240 + 256 * (size_t)(n_tiles - 1) + m + 36, row_pitch = row_len + row_len / 16 + 1;
     const size_t lds_mfma = ((size_t)dim * row_pitch + (size_t)dim * m) * sizeof(float);
     const char *force_direct = getenv("MMCMC_STATS_DIRECT"); /* measurement aid: the direct kernel */
-    if (lds_mfma <= 64 * 1024 && !(force_direct && force_direct[0] == '1')) {
+    const char *force_kernel = getenv("MMCMC_STATS_KERNEL"); /* measurement aid: "mfma" keeps the matrix-core kernel */
+    /* register tiles on the vector ALU where a lane's share of the D x tiles(m) tiles fits its registers (at most 8
+     * tiles of 16 lag sums: [., 400, 3] just fits) */
+    const size_t tiles_total = dim * (size_t)stats_tile_count(m);
+    const unsigned int tpl = (unsigned int)((tiles_total + 63) / 64);
+    const size_t pitch_t = 12 * ((m + 8 + 16 + 8 + 7) / 8) + 4; /* the kernel's row pitch */
+    const size_t lds_tile = (dim * pitch_t + dim * m + 64 * 16) * sizeof(float);
+    if (tpl <= 8 && lds_tile <= 40 * 1024 && /* 8 tiles = 128 lag sums + operands = 218 registers: two waves per SIMD */ !(force_direct && force_direct[0] == '1') &&
+        !(force_kernel && !strcmp(force_kernel, "mfma"))) {
+        if (!slabs)
+            MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+        /* this kernel holds two waves per SIMD (250 registers): exactly the resident waves, each with a longer list of
+         * half-chains (measured at [65 536, 400, 3]: 1024 waves 0.62 ms, 2048 0.39, 4096 0.43, 8192 0.54) */
+        if (!getenv("MMCMC_STATS_WAVES"))
+            n_slabs = std::min(n_slabs, 2048u);
+        /* 16-byte loads where every half-chain's [m, D] block starts on a 16-byte boundary and is whole vectors long */
+        const bool vec_ok = dtype == MMCMC_F32 && (n * dim) % 4 == 0 && ((n - m) * dim) % 4 == 0 && (m * dim) % 4 == 0 &&
+                            ((uintptr_t)sample % 16) == 0 && m * dim <= 4 * 256;
+#define MM_TILE_LAUNCH1(TT, TPLV, VECV)                                                                             \
+    hipLaunchKernelGGL((mm_half_chain_tile_kernel<TT, TPLV, VECV>), dim3(n_slabs), dim3(64), lds_tile, stream,      \
+                       (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,        \
+                       (unsigned int)m, means, ssq, slabs)
+#define MM_TILE_LAUNCH(TT, TPLV)                                                                                    \
+    do {                                                                                                            \
+        if (sizeof(TT) == 4 && vec_ok)                                                                              \
+            MM_TILE_LAUNCH1(float, TPLV, true);                                                                     \
+        else                                                                                                        \
+            MM_TILE_LAUNCH1(TT, TPLV, false);                                                                       \
+    } while (0)
+#define MM_TILE_PICK(TT)                                                                                            \
+    do {                                                                                                            \
+        if (tpl <= 2)                                                                                               \
+            MM_TILE_LAUNCH(TT, 2);                                                                                  \
+        else if (tpl <= 4)                                                                                          \
+            MM_TILE_LAUNCH(TT, 4);                                                                                  \
+        else                                                                                                        \
+            MM_TILE_LAUNCH(TT, 8);                                                                                  \
+    } while (0)
+        if (dtype == MMCMC_F32)
+            MM_TILE_PICK(float);
+        else
+            MM_TILE_PICK(double);
+#undef MM_TILE_PICK
+#undef MM_TILE_LAUNCH
+#undef MM_TILE_LAUNCH1
+    } else if (lds_mfma <= 64 * 1024 && !(force_direct && force_direct[0] == '1')) {
         if (!slabs)
             MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
         if (dtype == MMCMC_F32)

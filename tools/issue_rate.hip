@@ -80,6 +80,31 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(unsigned long long
                 asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
                              : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(da), "v"(db));
             }
+        } else if (MODE == 12 || MODE == 13) { // 16 f64 MFMAs with 8 independent 32-bit VALU ops after each: integer (12) / f32 FMA (13)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, d1, acc0, 0, 0, 0);
+                if (MODE == 12)
+                    asm volatile("v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n"
+                                 : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(a));
+                else
+                    asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n"
+                                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b));
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d2, d3, acc1, 0, 0, 0);
+                if (MODE == 12)
+                    asm volatile("v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n"
+                                 : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(a));
+                else
+                    asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n"
+                                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b));
+            }
+        } else if (MODE == 14) { // 16 f64 MFMAs with 4 ds_read_b64 after each
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, d1, acc0, 0, 0, 0);
+                e0 += ((volatile double *)lds)[threadIdx.x & 63];
+                e1 += ((volatile double *)lds)[64 + (threadIdx.x & 63)];
+            }
         } else if (MODE == 6) { // integer xor / add, independent
             asm volatile(REP16("v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n")
                          REP4("v_xor_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %4\n")
@@ -125,7 +150,7 @@ template <int MODE> void run(const char *name, int inst_per_iter, int waves_per_
 
 int main()
 {
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2}) {
         run<0>("v_fma_f32 independent (8 regs)", 192, w);
         run<1>("v_fma_f32 dependent chain", 80, w);
         run<2>("v_fma_f32 two chains interleaved", 80, w);
@@ -138,6 +163,9 @@ int main()
         run<9>("v_fma_f64 dependent chain", 80, w);
         run<10>("v_mfma_f64_16x16x4 back to back", 16, w);
         run<11>("16 MFMA f64 + 64 v_fma_f64 (per MFMA)", 16, w);
+        run<12>("16 MFMA f64 + 128 int VALU (per MFMA)", 16, w);
+        run<13>("16 MFMA f64 + 128 v_fma_f32 (per MFMA)", 16, w);
+        run<14>("16 MFMA f64 + 32 LDS f64 reads+adds (per MFMA)", 16, w);
     }
     return 0;
 }
