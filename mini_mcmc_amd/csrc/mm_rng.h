@@ -10,7 +10,7 @@
  *
  * which makes results independent of launch partitioning, iterations-per-launch and GPU count.
  *
- * Draw schedule (normative; oracle/philox_stream.c restates it independently in plain C):
+ * Draw schedule (normative; oracle/orng.c restates it independently in plain C):
  *   counter = { chain & 0xffffffff, chain >> 32, iteration, block },  key = { seed & 0xffffffff, seed >> 32 }
  *   u53(hi, lo)  = (double)((((u64)hi << 21) | (lo >> 11)) + 1) * 2^-53   in (0,1]
  *   f32 block b: words w0..w3

@@ -32,6 +32,51 @@ def M():
     return ns
 
 
+# ---------------------------------------------------------------- the stream, against scipy / numpy (no shared header)
+
+
+def test_gpu_noise_against_scipy_and_numpy(M, O):
+    """The oracle restates the engine's stream but reads the inverse-CDF table and mm_log / mm_sincos2pi from the
+    product's own headers (oracle/orng.c), so a wrong table row or polynomial would be invisible to both.  Here the
+    GPU's normals and uniforms are held against functions neither side owns: the Philox words come from the oracle's
+    independent restatement (pinned by Random123's known-answer vectors in tests/test_engine_stream.py), the f32 normals
+    are -Phi^-1(n 2^-25) by scipy.special.ndtri, the f64 ones Box-Muller by numpy's libm."""
+    import ctypes as C
+
+    from scipy.special import ndtri
+
+    seed, off, it, n, dim = 987654321, 5, 41, 4096, 8
+    z, u = M.core.draw_noise(seed, off, it, n, dim, np.float32)
+    L = O.lib()
+    words = np.zeros((n, dim // 4, 4), dtype=np.uint32)
+    buf = (C.c_uint32 * 4)()
+    for c in range(n):
+        for b in range(dim // 4):
+            L.o_engine_block(seed, off + c, it, b, buf)
+            words[c, b] = list(buf)
+    w = words.reshape(n, dim).astype(np.uint64)
+    nn = ((w >> np.uint64(8)) | np.uint64(1)).astype(np.float64)
+    sign = np.where((w >> np.uint64(8)) & np.uint64(1), -1.0, 1.0)
+    ref = sign * -ndtri(nn * 2.0**-25)
+    assert np.max(np.abs(z.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))) < 2e-7
+    assert np.abs(z).max() <= 5.42 and abs(z.mean()) < 0.02 and abs(z.var() - 1.0) < 0.02
+    s = (w[:, 0] & np.uint64(255)) | ((w[:, 1] & np.uint64(255)) << np.uint64(8)) | ((w[:, 2] & np.uint64(255)) << np.uint64(16))
+    assert np.array_equal(u, ((s + np.uint64(1)).astype(np.float64) * 2.0**-24).astype(np.float32))
+    # f64: z[2b], z[2b + 1] = Box-Muller of the 53-bit uniforms of block b; accept uniform = u53 of the AUX block
+    z64, u64 = M.core.draw_noise(seed, off, it, 512, 4, np.float64)
+    for c in range(0, 512, 37):
+        for b in range(2):
+            L.o_engine_block(seed, off + c, it, b, buf)
+            w0, w1, w2, w3 = [int(v) for v in buf]
+            u1 = (((w0 << 21) | (w1 >> 11)) + 1) * 2.0**-53
+            u2 = (((w2 << 21) | (w3 >> 11)) + 1) * 2.0**-53
+            r = np.sqrt(-2.0 * np.log(u1))
+            np.testing.assert_allclose(z64[c, 2 * b], r * np.cos(2 * np.pi * u2), rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(z64[c, 2 * b + 1], r * np.sin(2 * np.pi * u2), rtol=1e-12, atol=1e-13)
+        L.o_engine_block(seed, off + c, it, 0x40000000, buf)
+        assert u64[c] == (((int(buf[0]) << 21) | (int(buf[1]) >> 11)) + 1) * 2.0**-53
+
+
 # ---------------------------------------------------------------- HMC / MH (hmc.rs:304-431, metropolis_hastings.rs:303-315)
 
 
