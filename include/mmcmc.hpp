@@ -222,6 +222,61 @@ template <class T> class HMC {
     }
 };
 
+/* ---- a target of the user's own: the GPU analogue of `impl GradientTarget for MyDensity` (distributions.rs:65-108).
+ * `hip_source` defines `template <class T> struct mmcmc_user_target` (dim, logp, logp_grad; include/mmcmc.h); it is
+ * compiled at run time and the returned Target is accepted wherever a built-in one is (MH / HMC, dim <= 32). ---- */
+inline Target UserTarget(const std::string &name, int dim, const std::string &hip_source, const std::vector<double> &params = {})
+{
+    int kind = 0;
+    std::string log(1 << 16, '\0');
+    const int st = mmcmc_target_register_source(name.c_str(), dim, hip_source.c_str(), &kind, &log[0], log.size());
+    if (st != MMCMC_OK)
+        throw Error(st, "mmcmc_target_register_source: " + std::string(log.c_str()));
+    Target t;
+    t.d.kind = kind;
+    t.d.dim = dim;
+    for (size_t i = 0; i < params.size() && i < 8; ++i)
+        t.d.params[i] = params[i];
+    return t;
+}
+
+/* ---- HMC over several GPUs from one call: run() executes every chain (ChainRunner::run, core.rs:176-186) ---- */
+template <class T> class HMCGroup {
+    mmcmc_hmc_group *g_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    HMCGroup(Target target, const std::vector<T> &initial_positions, size_t n_chains, T step_size, int n_leapfrog,
+             const std::vector<int> &devices)
+        : n_chains_(n_chains), dim_(initial_positions.size() / n_chains)
+    {
+        check(mmcmc_hmc_group_create(&g_, target.desc(), initial_positions.data(), n_chains, (double)step_size, n_leapfrog,
+                                     dtype_of<T>(), devices.data(), (int)devices.size()),
+              "mmcmc_hmc_group_create");
+    }
+    HMCGroup(const HMCGroup &) = delete;
+    HMCGroup &operator=(const HMCGroup &) = delete;
+    ~HMCGroup() { mmcmc_hmc_group_destroy(g_); }
+    HMCGroup &set_seed(uint64_t s)
+    {
+        check(mmcmc_hmc_group_seed(g_, s), "mmcmc_hmc_group_seed");
+        return *this;
+    }
+    std::vector<T> run(size_t n_collect, size_t n_discard)
+    {
+        std::vector<T> out(n_chains_ * n_collect * dim_);
+        check(mmcmc_hmc_group_run(g_, n_collect, n_discard, out.data(), nullptr), "mmcmc_hmc_group_run");
+        return out;
+    }
+    /* stats::split_rhat_mean_ess of the last run over the chains of all devices (RCCL inside the library) */
+    std::pair<std::vector<float>, std::vector<float>> split_rhat_mean_ess()
+    {
+        std::vector<float> rhat(dim_), ess(dim_);
+        check(mmcmc_hmc_group_split_rhat_mean_ess(g_, rhat.data(), ess.data(), nullptr), "mmcmc_hmc_group_split_rhat_mean_ess");
+        return {rhat, ess};
+    }
+};
+
 /* ---- NUTS: tensors f32, scalars T (mode 0 for T = double, 1 for T = float), like the reference backend ---- */
 template <class T> class NUTS {
     mmcmc_nuts *h_ = nullptr;

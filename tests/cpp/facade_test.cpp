@@ -99,6 +99,28 @@ int main(int argc, char **argv)
         MultiChainTracker tr(4, 3);
         tr.step(s3);
         REQUIRE(tr.max_rhat() > 0.9f && tr.p_accept() > 0.3f && tr.rhat().size() == 3);
+        // one call for every chain on a device group (here: two shards on device 0) == a single handle
+        {
+            auto init3 = init_with_seed<float>(130, 3, 42);
+            HMC<float> one(RosenbrockND(3), init3, 130, 0.032f, 10);
+            auto a = one.set_seed(7).run(30, 5);
+            HMCGroup<float> grp(RosenbrockND(3), init3, 130, 0.032f, 10, {0, 0});
+            auto b = grp.set_seed(7).run(30, 5);
+            REQUIRE(a == b);
+            auto re = grp.split_rhat_mean_ess();
+            REQUIRE(re.first.size() == 3 && re.second[0] > 1.0f);
+        }
+        // a target of the user's own, compiled at run time: a restatement of StandardNormal(2) must reproduce the built-in
+        {
+            const char *src =
+                "template <class T> struct mmcmc_user_target { static constexpr int dim = 2;\n"
+                "  MM_HD static T logp(const mm_tparams<T> &, const T *x) { T s = 0; for (int i = 0; i < 2; ++i) s = mm_fma(x[i], x[i], s); return T(-0.5) * s; }\n"
+                "  MM_HD static T logp_grad(const mm_tparams<T> &, const T *x, T *g) { T s = 0; for (int i = 0; i < 2; ++i) { s = mm_fma(x[i], x[i], s); g[i] = -x[i]; } return T(-0.5) * s; } };\n";
+            auto init2 = init_with_seed<double>(70, 2, 5);
+            HMC<double> builtin(StandardNormal(2), init2, 70, 0.3, 5);
+            HMC<double> user(UserTarget("std2", 2, src), init2, 70, 0.3, 5);
+            REQUIRE(builtin.set_seed(3).run(20, 4) == user.set_seed(3).run(20, 4));
+        }
         std::printf("facade ok (gpu)\n");
         return 0;
     } catch (const Error &e) {
