@@ -69,7 +69,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_hmc_lg_kernel(const mm
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         x[s] = active ? a.state[cl * D + 4 * s + L.q] : 0.0;
-    double lp = mm_lg_logp_ax<D>(L.Aop, x, y);
+    double lp = mm_lg_logp_ax<D>(L, x, y);
     const double eps = a.eps, h = eps * 0.5;
     unsigned long long n_acc = 0, wave_acc = 0;
     const unsigned int total = a.n_discard + a.n_collect;
@@ -109,7 +109,7 @@ template <int D> __global__ __launch_bounds__(64) void mm_hmc_lg_kernel(const mm
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 xn[s] = fma(eps, p[s], xn[s]);
-            lpn = mm_lg_logp_ax<D>(L.Aop, xn, yn);
+            lpn = mm_lg_logp_ax<D>(L, xn, yn);
             const double k = (l + 1 == a.n_leapfrog) ? -h : -eps; /* merged half kicks between steps (Q6) */
 #pragma unroll
             for (int s = 0; s < NS; ++s)

@@ -157,10 +157,14 @@ template <int D, int OCC = 1> struct mm_lg_cfg {
 };
 
 typedef double mm_d4 __attribute__((ext_vector_type(4)));
+#ifndef MM_LG_ASM_MFMA
+#define MM_LG_ASM_MFMA 1
+#endif
 /* LDS is addressed through an explicitly address-space-3 pointer: where an accessor picks LDS or HBM by a uniform
  * index, same-typed generic pointers let the optimiser merge the two branches into one flat_load / flat_store on a
  * selected pointer (which then waits on both memory counters); distinct pointer types keep ds_* and global_* apart */
 typedef __attribute__((address_space(3))) double mm_lds_double;
+typedef __attribute__((address_space(1))) double mm_glb_double;
 
 /* sum over the four lanes of a chain (lanes c, c + 16, c + 32, c + 48): (c0 + c1) + (c2 + c3), the same value in all
  * four.  v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- / 32-lane rows between two registers in the VALU
@@ -192,16 +196,78 @@ template <int NS> __device__ __forceinline__ double mm_lg_dot(const double *a, c
 /* y = A x for the 16 chains of the wave; returns logp = -1/2 x.y.  The gradient is -y: the kernels carry y itself
  * (registers and edge records) and kick with -h -- fma(-h, y, p) and fma(h, -y, p) round the same exact product, so
  * this is the twin's fma(h, g, p) bit for bit, without eight negations per leaf */
-template <int D>
-__device__ __forceinline__ double mm_lg_logp_ax(const double (&Aop)[D / 16][D / 4], const double *x, double *y)
+template <int D, bool ALDS = false, class Lane>
+__device__ __forceinline__ double mm_lg_logp_ax(const Lane &L, const double *x, double *y)
 {
     constexpr int NS = D / 4, NT = D / 16;
+#if MM_LG_ASM_MFMA
+    /* The A-operand blocks stay in accumulation registers and the MFMA reads them there ("a"), the products land in
+     * ordinary registers ("v").  Through the builtin the compiler parks the blocks in AGPRs too, but copies each to a
+     * VGPR before its MFMA (2 v_accvgpr_read + a wait state) and accumulates in AGPRs that it reads back (16 more):
+     * 63 of a leaf's ~730 instructions.  Inline assembly is opaque to the hazard recogniser, so the wait states are
+     * written out: 2 between a VALU write of x and the first MFMA, 18 after the last 16-pass MFMA before its result
+     * is read (what the compiler itself emits around the builtin); accumulate chains need none. */
+    if constexpr (!ALDS && D == 32) {
+        mm_d4 acc0, acc1;
+        asm volatile("s_nop 1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %2, %18, 0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %10, %18, 0\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %3, %19, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %11, %19, %1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %4, %20, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %12, %20, %1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %5, %21, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %13, %21, %1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %6, %22, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %14, %22, %1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %7, %23, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %15, %23, %1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %8, %24, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %16, %24, %1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %9, %25, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %1, %17, %25, %1\n"
+                     "s_nop 15\n"
+                     "s_nop 2\n"
+                     : "=&v"(acc0), "=&v"(acc1)
+                     : "a"(L.Aop[0][0]), "a"(L.Aop[0][1]), "a"(L.Aop[0][2]), "a"(L.Aop[0][3]), "a"(L.Aop[0][4]),
+                       "a"(L.Aop[0][5]), "a"(L.Aop[0][6]), "a"(L.Aop[0][7]), "a"(L.Aop[1][0]), "a"(L.Aop[1][1]),
+                       "a"(L.Aop[1][2]), "a"(L.Aop[1][3]), "a"(L.Aop[1][4]), "a"(L.Aop[1][5]), "a"(L.Aop[1][6]),
+                       "a"(L.Aop[1][7]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]),
+                       "v"(x[7]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y[r] = acc0[r];
+            y[4 + r] = acc1[r];
+        }
+        return -0.5 * mm_lg_dot<NS>(x, y);
+    } else if constexpr (!ALDS && D == 16) {
+        mm_d4 acc0;
+        asm volatile("s_nop 1\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %1, %5, 0\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n"
+                     "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n"
+                     "s_nop 15\n"
+                     "s_nop 2\n"
+                     : "=&v"(acc0)
+                     : "a"(L.Aop[0][0]), "a"(L.Aop[0][1]), "a"(L.Aop[0][2]), "a"(L.Aop[0][3]), "v"(x[0]), "v"(x[1]),
+                       "v"(x[2]), "v"(x[3]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            y[r] = acc0[r];
+        return -0.5 * mm_lg_dot<NS>(x, y);
+    }
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         mm_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[t][s], x[s], acc, 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+            /* ALDS (two waves per SIMD: half the registers): the A-operand blocks are read from the workgroup's LDS
+             * copy, one ds_read_b64 per MFMA (the read of block s + 1 is in flight during MFMA s) */
+            const double a_ts = ALDS ? L.Alds[(size_t)(t * NS + s) * 64] : L.Aop[t][s];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ts, x[s], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             y[4 * t + r] = acc[r];
@@ -247,6 +313,7 @@ template <bool COH> __device__ __forceinline__ void mm_lg_st_adapt(mm_nuts_adapt
 template <int D> struct mm_lg_lane {
     static constexpr int NS = D / 4, NT = D / 16;
     double Aop[NT][NS];   /* A-operand blocks: lane (i = l & 15, k = l >> 4) holds A[16 t + i][4 s + k] */
+    const mm_lds_double *Alds; /* ... or (two-waves-per-SIMD build) their LDS copy: block (t, s) of lane l at [(t NS + s) 64 + l] */
     double x[NS];         /* current sample */
     double joint, logu;   /* log joint at the start of the transition, log slice level */
     unsigned int n;       /* points of the trajectory inside the slice */
@@ -297,9 +364,9 @@ template <int D> __device__ __forceinline__ double *mm_lg_rec_scalar(const mm_nu
 }
 
 /* start of a transition (nuts.rs:550-576): momentum, log joint, slice; both edges = (x, p0, grad) */
-template <int D, bool COH = false> __device__ __forceinline__ void mm_lg_begin(mm_lg_lane<D> &L, const mm_nuts_lg_args &a)
+template <int D, bool COH = false, int OCC = 1> __device__ __forceinline__ void mm_lg_begin(mm_lg_lane<D> &L, const mm_nuts_lg_args &a)
 {
-    using Cfg = mm_lg_cfg<D>;
+    using Cfg = mm_lg_cfg<D, OCC>;
     constexpr int NS = Cfg::NS;
     L.aux_k = 0;
     L.aux_have = 0xffffffffu;
@@ -313,7 +380,7 @@ template <int D, bool COH = false> __device__ __forceinline__ void mm_lg_begin(m
         mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
         p0[s] = (d & 1) ? z1 : z0;
     }
-    const double ulogp = mm_lg_logp_ax<D>(L.Aop, L.x, grad); /* grad holds A x = -gradient (see mm_lg_logp_ax) */
+    const double ulogp = mm_lg_logp_ax<D, OCC == 2>(L, L.x, grad); /* grad holds A x = -gradient (see mm_lg_logp_ax) */
     L.joint = ulogp - mm_lg_dot<NS>(p0, p0) * 0.5;
     const double exp1_obs = -mm_log(mm_lg_aux_peek<D>(L, a.seed));
     L.aux_k += 1;
@@ -429,29 +496,26 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     auto leaf_eval = [&](unsigned int leaf) {
         MM_LG_COUNT(L, 6);
         L.n_leaf_iters += 1;
-        if (!done) {
+        /* The VECTORS of a chain that is done (edge, proposal) are never read again: a chain is done before the last
+         * leaf only when its doubling was cut short, which ends the transition (s' = 0: no proposal taken, edges
+         * rebuilt by the next mm_lg_begin), and the columns of lanes that take no part are scratch.  So they are
+         * updated for all 64 lanes -- a masked update costs a v_mov per register -- and only the scalars are guarded */
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                cp[s] = fma(nh, cg[s], cp[s]);
-                cx[s] = fma(epsv, cp[s], cx[s]);
-            }
+        for (int s = 0; s < NS; ++s) {
+            cp[s] = fma(nh, cg[s], cp[s]);
+            cx[s] = fma(epsv, cp[s], cx[s]);
         }
-        double y[NS];
         MM_LG_TICK(L, 8);
-        const double lp = mm_lg_logp_ax<D>(L.Aop, cx, y); /* y = A x */
+        const double lp = mm_lg_logp_ax<D, OCC == 2>(L, cx, cg); /* cg = A x */
         MM_LG_TICK(L, 9);
-        if (!done) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                cg[s] = y[s];
-                cp[s] = fma(nh, y[s], cp[s]);
-            }
-        }
+        for (int s = 0; s < NS; ++s)
+            cp[s] = fma(nh, cg[s], cp[s]);
         const double jointp = lp - mm_lg_dot<NS>(cp, cp) * 0.5;
-        if (!done) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                S_prime[s] = cx[s];
+        for (int s = 0; s < NS; ++s)
+            S_prime[s] = cx[s];
+        if (!done) {
             L.n_lf += 1;
             S_n = (L.logu < jointp) ? 1u : 0u;
             S_s = (L.logu - 1000.0) < jointp;
@@ -497,6 +561,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         ca = mm_lg_group_sum(ca);
         cb = mm_lg_group_sum(cb);
         const bool crit = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
+        bool take2 = false;
         if (walking) {
             L.aux_k += 1;
             const unsigned long long cnt = (unsigned long long)__double_as_longlong(cnt_d);
@@ -504,15 +569,16 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             unsigned int den = n1 + S_n;
             if (den < 1)
                 den = 1;
-            const bool take2 = u < ((double)S_n / (double)den);
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                S_prime[s] = take2 ? S_prime[s] : prime[s];
+            take2 = u < ((double)S_n / (double)den);
             S_n += n1;
             S_alpha = alpha + S_alpha;
             S_nalpha += na1;
             S_s = S_s && crit;
         }
+        /* the proposal of a lane that is not walking is dead (filed, or done): select for all lanes */
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            S_prime[s] = take2 ? S_prime[s] : prime[s];
         MM_LG_TICK(L, 10);
     };
     /* first child at level k >= 1: wait for the sibling if still valid; with s' = 0 the parent returns it as it is, so
@@ -572,13 +638,13 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 break;
             /* ---- the first leaf of a level-1 subtree: its one-leaf subtree (level 0) waits for the sibling in registers */
             leaf_eval(leaf);
-            double fx[NS], fp[NS], P_prime[NS], P_alpha;
+            /* its proposal is its own x: (fx, fp) serve as the first leaf of the pair AND as the waiting proposal */
+            double fx[NS], fp[NS], P_alpha;
             unsigned int P_n, P_nalpha;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 fx[s] = cx[s];
                 fp[s] = cp[s];
-                P_prime[s] = S_prime[s];
             }
             P_alpha = S_alpha;
             P_n = S_n;
@@ -592,7 +658,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             /* ---- its sibling: merge at level 0 with the waiting subtree, then hand the pair up */
             leaf_eval(leaf + 1u);
             MM_LG_COUNT(L, 7);
-            merge(fx, fp, P_prime, P_alpha,
+            merge(fx, fp, fx, P_alpha,
                   __longlong_as_double((long long)((unsigned long long)P_n | ((unsigned long long)P_nalpha << 32))));
             walk_up(leaf + 1u);
         }
@@ -622,9 +688,18 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         L.n_alpha = S_nalpha;
         L.aux_k += 1;
         if (S_s && (u_run_2 < tmp)) {
+            if constexpr (OCC == 2) {
+                /* the current sample lives in the chain's record (V_X) between the pieces of a transition: nothing of
+                 * it is carried in registers across the leaf loop */
+                double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                L.x[s] = S_prime[s];
+                for (int s = 0; s < NS; ++s)
+                    mm_lg_st<COH>(&xs[s * st], S_prime[s]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    L.x[s] = S_prime[s];
+            }
         }
         L.n += S_n;
         bool s_new = S_s && crit_all;
@@ -634,6 +709,68 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         alive = s_new;
     }
     MM_LG_TICK(L, 4);
+}
+
+/* Two waves per SIMD (OCC = 2): the doubling as an OUT-OF-LINE call with its state passed and returned by value.
+ * Inlined into the scheduler kernel under a 256-register cap the allocator spilled across the leaf loop (46 scratch
+ * reloads per leaf pair); as a function of its own the loop is allocated by itself (255 registers, no spills) and the
+ * caller's live values are saved once per doubling.  By value, because a reference to the lane state would be a
+ * generic pointer into scratch (every access a flat_load / flat_store). */
+struct mm_lg_call_io {
+    double joint, logu, alpha;
+    unsigned long long chain, cl, n_lf, n_leaf_iters;
+    unsigned int n, aux_k, aux_have, n_alpha, m;
+    int depth, lane, q;
+    mm_u32x4 aux_blk;
+    int alive;
+};
+struct mm_lg_call_env {
+    mm_glb_double *rec;
+    unsigned long long c_pad, seed;
+    int max_depth;
+};
+template <int D>
+__device__ __attribute__((noinline)) mm_lg_call_io mm_lg_doubling_ool(mm_lg_call_io io, mm_lg_call_env env, int j, double epsilon,
+                                                                    mm_lds_double *lds, mm_glb_double *scr, const mm_lds_double *Alds)
+{
+    mm_lg_lane<D> L;
+    L.Alds = Alds;
+    L.joint = io.joint;
+    L.logu = io.logu;
+    L.alpha = io.alpha;
+    L.chain = io.chain;
+    L.cl = io.cl;
+    L.n_lf = io.n_lf;
+    L.n_leaf_iters = io.n_leaf_iters;
+    L.n = io.n;
+    L.aux_k = io.aux_k;
+    L.aux_have = io.aux_have;
+    L.n_alpha = io.n_alpha;
+    L.m = io.m;
+    L.depth = io.depth;
+    L.lane = io.lane;
+    L.q = io.q;
+    L.aux_blk = io.aux_blk;
+    L.active = true;
+    mm_nuts_lg_args a;
+    /* pointers that cross a call lose their address space: name it again, or every record access becomes a flat_ one */
+    a.rec = (double *)env.rec;
+    a.c_pad = env.c_pad;
+    a.seed = env.seed;
+    a.max_depth = env.max_depth;
+    bool alive = io.alive != 0;
+    mm_lg_doubling<D, true, 2>(L, a, j, alive, epsilon, lds, (double *)scr);
+    io.alpha = L.alpha;
+    io.n_lf = L.n_lf;
+    io.n_leaf_iters = L.n_leaf_iters;
+    io.n = L.n;
+    io.aux_k = L.aux_k;
+    io.aux_have = L.aux_have;
+    io.n_alpha = L.n_alpha;
+    io.depth = L.depth;
+    io.aux_blk = L.aux_blk;
+    io.alive = alive ? 1 : 0;
+    return io;
 }
 
 /* end of a transition: dual averaging (nuts.rs:676-690), depth histogram */
@@ -971,26 +1108,48 @@ __device__ __forceinline__ void mm_lgq_append(const mm_lg_lane<D> &L, const mm_n
     }
 }
 
-template <int D, int OCC = 1> __global__ __launch_bounds__(64, OCC) void mm_nuts_lgq_kernel(const mm_nuts_lg_args a)
+/* OCC = 1: one wave per workgroup, A-operand blocks in registers.  OCC = 2: workgroups of 8 waves (two per SIMD) that
+ * share ONE LDS copy of the A-operand blocks (8 KB at D = 32) and are otherwise independent: a wave's index in the launch
+ * is blockIdx.x * WPB + its index in the workgroup */
+template <int D, int OCC = 1>
+__global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts_lgq_kernel(const mm_nuts_lg_args a)
 {
     using Cfg = mm_lg_cfg<D, OCC>;
     constexpr int NS = Cfg::NS;
+    constexpr unsigned int WPB = OCC == 2 ? 8u : 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
-    __shared__ unsigned int hist_lds[MM_NUTS_JMAX + 1];
+    __shared__ unsigned int hist_all[WPB][MM_NUTS_JMAX + 1];
+    const unsigned int wib = threadIdx.x >> 6, wid = blockIdx.x * WPB + wib;
+    unsigned int *const hist_lds = hist_all[wib];
     mm_lg_hist_zero(hist_lds, (int)(threadIdx.x & 63));
     mm_lg_lane<D> L;
     L.lane = threadIdx.x & 63;
     L.q = L.lane >> 4;
     L.cl = 0;
     L.n_leaf_iters = 0;
-    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + L.lane;
-    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
-    mm_lg_load_A<D>(L, a.mat);
+    /* LDS: [OCC 2: the A-operand blocks, NT NS slots of 64 doubles][per wave: Cfg::lds_slots slots] */
+    constexpr size_t A_SLOTS = OCC == 2 ? (size_t)(D / 16) * NS : 0;
+    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw + (A_SLOTS + (size_t)wib * Cfg::lds_slots) * 64 + L.lane;
+    double *const scr = a.scratch + (size_t)wid * Cfg::scratch_doubles_per_wave + L.lane;
+    L.Alds = (const mm_lds_double *)mm_lds_raw + L.lane;
+    if (OCC == 2) {
+        if (wib == 0) {
+            const int c = L.lane & 15;
+#pragma unroll
+            for (int t = 0; t < D / 16; ++t)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    ((mm_lds_double *)mm_lds_raw)[(size_t)(t * NS + s) * 64 + L.lane] = a.mat[(size_t)(16 * t + c) * D + 4 * s + L.q];
+        }
+        __syncthreads(); /* the only workgroup-wide rendezvous of the kernel */
+    } else {
+        mm_lg_load_A<D>(L, a.mat);
+    }
     const size_t st = (size_t)a.c_pad * 4;
     const unsigned int m_end = a.m0 + a.n_pre + a.n_rec;
     mm_lgq_ctrl *const ctrl = a.ctrl;
     const unsigned int col = (unsigned int)(L.lane & 15);
-    const int home = (int)(blockIdx.x % MM_LGQ_SHARDS);
+    const int home = (int)(wid % MM_LGQ_SHARDS);
     unsigned long long st_units = 0, st_chains = 0, st_polls = 0, st_t[4] = {0, 0, 0, 0};
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #define MM_LGQ_T(i)                                                                                               \
@@ -1213,15 +1372,24 @@ template <int D, int OCC = 1> __global__ __launch_bounds__(64, OCC) void mm_nuts
                 L.x[s] = mm_lg_ld<true>(&a.state[L.cl * D + 4 * s + L.q]);
             if (a.write_initial && a.out && valid && m_done == a.m0)
                 mm_lg_write_row<D>(L, a, a.out_t0); /* row 0 = the initial position (nuts.rs:534) */
-            mm_lg_begin<D, true>(L, a);
+            mm_lg_begin<D, true, OCC>(L, a);
+            if (OCC == 2 && valid) {
+                /* two waves per SIMD: the current sample lives in the chain's record from here to the end of the transition */
+                double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    mm_lg_st<true>(&xs[s * st], L.x[s]);
+            }
             j_first = 0;
             j_next = a.j0;
         } else {
             const int j = qi - 1;
-            const double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+            if (OCC != 2) {
+                const double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                L.x[s] = mm_lg_ld<true>(&xs[s * st]);
+                for (int s = 0; s < NS; ++s)
+                    L.x[s] = mm_lg_ld<true>(&xs[s * st]);
+            }
             L.joint = mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT));
             L.logu = mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_LOGU));
             const unsigned long long pk =
@@ -1238,17 +1406,57 @@ template <int D, int OCC = 1> __global__ __launch_bounds__(64, OCC) void mm_nuts
             j_next = j + 1;
         }
         /* one copy of the doubling code for both kinds of unit (the kernel's hot loop should stay small) */
-        for (int j = j_first; j < j_next && __ballot(alive) != 0ull; ++j)
-            mm_lg_doubling<D, true, OCC>(L, a, j, alive, ad.epsilon, lds, scr);
+        if constexpr (OCC == 2) {
+            mm_lg_call_io io;
+            io.joint = L.joint;
+            io.logu = L.logu;
+            io.alpha = L.alpha;
+            io.chain = L.chain;
+            io.cl = L.cl;
+            io.n_lf = L.n_lf;
+            io.n_leaf_iters = L.n_leaf_iters;
+            io.n = L.n;
+            io.aux_k = L.aux_k;
+            io.aux_have = L.aux_have;
+            io.n_alpha = L.n_alpha;
+            io.m = L.m;
+            io.depth = L.depth;
+            io.lane = L.lane;
+            io.q = L.q;
+            io.aux_blk = L.aux_blk;
+            io.alive = alive ? 1 : 0;
+            mm_lg_call_env env;
+            env.rec = (mm_glb_double *)a.rec;
+            env.c_pad = a.c_pad;
+            env.seed = a.seed;
+            env.max_depth = a.max_depth;
+            for (int j = j_first; j < j_next && __ballot(io.alive != 0) != 0ull; ++j)
+                io = mm_lg_doubling_ool<D>(io, env, j, ad.epsilon, lds, (mm_glb_double *)scr, L.Alds);
+            L.alpha = io.alpha;
+            L.n_lf = io.n_lf;
+            L.n_leaf_iters = io.n_leaf_iters;
+            L.n = io.n;
+            L.aux_k = io.aux_k;
+            L.aux_have = io.aux_have;
+            L.n_alpha = io.n_alpha;
+            L.depth = io.depth;
+            L.aux_blk = io.aux_blk;
+            alive = io.alive != 0;
+        } else {
+            for (int j = j_first; j < j_next && __ballot(alive) != 0ull; ++j)
+                mm_lg_doubling<D, true, OCC>(L, a, j, alive, ad.epsilon, lds, scr);
+        }
 
         MM_LGQ_T(2);
         /* ---- hand the chains on ---- */
         bool again = false; /* finished this transition, more to go */
         if (valid && alive) {
-            double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+            if (OCC != 2) { /* OCC 2: the record already holds the current sample */
+                double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                mm_lg_st<true>(&xs[s * st], L.x[s]);
+                for (int s = 0; s < NS; ++s)
+                    mm_lg_st<true>(&xs[s * st], L.x[s]);
+            }
             if (L.q == 0) {
                 mm_lg_st<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT), L.joint);
                 mm_lg_st<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_LOGU), L.logu);
@@ -1257,6 +1465,12 @@ template <int D, int OCC = 1> __global__ __launch_bounds__(64, OCC) void mm_nuts
             }
         } else if (valid) {
             mm_lg_finish<D>(L, a, ad, a.depth_hist ? hist_lds : nullptr);
+            if (OCC == 2) {
+                const double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    L.x[s] = mm_lg_ld<true>(&xs[s * st]);
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 mm_lg_st<true>(&a.state[L.cl * D + 4 * s + L.q], L.x[s]);
@@ -1305,9 +1519,22 @@ template <int D> hipError_t mm_launch_nuts_lgq(const mm_nuts_lg_args &a, unsigne
     hipLaunchKernelGGL((mm_nuts_lgq_init_kernel<D>), dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0, stream, a, scalar_base);
     using Cfg1 = mm_lg_cfg<D, 1>;
     using Cfg2 = mm_lg_cfg<D, 2>;
-    if (occ == 2)
-        hipLaunchKernelGGL((mm_nuts_lgq_kernel<D, 2>), dim3(n_waves), dim3(64), Cfg2::lds_bytes, stream, a);
-    else
+    if (occ == 2) {
+        /* workgroups of 8 waves: n_waves is rounded down to whole workgroups (the caller asks for two per SIMD) */
+        const size_t lds2 = ((size_t)(D / 16) * (D / 4) * 64 + 8 * (size_t)Cfg2::lds_slots * 64) * sizeof(double);
+        static unsigned long long attr_set = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mm_nuts_lgq_kernel<D, 2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e != hipSuccess)
+                return e;
+            if (dev < 64)
+                attr_set |= 1ull << dev;
+        }
+        hipLaunchKernelGGL((mm_nuts_lgq_kernel<D, 2>), dim3(n_waves / 8 ? n_waves / 8 : 1), dim3(512), lds2, stream, a);
+    } else
         hipLaunchKernelGGL((mm_nuts_lgq_kernel<D, 1>), dim3(n_waves), dim3(64), Cfg1::lds_bytes, stream, a);
     return hipGetLastError();
 }
