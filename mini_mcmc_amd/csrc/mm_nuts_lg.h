@@ -157,8 +157,13 @@ template <int D, int OCC = 1> struct mm_lg_cfg {
 };
 
 typedef double mm_d4 __attribute__((ext_vector_type(4)));
+struct mm_true_t { static constexpr bool value = true; };
+struct mm_false_t { static constexpr bool value = false; };
 #ifndef MM_LG_ASM_MFMA
 #define MM_LG_ASM_MFMA 1
+#endif
+#ifndef MM_LG_AUX_SHARED
+#define MM_LG_AUX_SHARED 1
 #endif
 /* LDS is addressed through an explicitly address-space-3 pointer: where an accessor picks LDS or HBM by a uniform
  * index, same-typed generic pointers let the optimiser merge the two branches into one flat_load / flat_store on a
@@ -346,12 +351,28 @@ template <int D> __device__ __forceinline__ void mm_lg_load_A(mm_lg_lane<D> &L, 
 
 template <int D> __device__ __forceinline__ double mm_lg_aux_peek(mm_lg_lane<D> &L, unsigned long long seed)
 {
-    const unsigned int b = L.aux_k >> 1;
-    if (b != L.aux_have) {
-        L.aux_blk = mm_block(seed, L.chain, L.m, MM_AUX_BLOCK + b);
-        L.aux_have = b;
+    /* Draw k is a half of block AUX + (k >> 1).  The four lanes of a chain hold four CONSECUTIVE blocks (lane q block
+     * 4 g + q) instead of four copies of one, so the ten Philox rounds run once per eight draws, not once per two;
+     * the draw is fetched from the lane that holds its block through the LDS crossbar (ds_bpermute: no memory).  The
+     * lanes of a chain share aux_k, so they refill in the same call. */
+#if !MM_LG_AUX_SHARED
+    const unsigned int b1 = L.aux_k >> 1;
+    if (b1 != L.aux_have) {
+        L.aux_blk = mm_block(seed, L.chain, L.m, MM_AUX_BLOCK + b1);
+        L.aux_have = b1;
     }
     return (L.aux_k & 1u) ? mm_u53(L.aux_blk.w[2], L.aux_blk.w[3]) : mm_u53(L.aux_blk.w[0], L.aux_blk.w[1]);
+#endif
+    const unsigned int b = L.aux_k >> 1, g = b >> 2;
+    if (g != L.aux_have) {
+        L.aux_blk = mm_block(seed, L.chain, L.m, MM_AUX_BLOCK + 4u * g + (unsigned int)L.q);
+        L.aux_have = g;
+    }
+    const bool odd = (L.aux_k & 1u) != 0u;
+    const int src = ((L.lane & 15) + 16 * (int)(b & 3u)) * 4;
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? L.aux_blk.w[2] : L.aux_blk.w[0]));
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? L.aux_blk.w[3] : L.aux_blk.w[1]));
+    return mm_u53(hi, lo);
 }
 
 template <int D> __device__ __forceinline__ double *mm_lg_rec_vec(const mm_nuts_lg_args &a, const mm_lg_lane<D> &L, int v)
@@ -418,7 +439,11 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     struct rec {
         double fx[NS], fp[NS], prime[NS], alpha, cnt;
     };
-    auto load_rec = [&](int k, int cc, rec &r) {
+    auto load_rec = [&](int k, int cc, rec &r) __attribute__((always_inline)) {
+#ifdef MM_LG_EXPERIMENT_NO_HBM /* timing experiment only (wrong trees): every record in LDS */
+        cc = cc > 1 + Cfg::LF ? 1 + Cfg::LF : cc;
+        k = k > Cfg::LE ? Cfg::LE : k;
+#endif
         if (cc <= 1 + Cfg::LF) {
             const mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
 #pragma unroll
@@ -493,7 +518,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     /* one leaf: leapfrog of the outer edge (nuts.rs:979-996), in place, and the base case of build_tree
      * (nuts.rs:782-856); chains that are done keep their edge (the matrix product runs for all 64 lanes: MFMA has no
      * per-lane mask, their columns are recomputed) */
-    auto leaf_eval = [&](unsigned int leaf) {
+    auto leaf_eval = [&](unsigned int leaf) __attribute__((always_inline)) {
         MM_LG_COUNT(L, 6);
         L.n_leaf_iters += 1;
         /* The VECTORS of a chain that is done (edge, proposal) are never read again: a chain is done before the last
@@ -512,9 +537,8 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         for (int s = 0; s < NS; ++s)
             cp[s] = fma(nh, cg[s], cp[s]);
         const double jointp = lp - mm_lg_dot<NS>(cp, cp) * 0.5;
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            S_prime[s] = cx[s];
+        /* the proposal of a one-leaf subtree is the leaf itself: S_prime is not set here but by the level-0 merge,
+         * which picks between the pair's two leaves (cx and the copy of the first one) */
         if (!done) {
             L.n_lf += 1;
             S_n = (L.logu < jointp) ? 1u : 0u;
@@ -524,7 +548,10 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             /* a leaf that starts a subtree of level >= 2 files its (x, p) under the highest level it starts (the first
              * leaf of a level-1 subtree waits in registers, below) */
             if (j > 1 && (leaf & 3u) == 0u) {
-                const int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
+                int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
+#ifdef MM_LG_EXPERIMENT_NO_HBM
+                cc = cc > 1 + Cfg::LF ? 1 + Cfg::LF : cc;
+#endif
                 if (cc <= 1 + Cfg::LF) {
                     mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
 #pragma unroll
@@ -546,7 +573,8 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         MM_LG_TICK(L, 2);
     };
     /* a sibling waits: S is the second child, merge (nuts.rs:900-928); (fx, fp) = the sibling's first leaf */
-    auto merge = [&](const double *fx, const double *fp, const double *prime, double alpha, double cnt_d) {
+    auto merge = [&](const double *fx, const double *fp, const double *prime, auto level0, double alpha,
+                     double cnt_d) __attribute__((always_inline)) {
         MM_LG_TICK(L, 3);
         MM_LG_COUNT(L, 12);
         const double u = mm_lg_aux_peek<D>(L, a.seed);
@@ -578,12 +606,24 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         /* the proposal of a lane that is not walking is dead (filed, or done): select for all lanes */
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            S_prime[s] = take2 ? S_prime[s] : prime[s];
+        {
+            /* the second child's proposal: at level 0 the leaf itself (leaf_eval does not copy it to S_prime) */
+            double second;
+            if constexpr (decltype(level0)::value)
+                second = cx[s];
+            else
+                second = S_prime[s];
+            const double first = prime[s];
+            S_prime[s] = take2 ? second : first;
+        }
         MM_LG_TICK(L, 10);
     };
     /* first child at level k >= 1: wait for the sibling if still valid; with s' = 0 the parent returns it as it is, so
      * it keeps walking */
-    auto push = [&](int k) {
+    auto push = [&](int k) __attribute__((always_inline)) {
+#ifdef MM_LG_EXPERIMENT_NO_HBM
+        k = k > Cfg::LE ? Cfg::LE : k;
+#endif
         MM_LG_TICK(L, 3);
         MM_LG_COUNT(L, 13);
         if (walking && S_s) {
@@ -609,7 +649,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         MM_LG_TICK(L, 11);
     };
     /* hand S up the implicit recursion from level 1: walking lanes have S at level k at the top of iteration k */
-    auto walk_up = [&](unsigned int leaf) {
+    auto walk_up = [&](unsigned int leaf) __attribute__((always_inline)) {
         for (int k = 1; k < j; ++k) {
             if (__ballot(walking) == 0ull)
                 break;
@@ -617,7 +657,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if ((leaf >> k) & 1u) {
                 rec rk;
                 load_rec(k, first_slot(leaf, k), rk);
-                merge(rk.fx, rk.fp, rk.prime, rk.alpha, rk.cnt);
+                merge(rk.fx, rk.fp, rk.prime, mm_false_t(), rk.alpha, rk.cnt);
             } else {
                 push(k);
             }
@@ -626,10 +666,47 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         MM_LG_TICK(L, 3);
     };
 
+    /* the same for the FIRST leaf of a pair, which walks only when it is not valid (s' = 0; a valid one waits): s' stays
+     * 0 all the way up, so no proposal is kept, no criterion evaluated and nothing filed -- only the counts of the
+     * siblings it meets are added (and their draws consumed).  Keeps the proposal registers dead across the first
+     * leaf and the sibling records out of the register file. */
+    auto walk_up_invalid = [&](unsigned int leaf) __attribute__((always_inline)) {
+        for (int k = 1; k < j; ++k) {
+            if (__ballot(walking) == 0ull)
+                break;
+            MM_LG_COUNT(L, 7);
+            if ((leaf >> k) & 1u) {
+                double alpha, cnt_d;
+                if (k <= Cfg::LE) {
+                    const mm_lds_double *e = lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64;
+                    alpha = e[NS * 64];
+                    cnt_d = e[(NS + 1) * 64];
+                } else {
+                    const double *e = scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64;
+                    alpha = e[NS * 64];
+                    cnt_d = e[(NS + 1) * 64];
+                }
+                MM_LG_COUNT(L, 12);
+                if (walking) {
+                    L.aux_k += 1;
+                    const unsigned long long cnt = (unsigned long long)__double_as_longlong(cnt_d);
+                    S_n += (unsigned int)cnt;
+                    S_alpha = alpha + S_alpha;
+                    S_nalpha += (unsigned int)(cnt >> 32);
+                }
+            }
+        }
+        done = done || walking;
+        MM_LG_TICK(L, 3);
+    };
+
     MM_LG_TICK(L, 1);
     if (j == 0) {
         if (__ballot(!done) != 0ull) {
             leaf_eval(0u);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                S_prime[s] = cx[s];
             done = done || walking;
         }
     } else {
@@ -652,13 +729,13 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             MM_LG_COUNT(L, 7);
             MM_LG_COUNT(L, 13);
             walking = walking && !S_s; /* valid: it waits (nuts.rs:858-899); not valid: handed up as it is */
-            walk_up(leaf);
+            walk_up_invalid(leaf);
             if (__ballot(!done) == 0ull)
                 break;
             /* ---- its sibling: merge at level 0 with the waiting subtree, then hand the pair up */
             leaf_eval(leaf + 1u);
             MM_LG_COUNT(L, 7);
-            merge(fx, fp, fx, P_alpha,
+            merge(fx, fp, fx, mm_true_t(), P_alpha,
                   __longlong_as_double((long long)((unsigned long long)P_n | ((unsigned long long)P_nalpha << 32))));
             walk_up(leaf + 1u);
         }
