@@ -189,6 +189,44 @@ __device__ __forceinline__ double mm_lg_group_sum(double c)
     return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
 }
 
+/* A 64-bit constant the compiler must take from scalar registers where it is used: written inline, the leaf loop's
+ * polynomial coefficients are hoisted into vector registers for the whole doubling (a v_fmac destroys its addend, so
+ * each wants a VGPR copy), which is what pushed the loop over its register budget; from an SGPR pair v_fma_f64 reads
+ * them as an operand. */
+__device__ __forceinline__ double mm_lg_sconst(double c)
+{
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
+/* min(1, exp(d)): the arithmetic of mm_exp (mm_math.h) operation for operation -- the host twin calls mm_exp -- but
+ * without its three early returns: the range checks select at the end (the polynomial runs on whatever d is; an
+ * out-of-range d only produces a value that the selects discard), which takes three levels of exec-mask branching
+ * out of every leaf */
+__device__ __forceinline__ double mm_lg_accept_prob(double d)
+{
+    const double kf = rint(d * mm_lg_sconst(1.44269504088896338700e+00));
+    const int k = (int)kf;
+    const double hi = fma(kf, mm_lg_sconst(-6.93147180369123816490e-01), d);
+    const double lo = kf * mm_lg_sconst(1.90821492927058770002e-10);
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c =
+        r - t * fma(t, fma(t, fma(t, fma(t, mm_lg_sconst(4.13813679705723846039e-08), mm_lg_sconst(-1.65339022054652515390e-06)),
+                                  mm_lg_sconst(6.61375632143793436117e-05)),
+                           mm_lg_sconst(-2.77777777770155933842e-03)),
+                    mm_lg_sconst(1.66666666666666019037e-01));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const int k1 = k / 2, k2 = k - k1;
+    const double s1 = mm_u2d((uint64_t)(k1 + 1023) << 52);
+    const double s2 = mm_u2d((uint64_t)(k2 + 1023) << 52);
+    double e = (y * s1) * s2;
+    e = d < -745.1332191019411 ? 0.0 : e;
+    e = d > 709.782712893384 ? (double)MM_INFINITY_F : e;
+    e = d == d ? e : d;
+    return fmin(1.0, e);
+}
+
 template <int NS> __device__ __forceinline__ double mm_lg_dot(const double *a, const double *b)
 {
     double c = 0;
@@ -486,17 +524,17 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         L.aux_k += 1;
     const bool neg = !(u_run_1 < 0.5); /* v = -1 */
     /* the outer edge in direction v, advanced in place: after the doubling it IS the returned edge */
-    double *const ex = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_XM : Cfg::V_XP);
-    double *const ep = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_PM : Cfg::V_PP);
-    double *const eg = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_GM : Cfg::V_GP);
-    const double *const ox = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_XP : Cfg::V_XM);
-    const double *const op = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_PP : Cfg::V_PM);
     double cx[NS], cp[NS], cg[NS];
+    {
+        const double *const ex0 = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_XM : Cfg::V_XP);
+        const double *const ep0 = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_PM : Cfg::V_PP);
+        const double *const eg0 = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_GM : Cfg::V_GP);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        cx[s] = mm_lg_ld<COH>(&ex[s * st]);
-        cp[s] = mm_lg_ld<COH>(&ep[s * st]);
-        cg[s] = mm_lg_ld<COH>(&eg[s * st]);
+        for (int s = 0; s < NS; ++s) {
+            cx[s] = mm_lg_ld<COH>(&ex0[s * st]);
+            cp[s] = mm_lg_ld<COH>(&ep0[s * st]);
+            cg[s] = mm_lg_ld<COH>(&eg0[s * st]);
+        }
     }
     const double epsv = neg ? -epsilon : epsilon;
     const double h = epsv * 0.5, nh = -h; /* cg holds A x = -gradient */
@@ -506,6 +544,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     __builtin_amdgcn_s_waitcnt(0);
 
     bool done = !alive;
+    unsigned int lf = 0, leaf_iters = 0; /* added to the lane's 64-bit counters once, after the loop */
     unsigned int S_n = 0, S_nalpha = 0;
     bool S_s = true;
     double S_alpha = 0.0;
@@ -520,7 +559,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
      * per-lane mask, their columns are recomputed) */
     auto leaf_eval = [&](unsigned int leaf) __attribute__((always_inline)) {
         MM_LG_COUNT(L, 6);
-        L.n_leaf_iters += 1;
+        leaf_iters += 1u;
         /* The VECTORS of a chain that is done (edge, proposal) are never read again: a chain is done before the last
          * leaf only when its doubling was cut short, which ends the transition (s' = 0: no proposal taken, edges
          * rebuilt by the next mm_lg_begin), and the columns of lanes that take no part are scratch.  So they are
@@ -540,10 +579,10 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         /* the proposal of a one-leaf subtree is the leaf itself: S_prime is not set here but by the level-0 merge,
          * which picks between the pair's two leaves (cx and the copy of the first one) */
         if (!done) {
-            L.n_lf += 1;
+            lf += 1u;
             S_n = (L.logu < jointp) ? 1u : 0u;
             S_s = (L.logu - 1000.0) < jointp;
-            S_alpha = fmin(1.0, mm_exp(jointp - L.joint));
+            S_alpha = mm_lg_accept_prob(jointp - L.joint);
             S_nalpha = 1;
             /* a leaf that starts a subtree of level >= 2 files its (x, p) under the highest level it starts (the first
              * leaf of a level-1 subtree waits in registers, below) */
@@ -741,7 +780,21 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         }
     }
 
-    /* write the advanced edge back; whole-trajectory criterion against the other edge (d = x_cur - x_other) */
+    L.n_lf += lf;
+    L.n_leaf_iters += leaf_iters;
+    /* write the advanced edge back; whole-trajectory criterion against the other edge (d = x_cur - x_other).  The
+     * record addresses are formed again from an opaque copy of the chain index: kept from the top of the doubling they
+     * would hold ten registers across the leaf loop */
+    unsigned long long cl_end = L.cl;
+    asm volatile("" : "+v"(cl_end));
+    auto vec_end = [&](int v) __attribute__((always_inline)) {
+        return a.rec + ((size_t)v * NS * a.c_pad + cl_end) * 4 + L.q;
+    };
+    double *const ex = vec_end(neg ? Cfg::V_XM : Cfg::V_XP);
+    double *const ep = vec_end(neg ? Cfg::V_PM : Cfg::V_PP);
+    double *const eg = vec_end(neg ? Cfg::V_GM : Cfg::V_GP);
+    const double *const ox = vec_end(neg ? Cfg::V_XP : Cfg::V_XM);
+    const double *const op = vec_end(neg ? Cfg::V_PP : Cfg::V_PM);
     double ca = 0.0, cb = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
