@@ -130,6 +130,17 @@ struct mm_nuts_lg_args {
 #endif
 };
 
+/* build switches of the experiments kept for comparison */
+#ifndef MM_LG_ASM_MFMA
+#define MM_LG_ASM_MFMA 1
+#endif
+#ifndef MM_LG_AUX_SHARED
+#define MM_LG_AUX_SHARED 1
+#endif
+#ifndef MM_LG_PREFETCH
+#define MM_LG_PREFETCH 0 /* touch-ahead of HBM records in the two-waves-per-SIMD build: measured 533 -> 549 ms, off */
+#endif
+
 /* OCC = waves per SIMD the kernel is built for: 1 = the 512-register budget and 40 KB of LDS per wave; 2 = 256 registers
  * and 20 KB (persistent scheduler only).  Level 0 of the pending-subtree stack never reaches memory: leaves are taken
  * in pairs and the first leaf's subtree waits for its sibling in registers (so does its (x, p) for the stop criterion).
@@ -143,7 +154,10 @@ template <int D, int OCC = 1> struct mm_lg_cfg {
     static constexpr int FS = 2 * NS;          /* first-leaf record: x[NS], p[NS] */
     static constexpr int LE = OCC == 1 ? 3 : 2; /* entry(k), 1 <= k <= LE, in LDS */
     static constexpr int LF = OCC == 1 ? 3 : 1; /* first(c), 2 <= c <= 1 + LF, in LDS */
-    static constexpr int lds_E = 0, lds_F = LE * ES, lds_slots = LE * ES + LF * FS;
+    /* OCC 2 keeps fewer records in LDS and feels the latency of the others (22 % of its time): the records a walk will
+     * read from HBM are touched a leaf ahead (one 4-byte LDS-DMA load per 128-byte line, landing in a dump slot) */
+    static constexpr bool PREFETCH = OCC == 2 && MM_LG_PREFETCH;
+    static constexpr int lds_E = 0, lds_F = LE * ES, lds_dump = LE * ES + LF * FS, lds_slots = lds_dump + (PREFETCH ? 1 : 0);
     static constexpr size_t lds_bytes = (size_t)lds_slots * 64 * sizeof(double);
     /* HBM slots per wave: entry(k), k = LE + 1 .. JMAX - 1 | first(c), c = LF + 2 .. JMAX */
     static constexpr int hbm_E = 0, hbm_F = (MM_NUTS_JMAX - 1 - LE) * ES, hbm_slots = hbm_F + (MM_NUTS_JMAX - 1 - LF) * FS;
@@ -159,12 +173,6 @@ template <int D, int OCC = 1> struct mm_lg_cfg {
 typedef double mm_d4 __attribute__((ext_vector_type(4)));
 struct mm_true_t { static constexpr bool value = true; };
 struct mm_false_t { static constexpr bool value = false; };
-#ifndef MM_LG_ASM_MFMA
-#define MM_LG_ASM_MFMA 1
-#endif
-#ifndef MM_LG_AUX_SHARED
-#define MM_LG_AUX_SHARED 1
-#endif
 /* LDS is addressed through an explicitly address-space-3 pointer: where an accessor picks LDS or HBM by a uniform
  * index, same-typed generic pointers let the optimiser merge the two branches into one flat_load / flat_store on a
  * selected pointer (which then waits on both memory counters); distinct pointer types keep ds_* and global_* apart */
@@ -479,8 +487,8 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     };
     auto load_rec = [&](int k, int cc, rec &r) __attribute__((always_inline)) {
 #ifdef MM_LG_EXPERIMENT_NO_HBM /* timing experiment only (wrong trees): every record in LDS */
-        cc = cc > 1 + Cfg::LF ? 1 + Cfg::LF : cc;
-        k = k > Cfg::LE ? Cfg::LE : k;
+        cc = cc > 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM ? 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM : cc;
+        k = k > Cfg::LE + MM_LG_EXPERIMENT_NO_HBM ? Cfg::LE + MM_LG_EXPERIMENT_NO_HBM : k;
 #endif
         if (cc <= 1 + Cfg::LF) {
             const mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
@@ -589,7 +597,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if (j > 1 && (leaf & 3u) == 0u) {
                 int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
 #ifdef MM_LG_EXPERIMENT_NO_HBM
-                cc = cc > 1 + Cfg::LF ? 1 + Cfg::LF : cc;
+                cc = cc > 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM ? 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM : cc;
 #endif
                 if (cc <= 1 + Cfg::LF) {
                     mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
@@ -661,7 +669,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
      * it keeps walking */
     auto push = [&](int k) __attribute__((always_inline)) {
 #ifdef MM_LG_EXPERIMENT_NO_HBM
-        k = k > Cfg::LE ? Cfg::LE : k;
+        k = k > Cfg::LE + MM_LG_EXPERIMENT_NO_HBM ? Cfg::LE + MM_LG_EXPERIMENT_NO_HBM : k;
 #endif
         MM_LG_TICK(L, 3);
         MM_LG_COUNT(L, 13);
@@ -705,6 +713,24 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         MM_LG_TICK(L, 3);
     };
 
+    /* touch the HBM-resident records walk_up(leaf) is going to read (same level / slot arithmetic as walk_up) */
+    auto prefetch_walk = [&](unsigned int leaf) __attribute__((always_inline)) {
+        if constexpr (Cfg::PREFETCH) {
+            typedef __attribute__((address_space(1))) void gvoid;
+            typedef __attribute__((address_space(3))) void lvoid;
+            lvoid *const dump = (lvoid *)(lds - L.lane + (size_t)Cfg::lds_dump * 64);
+            const double *const wave_scr = scr - L.lane + 16 * L.lane; /* lane l touches line l of a record */
+            for (int k = 1; k < j && ((leaf >> k) & 1u); ++k) {
+                const int cc = first_slot(leaf, k);
+                if (cc > 1 + Cfg::LF)
+                    __builtin_amdgcn_global_load_lds((gvoid *)(wave_scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64),
+                                                     dump, 4, 0, 0);
+                if (k > Cfg::LE && L.lane < ES * 4)
+                    __builtin_amdgcn_global_load_lds((gvoid *)(wave_scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64),
+                                                     dump, 4, 0, 0);
+            }
+        }
+    };
     /* the same for the FIRST leaf of a pair, which walks only when it is not valid (s' = 0; a valid one waits): s' stays
      * 0 all the way up, so no proposal is kept, no criterion evaluated and nothing filed -- only the counts of the
      * siblings it meets are added (and their draws consumed).  Keeps the proposal registers dead across the first
@@ -772,6 +798,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if (__ballot(!done) == 0ull)
                 break;
             /* ---- its sibling: merge at level 0 with the waiting subtree, then hand the pair up */
+            prefetch_walk(leaf + 1u);
             leaf_eval(leaf + 1u);
             MM_LG_COUNT(L, 7);
             merge(fx, fp, fx, mm_true_t(), P_alpha,
