@@ -490,36 +490,32 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         cc = cc > 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM ? 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM : cc;
         k = k > Cfg::LE + MM_LG_EXPERIMENT_NO_HBM ? Cfg::LE + MM_LG_EXPERIMENT_NO_HBM : k;
 #endif
-        if (cc <= 1 + Cfg::LF) {
-            const mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                r.fx[s] = f[s * 64];
-                r.fp[s] = f[(NS + s) * 64];
-            }
-        } else {
-            const double *f = scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                r.fx[s] = f[s * 64];
-                r.fp[s] = f[(NS + s) * 64];
-            }
-        }
-        if (k <= Cfg::LE) {
-            const mm_lds_double *e = lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64;
+        /* Three cases, each ONE block that issues all 26 loads before anything waits: written as two independent
+         * if / else (first-leaf record, then entry) the entry's loads were sunk below the stop criterion, i.e. behind
+         * the first-leaf record's wait -- two memory latencies per merge where the records are in HBM.  An entry
+         * in HBM (k > LE) implies its first-leaf record is too (cc >= k + 1 > 1 + LF, as LF <= LE). */
+        static_assert(Cfg::LF <= Cfg::LE, "record placement: LF <= LE");
+        auto take = [&](auto *f, auto *e) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 r.prime[s] = e[s * 64];
             r.alpha = e[NS * 64];
             r.cnt = e[(NS + 1) * 64];
-        } else {
-            const double *e = scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64;
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                r.prime[s] = e[s * 64];
-            r.alpha = e[NS * 64];
-            r.cnt = e[(NS + 1) * 64];
-        }
+            for (int s = 0; s < NS; ++s) {
+                r.fx[s] = f[s * 64];
+                r.fp[s] = f[(NS + s) * 64];
+            }
+        };
+        if (k > Cfg::LE)
+            take((const double *)(scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64),
+                 (const double *)(scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64));
+        else if (cc > 1 + Cfg::LF)
+            take((const double *)(scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64),
+                 (const mm_lds_double *)(lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64));
+        else
+            take((const mm_lds_double *)(lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64),
+                 (const mm_lds_double *)(lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64));
     };
     /* where the first leaf of the sibling at level k of `leaf` is filed */
     auto first_slot = [](unsigned int leaf, int k) -> int {
