@@ -256,6 +256,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 /* persistent scheduler: one resident wave per SIMD (fewer if there are fewer groups of 16 chains) */
                 g.ctrl = d_lg_ctrl;
                 g.slots = d_lg_lists;
+                g.patience = 8u; /* 65 536 chains: 4 -> 516.5 ms, 16 -> 518.5, 64 -> 520.9, 256 -> 530.3 */
+                if (const char *ev = getenv("MMCMC_LGQ_PATIENCE"))
+                    g.patience = (unsigned int)atoi(ev);
                 const unsigned int groups16 = (unsigned int)(c_pad / 16);
                 /* waves per SIMD the scheduler is built for (mm_lg_cfg): 2 wherever two per SIMD can be filled */
                 int occ = lgq_occ;

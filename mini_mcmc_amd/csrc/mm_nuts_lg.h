@@ -124,6 +124,7 @@ struct mm_nuts_lg_args {
     unsigned int row;               /* output row of this transition, or 0xffffffff */
     /* persistent kernel only */
     struct mm_lgq_ctrl *ctrl;       /* queue heads / tails, chains left, error flag */
+    unsigned int patience;          /* idle polls before a wave settles for a unit of fewer than 16 chains */
     unsigned int *slots;            /* [MM_LGQ_SHARDS][MM_LGQ_NQ][c_pad] rings of tagged local chain indices */
 #ifdef MM_LG_PROFILE
     unsigned long long *prof;       /* [waves][8] */
@@ -136,9 +137,6 @@ struct mm_nuts_lg_args {
 #endif
 #ifndef MM_LG_AUX_SHARED
 #define MM_LG_AUX_SHARED 1
-#endif
-#ifndef MM_LG_PREFETCH
-#define MM_LG_PREFETCH 0 /* touch-ahead of HBM records in the two-waves-per-SIMD build: measured 533 -> 549 ms, off */
 #endif
 
 /* OCC = waves per SIMD the kernel is built for: 1 = the 512-register budget and 40 KB of LDS per wave; 2 = 256 registers
@@ -154,10 +152,7 @@ template <int D, int OCC = 1> struct mm_lg_cfg {
     static constexpr int FS = 2 * NS;          /* first-leaf record: x[NS], p[NS] */
     static constexpr int LE = OCC == 1 ? 3 : 2; /* entry(k), 1 <= k <= LE, in LDS */
     static constexpr int LF = OCC == 1 ? 3 : 1; /* first(c), 2 <= c <= 1 + LF, in LDS */
-    /* OCC 2 keeps fewer records in LDS and feels the latency of the others (22 % of its time): the records a walk will
-     * read from HBM are touched a leaf ahead (one 4-byte LDS-DMA load per 128-byte line, landing in a dump slot) */
-    static constexpr bool PREFETCH = OCC == 2 && MM_LG_PREFETCH;
-    static constexpr int lds_E = 0, lds_F = LE * ES, lds_dump = LE * ES + LF * FS, lds_slots = lds_dump + (PREFETCH ? 1 : 0);
+    static constexpr int lds_E = 0, lds_F = LE * ES, lds_slots = LE * ES + LF * FS;
     static constexpr size_t lds_bytes = (size_t)lds_slots * 64 * sizeof(double);
     /* HBM slots per wave: entry(k), k = LE + 1 .. JMAX - 1 | first(c), c = LF + 2 .. JMAX */
     static constexpr int hbm_E = 0, hbm_F = (MM_NUTS_JMAX - 1 - LE) * ES, hbm_slots = hbm_F + (MM_NUTS_JMAX - 1 - LF) * FS;
@@ -709,24 +704,6 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         MM_LG_TICK(L, 3);
     };
 
-    /* touch the HBM-resident records walk_up(leaf) is going to read (same level / slot arithmetic as walk_up) */
-    auto prefetch_walk = [&](unsigned int leaf) __attribute__((always_inline)) {
-        if constexpr (Cfg::PREFETCH) {
-            typedef __attribute__((address_space(1))) void gvoid;
-            typedef __attribute__((address_space(3))) void lvoid;
-            lvoid *const dump = (lvoid *)(lds - L.lane + (size_t)Cfg::lds_dump * 64);
-            const double *const wave_scr = scr - L.lane + 16 * L.lane; /* lane l touches line l of a record */
-            for (int k = 1; k < j && ((leaf >> k) & 1u); ++k) {
-                const int cc = first_slot(leaf, k);
-                if (cc > 1 + Cfg::LF)
-                    __builtin_amdgcn_global_load_lds((gvoid *)(wave_scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64),
-                                                     dump, 4, 0, 0);
-                if (k > Cfg::LE && L.lane < ES * 4)
-                    __builtin_amdgcn_global_load_lds((gvoid *)(wave_scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64),
-                                                     dump, 4, 0, 0);
-            }
-        }
-    };
     /* the same for the FIRST leaf of a pair, which walks only when it is not valid (s' = 0; a valid one waits): s' stays
      * 0 all the way up, so no proposal is kept, no criterion evaluated and nothing filed -- only the counts of the
      * siblings it meets are added (and their draws consumed).  Keeps the proposal registers dead across the first
@@ -794,7 +771,6 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if (__ballot(!done) == 0ull)
                 break;
             /* ---- its sibling: merge at level 0 with the waiting subtree, then hand the pair up */
-            prefetch_walk(leaf + 1u);
             leaf_eval(leaf + 1u);
             MM_LG_COUNT(L, 7);
             merge(fx, fp, fx, mm_true_t(), P_alpha,
@@ -1404,7 +1380,7 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
             }
             if (found)
                 break;
-            if (polls >= 64u) {
+            if (polls >= a.patience) {
                 /* waited long enough: the fullest queue of the own shard, whatever it holds; else of another shard */
                 unsigned int mx = 0u;
                 int best = -1;
