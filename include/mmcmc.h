@@ -167,7 +167,11 @@ int mmcmc_nuts_set_chain_offset(mmcmc_nuts *h, uint64_t chain_offset);
 int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
 /* Kernel mapping (not in the reference).  0 = one chain per lane, the lanes of a wave taking their transitions in step
  * (every target / mode); 4 = one chain per lane, every lane advancing through its transitions on its own, one leaf per
- * tick (dim <= 8; the default there; results identical to 0).  1 = lane-group mapping with
+ * tick (dim <= 8; the default there; results identical to 0).  6 = one chain per lane at RUN-TIME dimension, the
+ * transition's vectors in an HBM store (csrc/mm_nuts_generic.h): the N-dimensional built-in targets (isotropic / standard
+ * / dense Gaussian, RosenbrockND) at ANY dimension, all three modes; the default where there is no compiled instance of
+ * 0 (those exist for every dim <= 8 and 10, 16, 20, 24 / 32 for the dense Gaussian), selectable everywhere, results
+ * identical to 0 where both exist.  1 = lane-group mapping with
  * the gradient on the matrix cores: 16 chains per wave, four lanes per chain, v_mfma_f64_16x16x4 for A x, the whole
  * run in one launch, every wave keeping its 16 chains.  2 and 3 = the same arithmetic with tree-depth compaction
  * (BASELINE.json config 5): a transition is cut at the doubling boundaries and the chains that still double are

@@ -17,6 +17,7 @@
 
 #include "mm_nuts_kernels.h"
 #include "mm_nuts_lg.h"
+#include "mm_nuts_generic.h"
 #include "mm_params.h"
 
 #define MM_HIP(expr)                                                                                              \
@@ -74,8 +75,17 @@ template <> const mm_nuts_entry<float, double> *nuts_table<float, double>(int *n
 template <> const mm_nuts_entry<float, float> *nuts_table<float, float>(int *n) { return mm_nuts_table_m1(n); }
 template <> const mm_nuts_entry<double, double> *nuts_table<double, double>(int *n) { return mm_nuts_table_m2(n); }
 
+inline hipError_t launch_generic(const mm_gen_nuts_args<float, double> &a, int init, hipStream_t st) { return mm_launch_nuts_generic_m0(a, init, st); }
+inline hipError_t launch_generic(const mm_gen_nuts_args<float, float> &a, int init, hipStream_t st) { return mm_launch_nuts_generic_m1(a, init, st); }
+inline hipError_t launch_generic(const mm_gen_nuts_args<double, double> &a, int init, hipStream_t st) { return mm_launch_nuts_generic_m2(a, init, st); }
+
 template <class TT, class ST> struct Nuts : NutsBase {
     const mm_nuts_entry<TT, ST> *k = nullptr;
+    /* run-time-dimension path (mm_nuts_generic.h, variant 6): the only one where the table has no (kind, dim) entry */
+    bool generic_ok = false;
+    TT *d_gstore = nullptr;
+    int gstore_depth = 0;
+    size_t g_pad = 0;
     mm_tparams<TT> P;
     TT *d_state = nullptr, *d_mat = nullptr;
     mm_nuts_adapt<ST> *d_adapt = nullptr;
@@ -107,6 +117,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
         (void)hipFree(d_nlf);
         (void)hipFree(d_hist);
         (void)hipFree(d_scratch);
+        (void)hipFree(d_gstore);
         (void)hipFree(d_lg_scratch);
         (void)hipFree(d_lg_rec);
         (void)hipFree(d_lg_lists);
@@ -135,10 +146,12 @@ template <class TT, class ST> struct Nuts : NutsBase {
         for (int i = 0; i < n; ++i)
             if (tab[i].kind == t->kind && tab[i].dim == t->dim)
                 k = &tab[i];
-        if (!k)
+        generic_ok = mm_generic_kind_ok(t->kind) && t->dim >= 1;
+        if (!k && !generic_ok)
             return MMCMC_ERR_UNSUPPORTED;
         if (mm_fill_params<TT>(t->kind, t->params, &P) != 0)
             return MMCMC_ERR_INVALID_ARG;
+        g_pad = (n_chains + 63) / 64 * 64;
         DevGuard g(device);
         const size_t cd = n_chains * (size_t)dim;
         if (t->kind == MMCMC_GAUSSIAN_ND) {
@@ -168,13 +181,17 @@ template <class TT, class ST> struct Nuts : NutsBase {
         MM_HIP(hipMemset(d_nlf, 0, n_chains * sizeof(unsigned long long)));
         MM_HIP(hipMalloc((void **)&d_hist, (MM_NUTS_JMAX + 1) * sizeof(unsigned int)));
         MM_HIP(hipMemset(d_hist, 0, (MM_NUTS_JMAX + 1) * sizeof(unsigned int)));
-        /* the pending-subtree stack goes to LDS when tile + stack fit comfortably, else to HBM scratch */
-        stack_in_lds = (k->tile_bytes_per_wave + k->stack_bytes_per_wave) <= 40 * 1024;
-        /* the scratch area also serves the asynchronous-lane kernel when ITS stack (max_depth levels, no tile) is over
-         * the LDS limit; max_depth can change after create, so allocate whenever the full stack is */
-        if (!stack_in_lds || k->stack_bytes_per_wave > 40 * 1024) {
-            const size_t waves = (n_chains + 63) / 64;
-            MM_HIP(hipMalloc((void **)&d_scratch, waves * k->stack_bytes_per_wave));
+        if (k) {
+            /* the pending-subtree stack goes to LDS when tile + stack fit comfortably, else to HBM scratch */
+            stack_in_lds = (k->tile_bytes_per_wave + k->stack_bytes_per_wave) <= 40 * 1024;
+            /* the scratch area also serves the asynchronous-lane kernel when ITS stack (max_depth levels, no tile) is
+             * over the LDS limit; max_depth can change after create, so allocate whenever the full stack is */
+            if (!stack_in_lds || k->stack_bytes_per_wave > 40 * 1024) {
+                const size_t waves = (n_chains + 63) / 64;
+                MM_HIP(hipMalloc((void **)&d_scratch, waves * k->stack_bytes_per_wave));
+            }
+        } else {
+            variant = 6;
         }
         if (std::is_same<TT, double>::value && std::is_same<ST, double>::value && t->kind == MMCMC_GAUSSIAN_ND) {
             int nl = 0;
@@ -197,7 +214,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 variant = 3; /* the default where it exists */
             }
         }
-        if (!lg && k->run_async)
+        if (!lg && k && k->run_async)
             variant = 4; /* asynchronous lanes: the default for the one-chain-per-lane kernels */
         MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamDefault));
         MM_HIP(hipEventCreate(&ev0));
@@ -207,11 +224,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int set_variant(int v) override
     {
-        if (v == 0 || (v >= 1 && v <= 3 && lg) || (v == 4 && k->run_async)) {
+        if ((v == 0 && k) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 6 && generic_ok)) {
             variant = v;
             return MMCMC_OK;
         }
-        return (v >= 1 && v <= 4) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
+        return (v >= 0 && v <= 6 && v != 5) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
     }
 
     /* the lane-group launch exists for <double, double> only; the other instantiations never reach it */
@@ -446,7 +463,39 @@ template <class TT, class ST> struct Nuts : NutsBase {
         n_launches_run = 0;
         /* init_chain (nuts.rs:528-545) on every run() call */
         const bool use_lg = variant >= 1 && variant <= 3 && lg;
-        hipError_t e = use_lg ? init_lg(st) : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
+        const bool use_generic = variant == 6;
+        mm_gen_nuts_args<TT, ST> ga;
+        if (use_generic) {
+            /* the store: mm_gen_nuts_vectors(max_depth) vectors of dim elements per chain, lane-interleaved */
+            if (!d_gstore || gstore_depth < max_depth) {
+                (void)hipFree(d_gstore);
+                d_gstore = nullptr;
+                MM_HIP(hipMalloc((void **)&d_gstore, (size_t)mm_gen_nuts_vectors(max_depth) * (size_t)dim * g_pad * sizeof(TT)));
+                gstore_depth = max_depth;
+            }
+            ga.P = P;
+            ga.kind = kind;
+            ga.dim = dim;
+            ga.max_depth = max_depth;
+            ga.state = d_state;
+            ga.adapt = d_adapt;
+            ga.out = nullptr;
+            ga.n_leapfrog = d_nlf;
+            ga.depth_hist = d_hist;
+            ga.store = d_gstore;
+            ga.n_chains = n_chains;
+            ga.c_pad = g_pad;
+            ga.seed = seed;
+            ga.chain_offset = chain_offset;
+            ga.n_total = n_collect;
+            ga.m0 = m;
+            ga.n_pre = ga.n_rec = ga.write_initial = ga.out_t0 = 0;
+            ga.n_discard = (unsigned int)n_discard;
+            ga.target_accept_p = (ST)target_accept_p;
+            ga.eps_tol = sizeof(ST) == 4 ? (ST)1.1920929e-7 : (ST)2.220446049250313e-16; /* T::epsilon() */
+        }
+        hipError_t e = use_lg ? init_lg(st) : use_generic ? launch_generic(ga, 1, st)
+                                                          : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
         if (e != hipSuccess)
             return (int)e;
         mm_nuts_args<TT, ST> a;
@@ -490,7 +539,15 @@ template <class TT, class ST> struct Nuts : NutsBase {
             a.n_rec = (unsigned int)n_collect;
         }
         MM_HIP(hipEventRecord(ev0, st));
-        e = use_lg ? run_lg(a, st) : (variant == 4 && k->run_async) ? k->run_async(a, st) : k->run(a, st);
+        if (use_generic) {
+            ga.out = d_out;
+            ga.n_pre = a.n_pre;
+            ga.n_rec = a.n_rec;
+            ga.write_initial = a.write_initial;
+            e = launch_generic(ga, 0, st);
+        } else {
+            e = use_lg ? run_lg(a, st) : (variant == 4 && k->run_async) ? k->run_async(a, st) : k->run(a, st);
+        }
         if (e != hipSuccess)
             return (int)e;
         MM_HIP(hipEventRecord(ev1, st));

@@ -4,8 +4,8 @@
  * reference's NUTS takes any target that implements GradientTarget (nuts.rs:123-129); its N-dimensional built-ins
  * (distributions.rs:350-402, 531-547; nuts.rs:1027-1037) are covered at every dimension up to 8 and at 10, 16, 20
  * (24 / 32 for the dense Gaussian): a NUTS transition keeps both trajectory edges, the proposal and the working leaf
- * in registers, so the dimension is a compile-time constant here (MH / HMC have a run-time-dimension path,
- * mm_generic.h).
+ * in registers, so the dimension is a compile-time constant here; every other dimension runs the run-time-dimension
+ * kernel (mm_nuts_generic.h; MH / HMC: mm_generic.h).
  */
 #ifndef MM_NUTS_DIMS_H
 #define MM_NUTS_DIMS_H

@@ -75,6 +75,30 @@ template <class T, int D> struct mm_split_mh_qp {
     static constexpr int value = rb >= 8 ? MM_SPLIT_MH_QP : (rb >= 4 && MM_SPLIT_MH_QP ? 1 : 0);
 };
 
+/* Role timing for tools/split_probe.hip (-DMM_SPLIT_PROFILE): s_memtime ticks each role spends at the batch barrier
+ * and in total, summed over waves into mm_split_prof[role][0 / 1]; compiled out of the product. */
+#ifdef MM_SPLIT_PROFILE
+__device__ unsigned long long mm_split_prof[2][2];
+#define MM_SPLIT_SYNC()                                                                                           \
+    do {                                                                                                          \
+        const unsigned long long _t0 = __builtin_amdgcn_s_memtime();                                              \
+        __syncthreads();                                                                                          \
+        prof_wait += __builtin_amdgcn_s_memtime() - _t0;                                                          \
+    } while (0)
+#define MM_SPLIT_PROF_BEGIN() unsigned long long prof_wait = 0; const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime()
+#define MM_SPLIT_PROF_END(role)                                                                                   \
+    do {                                                                                                          \
+        if ((threadIdx.x & 63) == 0) {                                                                            \
+            atomicAdd(&mm_split_prof[role][0], prof_wait);                                                        \
+            atomicAdd(&mm_split_prof[role][1], __builtin_amdgcn_s_memtime() - prof_t0);                           \
+        }                                                                                                         \
+    } while (0)
+#else
+#define MM_SPLIT_SYNC() __syncthreads()
+#define MM_SPLIT_PROF_BEGIN() ((void)0)
+#define MM_SPLIT_PROF_END(role) ((void)0)
+#endif
+
 template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0>
 __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> a)
 {
@@ -116,6 +140,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
 
     if (noise_wave) {
         __syncthreads(); /* the table is complete */
+        MM_SPLIT_PROF_BEGIN();
         unsigned int it = a.iter0;
         int half = 0;
         /* noise of iterations [it + QN, it + nb) of a batch into rows QN.. of the current ring half */
@@ -154,7 +179,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
         };
         for (unsigned int done = 0; done < n_silent; done += RB) {
             fill(min((unsigned int)RB, n_silent - done));
-            __syncthreads();
+            MM_SPLIT_SYNC();
         }
         /* collected transitions: after the barrier that hands batch b over, the partner has finished batch b - 1; a tile
          * that batch completed is written out while the partner stages into the other one */
@@ -163,7 +188,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
         for (unsigned int done = 0; done < n_loud; done += RB) {
             const unsigned int nb = min((unsigned int)RB, n_loud - done);
             fill(nb);
-            __syncthreads();
+            MM_SPLIT_SYNC();
             if (PFLUSH && pend) {
                 mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
                                               (unsigned long long)a.out_t0 + rows_out, pend);
@@ -178,10 +203,11 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
                 tcol = 0;
             }
         }
-        __syncthreads(); /* the partner has finished its last batch */
+        MM_SPLIT_SYNC(); /* the partner has finished its last batch */
         if (PFLUSH && pend)
             mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
                                           (unsigned long long)a.out_t0 + rows_out, pend);
+        MM_SPLIT_PROF_END(0);
         return;
     }
 
@@ -196,6 +222,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
     else
         lp = Tgt::logp(a.P, x);
     __syncthreads(); /* the table is complete */
+    MM_SPLIT_PROF_BEGIN();
 
     unsigned int n_acc32 = 0;
     unsigned long long wave_acc = 0;
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
     if (QN)
         draw_own(it);
     for (unsigned int done = 0; done < n_silent; done += RB) {
-        __syncthreads(); /* ring half `half` is full; the other one is free again */
+        MM_SPLIT_SYNC(); /* ring half `half` is full; the other one is free again */
         batch(min((unsigned int)RB, n_silent - done), nullptr);
         if (QN)
             draw_own(it); /* for the next batch (a batch past the end of the run: drawn, never used) */
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
     int tb = 0;
     for (unsigned int done = 0; done < n_loud; done += RB) {
         const unsigned int nb = min((unsigned int)RB, n_loud - done);
-        __syncthreads(); /* ... and (PFLUSH) the tile this batch may be the first to write into has been flushed */
+        MM_SPLIT_SYNC(); /* ... and (PFLUSH) the tile this batch may be the first to write into has been flushed */
         batch(nb, tiles + (size_t)tb * TILE_ELEMS + lane * STRIDE + tcol * D);
         if (QN)
             draw_own(it);
@@ -296,7 +323,8 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
             tcol = 0;
         }
     }
-    __syncthreads(); /* hands the last tile over */
+    MM_SPLIT_SYNC(); /* hands the last tile over */
+    MM_SPLIT_PROF_END(1);
 
     if (active) {
         MM_UNROLL

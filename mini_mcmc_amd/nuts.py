@@ -54,7 +54,8 @@ class NUTS:
         """One chain per lane: 0 = the lanes of a wave take their transitions in step, 4 = every lane advances on its
         own, one leaf per tick (default for dim <= 8; same results as 0).  1 = lane-group / MFMA mapping in one launch;
         2 / 3 = the same with tree-depth compaction by one launch per level / by a persistent scheduler (1..3: mode 2,
-        GaussianND, dim 16 or 32, where 3 is the default; all three give bit-identical samples)."""
+        GaussianND, dim 16 or 32, where 3 is the default; all three give bit-identical samples).  6 = run-time dimension
+        (the N-dimensional built-in targets at any dim; the default where no compiled instance exists; same results as 0)."""
         L.check(L.lib().mmcmc_nuts_set_kernel_variant(self._h, int(variant)), "mmcmc_nuts_set_kernel_variant")
         return self
 

@@ -17,6 +17,7 @@
 #include "../mini_mcmc_amd/csrc/mm_params.h"
 #include "../mini_mcmc_amd/csrc/mm_nuts.h"
 #include "../mini_mcmc_amd/csrc/mm_nuts_dims.h"
+#include "../mini_mcmc_amd/csrc/mm_nuts_generic.h"
 #include "../mini_mcmc_amd/csrc/mm_samplers.h"
 #include "../mini_mcmc_amd/csrc/mm_generic.h"
 
@@ -249,10 +250,57 @@ static void nuts_chains(const mm_tparams<TT> &P, double *positions, size_t n, do
     for (auto &t : th) t.join();
 }
 
+/* the same at run-time dimension (mm_nuts_generic.h): the twin of the device's generic NUTS kernel */
+template <class TT, class ST>
+static void nuts_chains_generic(int kind, int D, const mm_tparams<TT> &P, double *positions, size_t n, double tap, uint64_t seed,
+                                uint64_t off, uint32_t m0, size_t n_collect, size_t n_discard, int progress, int max_depth,
+                                double *adapt, TT *out, uint64_t *nlf, int nth)
+{
+    const ST eps_tol = sizeof(ST) == 4 ? (ST)1.1920929e-7 : (ST)2.220446049250313e-16;
+    unsigned n_pre, n_rec, write_initial;
+    const size_t total = n_collect + n_discard;
+    if (progress) { write_initial = 0; n_pre = (unsigned)n_discard; n_rec = (unsigned)n_collect; }
+    else if (total == 0) { write_initial = 0; n_pre = n_rec = 0; }
+    else if (n_discard == 0) { write_initial = n_collect > 0; n_pre = 0; n_rec = (unsigned)(n_collect > 0 ? n_collect - 1 : 0); }
+    else { write_initial = 0; n_pre = (unsigned)(n_discard - 1); n_rec = (unsigned)n_collect; }
+    auto work = [&](size_t lo, size_t hi) {
+        std::vector<TT> store((size_t)mm_gen_nuts_vectors(max_depth) * D);
+        mm_gstore<TT, TT *> s;
+        s.base = store.data(); s.stride = 1; s.dim = D;
+        for (size_t c = lo; c < hi; ++c) {
+            for (int i = 0; i < D; ++i) s.st(MM_NV_X, i, (TT)positions[c * D + i]);
+            mm_nuts_adapt<ST> ad;
+            ad.epsilon = (ST)adapt[4 * c]; ad.epsilon_bar = (ST)adapt[4 * c + 1];
+            ad.h_bar = (ST)adapt[4 * c + 2]; ad.mu = (ST)adapt[4 * c + 3];
+            mm_gen_nuts_init_chain<TT, ST>(kind, P, s, &ad, eps_tol, seed, off + c);
+            size_t row = 0;
+            uint64_t lf = 0;
+            uint32_t m = m0;
+            auto rec = [&]() { if (out) { for (int i = 0; i < D; ++i) out[(c * n_collect + row) * D + i] = s.ld(MM_NV_X, i); } ++row; };
+            if (write_initial) rec();
+            for (unsigned t = 0; t < n_pre + n_rec; ++t) {
+                ++m;
+                mm_nuts_info inf = mm_gen_nuts_step<TT, ST>(kind, P, s, &ad, m, (uint32_t)n_discard, (ST)tap, max_depth, seed, off + c);
+                lf += inf.n_leapfrog;
+                if (t >= n_pre) rec();
+            }
+            for (int i = 0; i < D; ++i) positions[c * D + i] = (double)s.ld(MM_NV_X, i);
+            adapt[4 * c] = (double)ad.epsilon; adapt[4 * c + 1] = (double)ad.epsilon_bar;
+            adapt[4 * c + 2] = (double)ad.h_bar; adapt[4 * c + 3] = (double)ad.mu;
+            if (nlf) nlf[c] = lf;
+        }
+    };
+    if (nth <= 1 || n < 2) { work(0, n); return; }
+    std::vector<std::thread> th;
+    size_t nt = std::min<size_t>((size_t)nth, n);
+    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto &t : th) t.join();
+}
+
 template <class TT, class ST>
 static int nuts_t(int kind, int dim, const double params[8], const double *matrix, double *positions, size_t n, double tap,
                   uint64_t seed, uint64_t off, uint32_t m0, size_t nc, size_t nd, int progress, int max_depth,
-                  double *adapt, void *out, uint64_t *nlf, int nth)
+                  double *adapt, void *out, uint64_t *nlf, int nth, bool force_generic = false)
 {
     mm_tparams<TT> P;
     if (mm_fill_params<TT>(kind, params, &P) != 0) return -1;
@@ -269,9 +317,15 @@ static int nuts_t(int kind, int dim, const double params[8], const double *matri
                                                      adapt, (TT *)out, nlf, nth);                                 \
         return 0;                                                                                                 \
     }
-    MM_NUTS_INSTANCES(NT)
+    if (!force_generic) {
+        MM_NUTS_INSTANCES(NT)
+    }
 #undef NT
-    return -2;
+    if (!mm_generic_kind_ok(kind) || dim < 1 || max_depth > MM_NUTS_JMAX)
+        return -2;
+    nuts_chains_generic<TT, ST>(kind, dim, P, positions, n, tap, seed, off, m0, nc, nd, progress, max_depth, adapt, (TT *)out, nlf,
+                                nth);
+    return 0;
 }
 
 extern "C" {
@@ -297,14 +351,19 @@ int eh_nuts_run(int mode, int kind, int dim, const double params[8], const doubl
                 (double *)out, nlf, n_threads);
         return 0;
     }
+    /* modes 4, 5, 6: type modes 0, 1, 2 through the run-time-dimension path (also the fallback of 0, 1, 2 for a
+     * (kind, dim) without a fixed-D instance) */
+    const bool force_generic = mode >= 4 && mode <= 6;
+    if (force_generic)
+        mode -= 4;
     if (mode == 0)
         return nuts_t<float, double>(kind, dim, params, matrix, positions, n, target_accept_p, seed, chain_offset, m0,
-                                     n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);
+                                     n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads, force_generic);
     if (mode == 1)
         return nuts_t<float, float>(kind, dim, params, matrix, positions, n, target_accept_p, seed, chain_offset, m0,
-                                    n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);
+                                    n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads, force_generic);
     return nuts_t<double, double>(kind, dim, params, matrix, positions, n, target_accept_p, seed, chain_offset, m0,
-                                  n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads);
+                                  n_collect, n_discard, progress, max_depth, adapt, out, nlf, n_threads, force_generic);
 }
 
 /* the product's f32 normal of one Philox word (mm_rng.h: mm_icdf_f32), word by word */

@@ -115,7 +115,7 @@ struct o_nuts {
 o_nuts *o_nuts_create(const ot_target *target, const double *init, int n_chains, double target_accept_p,
                       int mode)
 {
-    if (!target || !init || n_chains <= 0 || target->dim <= 0 || target->dim > 64 || mode < 0 || mode > 2)
+    if (!target || !init || n_chains <= 0 || target->dim <= 0 || target->dim > 128 || mode < 0 || mode > 2)
         return NULL;
     o_nuts *s = (o_nuts *)calloc(1, sizeof *s);
     s->mode = mode;
@@ -281,7 +281,7 @@ double o_nuts_find_reasonable_epsilon(const ot_target *target, const double *pos
         nuts_chain_init_m2(&c, target, position, 0.8);
         return find_reasonable_epsilon_m2(&c, position, mom);
     }
-    float p[64], m[64];
+    float p[128], m[128];
     for (int i = 0; i < d; ++i) {
         p[i] = (float)position[i];
         m[i] = (float)mom[i];
@@ -309,7 +309,7 @@ void o_nuts_build_tree(const ot_target *target, const double *position, const do
         nuts_chain_##M c;                                                                                    \
         nuts_chain_init_##M(&c, target, position, 0.8);                                                      \
         o_rng_init_rand_compat(&c.rng, rng_seed);                                                            \
-        TTYPE p[64], mo[64], g[64];                                                                          \
+        TTYPE p[128], mo[128], g[128];                                                                         \
         for (int i = 0; i < d; ++i) {                                                                        \
             p[i] = (TTYPE)position[i];                                                                       \
             mo[i] = (TTYPE)mom[i];                                                                           \

@@ -808,7 +808,8 @@ def engine_host_nuts_run(mode, kind, dim, params, init, target_accept_p, n_colle
     if x.ndim == 1:
         x = x[None, :]
     n = x.shape[0]
-    tdt = np.float64 if mode >= 2 else np.float32  # mode 3: host twin of the lane-group / MFMA kernel (f64)
+    # mode 3: host twin of the lane-group / MFMA kernel (f64); 4, 5, 6: type modes 0, 1, 2 through mm_nuts_generic.h
+    tdt = np.float64 if mode in (2, 3, 6) else np.float32
     out = np.empty((n, n_collect, dim), dtype=tdt)
     ad = np.empty((n, 4), dtype=np.float64)
     if adapt is None:

@@ -211,5 +211,101 @@ def test_gpu_nuts_more_dimensions_bit_exact_vs_host_build(M, O, mode):
         assert np.array_equal(s.leapfrog_counts(), nlf), name
         a = s.adapt_state()
         assert np.array_equal(a["epsilon"], ad[:, 0]) and np.array_equal(a["h_bar"], ad[:, 2]), name
-    with pytest.raises(Exception):  # not every dimension: NUTS has no run-time-D path
-        NUTS(M.dist.RosenbrockND(11), M.core.init_with_seed(4, 11, 1), 0.8, mode=mode)
+
+
+def _spd(rng, d):
+    A = rng.standard_normal((d, d))
+    return A @ A.T / d + np.eye(d)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_generic_nuts_twin_equals_fixed_dimension_twin(O, mode):
+    """mm_nuts_generic.h (run-time D, vectors in a store) is mm_nuts.h operation for operation: at the dimensions both
+    have, the two host builds give the same bits -- samples, positions, adaptation state, tree shapes."""
+    rng = np.random.default_rng(4)
+    A6 = _spd(rng, 6)
+    for kind, dim, params, mat in ((O.ROSENBROCK_ND, 3, [], None), (O.ROSENBROCK_ND, 10, [], None), (O.STANDARD_NORMAL, 5, [], None),
+                                   (O.ISOTROPIC_GAUSSIAN, 7, [1.5], None), (O.GAUSSIAN_ND, 6, [], A6), (O.STANDARD_NORMAL, 1, [], None)):
+        init = O.init_with_seed(9, dim, 12) * 0.7
+        for progress in (False, True):
+            a = O.engine_host_nuts_run(mode, kind, dim, params, init, 0.8, 9, 6, seed=31, matrix=mat, progress=progress, n_threads=2)
+            b = O.engine_host_nuts_run(mode + 4, kind, dim, params, init, 0.8, 9, 6, seed=31, matrix=mat, progress=progress, n_threads=2)
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v), (kind, dim, mode, progress)
+
+
+def test_generic_nuts_twin_vs_recursive_oracle_at_new_dimensions(O):
+    """Dimensions without a fixed-D instance (RosenbrockND(11), GaussianND(40), IsotropicGaussian(.., 100)): the
+    run-time-D twin against the recursive restatement of nuts.rs (pinned by the reference's seeded vectors) on the
+    engine's stream, f64 -- identical tree shapes, samples to the rounding a trajectory amplifies."""
+    rng = np.random.default_rng(5)
+    A40 = _spd(rng, 40)
+    for kind, dim, params, mat, otgt in ((O.ROSENBROCK_ND, 11, [], None, O.rosenbrock_nd(11)), (O.GAUSSIAN_ND, 40, [], A40, O.gaussian_nd(A40)),
+                                         (O.ISOTROPIC_GAUSSIAN, 100, [1.5], None, O.isotropic_gaussian(1.5, 100)),
+                                         (O.STANDARD_NORMAL, 33, [], None, O.standard_normal(33))):
+        init = O.init_with_seed(6, dim, 17) * 0.5
+        out_e, pos_e, ad_e, nlf = O.engine_host_nuts_run(2, kind, dim, params, init, 0.8, 12, 10, seed=5, matrix=mat, n_threads=2)
+        s = O.NUTS(otgt, init, 0.8, mode=2).use_engine_stream(5).set_max_depth(10)
+        out_o = s.run(12, 10, n_threads=2)
+        lf_o = np.array([s.chain_state(i)["n_leapfrog_total"] for i in range(6)])
+        assert np.array_equal(nlf.astype(np.int64), lf_o.astype(np.int64)), (kind, dim)
+        np.testing.assert_allclose(out_e, out_o, rtol=1e-6, atol=1e-6, err_msg=f"kind {kind} D {dim}")
+        eps_o = np.array([s.chain_state(i)["epsilon"] for i in range(6)])
+        np.testing.assert_allclose(ad_e[:, 0], eps_o, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gpu_nuts_any_dimension_bit_exact_vs_host_build(M, O, mode):
+    """NUTS at dimensions without a fixed-D instance runs the run-time-D kernel (mm_nuts_generic.h, variant 6): bit-exact
+    against its host build; and where both exist (variant 6 forced) it equals the fixed-D kernel."""
+    from mini_mcmc_amd.nuts import NUTS
+
+    rng = np.random.default_rng(8)
+    A40, A5 = _spd(rng, 40), _spd(rng, 5)
+    for tgt, kind, params, mat in ((M.dist.RosenbrockND(11), O.ROSENBROCK_ND, [], None), (M.dist.IsotropicGaussian(1.5, 100), O.ISOTROPIC_GAUSSIAN, [1.5], None),
+                                   (M.dist.StandardNormal(33), O.STANDARD_NORMAL, [], None), (M.dist.GaussianND(A40), O.GAUSSIAN_ND, [], A40)):
+        init = M.core.init_with_seed(70, tgt.dim, 31) * 0.5
+        s = NUTS(tgt, init, 0.8, mode=mode).set_seed(77)
+        assert s.kernel_variant == 6
+        out = s._run(7, 6, False, "numpy")
+        ref, pos, ad, nlf = O.engine_host_nuts_run(mode, kind, tgt.dim, params, init, 0.8, 7, 6, seed=77, matrix=mat)
+        name = f"{type(tgt).__name__} D={tgt.dim} mode={mode}"
+        assert np.array_equal(out, ref) and np.array_equal(s.positions(), pos), name
+        assert np.array_equal(s.leapfrog_counts(), nlf), name
+        a = s.adapt_state()
+        assert np.array_equal(a["epsilon"], ad[:, 0]) and np.array_equal(a["h_bar"], ad[:, 2]), name
+        # a second run continues the chain (self.m, adaptation state) exactly like the host build does
+        out2 = s._run(5, 0, False, "numpy")
+        ref2, pos2, ad2, nlf2 = O.engine_host_nuts_run(mode, kind, tgt.dim, params, pos, 0.8, 5, 0, seed=77, matrix=mat, m0=12, adapt=ad)
+        assert np.array_equal(out2, ref2) and np.array_equal(s.positions(), pos2), name
+    for tgt in (M.dist.RosenbrockND(3), M.dist.GaussianND(A5), M.dist.IsotropicGaussian(0.7, 6)):
+        init = M.core.init_with_seed(130, tgt.dim, 3) * 0.6
+        a = NUTS(tgt, init, 0.8, mode=mode).set_seed(5)
+        b = NUTS(tgt, init, 0.8, mode=mode).set_seed(5).set_kernel_variant(6)
+        assert np.array_equal(a._run(6, 8, True, "numpy"), b._run(6, 8, True, "numpy")), type(tgt).__name__
+        assert np.array_equal(a.leapfrog_counts(), b.leapfrog_counts())
+        assert np.array_equal(a.depth_histogram(), b.depth_histogram())
+
+
+@pytest.mark.gpu
+def test_gpu_nuts_any_dimension_vs_recursive_oracle_and_posterior(M, O):
+    """The run-time-D NUTS kernel directly against the recursive restatement of nuts.rs (f64, engine stream) at D = 11 /
+    40 / 100: identical tree shapes, samples to rounding; and IsotropicGaussian(2, 20): posterior mean and variance."""
+    from mini_mcmc_amd.nuts import NUTS
+
+    rng = np.random.default_rng(9)
+    A40 = _spd(rng, 40)
+    for tgt, otgt in ((M.dist.RosenbrockND(11), O.rosenbrock_nd(11)), (M.dist.GaussianND(A40), O.gaussian_nd(A40)),
+                      (M.dist.IsotropicGaussian(1.5, 100), O.isotropic_gaussian(1.5, 100))):
+        init = M.core.init_with_seed(48, tgt.dim, 17) * 0.5
+        s = NUTS(tgt, init, 0.8, mode=2).set_seed(5)
+        out = s._run(10, 8, False, "numpy")
+        o = O.NUTS(otgt, init, 0.8, mode=2).use_engine_stream(5).set_max_depth(10)
+        ref = o.run(10, 8, n_threads=2)
+        lf_o = np.array([o.chain_state(i)["n_leapfrog_total"] for i in range(48)])
+        assert np.array_equal(s.leapfrog_counts().astype(np.int64), lf_o.astype(np.int64)), type(tgt).__name__
+        np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-6)
+    s = NUTS(M.dist.IsotropicGaussian(2.0, 20), M.core.init_with_seed(4096, 20, 1) * 0.5, 0.8, mode=0).set_seed(2)
+    x = s._run(60, 60, True, "numpy").reshape(-1, 20).astype(np.float64)
+    assert np.abs(x.mean(axis=0)).max() < 0.03 and np.abs(x.var(axis=0) / 4.0 - 1.0).max() < 0.02
