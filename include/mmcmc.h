@@ -236,9 +236,10 @@ int mmcmc_hmc_kernel_variant(mmcmc_hmc *h); /* the variant in use (>= 0) or a ne
  *     };
  * (P.p[0..8) = `params` of the mmcmc_target_desc a sampler is later created with, P.mat = its `matrix` [dim, dim] or
  * NULL; everything in csrc/mm_math.h / mm_targets.h -- mm_fma, mm_logf, mm_exp, ... -- is in scope) is compiled with
- * hipRTC into the engine's own MH / HMC kernel skeleton for f32 and f64 and registered under a new target kind
- * (>= MMCMC_USER_KIND_BASE), which mmcmc_mh_create, mmcmc_hmc_create, mmcmc_*_group_create and mmcmc_logp_grad_batch
- * then accept like a built-in kind (dim 1..32).  `log` (may be NULL) receives the compiler's diagnostics.
+ * hipRTC into the engine's own MH / HMC kernel skeleton for f32 and f64 and its one-chain-per-lane NUTS kernel for the
+ * three type modes (NUTS kernel variant 7), and registered under a new target kind (>= MMCMC_USER_KIND_BASE), which
+ * mmcmc_mh_create, mmcmc_hmc_create, mmcmc_nuts_create (nuts.rs:123-129 takes any GradientTarget), mmcmc_*_group_create
+ * and mmcmc_logp_grad_batch then accept like a built-in kind (dim 1..32).  `log` (may be NULL) receives the compiler's diagnostics.
  * MMCMC_ERR_INVALID_ARG: the source does not compile (see log); MMCMC_ERR_UNSUPPORTED: no libhiprtc on this machine. */
 #define MMCMC_USER_KIND_BASE 1000
 int mmcmc_target_register_source(const char *name, int dim, const char *hip_source, int *kind_out, char *log, size_t log_len);

@@ -51,8 +51,8 @@ MM_HD float mm_sqrtT(float x) { return sqrtf(x); }
 MM_HD double mm_sqrtT(double x) { return sqrt(x); }
 MM_HD float mm_minT(float a, float b) { return fminf(a, b); }
 MM_HD double mm_minT(double a, double b) { return fmin(a, b); }
-MM_HD bool mm_is_real(float x) { return x == x && x != INFINITY && x != -INFINITY; }
-MM_HD bool mm_is_real(double x) { return x == x && x != (double)INFINITY && x != -(double)INFINITY; }
+MM_HD bool mm_is_real(float x) { return x == x && x != MM_INFINITY_F && x != -MM_INFINITY_F; }
+MM_HD bool mm_is_real(double x) { return x == x && x != (double)MM_INFINITY_F && x != -(double)MM_INFINITY_F; }
 
 /* momentum draw: z[0..D) of (chain, iteration) in the element type's schedule (mm_rng.h) */
 template <int D> MM_HD void mm_nuts_momentum(uint64_t seed, uint64_t chain, uint32_t iter, float *z)

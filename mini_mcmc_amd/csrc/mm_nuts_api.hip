@@ -18,6 +18,7 @@
 #include "mm_nuts_kernels.h"
 #include "mm_nuts_lg.h"
 #include "mm_nuts_generic.h"
+#include "mm_rtc.h"
 #include "mm_params.h"
 
 #define MM_HIP(expr)                                                                                              \
@@ -83,6 +84,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
     const mm_nuts_entry<TT, ST> *k = nullptr;
     /* run-time-dimension path (mm_nuts_generic.h, variant 6): the only one where the table has no (kind, dim) entry */
     bool generic_ok = false;
+    const mm_user_target *user = nullptr; /* run-time compiled target (mm_rtc.hip, variant 7) */
+    size_t user_stack_bytes = 0, user_lds = 0;
     TT *d_gstore = nullptr;
     int gstore_depth = 0;
     size_t g_pad = 0;
@@ -147,14 +150,36 @@ template <class TT, class ST> struct Nuts : NutsBase {
             if (tab[i].kind == t->kind && tab[i].dim == t->dim)
                 k = &tab[i];
         generic_ok = mm_generic_kind_ok(t->kind) && t->dim >= 1;
-        if (!k && !generic_ok)
+        if (t->kind >= MM_USER_KIND_BASE) {
+            user = mm_rtc_find(t->kind);
+            if (!user)
+                return MMCMC_ERR_INVALID_ARG;
+            if (mm_rtc_dim(user) != t->dim)
+                return MMCMC_ERR_SHAPE;
+            /* mm_nuts_stack_layout<TT, ST, D>::bytes and the output tile of mm_tile<TT, D>, for a run-time D */
+            const size_t D = (size_t)t->dim, a16 = 15;
+            user_stack_bytes = (((size_t)MM_NUTS_JMAX * 3 * D * 64 * sizeof(TT) + a16) / 16 * 16) +
+                               (((size_t)MM_NUTS_JMAX * 64 * sizeof(ST) + a16) / 16 * 16) +
+                               (((size_t)MM_NUTS_JMAX * 3 * 64 * sizeof(uint32_t) + a16) / 16 * 16);
+            const int target = sizeof(TT) == 4 ? 96 : 48;
+            const int tile_t = (target / (int)D) >= 2 ? ((target / (int)D) & ~1) : 1;
+            const int run_len = tile_t * (int)D, epl = (int)(16 / sizeof(TT));
+            const int stride = (run_len % epl) == 0 ? run_len + epl : (run_len | 1);
+            user_lds = ((size_t)64 * stride * sizeof(TT) + 15) / 16 * 16; /* must mirror mm_kernels.h (mm_tile_default) */
+        } else if (!k && !generic_ok) {
             return MMCMC_ERR_UNSUPPORTED;
-        if (mm_fill_params<TT>(t->kind, t->params, &P) != 0)
+        }
+        if (user) {
+            for (int i = 0; i < 8; ++i) /* P.p[0..8) = the description's params (mm_rtc.hip) */
+                P.p[i] = (TT)t->params[i];
+            P.mat = nullptr;
+        } else if (mm_fill_params<TT>(t->kind, t->params, &P) != 0) {
             return MMCMC_ERR_INVALID_ARG;
+        }
         g_pad = (n_chains + 63) / 64 * 64;
         DevGuard g(device);
         const size_t cd = n_chains * (size_t)dim;
-        if (t->kind == MMCMC_GAUSSIAN_ND) {
+        if (t->kind == MMCMC_GAUSSIAN_ND || (user && t->matrix)) {
             std::vector<TT> h((size_t)dim * dim);
             for (size_t i = 0; i < h.size(); ++i)
                 h[i] = (TT)t->matrix[i];
@@ -190,6 +215,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 const size_t waves = (n_chains + 63) / 64;
                 MM_HIP(hipMalloc((void **)&d_scratch, waves * k->stack_bytes_per_wave));
             }
+        } else if (user) {
+            variant = 7;
+            const size_t waves = (n_chains + 63) / 64;
+            MM_HIP(hipMalloc((void **)&d_scratch, waves * user_stack_bytes));
+            stack_in_lds = false;
         } else {
             variant = 6;
         }
@@ -224,11 +254,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int set_variant(int v) override
     {
-        if ((v == 0 && k) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 6 && generic_ok)) {
+        if ((v == 0 && k) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 6 && generic_ok) || (v == 7 && user)) {
             variant = v;
             return MMCMC_OK;
         }
-        return (v >= 0 && v <= 6 && v != 5) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
+        return (v >= 0 && v <= 7 && v != 5) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
     }
 
     /* the lane-group launch exists for <double, double> only; the other instantiations never reach it */
@@ -494,8 +524,22 @@ template <class TT, class ST> struct Nuts : NutsBase {
             ga.target_accept_p = (ST)target_accept_p;
             ga.eps_tol = sizeof(ST) == 4 ? (ST)1.1920929e-7 : (ST)2.220446049250313e-16; /* T::epsilon() */
         }
-        hipError_t e = use_lg ? init_lg(st) : use_generic ? launch_generic(ga, 1, st)
-                                                          : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
+        const int type_mode = std::is_same<TT, double>::value ? 2 : (std::is_same<ST, double>::value ? 0 : 1);
+        const unsigned int grid64 = (unsigned int)((n_chains + 63) / 64);
+        hipError_t e;
+        if (variant == 7) {
+            mm_nuts_init_args<TT, ST> ia;
+            ia.P = P;
+            ia.state = d_state;
+            ia.adapt = d_adapt;
+            ia.n_chains = n_chains;
+            ia.seed = seed;
+            ia.chain_offset = chain_offset;
+            ia.eps_tol = sizeof(ST) == 4 ? (ST)1.1920929e-7 : (ST)2.220446049250313e-16;
+            e = mm_rtc_launch_nuts(user, type_mode, 1, &ia, sizeof(ia), grid64, 0, st);
+        } else {
+            e = use_lg ? init_lg(st) : use_generic ? launch_generic(ga, 1, st) : k->init(P, d_state, d_adapt, n_chains, seed, chain_offset, st);
+        }
         if (e != hipSuccess)
             return (int)e;
         mm_nuts_args<TT, ST> a;
@@ -539,7 +583,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
             a.n_rec = (unsigned int)n_collect;
         }
         MM_HIP(hipEventRecord(ev0, st));
-        if (use_generic) {
+        if (variant == 7) {
+            e = mm_rtc_launch_nuts(user, type_mode, 0, &a, sizeof(a), grid64, user_lds, st);
+        } else if (use_generic) {
             ga.out = d_out;
             ga.n_pre = a.n_pre;
             ga.n_rec = a.n_rec;

@@ -70,10 +70,17 @@ template <class TT, class ST, int D> struct mm_nuts_stack_layout {
 };
 
 /* init_chain for every chain (nuts.rs:528-545): epsilon search on the first run, mu = ln(10 eps) */
+template <class TT, class ST> struct mm_nuts_init_args { /* the same as one block, for the kernels of user targets (mm_rtc.hip) */
+    mm_tparams<TT> P;
+    const TT *state;
+    mm_nuts_adapt<ST> *adapt;
+    unsigned long long n_chains, seed, chain_offset;
+    ST eps_tol;
+};
 template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
-__global__ void mm_nuts_init_kernel(const mm_tparams<TT> P, const TT *state, mm_nuts_adapt<ST> *adapt,
-                                    unsigned long long n_chains, unsigned long long seed,
-                                    unsigned long long chain_offset, ST eps_tol)
+__device__ __forceinline__ void mm_nuts_init_body(const mm_tparams<TT> &P, const TT *state, mm_nuts_adapt<ST> *adapt,
+                                                  unsigned long long n_chains, unsigned long long seed,
+                                                  unsigned long long chain_offset, ST eps_tol)
 {
     constexpr int D = Tgt::dim;
     const unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,11 +94,18 @@ __global__ void mm_nuts_init_kernel(const mm_tparams<TT> P, const TT *state, mm_
     mm_nuts_init_chain<TT, ST, Tgt, Red>(P, x, &ad, eps_tol, seed, chain_offset + c);
     adapt[c] = ad;
 }
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
+__global__ void mm_nuts_init_kernel(const mm_tparams<TT> P, const TT *state, mm_nuts_adapt<ST> *adapt,
+                                    unsigned long long n_chains, unsigned long long seed,
+                                    unsigned long long chain_offset, ST eps_tol)
+{
+    mm_nuts_init_body<TT, ST, Tgt, Red>(P, state, adapt, n_chains, seed, chain_offset, eps_tol);
+}
 
 /* LDS_STACK is a template parameter, not a run-time choice: a pointer that may be LDS or HBM is a generic pointer and
  * every stack access a flat_load / flat_store (which is what these kernels did at first, stack "in LDS" included). */
 template <class TT, class ST, class Tgt, bool LDS_STACK>
-__global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, ST> a)
+__device__ __forceinline__ void mm_nuts_run_body(const mm_nuts_args<TT, ST> &a)
 {
     constexpr int D = Tgt::dim;
     using Tile = mm_tile<TT, D>;
@@ -176,6 +190,11 @@ __global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, 
         if (a.n_leapfrog)
             a.n_leapfrog[c] += n_lf;
     }
+}
+template <class TT, class ST, class Tgt, bool LDS_STACK>
+__global__ __launch_bounds__(64) void mm_nuts_run_kernel(const mm_nuts_args<TT, ST> a)
+{
+    mm_nuts_run_body<TT, ST, Tgt, LDS_STACK>(a);
 }
 
 #define MM_NUTS_ASYNC_LDS_LIMIT (40u * 1024u) /* four waves per CU must fit 160 KB */
@@ -309,6 +328,7 @@ __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT
     }
 }
 
+#if !defined(__HIPCC_RTC__) /* host side: not part of the run-time compiled kernels of user targets (mm_rtc.hip) */
 template <class TT, class ST, class Tgt>
 hipError_t mm_launch_nuts_run_async(const mm_nuts_args<TT, ST> &a, hipStream_t stream)
 {
@@ -375,5 +395,6 @@ struct mm_nuts_lg_entry {
     size_t rec_doubles_per_chain;
 };
 const mm_nuts_lg_entry *mm_nuts_lg_table(int *n);
+#endif /* !__HIPCC_RTC__ */
 
 #endif /* MM_NUTS_KERNELS_H */

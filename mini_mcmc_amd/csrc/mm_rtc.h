@@ -12,6 +12,10 @@ int mm_rtc_dim(const mm_user_target *t);
 /* kernels of a registered target: sampler 0 MH / 1 HMC, dtype 0 f32 / 1 f64; `args` = the mm_run_args<T> block */
 hipError_t mm_rtc_launch_run(const mm_user_target *t, int sampler, int dtype, void *args, size_t args_bytes, unsigned int grid,
                              unsigned int block, size_t lds, hipStream_t stream);
+/* NUTS kernels of a registered target: mode 0 / 1 / 2 (mm_nuts_api.hip), init != 0: init_chain (`args` = mm_nuts_init_args<TT, ST>),
+ * else the run (`args` = mm_nuts_args<TT, ST>, stack in the HBM scratch area); one wave per workgroup */
+hipError_t mm_rtc_launch_nuts(const mm_user_target *t, int mode, int init, void *args, size_t args_bytes, unsigned int grid, size_t lds,
+                              hipStream_t stream);
 /* unnorm_logp / unnorm_logp_and_grad of n rows; `args` = {mm_tparams<T> P, const T *x, T *logp, T *grad, u64 n} packed */
 hipError_t mm_rtc_launch_logp_grad(const mm_user_target *t, int dtype, void *args, size_t args_bytes, unsigned long long n,
                                    hipStream_t stream);

@@ -152,7 +152,7 @@ class UserTarget(Target):
 
     `source` is HIP C++ defining `template <class T> struct mmcmc_user_target` with `static constexpr int dim`,
     `logp(P, x)` and `logp_grad(P, x, g)` (include/mmcmc.h: mmcmc_target_register_source); it is compiled at run time
-    (hipRTC) into the engine's MH / HMC kernels for f32 and f64.  `params` (up to 8 numbers) arrive as `P.p[i]`,
+    (hipRTC) into the engine's MH / HMC kernels for f32 and f64 and its NUTS kernel for the three type modes.  `params` (up to 8 numbers) arrive as `P.p[i]`,
     `matrix` ([dim, dim]) as `P.mat`.  `UserTarget.compile_log` holds the compiler's diagnostics."""
 
     def __init__(self, name: str, dim: int, source: str, params=(), matrix=None):
