@@ -274,6 +274,20 @@ int mmcmc_mh_group_run(mmcmc_mh_group *g, size_t n_collect, size_t n_discard, vo
 int mmcmc_mh_group_state(mmcmc_mh_group *g, void *out);
 int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *g, float *rhat, float *ess, int *used_rccl);
 int mmcmc_mh_group_destroy(mmcmc_mh_group *g);
+/* NUTS::run / run_progress (nuts.rs:163-170, 194-338) of every chain on N devices: `init` host [n_chains, dim] doubles
+ * and `mode` as in mmcmc_nuts_create; out_host [n_chains, n_collect, dim] of the mode's tensor type (f32 for modes 0 and
+ * 1, f64 for mode 2) or NULL; progress as in mmcmc_nuts_run.  Chain i's results do not depend on the number of devices. */
+typedef struct mmcmc_nuts_group mmcmc_nuts_group;
+int mmcmc_nuts_group_create(mmcmc_nuts_group **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
+                            double target_accept_p, int mode, const int *devices, int n_devices);
+int mmcmc_nuts_group_seed(mmcmc_nuts_group *g, uint64_t seed);
+int mmcmc_nuts_group_set_chain_offset(mmcmc_nuts_group *g, uint64_t first_global_chain);
+int mmcmc_nuts_group_set_max_depth(mmcmc_nuts_group *g, int max_depth);
+int mmcmc_nuts_group_run(mmcmc_nuts_group *g, size_t n_collect, size_t n_discard, void *out_host, int progress);
+int mmcmc_nuts_group_state(mmcmc_nuts_group *g, void *out); /* host [n_chains, dim] of the tensor type */
+int mmcmc_nuts_group_leapfrog_counts(mmcmc_nuts_group *g, uint64_t *out); /* host [n_chains] */
+int mmcmc_nuts_group_split_rhat_mean_ess(mmcmc_nuts_group *g, float *rhat, float *ess, int *used_rccl);
+int mmcmc_nuts_group_destroy(mmcmc_nuts_group *g);
 
 /* ---- diagnostics: stats.rs ------------------------------------------------------------------------------
  * split_rhat_mean_ess(sample[chains, n, params]) -> (rhat[params], ess[params])   stats.rs:416-423

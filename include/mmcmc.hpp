@@ -309,6 +309,42 @@ template <class T> class NUTS {
     }
 };
 
+/* NUTS over several GPUs from one call (mmcmc_nuts_group_*): tensors f32, scalars T, like NUTS<T> */
+template <class T> class NUTSGroup {
+    mmcmc_nuts_group *g_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    NUTSGroup(Target target, const std::vector<T> &initial_positions, size_t n_chains, T target_accept_p, const std::vector<int> &devices)
+        : n_chains_(n_chains), dim_(initial_positions.size() / n_chains)
+    {
+        std::vector<double> init(initial_positions.begin(), initial_positions.end());
+        check(mmcmc_nuts_group_create(&g_, target.desc(), init.data(), n_chains, (double)target_accept_p,
+                                      std::is_same<T, double>::value ? 0 : 1, devices.data(), (int)devices.size()),
+              "mmcmc_nuts_group_create");
+    }
+    NUTSGroup(const NUTSGroup &) = delete;
+    NUTSGroup &operator=(const NUTSGroup &) = delete;
+    ~NUTSGroup() { mmcmc_nuts_group_destroy(g_); }
+    NUTSGroup &set_seed(uint64_t s)
+    {
+        check(mmcmc_nuts_group_seed(g_, s), "mmcmc_nuts_group_seed");
+        return *this;
+    }
+    std::vector<float> run(size_t n_collect, size_t n_discard)
+    {
+        std::vector<float> out(n_chains_ * n_collect * dim_);
+        check(mmcmc_nuts_group_run(g_, n_collect, n_discard, out.data(), 0), "mmcmc_nuts_group_run");
+        return out;
+    }
+    std::pair<std::vector<float>, std::vector<float>> split_rhat_mean_ess()
+    {
+        std::vector<float> rhat(dim_), ess(dim_);
+        check(mmcmc_nuts_group_split_rhat_mean_ess(g_, rhat.data(), ess.data(), nullptr), "mmcmc_nuts_group_split_rhat_mean_ess");
+        return {rhat, ess};
+    }
+};
+
 /* NUTS in f64 tensors / f64 scalars (mode 2 of the C ABI; BASELINE.json config 5): for mmcmc::GaussianND of dim 16
  * or 32 this runs the lane-group / MFMA kernel with tree-depth compaction (include/mmcmc.h, kernel variants). */
 class NUTS64 {

@@ -154,6 +154,15 @@ SIGNATURES = {
     "mmcmc_mh_group_state": (C.c_int, [_vp, _vp]),
     "mmcmc_mh_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mmcmc_mh_group_destroy": (C.c_int, [_vp]),
+    "mmcmc_nuts_group_create": (C.c_int, [C.POINTER(_vp), _TP, C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "mmcmc_nuts_group_seed": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_nuts_group_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
+    "mmcmc_nuts_group_set_max_depth": (C.c_int, [_vp, C.c_int]),
+    "mmcmc_nuts_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int]),
+    "mmcmc_nuts_group_state": (C.c_int, [_vp, _vp]),
+    "mmcmc_nuts_group_leapfrog_counts": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "mmcmc_nuts_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mmcmc_nuts_group_destroy": (C.c_int, [_vp]),
 }
 
 

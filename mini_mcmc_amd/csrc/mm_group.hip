@@ -129,6 +129,7 @@ struct Shard {
     size_t first = 0, n = 0; /* global chains [first, first + n) */
     mmcmc_hmc *hmc = nullptr;
     mmcmc_mh *mh = nullptr;
+    mmcmc_nuts *nuts = nullptr;
     void *d_sample = nullptr; /* [n, n_collect, dim] of the last run, on the device */
     size_t sample_cap = 0;
     hipStream_t stream = nullptr;
@@ -139,7 +140,8 @@ struct Shard {
 };
 
 struct Group {
-    int sampler = 0; /* 0 MH, 1 HMC */
+    int sampler = 0; /* 0 MH, 1 HMC, 2 NUTS */
+    int progress = 0; /* NUTS: run (N - 1 transitions) or run_progress stepping (nuts.rs:457-471 / 491-522) */
     int dtype = MMCMC_F32, dim = 0;
     size_t n_chains = 0, cmax = 0;
     size_t last_collect = 0;
@@ -178,6 +180,8 @@ int group_destroy(Group *g)
             (void)mmcmc_hmc_destroy(s.hmc);
         if (s.mh)
             (void)mmcmc_mh_destroy(s.mh);
+        if (s.nuts)
+            (void)mmcmc_nuts_destroy(s.nuts);
         if (s.d_sample)
             (void)hipFree(s.d_sample);
         if (s.d_stats)
@@ -228,12 +232,16 @@ int group_create(Group **out, int sampler, const mmcmc_target_desc *target, cons
         g->cmax = s.n > g->cmax ? s.n : g->cmax;
     }
     const int st = for_each_shard(g, [&](Shard &s, int) -> int {
-        const char *p = (const char *)init + s.first * (size_t)g->dim * esz;
-        int rc = sampler ? mmcmc_hmc_create(&s.hmc, target, p, s.n, scale, n_leapfrog, dtype, s.device)
-                         : mmcmc_mh_create(&s.mh, target, proposal, p, s.n, dtype, s.device);
+        /* NUTS: init is [n_chains, dim] doubles whatever the mode (Vec<Vec<T>>, nuts.rs:123-129); scale = target_accept_p,
+         * n_leapfrog = the type mode */
+        const char *p = (const char *)init + s.first * (size_t)g->dim * (sampler == 2 ? sizeof(double) : esz);
+        int rc = sampler == 2   ? mmcmc_nuts_create(&s.nuts, target, (const double *)p, s.n, scale, n_leapfrog, s.device)
+                 : sampler == 1 ? mmcmc_hmc_create(&s.hmc, target, p, s.n, scale, n_leapfrog, dtype, s.device)
+                                : mmcmc_mh_create(&s.mh, target, proposal, p, s.n, dtype, s.device);
         if (rc != MMCMC_OK)
             return rc;
-        rc = sampler ? mmcmc_hmc_set_chain_offset(s.hmc, s.first) : mmcmc_mh_set_chain_offset(s.mh, s.first);
+        rc = sampler == 2 ? mmcmc_nuts_set_chain_offset(s.nuts, s.first)
+                          : sampler ? mmcmc_hmc_set_chain_offset(s.hmc, s.first) : mmcmc_mh_set_chain_offset(s.mh, s.first);
         if (rc != MMCMC_OK)
             return rc;
         if (hipSetDevice(s.device) != hipSuccess)
@@ -254,7 +262,7 @@ int group_seed(Group *g, uint64_t seed)
     if (!g)
         return MMCMC_ERR_INVALID_ARG;
     for (Shard &s : g->sh) {
-        const int rc = g->sampler ? mmcmc_hmc_seed(s.hmc, seed) : mmcmc_mh_seed(s.mh, seed);
+        const int rc = g->sampler == 2 ? mmcmc_nuts_seed(s.nuts, seed) : g->sampler ? mmcmc_hmc_seed(s.hmc, seed) : mmcmc_mh_seed(s.mh, seed);
         if (rc != MMCMC_OK)
             return rc;
     }
@@ -267,7 +275,9 @@ int group_set_chain_offset(Group *g, uint64_t off)
         return MMCMC_ERR_INVALID_ARG;
     g->user_offset = off;
     for (Shard &s : g->sh) {
-        const int rc = g->sampler ? mmcmc_hmc_set_chain_offset(s.hmc, off + s.first) : mmcmc_mh_set_chain_offset(s.mh, off + s.first);
+        const int rc = g->sampler == 2 ? mmcmc_nuts_set_chain_offset(s.nuts, off + s.first)
+                       : g->sampler    ? mmcmc_hmc_set_chain_offset(s.hmc, off + s.first)
+                                       : mmcmc_mh_set_chain_offset(s.mh, off + s.first);
         if (rc != MMCMC_OK)
             return rc;
     }
@@ -297,8 +307,9 @@ int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint
         }
         uint64_t *acc = accept_counts ? accept_counts + s.first : nullptr;
         void *d_out = n_collect ? s.d_sample : nullptr;
-        int rc = g->sampler ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, acc, s.stream)
-                            : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, acc, s.stream);
+        int rc = g->sampler == 2 ? mmcmc_nuts_run(s.nuts, n_collect, n_discard, d_out, 1, g->progress, s.stream)
+                 : g->sampler    ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, acc, s.stream)
+                                 : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, acc, s.stream);
         if (rc != MMCMC_OK)
             return rc;
         hipError_t e = hipSuccess;
@@ -320,7 +331,7 @@ int group_state(Group *g, void *out)
     const size_t esz = g->esize();
     return for_each_shard(g, [&](Shard &s, int) -> int {
         void *p = (char *)out + s.first * (size_t)g->dim * esz;
-        return g->sampler ? mmcmc_hmc_state(s.hmc, p) : mmcmc_mh_state(s.mh, p);
+        return g->sampler == 2 ? mmcmc_nuts_state(s.nuts, p) : g->sampler ? mmcmc_hmc_state(s.hmc, p) : mmcmc_mh_state(s.mh, p);
     });
 }
 
@@ -427,6 +438,9 @@ struct mmcmc_hmc_group {
 struct mmcmc_mh_group {
     Group *g;
 };
+struct mmcmc_nuts_group {
+    Group *g;
+};
 
 extern "C" {
 
@@ -511,6 +525,66 @@ int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *h, float *rhat, float *es
     return h ? group_split_rhat_ess(h->g, rhat, ess, used_rccl) : MMCMC_ERR_INVALID_ARG;
 }
 int mmcmc_mh_group_destroy(mmcmc_mh_group *h)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    const int st = group_destroy(h->g);
+    delete h;
+    return st;
+}
+
+/* NUTS::run / run_progress (nuts.rs:163-170, 194-338) over N devices: `init` [n_chains, dim] doubles, mode as in
+ * mmcmc_nuts_create; the sample is of the mode's tensor type (f32 for modes 0 and 1, f64 for mode 2) */
+int mmcmc_nuts_group_create(mmcmc_nuts_group **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
+                            double target_accept_p, int mode, const int *devices, int n_devices)
+{
+    if (!out || mode < 0 || mode > 2)
+        return MMCMC_ERR_INVALID_ARG;
+    *out = nullptr;
+    Group *g = nullptr;
+    const int st = group_create(&g, 2, target, nullptr, init, n_chains, target_accept_p, mode, mode == 2 ? MMCMC_F64 : MMCMC_F32, devices,
+                                n_devices);
+    if (st != MMCMC_OK)
+        return st;
+    *out = new (std::nothrow) mmcmc_nuts_group{g};
+    if (!*out) {
+        group_destroy(g);
+        return (int)hipErrorOutOfMemory;
+    }
+    return MMCMC_OK;
+}
+int mmcmc_nuts_group_seed(mmcmc_nuts_group *h, uint64_t seed) { return h ? group_seed(h->g, seed) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_nuts_group_set_chain_offset(mmcmc_nuts_group *h, uint64_t off) { return h ? group_set_chain_offset(h->g, off) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_nuts_group_set_max_depth(mmcmc_nuts_group *h, int max_depth)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    for (Shard &s : h->g->sh) {
+        const int rc = mmcmc_nuts_set_max_depth(s.nuts, max_depth);
+        if (rc != MMCMC_OK)
+            return rc;
+    }
+    return MMCMC_OK;
+}
+int mmcmc_nuts_group_run(mmcmc_nuts_group *h, size_t n_collect, size_t n_discard, void *out_host, int progress)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    h->g->progress = progress ? 1 : 0;
+    return group_run(h->g, n_collect, n_discard, out_host, nullptr);
+}
+int mmcmc_nuts_group_state(mmcmc_nuts_group *h, void *out) { return h ? group_state(h->g, out) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_nuts_group_leapfrog_counts(mmcmc_nuts_group *h, uint64_t *out)
+{
+    if (!h || !out)
+        return MMCMC_ERR_INVALID_ARG;
+    return for_each_shard(h->g, [&](Shard &s, int) -> int { return mmcmc_nuts_leapfrog_counts(s.nuts, out + s.first); });
+}
+int mmcmc_nuts_group_split_rhat_mean_ess(mmcmc_nuts_group *h, float *rhat, float *ess, int *used_rccl)
+{
+    return h ? group_split_rhat_ess(h->g, rhat, ess, used_rccl) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_group_destroy(mmcmc_nuts_group *h)
 {
     if (!h)
         return MMCMC_ERR_INVALID_ARG;

@@ -119,3 +119,43 @@ class MetropolisHastingsGroup(_Group):
     def seed(self, seed: int) -> "MetropolisHastingsGroup":
         L.check(L.lib().mmcmc_mh_group_seed(self._h, int(seed)), "mmcmc_mh_group_seed")
         return self
+
+
+class NUTSGroup(_Group):
+    """NUTS::new(target, initial_positions, target_accept_p) (nuts.rs:123-129) over `devices`; mode as in `nuts.NUTS`."""
+
+    _prefix = "nuts"
+
+    def __init__(self, target: Target, initial_positions, target_accept_p: float, mode: int = 0, devices=(0,)):
+        init = np.ascontiguousarray(initial_positions, dtype=np.float64)
+        self.n_chains, self.dim = init.shape
+        self.mode = int(mode)
+        self.dtype = np.float64 if self.mode == 2 else np.float32
+        self.devices = [int(d) for d in devices]
+        dev = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        d = target.desc()
+        st = L.lib().mmcmc_nuts_group_create(C.byref(self._h), C.byref(d), init.ctypes.data_as(C.POINTER(C.c_double)), self.n_chains,
+                                             float(target_accept_p), self.mode, dev, len(self.devices))
+        L.check(st, "mmcmc_nuts_group_create")
+
+    def set_seed(self, seed: int) -> "NUTSGroup":
+        L.check(L.lib().mmcmc_nuts_group_seed(self._h, int(seed)), "mmcmc_nuts_group_seed")
+        return self
+
+    def set_max_depth(self, max_depth: int) -> "NUTSGroup":
+        L.check(L.lib().mmcmc_nuts_group_set_max_depth(self._h, int(max_depth)), "mmcmc_nuts_group_set_max_depth")
+        return self
+
+    def run(self, n_collect: int, n_discard: int = 0, to_host: bool = True, progress: bool = False):
+        """NUTS::run (N - 1 transitions, row 0 may be the initial point, nuts.rs:457-471) or, progress=True, the stepping
+        of run_progress (nuts.rs:491-522); sample [n_chains, n_collect, dim] of the mode's tensor type."""
+        out = np.empty((self.n_chains, n_collect, self.dim), dtype=self.dtype) if to_host else None
+        st = L.lib().mmcmc_nuts_group_run(self._h, n_collect, n_discard, out.ctypes.data if to_host else None, int(progress))
+        L.check(st, "mmcmc_nuts_group_run")
+        return out
+
+    def leapfrog_counts(self) -> np.ndarray:
+        out = np.zeros(self.n_chains, dtype=np.uint64)
+        L.check(L.lib().mmcmc_nuts_group_leapfrog_counts(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "group_leapfrog_counts")
+        return out

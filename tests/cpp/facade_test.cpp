@@ -110,6 +110,21 @@ int main(int argc, char **argv)
             auto re = grp.split_rhat_mean_ess();
             REQUIRE(re.first.size() == 3 && re.second[0] > 1.0f);
         }
+        // the same for NUTS, and NUTS at a dimension without a compiled instance (RosenbrockND(11): run-time-D kernel)
+        {
+            auto init3 = init_with_seed<double>(90, 3, 42);
+            for (auto &v : init3)
+                v *= 0.5;
+            NUTS<double> one(RosenbrockND(3), init3, 90, 0.8);
+            NUTSGroup<double> grp(RosenbrockND(3), init3, 90, 0.8, {0, 0});
+            REQUIRE(one.set_seed(7).run(12, 8) == grp.set_seed(7).run(12, 8));
+            auto init11 = init_with_seed<double>(40, 11, 1);
+            for (auto &v : init11)
+                v *= 0.3;
+            NUTS<double> n11(RosenbrockND(11), init11, 40, 0.8);
+            auto s11 = n11.set_seed(2).run(6, 6);
+            REQUIRE(s11.size() == 40u * 6u * 11u && std::isfinite(s11.back()));
+        }
         // a target of the user's own, compiled at run time: a restatement of StandardNormal(2) must reproduce the built-in
         {
             const char *src =

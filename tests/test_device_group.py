@@ -22,7 +22,7 @@ def test_group_symbols_exported_and_no_device_without_gpu():
 
     lib = mini_mcmc_amd.lib()
     for sym in ("create", "seed", "set_chain_offset", "run", "state", "split_rhat_mean_ess", "destroy"):
-        assert hasattr(lib, "mmcmc_hmc_group_" + sym) and hasattr(lib, "mmcmc_mh_group_" + sym)
+        assert hasattr(lib, "mmcmc_hmc_group_" + sym) and hasattr(lib, "mmcmc_mh_group_" + sym) and hasattr(lib, "mmcmc_nuts_group_" + sym)
     if not torch.cuda.is_available():
         from mini_mcmc_amd.distributions import RosenbrockND
 
@@ -102,3 +102,32 @@ def test_group_over_two_real_devices_uses_rccl():
     r0, e0 = S.split_rhat_mean_ess(ref)
     np.testing.assert_allclose(r1, r0, rtol=2e-6)
     np.testing.assert_allclose(e1, e0, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_nuts_group_reproduces_single_handle_run(O, devices):
+    """mmcmc_nuts_group_*: NUTS::run of every chain from one call; shards keyed by the global chain index, so the sample,
+    tree shapes and positions equal the single-handle run bit for bit (one-chain-per-lane kernel on RosenbrockND(3), the
+    lane-group / scheduler kernel on the 32-D Gaussian of config 5), and the diagnostics match the single-GPU entry."""
+    from mini_mcmc_amd import stats as S
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import GaussianND, RosenbrockND
+    from mini_mcmc_amd.group import NUTSGroup
+    from mini_mcmc_amd.nuts import NUTS
+
+    for tgt, mode, C_, scale in ((RosenbrockND(3), 0, 1000, 0.5), (GaussianND.ill_conditioned(32, 100.0, 5), 2, 700, 0.1)):
+        init = init_with_seed(C_, tgt.dim, 42) * scale
+        for progress in (False, True):
+            one = NUTS(tgt, init, 0.8, mode=mode).set_seed(42)
+            ref = one._run(40, 24, progress, "numpy")
+            g = NUTSGroup(tgt, init, 0.8, mode=mode, devices=devices).set_seed(42)
+            out = g.run(40, 24, progress=progress)
+            assert np.array_equal(out, ref), (type(tgt).__name__, progress)
+            assert np.array_equal(g.state(), one.positions()) and np.array_equal(g.leapfrog_counts(), one.leapfrog_counts())
+            r0, e0 = S.split_rhat_mean_ess(ref)
+            r1, e1 = g.split_rhat_mean_ess()
+            assert g.used_rccl == (len(devices) == 1)
+            np.testing.assert_allclose(r1, r0, rtol=2e-4)
+            np.testing.assert_allclose(e1, e0, rtol=2e-3)
+            g.close()
