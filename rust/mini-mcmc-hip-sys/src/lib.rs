@@ -51,6 +51,10 @@ pub struct mmcmc_nuts {
 pub struct mmcmc_hmc_group {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct mmcmc_nuts_group {
+    _p: [u8; 0],
+}
 
 pub const MMCMC_OK: c_int = 0;
 pub const MMCMC_ERR_INVALID_ARG: c_int = -1;
@@ -182,6 +186,21 @@ extern "C" {
     ) -> c_int;
     pub fn mmcmc_hmc_group_split_rhat_mean_ess(g: *mut mmcmc_hmc_group, rhat: *mut f32, ess: *mut f32, used_rccl: *mut c_int) -> c_int;
     pub fn mmcmc_hmc_group_destroy(g: *mut mmcmc_hmc_group) -> c_int;
+    /// NUTS::run / run_progress (nuts.rs:163-170, 194-338) of every chain on several GPUs; init: [n_chains, dim] f64
+    pub fn mmcmc_nuts_group_create(
+        out: *mut *mut mmcmc_nuts_group,
+        target: *const mmcmc_target_desc,
+        init: *const c_double,
+        n_chains: usize,
+        target_accept_p: c_double,
+        mode: c_int,
+        devices: *const c_int,
+        n_devices: c_int,
+    ) -> c_int;
+    pub fn mmcmc_nuts_group_seed(g: *mut mmcmc_nuts_group, seed: u64) -> c_int;
+    pub fn mmcmc_nuts_group_run(g: *mut mmcmc_nuts_group, n_collect: usize, n_discard: usize, out_host: *mut c_void, progress: c_int) -> c_int;
+    pub fn mmcmc_nuts_group_split_rhat_mean_ess(g: *mut mmcmc_nuts_group, rhat: *mut f32, ess: *mut f32, used_rccl: *mut c_int) -> c_int;
+    pub fn mmcmc_nuts_group_destroy(g: *mut mmcmc_nuts_group) -> c_int;
 
     /// stats::split_rhat_mean_ess (stats.rs:416-423); rhat = sqrt(W / var+), the crate's definition
     pub fn mmcmc_split_rhat_mean_ess(
