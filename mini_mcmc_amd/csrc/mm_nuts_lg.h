@@ -230,6 +230,26 @@ __device__ __forceinline__ double mm_lg_accept_prob(double d)
     return fmin(1.0, e);
 }
 
+/* Two group sums at once: both land in all four lanes of the chain, each the same (c0 + c1) + (c2 + c3) as
+ * mm_lg_group_sum (bit for bit), in 12 instructions instead of 2 x 10: the first swap pairs the rows of a with the
+ * rows of b ([a0 b0 a2 b2] + [a1 b1 a3 b3]), the second folds the halves ([A B A B]), the third separates A from B. */
+__device__ __forceinline__ void mm_lg_group_sum2(double a, double b, double *sum_a, double *sum_b)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    auto lo = [](double v) { return (unsigned int)__double2loint(v); };
+    auto hi = [](double v) { return (unsigned int)__double2hiint(v); };
+    u2 l = __builtin_amdgcn_permlane16_swap(lo(a), lo(b), false, false);
+    u2 h = __builtin_amdgcn_permlane16_swap(hi(a), hi(b), false, false);
+    double s = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]); /* [A01 B01 A23 B23] */
+    l = __builtin_amdgcn_permlane32_swap(lo(s), lo(s), false, false);
+    h = __builtin_amdgcn_permlane32_swap(hi(s), hi(s), false, false);
+    s = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);        /* [A B A B] */
+    l = __builtin_amdgcn_permlane16_swap(lo(s), lo(s), false, false);
+    h = __builtin_amdgcn_permlane16_swap(hi(s), hi(s), false, false);
+    *sum_a = __hiloint2double((int)h[0], (int)l[0]);
+    *sum_b = __hiloint2double((int)h[1], (int)l[1]);
+}
+
 template <int NS> __device__ __forceinline__ double mm_lg_dot(const double *a, const double *b)
 {
     double c = 0;
@@ -243,7 +263,7 @@ template <int NS> __device__ __forceinline__ double mm_lg_dot(const double *a, c
  * (registers and edge records) and kick with -h -- fma(-h, y, p) and fma(h, -y, p) round the same exact product, so
  * this is the twin's fma(h, g, p) bit for bit, without eight negations per leaf */
 template <int D, bool ALDS = false, class Lane>
-__device__ __forceinline__ double mm_lg_logp_ax(const Lane &L, const double *x, double *y)
+__device__ __forceinline__ void mm_lg_ax(const Lane &L, const double *x, double *y)
 {
     constexpr int NS = D / 4, NT = D / 16;
 #if MM_LG_ASM_MFMA
@@ -285,7 +305,7 @@ __device__ __forceinline__ double mm_lg_logp_ax(const Lane &L, const double *x, 
             y[r] = acc0[r];
             y[4 + r] = acc1[r];
         }
-        return -0.5 * mm_lg_dot<NS>(x, y);
+        return;
     } else if constexpr (!ALDS && D == 16) {
         mm_d4 acc0;
         asm volatile("s_nop 1\n"
@@ -301,7 +321,7 @@ __device__ __forceinline__ double mm_lg_logp_ax(const Lane &L, const double *x, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             y[r] = acc0[r];
-        return -0.5 * mm_lg_dot<NS>(x, y);
+        return;
     }
 #endif
 #pragma unroll
@@ -318,7 +338,12 @@ __device__ __forceinline__ double mm_lg_logp_ax(const Lane &L, const double *x, 
         for (int r = 0; r < 4; ++r)
             y[4 * t + r] = acc[r];
     }
-    return -0.5 * mm_lg_dot<NS>(x, y);
+}
+template <int D, bool ALDS = false, class Lane>
+__device__ __forceinline__ double mm_lg_logp_ax(const Lane &L, const double *x, double *y)
+{
+    mm_lg_ax<D, ALDS>(L, x, y);
+    return -0.5 * mm_lg_dot<D / 4>(x, y);
 }
 
 /* Loads / stores of data that is handed from wave to wave INSIDE a kernel (persistent scheduler): agent-scope relaxed
@@ -569,12 +594,18 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             cx[s] = fma(epsv, cp[s], cx[s]);
         }
         MM_LG_TICK(L, 8);
-        const double lp = mm_lg_logp_ax<D, OCC == 2>(L, cx, cg); /* cg = A x */
+        mm_lg_ax<D, OCC == 2>(L, cx, cg); /* cg = A x */
         MM_LG_TICK(L, 9);
+        double xy = 0.0, pp = 0.0; /* x . A x and p . p, reduced together */
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s) {
             cp[s] = fma(nh, cg[s], cp[s]);
-        const double jointp = lp - mm_lg_dot<NS>(cp, cp) * 0.5;
+            xy = fma(cx[s], cg[s], xy);
+            pp = fma(cp[s], cp[s], pp);
+        }
+        mm_lg_group_sum2(xy, pp, &xy, &pp);
+        const double lp = -0.5 * xy;
+        const double jointp = lp - pp * 0.5;
         /* the proposal of a one-leaf subtree is the leaf itself: S_prime is not set here but by the level-0 merge,
          * which picks between the pair's two leaves (cx and the copy of the first one) */
         if (!done) {
@@ -624,8 +655,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             ca = fma(d, fp[s], ca);
             cb = fma(d, cp[s], cb);
         }
-        ca = mm_lg_group_sum(ca);
-        cb = mm_lg_group_sum(cb);
+        mm_lg_group_sum2(ca, cb, &ca, &cb);
         const bool crit = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
         bool take2 = false;
         if (walking) {
@@ -807,8 +837,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         ca = fma(d, ops, ca);
         cb = fma(d, cp[s], cb);
     }
-    ca = mm_lg_group_sum(ca);
-    cb = mm_lg_group_sum(cb);
+    mm_lg_group_sum2(ca, cb, &ca, &cb);
     const bool crit_all = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
     const double tmp = fmin(1.0, (double)S_n / (double)L.n);
     const double u_run_2 = mm_lg_aux_peek<D>(L, a.seed);
