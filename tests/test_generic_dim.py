@@ -279,6 +279,17 @@ def test_gpu_nuts_any_dimension_bit_exact_vs_host_build(M, O, mode):
         out2 = s._run(5, 0, False, "numpy")
         ref2, pos2, ad2, nlf2 = O.engine_host_nuts_run(mode, kind, tgt.dim, params, pos, 0.8, 5, 0, seed=77, matrix=mat, m0=12, adapt=ad)
         assert np.array_equal(out2, ref2) and np.array_equal(s.positions(), pos2), name
+    # a different depth cap (the store is re-sized), run_progress stepping, one dimension, a chain count that is not a multiple of 64
+    tgt = M.dist.StandardNormal(1)
+    init = M.core.init_with_seed(37, 1, 2) * 0.5
+    s = NUTS(tgt, init, 0.8, mode=mode).set_seed(3).set_kernel_variant(6).set_max_depth(4)
+    out = s._run(5, 5, True, "numpy")
+    ref, pos, ad, nlf = O.engine_host_nuts_run(mode + 4, O.STANDARD_NORMAL, 1, [], init, 0.8, 5, 5, seed=3, progress=True, max_depth=4)
+    assert np.array_equal(out, ref) and np.array_equal(s.leapfrog_counts(), nlf)
+    s.set_max_depth(12)
+    out2 = s._run(5, 0, True, "numpy")
+    ref2, _, _, _ = O.engine_host_nuts_run(mode + 4, O.STANDARD_NORMAL, 1, [], pos, 0.8, 5, 0, seed=3, progress=True, max_depth=12, m0=10, adapt=ad)
+    assert np.array_equal(out2, ref2)
     for tgt in (M.dist.RosenbrockND(3), M.dist.GaussianND(A5), M.dist.IsotropicGaussian(0.7, 6)):
         init = M.core.init_with_seed(130, tgt.dim, 3) * 0.6
         a = NUTS(tgt, init, 0.8, mode=mode).set_seed(5)
