@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void mm_half_chain_tile_kernel(const T *__restr
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr unsigned int RT = 8, SK = 16; /* tile: RT time steps x SK lags */
-    const unsigned int nbt = (m + RT - 1) / RT, nbk = (m + SK - 1) / SK;
+    const unsigned int nbk = (m + SK - 1) / SK;
     /* a row of y: blocks of 8 elements, 12 words apart (element t at word 12 (t / 8) + t % 8), zeros behind (reads reach
      * element T0 + K0 + RT + SK).  The lanes of a 16-byte read are in consecutive time blocks: 48 bytes apart they cover
      * the 64 banks once per 16 lanes, 32 bytes apart (no pad) every read was a 2-way bank conflict */
