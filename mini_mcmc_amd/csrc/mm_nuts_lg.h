@@ -138,6 +138,9 @@ struct mm_nuts_lg_args {
 #ifndef MM_LG_AUX_SHARED
 #define MM_LG_AUX_SHARED 1
 #endif
+#ifndef MM_LG_WALK_UNROLL
+#define MM_LG_WALK_UNROLL 3 /* config 5: 0 510 ms, 1 496, 2 473, 3 469, 4 470 */
+#endif
 
 /* OCC = waves per SIMD the kernel is built for: 1 = the 512-register budget and 40 KB of LDS per wave; 2 = 256 registers
  * and 20 KB (persistent scheduler only).  Level 0 of the pending-subtree stack never reaches memory: leaves are taken
@@ -717,17 +720,31 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         MM_LG_TICK(L, 11);
     };
     /* hand S up the implicit recursion from level 1: walking lanes have S at level k at the top of iteration k */
+    auto walk_level = [&](unsigned int leaf, int k) __attribute__((always_inline)) {
+        MM_LG_COUNT(L, 7);
+        if ((leaf >> k) & 1u) {
+            rec rk;
+            load_rec(k, first_slot(leaf, k), rk);
+            merge(rk.fx, rk.fp, rk.prime, mm_false_t(), rk.alpha, rk.cnt);
+        } else {
+            push(k);
+        }
+    };
     auto walk_up = [&](unsigned int leaf) __attribute__((always_inline)) {
-        for (int k = 1; k < j; ++k) {
-            if (__ballot(walking) == 0ull)
-                break;
-            MM_LG_COUNT(L, 7);
-            if ((leaf >> k) & 1u) {
-                rec rk;
-                load_rec(k, first_slot(leaf, k), rk);
-                merge(rk.fx, rk.fp, rk.prime, mm_false_t(), rk.alpha, rk.cnt);
-            } else {
-                push(k);
+        /* levels 1 .. MM_LG_WALK_UNROLL (7 of 8 merges at 2 levels) are straight-line code with the level a constant:
+         * fixed LDS addresses, no loop-carried copies of the subtree's scalars */
+        bool more = true;
+#pragma unroll
+        for (int k = 1; k <= MM_LG_WALK_UNROLL; ++k) {
+            more = more && k < j && __ballot(walking) != 0ull;
+            if (more)
+                walk_level(leaf, k);
+        }
+        if (more) {
+            for (int k = MM_LG_WALK_UNROLL + 1; k < j; ++k) {
+                if (__ballot(walking) == 0ull)
+                    break;
+                walk_level(leaf, k);
             }
         }
         done = done || walking; /* reached level j: the doubling is complete, or was cut short */
