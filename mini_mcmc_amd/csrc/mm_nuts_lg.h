@@ -736,15 +736,16 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     auto walk_up = [&](unsigned int leaf) __attribute__((always_inline)) {
         /* levels 1 .. MM_LG_WALK_UNROLL (7 of 8 merges at 2 levels) are straight-line code with the level a constant:
          * fixed LDS addresses, no loop-carried copies of the subtree's scalars */
+        constexpr int WU = OCC == 2 ? 0 : MM_LG_WALK_UNROLL; /* the two-waves-per-SIMD build is slower with it (518 -> 582 ms) */
         bool more = true;
 #pragma unroll
-        for (int k = 1; k <= MM_LG_WALK_UNROLL; ++k) {
+        for (int k = 1; k <= WU; ++k) {
             more = more && k < j && __ballot(walking) != 0ull;
             if (more)
                 walk_level(leaf, k);
         }
         if (more) {
-            for (int k = MM_LG_WALK_UNROLL + 1; k < j; ++k) {
+            for (int k = WU + 1; k < j; ++k) {
                 if (__ballot(walking) == 0ull)
                     break;
                 walk_level(leaf, k);
