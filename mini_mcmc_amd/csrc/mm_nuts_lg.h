@@ -587,7 +587,10 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     /* one leaf: leapfrog of the outer edge (nuts.rs:979-996), in place, and the base case of build_tree
      * (nuts.rs:782-856); chains that are done keep their edge (the matrix product runs for all 64 lanes: MFMA has no
      * per-lane mask, their columns are recomputed) */
-    auto leaf_eval = [&](unsigned int leaf) __attribute__((always_inline)) {
+    /* defer: the leaf's acceptance statistic min(1, exp(d)) is not evaluated here, d is left in d_last (the pair loop
+     * evaluates the two of a pair in ONE pass, each on half of the chain's lanes) */
+    double d_last = 0.0;
+    auto leaf_eval = [&](unsigned int leaf, auto defer) __attribute__((always_inline)) {
         MM_LG_COUNT(L, 6);
         leaf_iters += 1u;
         /* The VECTORS of a chain that is done (edge, proposal) are never read again: a chain is done before the last
@@ -618,7 +621,8 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             lf += 1u;
             S_n = (L.logu < jointp) ? 1u : 0u;
             S_s = (L.logu - 1000.0) < jointp;
-            S_alpha = mm_lg_accept_prob(jointp - L.joint);
+            if constexpr (!decltype(defer)::value)
+                S_alpha = mm_lg_accept_prob(jointp - L.joint);
             S_nalpha = 1;
             /* a leaf that starts a subtree of level >= 2 files its (x, p) under the highest level it starts (the first
              * leaf of a level-1 subtree waits in registers, below) */
@@ -644,6 +648,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 }
             }
         }
+        d_last = jointp - L.joint;
         walking = !done;
         MM_LG_TICK(L, 2);
     };
@@ -792,7 +797,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     MM_LG_TICK(L, 1);
     if (j == 0) {
         if (__ballot(!done) != 0ull) {
-            leaf_eval(0u);
+            leaf_eval(0u, mm_false_t());
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 S_prime[s] = cx[s];
@@ -804,26 +809,54 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if (__ballot(!done) == 0ull)
                 return false;
             /* ---- the first leaf of a level-1 subtree: its one-leaf subtree (level 0) waits for the sibling in registers */
-            leaf_eval(leaf);
+            leaf_eval(leaf, mm_true_t());
+            const double d_first = d_last;
+            const bool live_first = !done;
             /* its proposal is its own x: (fx, fp) serve as the first leaf of the pair AND as the waiting proposal */
-            double fx[NS], fp[NS], P_alpha;
+            double fx[NS], fp[NS], P_alpha = 0.0;
             unsigned int P_n, P_nalpha;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 fx[s] = cx[s];
                 fp[s] = cp[s];
             }
-            P_alpha = S_alpha;
             P_n = S_n;
             P_nalpha = S_nalpha;
             MM_LG_COUNT(L, 7);
             MM_LG_COUNT(L, 13);
             walking = walking && !S_s; /* valid: it waits (nuts.rs:858-899); not valid: handed up as it is */
+            /* The two acceptance statistics of a pair are evaluated together after the second leaf: the four lanes of a
+             * chain all compute the same scalar, so even rows take the first leaf's d and odd rows the second's, one
+             * pass of mm_lg_accept_prob (~45 instructions) instead of two, and a row swap hands both to every lane.
+             * Only a first leaf that walks up now (not valid) needs its own at once: then both are evaluated in full */
+            bool first_ready = false;
+            if (__ballot(walking) != 0ull) {
+                P_alpha = mm_lg_accept_prob(d_first);
+                first_ready = true;
+                if (live_first)
+                    S_alpha = P_alpha;
+            }
             walk_up_invalid(leaf);
             if (__ballot(!done) == 0ull)
                 return false;
             /* ---- its sibling: merge at level 0 with the waiting subtree, then hand the pair up */
-            leaf_eval(leaf | 1u);
+            leaf_eval(leaf | 1u, mm_true_t());
+            {
+                double a_second;
+                if (first_ready) {
+                    a_second = mm_lg_accept_prob(d_last);
+                } else {
+                    const double e = mm_lg_accept_prob((L.q & 1) ? d_last : d_first);
+                    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+                    const unsigned int elo = (unsigned int)__double2loint(e), ehi = (unsigned int)__double2hiint(e);
+                    const u2 l = __builtin_amdgcn_permlane16_swap(elo, elo, false, false);
+                    const u2 h = __builtin_amdgcn_permlane16_swap(ehi, ehi, false, false);
+                    P_alpha = __hiloint2double((int)h[0], (int)l[0]);  /* rows 0, 2: the first leaf's */
+                    a_second = __hiloint2double((int)h[1], (int)l[1]); /* rows 1, 3: the second leaf's */
+                }
+                if (!done)
+                    S_alpha = a_second;
+            }
             MM_LG_COUNT(L, 7);
             merge(fx, fp, fx, mm_true_t(), P_alpha,
                   __longlong_as_double((long long)((unsigned long long)P_n | ((unsigned long long)P_nalpha << 32))));
