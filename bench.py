@@ -186,7 +186,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements of configs 2 and 5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--variant", type=int, default=5, help="kernel variant: 5 noise waves + transition waves, two waves per SIMD (default), 2 one wave per SIMD with paired + pipelined noise, 0 plain")
+    ap.add_argument("--variant", type=int, default=5, help="kernel variant: 5 noise waves + transition waves, four waves per SIMD (default), 2 one wave per SIMD with paired + pipelined noise, 0 plain")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time sampler and diagnostics as a two-stream pipeline (a measured negative result, DESIGN.md 5.2: "
+                         "slower than back to back; off by default so that a profiled run holds only undisturbed launches of the sampling kernel)")
     args = ap.parse_args()
 
     import numpy as np
@@ -276,7 +279,7 @@ def main() -> None:
     # the same work as a pipeline (N = 1): while the sampler writes run k + 1 into one buffer, the statistics of run k are
     # reduced from the other one on a second stream -- the diagnostics leave the critical path
     pipe_ms = None
-    if not distributed:
+    if not distributed and args.pipelined:
         out2 = torch.empty_like(out)
         bufs = (out, out2)
         s_stats = torch.cuda.Stream(dev)

@@ -60,8 +60,19 @@ template <class T, int D, bool MH, int I = 0> struct mm_split_pick {
 template <class T, int D, bool MH> struct mm_split_pick<T, D, MH, 12> {
     using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, (MH ? 2 : 1)>; /* RB = TILE_T = 2: always fits up to dim 8 */
 };
-template <class T, int D, bool MH> struct mm_split_plan : mm_split_pick<T, D, MH>::type {
-    using Base = typename mm_split_pick<T, D, MH>::type;
+/* RBF != 0: a ring half of exactly RBF transitions (several noise waves per pair want a batch their pairs divide), the
+ * largest tile that fits beside it */
+template <class T, int D, bool MH, int RBF, int I = 0> struct mm_split_pick_rb {
+    static constexpr int want[6] = {48, 40, 32, 24, 16, 8};
+    using Try = mm_split_try<T, D, RBF, want[I], (MH ? 2 : 1)>;
+    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick_rb<T, D, MH, RBF, I + 1>::type>::type;
+};
+template <class T, int D, bool MH, int RBF> struct mm_split_pick_rb<T, D, MH, RBF, 6> {
+    using type = mm_split_try<T, D, RBF, RBF * (int)(sizeof(T) / 4) * D, (MH ? 2 : 1)>;
+};
+template <class T, int D, bool MH, int RBF = 0>
+struct mm_split_plan : mm_cond<RBF == 0, typename mm_split_pick<T, D, MH>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2)>::type>::type {
+    using Base = typename mm_cond<RBF == 0, typename mm_split_pick<T, D, MH>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2)>::type>::type;
     static constexpr int rb = (int)(Base::ring_bytes / 2 / Base::row_bytes);
     static_assert(Base::tile_t >= rb && Base::lds_bytes <= 160 * 1024, "LDS plan of the split kernel");
 };
@@ -70,9 +81,17 @@ template <class T, int D, bool MH> struct mm_split_plan : mm_split_pick<T, D, MH
 #ifndef MM_SPLIT_MH_QP
 #define MM_SPLIT_MH_QP 2 /* config 2: 0.312 / 0.298 / 0.275 ms with 0 / 1 / 2 pairs */
 #endif
-template <class T, int D> struct mm_split_mh_qp {
+/* noise waves per pair of the f32 instances (mm_inst.inc): config 3 HMC 0.226 / 0.213 / 0.208 ms with 1 / 2 / 3 in
+ * tools/split_probe.hip; in the library (tools/time_cfg23.py, one box, back to back): HMC 0.215 -> 0.201-0.204 ms,
+ * config 2 MH 0.288 -> 0.253 ms with 3 */
+#ifndef MM_SPLIT_NOISE_WAVES
+#define MM_SPLIT_NOISE_WAVES 3
+#endif
+template <class T, int D, int NN = 1> struct mm_split_mh_qp {
     static constexpr int rb = mm_split_plan<T, D, true>::rb;
-    static constexpr int value = rb >= 8 ? MM_SPLIT_MH_QP : (rb >= 4 && MM_SPLIT_MH_QP ? 1 : 0);
+    static constexpr int one = rb >= 8 ? MM_SPLIT_MH_QP : (rb >= 4 && MM_SPLIT_MH_QP ? 1 : 0);
+    /* with three noise waves, in the library (tools/time_cfg23.py, config 2): 0 / 1 / 2 pairs 0.2514 / 0.2527 / 0.2503 ms */
+    static constexpr int value = one;
 };
 
 /* Role timing for tools/split_probe.hip (-DMM_SPLIT_PROFILE): s_memtime ticks each role spends at the batch barrier
@@ -99,11 +118,14 @@ __device__ unsigned long long mm_split_prof[2][2];
 #define MM_SPLIT_PROF_END(role) ((void)0)
 #endif
 
-template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0>
-__global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> a)
+/* NN noise waves per pair (1: the workgroup above; 2, 3: 768 / 1024 threads, three / four waves per SIMD -- the noise
+ * pairs of a batch are dealt to the noise waves in turn, noise wave 0 writes the tiles out): more waves to cover each
+ * other's LDS and issue latencies where the step is short (MH).  RBF: ring half (0 = the plan's choice). */
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
+__global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_run_args<T> a)
 {
     constexpr int D = Tgt::dim;
-    using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH>;
+    using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH, RBF>;
     using Tile = typename Plan::Tile;
     constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride, NW = Plan::nw, RB = Plan::rb, EPL = Plan::epl;
     constexpr int QN = 2 * QP; /* transitions per batch whose noise the transition wave draws itself */
@@ -113,9 +135,10 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6; /* 0..3 transition waves, 4..7 noise waves */
+    const int wave = threadIdx.x >> 6; /* 0..3 transition waves, 4.. noise waves (NN per pair) */
     const int pair = wave & 3;
     const bool noise_wave = wave >= 4;
+    const int noise_rank = (wave >> 2) - 1; /* which of the pair's NN noise waves */
     T *const tiles = reinterpret_cast<T *>(mm_lds_raw + Plan::table_bytes + (size_t)pair * Plan::ntile * Plan::tile_bytes);
     constexpr size_t TILE_ELEMS = Plan::tile_bytes / sizeof(T);
     T *const ring = reinterpret_cast<T *>(mm_lds_raw + Plan::table_bytes + 4 * Plan::ntile * Plan::tile_bytes + (size_t)pair * Plan::ring_bytes);
@@ -130,7 +153,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
     using Tab = typename mm_cond<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
     Tab tab;
     if constexpr (sizeof(T) == 4) {
-        mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, 512u);
+        mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, 256u * (1u + NN));
         tab.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(mm_lds_raw);
     }
 #ifdef MM_SPLIT_PRIO_Q /* experiment hook of tools/split_probe.hip */
@@ -149,10 +172,11 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
 #ifndef MM_SPLIT_FILL_PAIRS
 #define MM_SPLIT_FILL_PAIRS 1 /* 2 and 4 measured: no difference (config 2: 0.273 / 0.280 / 0.272 ms) */
 #endif
-        constexpr int PAIRS = ((RB - QN) % (2 * MM_SPLIT_FILL_PAIRS) == 0 && RB > QN) ? MM_SPLIT_FILL_PAIRS : 1;
+        constexpr int PAIRS = ((RB - QN) % (2 * MM_SPLIT_FILL_PAIRS * NN) == 0 && RB > QN) ? MM_SPLIT_FILL_PAIRS : 1;
+        static_assert((RB - QN) % 2 == 0, "whole noise pairs");
         auto fill = [&](unsigned int nb) __attribute__((always_inline)) {
-            T *dst = ring + ((size_t)half * RB + QN) * 64 * NW + (size_t)lane * NW;
-            for (unsigned int j = QN; j < nb; j += 2 * PAIRS) {
+            T *dst = ring + ((size_t)half * RB + QN + 2 * PAIRS * noise_rank) * 64 * NW + (size_t)lane * NW;
+            for (unsigned int j = QN + 2u * PAIRS * (unsigned int)noise_rank; j < nb; j += 2 * PAIRS * NN) {
                 T rows[2 * PAIRS][NW];
                 MM_UNROLL
                 for (int q = 0; q < PAIRS; ++q)
@@ -172,7 +196,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
                         *reinterpret_cast<mm_vrow *>(dst + (size_t)r * 64 * NW + k) = v;
                     }
                 }
-                dst += 2 * PAIRS * 64 * NW;
+                dst += (size_t)2 * PAIRS * NN * 64 * NW;
             }
             it += nb;
             half ^= 1;
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
             const unsigned int nb = min((unsigned int)RB, n_loud - done);
             fill(nb);
             MM_SPLIT_SYNC();
-            if (PFLUSH && pend) {
+            if (PFLUSH && pend && noise_rank == 0) {
                 mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
                                               (unsigned long long)a.out_t0 + rows_out, pend);
                 rows_out += pend;
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
             }
         }
         MM_SPLIT_SYNC(); /* the partner has finished its last batch */
-        if (PFLUSH && pend)
+        if (PFLUSH && pend && noise_rank == 0)
             mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
                                           (unsigned long long)a.out_t0 + rows_out, pend);
         MM_SPLIT_PROF_END(0);
@@ -337,12 +361,12 @@ __global__ __launch_bounds__(512) void mm_run_split_kernel(const mm_run_args<T> 
         atomicAdd(a.accept_total, wave_acc);
 }
 
-template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0>
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
 hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
 {
-    using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH>;
+    using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH, RBF>;
     static unsigned long long attr_set = 0; /* > 64 KB of dynamic LDS has to be allowed once per kernel and device */
-    auto kern = mm_run_split_kernel<T, Tgt, SAMPLER, LCT, QP>;
+    auto kern = mm_run_split_kernel<T, Tgt, SAMPLER, LCT, QP, NN, RBF>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
@@ -354,7 +378,7 @@ hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
             attr_set |= 1ull << dev;
     }
     const unsigned int grid = (unsigned int)((a.n_chains + 255ull) / 256ull);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Plan::lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * (1 + NN)), Plan::lds_bytes, stream, a);
     return hipGetLastError();
 }
 

@@ -7,6 +7,27 @@
 #include <cstdio>
 #include <vector>
 
+/* role layout of the split kernel under test: pairs the transition wave draws itself, noise waves per pair, ring half
+ * (0 = the plan's): -DMM_PROBE_MH_NN=3 -DMM_PROBE_MH_RB=6 -DMM_PROBE_MH_QP=0 ... */
+#ifndef MM_PROBE_MH_QP
+#define MM_PROBE_MH_QP (mm_split_mh_qp<float, 2>::value)
+#endif
+#ifndef MM_PROBE_MH_NN
+#define MM_PROBE_MH_NN 1
+#endif
+#ifndef MM_PROBE_MH_RB
+#define MM_PROBE_MH_RB 0
+#endif
+#ifndef MM_PROBE_HMC_QP
+#define MM_PROBE_HMC_QP 0
+#endif
+#ifndef MM_PROBE_HMC_NN
+#define MM_PROBE_HMC_NN 1
+#endif
+#ifndef MM_PROBE_HMC_RB
+#define MM_PROBE_HMC_RB 0
+#endif
+
 template <class Tgt, int SAMPLER, int LCT> static void bench(const char *name, int D, unsigned NC, unsigned ND, float scale, mm_tparams<float> P)
 {
     const unsigned long long C = 65536;
@@ -33,7 +54,9 @@ template <class Tgt, int SAMPLER, int LCT> static void bench(const char *name, i
                 if (kern == 0)
                     (void)mm_launch_run<float, Tgt, SAMPLER, 2, LCT>(a, 1024, 64, 0);
                 else
-                    (void)mm_launch_run_split<float, Tgt, SAMPLER, LCT, (SAMPLER == MM_SAMPLER_MH ? mm_split_mh_qp<float, Tgt::dim>::value : 0)>(a, 0);
+                    (void)mm_launch_run_split<float, Tgt, SAMPLER, LCT, (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_QP : MM_PROBE_HMC_QP),
+                                              (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_NN : MM_PROBE_HMC_NN),
+                                              (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_RB : MM_PROBE_HMC_RB)>(a, 0);
                 (void)hipEventRecord(e1);
                 (void)hipEventSynchronize(e1);
                 float ms;
