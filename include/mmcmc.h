@@ -211,8 +211,8 @@ int mmcmc_nuts_destroy(mmcmc_nuts *h);
 /* knobs shared by the samplers:
  * iterations per kernel launch (0 = the whole run in one launch, the default) -- never changes a result;
  * kernel variant: 2 = noise of two iterations packed and software-pipelined (default up to dim 16 in f64, at dim 16 in
- *   f32), 0 = plain (default at dim 32), 5 = 512-thread workgroups of four transition waves fed by four noise waves
- *   through an LDS ring, two waves per SIMD (csrc/mm_split_kernels.h; up to dim 8, the default there in f32, elsewhere
+ *   f32), 0 = plain (default at dim 32), 5 = workgroups of four transition waves fed by noise waves through an LDS ring
+ *   (f32: three noise waves each, 1024 threads, four waves per SIMD; f64: one, 512 threads, two per SIMD) (csrc/mm_split_kernels.h; up to dim 8, the default there in f32, elsewhere
  *   MMCMC_ERR_UNSUPPORTED) -- all bit-identical;
  *   HMC only: 3 = the lane-group mapping with the gradient on the matrix cores (16 chains per wave, four lanes per
  *   chain, v_mfma_f64_16x16x4 / v_mfma_f32_16x16x4; csrc/mm_hmc_lg.h), for MMCMC_GAUSSIAN_ND of dim 16 or 32 in f64 and

@@ -51,7 +51,7 @@ class _Sampler:
         return self
 
     def set_kernel_variant(self, variant: int):
-        """5 = noise waves + transition waves, two waves per SIMD (default for f32 up to dim 8), 2 = paired + pipelined
+        """5 = noise waves + transition waves, up to four waves per SIMD (default for f32 up to dim 8), 2 = paired + pipelined
         noise, 0 = plain; results are identical."""
         L.check(self._fn("set_kernel_variant")(self._h, int(variant)), "set_kernel_variant")
         return self

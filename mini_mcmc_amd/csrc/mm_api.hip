@@ -224,7 +224,7 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
      * is twice as fast there (RosenbrockND(32) f32: 1.0 ms vs 2.2 ms for run(100, 20) of 65 536 chains) */
     if (s->dim > 16 && !s->generic && !s->user)
         s->variant = 0;
-    /* f32 up to dim 8: noise waves + transition waves, two waves per SIMD (mm_split_kernels.h; config 3: 0.225 ms
+    /* f32 up to dim 8: noise waves + transition waves, four waves per SIMD (mm_split_kernels.h; config 3: 0.192 ms
      * against 0.268 ms for variant 2) */
     if (dtype == MMCMC_F32 && s->kf && s->kf->run_mh_split)
         s->variant = 5;
@@ -750,7 +750,7 @@ int mmcmc_mh_set_chain_offset(mmcmc_mh *h, uint64_t off)
     h->s->chain_offset = off;
     return MMCMC_OK;
 }
-/* variant 5 (two waves per SIMD: noise waves + transition waves) exists up to dim 8 */
+/* variant 5 (noise waves + transition waves, two to four waves per SIMD) exists up to dim 8 */
 static bool split_ok(const Sampler *s)
 {
     return s->dtype == MMCMC_F32 ? (s->kf && s->kf->run_mh_split) : (s->kd && s->kd->run_mh_split);
