@@ -259,6 +259,47 @@ impl Drop for GpuNuts {
     }
 }
 
+/// The same sampler over several GPUs from one call (`mmcmc_nuts_group_*`): `run` executes every chain, chain i's
+/// results do not depend on the number of devices (the stream is keyed by the global chain index).
+pub struct GpuNutsGroup {
+    g: *mut sys::mmcmc_nuts_group,
+    n_chains: usize,
+    dim: usize,
+}
+unsafe impl Send for GpuNutsGroup {}
+impl GpuNutsGroup {
+    pub fn new_on(devices: &[i32], target: GpuTarget, initial_positions: Vec<Vec<f64>>, target_accept_p: f64, scalars_f64: bool) -> Result<Self, MmcmcError> {
+        let (flat, n, d) = flatten(&initial_positions);
+        let desc = target.desc(d);
+        let mut g = null_mut();
+        check(unsafe {
+            sys::mmcmc_nuts_group_create(&mut g, &desc, flat.as_ptr(), n, target_accept_p, if scalars_f64 { 0 } else { 1 }, devices.as_ptr(), devices.len() as i32)
+        })?;
+        Ok(Self { g, n_chains: n, dim: d })
+    }
+    pub fn set_seed(self, seed: u64) -> Self {
+        unsafe { sys::mmcmc_nuts_group_seed(self.g, seed) };
+        self
+    }
+    /// `NUTS::run(n_collect, n_discard)` of every chain on every device of the group
+    pub fn run(&mut self, n_collect: usize, n_discard: usize) -> Result<Array3<f32>, ShapeError> {
+        let mut out = Array3::<f32>::default((self.n_chains, n_collect, self.dim));
+        let st = unsafe { sys::mmcmc_nuts_group_run(self.g, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, 0) };
+        if st == sys::MMCMC_OK { Ok(out) } else { Err(shape_error(st)) }
+    }
+    /// `(rhat, ess)` of the last run over the chains of all devices (RCCL inside the library)
+    pub fn split_rhat_mean_ess(&mut self) -> Result<(Array1<f32>, Array1<f32>), MmcmcError> {
+        let (mut rhat, mut ess) = (Array1::<f32>::zeros(self.dim), Array1::<f32>::zeros(self.dim));
+        check(unsafe { sys::mmcmc_nuts_group_split_rhat_mean_ess(self.g, rhat.as_mut_ptr(), ess.as_mut_ptr(), null_mut()) })?;
+        Ok((rhat, ess))
+    }
+}
+impl Drop for GpuNutsGroup {
+    fn drop(&mut self) {
+        unsafe { sys::mmcmc_nuts_group_destroy(self.g) };
+    }
+}
+
 /// `stats::split_rhat_mean_ess(sample)` (stats.rs:416-423): `(rhat, ess)`, rhat = sqrt(W / var+) as the crate defines it.
 pub fn split_rhat_mean_ess(sample: ArrayView3<f32>) -> Result<(Array1<f32>, Array1<f32>), MmcmcError> {
     let (c, n, p) = sample.dim();
