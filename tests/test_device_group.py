@@ -131,3 +131,49 @@ def test_nuts_group_reproduces_single_handle_run(O, devices):
             np.testing.assert_allclose(r1, r0, rtol=2e-4)
             np.testing.assert_allclose(e1, e0, rtol=2e-3)
             g.close()
+
+
+@pytest.mark.gpu
+def test_config4_shape_on_one_device(O):
+    """BASELINE config 4 at full size -- 3-D Rosenbrock HMC, 8 x 65 536 = 524 288 chains, run(400, 50) -- with its eight
+    shards on the ONE device of the test box (no 8-GPU node here): the sharding, the global-index keying and the
+    reduction over all 1 048 576 half-chains at the real sizes.  A shard must equal a single handle given the shard's
+    slice of the initial positions and its chain offset, the first chains of a shard the host build, and the diagnostics
+    of the group the single-GPU entry point's on the gathered sample (rounding of the lag sums apart)."""
+    import torch
+
+    from mini_mcmc_amd import stats as S
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import RosenbrockND
+    from mini_mcmc_amd.group import HMCGroup
+    from mini_mcmc_amd.hmc import HMC
+
+    n_shards, per = 8, 65536
+    C_ = n_shards * per
+    init = init_with_seed(C_, 3, 42, np.float32)
+    g = HMCGroup(RosenbrockND(3), init, 0.032, 10, devices=[0] * n_shards).set_seed(42)
+    g.run(400, 50, to_host=False)
+    sh = g.shards()
+    assert [s[2] for s in sh] == [per] * n_shards and [s[1] for s in sh] == [per * i for i in range(n_shards)]
+    # shard 5 == a single handle on that slice with that offset (bit for bit, all 65 536 chains)
+    k = 5
+    one = HMC(RosenbrockND(3), init[k * per:(k + 1) * per], 0.032, 10).set_seed(42).set_chain_offset(k * per)
+    ref = one.run(400, 50, to="torch")
+    import ctypes as C
+
+    shard = torch.empty_like(ref)
+    assert torch.cuda.current_device() == sh[k][0]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(shard.data_ptr(), sh[k][3], ref.numel() * 4, 4) == 0  # hipMemcpyDefault, device to device
+    torch.cuda.synchronize()
+    assert torch.equal(shard, ref)
+    # its first chains == the host build of the engine
+    twin, _, _ = O.engine_host_run("hmc", O.ROSENBROCK_ND, 3, [], init[k * per:k * per + 64], 0.032, 400, 50, seed=42, n_leapfrog=10,
+                                   dtype=np.float32, chain_offset=k * per)
+    assert np.array_equal(ref[:64].cpu().numpy(), twin)
+    # diagnostics over all 524 288 chains (host exchange: a device listed eight times)
+    rhat, ess = g.split_rhat_mean_ess()
+    assert not g.used_rccl and np.all(np.isfinite(rhat)) and np.all(ess > 1e5)
+    st = g.state()
+    assert st.shape == (C_, 3) and np.array_equal(st[k * per:(k + 1) * per], one.state())
