@@ -86,9 +86,10 @@ MM_HD double mm_nonneg_logq(const mm_discrete_params &P, int x, int y)
 }
 
 /* one transition; returns 1 iff the proposal was accepted */
-MM_HD int mm_discrete_step(const mm_discrete_params &P, int32_t *x, uint64_t seed, uint64_t chain, uint32_t iter)
+/* the transition given its noise block b = mm_block(seed, chain, iteration, 0): direction = top bit of word 0, accept
+ * uniform = u53 of words 2, 3 */
+MM_HD int mm_discrete_step_block(const mm_discrete_params &P, int32_t *x, const mm_u32x4 &b)
 {
-    const mm_u32x4 b = mm_block(seed, chain, iter, 0u);
     const int step = (b.w[0] >> 31) ? 1 : -1;
     const int cur = *x;
     int prop;
@@ -114,6 +115,10 @@ MM_HD int mm_discrete_step(const mm_discrete_params &P, int32_t *x, uint64_t see
         return 1;
     }
     return 0;
+}
+MM_HD int mm_discrete_step(const mm_discrete_params &P, int32_t *x, uint64_t seed, uint64_t chain, uint32_t iter)
+{
+    return mm_discrete_step_block(P, x, mm_block(seed, chain, iter, 0u));
 }
 
 #endif /* MM_DISCRETE_H */

@@ -91,6 +91,79 @@ __global__ __launch_bounds__(64) void mm_discrete_kernel(const run_args a)
     }
 }
 
+/* The same run with the work of a chain spread over four waves of one SIMD, like the continuous samplers'
+ * (mm_split_kernels.h): workgroup = 1024 threads = 4 transition waves (64 chains each) + 3 noise waves per transition
+ * wave.  A transition is ~65 instructions of Philox and ~40 of table look-ups and accept test; one wave per SIMD (all
+ * that 65 536 chains give mm_discrete_kernel) issues an instruction every 4.4+ cycles and waits out every LDS look-up.
+ * The noise block is a pure function of (seed, chain, iteration): noise wave r draws the blocks of iterations
+ * r, r + 3, ... of a batch of RB into an LDS ring (16 bytes per chain and iteration), one barrier per batch hands a
+ * filled half over.  Bit-identical to mm_discrete_kernel (same blocks, same mm_discrete_step_block). */
+constexpr int DS_NN = 3, DS_RB = 12, DS_TILE_T = 48;
+using DsTile = mm_tile_t<int32_t, 1, DS_TILE_T>;
+constexpr size_t DS_TILE_BYTES = (DsTile::lds_bytes_per_wave + 15) / 16 * 16;
+constexpr size_t DS_RING_BYTES = (size_t)2 * DS_RB * 64 * 16;
+constexpr size_t DS_TABLE_BYTES = (size_t)MM_DISCRETE_POISSON_TABLE * sizeof(double);
+constexpr size_t DS_LDS_BYTES = DS_TABLE_BYTES + 4 * DS_TILE_BYTES + 4 * DS_RING_BYTES;
+static_assert(DS_LDS_BYTES <= 160 * 1024 && DS_RB % DS_NN == 0 && DS_TILE_T % DS_RB == 0, "LDS plan of the split discrete kernel");
+
+__global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(const run_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ds_lds[];
+    double *tab_lds = reinterpret_cast<double *>(ds_lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave & 3, noise_rank = (wave >> 2) - 1;
+    int32_t *tile = reinterpret_cast<int32_t *>(ds_lds + DS_TABLE_BYTES + (size_t)pair * DS_TILE_BYTES);
+    mm_u32x4 *ring = reinterpret_cast<mm_u32x4 *>(ds_lds + DS_TABLE_BYTES + 4 * DS_TILE_BYTES + (size_t)pair * DS_RING_BYTES);
+    mm_discrete_params P = a.P;
+    for (int i = threadIdx.x; i < P.table_len && i < MM_DISCRETE_POISSON_TABLE; i += 256 * (1 + DS_NN))
+        tab_lds[i] = a.P.logp[i];
+    P.logp = tab_lds;
+    P.table_len = P.table_len < MM_DISCRETE_POISSON_TABLE ? P.table_len : MM_DISCRETE_POISSON_TABLE;
+    const unsigned long long c0 = (unsigned long long)blockIdx.x * 256ull + (unsigned long long)pair * 64ull, c = c0 + lane;
+    const unsigned long long chain = a.chain_offset + c;
+    const unsigned int total = a.n_discard + a.n_collect;
+    __syncthreads(); /* the table is complete */
+    if (noise_rank >= 0) {
+        int half = 0;
+        for (unsigned int done = 0; done < total; done += DS_RB) {
+            const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
+            for (unsigned int j = (unsigned int)noise_rank; j < nb; j += DS_NN)
+                ring[((size_t)half * DS_RB + j) * 64 + lane] = mm_block(a.seed, chain, a.iter0 + done + j, 0u);
+            half ^= 1;
+            __syncthreads();
+        }
+        __syncthreads();
+        return;
+    }
+    const bool active = c < a.n_chains;
+    int32_t x = active ? a.state[c] : 0;
+    unsigned long long n_acc = 0;
+    unsigned int col = 0, t0 = 0;
+    int half = 0;
+    for (unsigned int done = 0; done < total; done += DS_RB) {
+        const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
+        __syncthreads(); /* ring half `half` holds the blocks of this batch */
+        for (unsigned int j = 0; j < nb; ++j) {
+            const mm_u32x4 b = ring[((size_t)half * DS_RB + j) * 64 + lane];
+            n_acc += (unsigned long long)mm_discrete_step_block(P, &x, b);
+            const unsigned int t = done + j;
+            if (t >= a.n_discard && a.out) {
+                tile[lane * DsTile::stride + col++] = x;
+                if (col == (unsigned int)DS_TILE_T || t + 1 == total) {
+                    mm_flush_tile_raw<int32_t, 1, DsTile>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
+                    t0 += col;
+                    col = 0;
+                }
+            }
+        }
+        half ^= 1;
+    }
+    __syncthreads();
+    if (active) {
+        a.state[c] = x;
+        a.accept[c] += n_acc;
+    }
+}
+
 } // namespace
 
 struct mmcmc_mh_discrete {
@@ -218,8 +291,27 @@ int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_disca
     a.iter0 = h->iter;
     a.n_discard = (unsigned int)n_discard;
     a.n_collect = (unsigned int)n_collect;
-    hipLaunchKernelGGL(mm_discrete_kernel, dim3((unsigned int)((h->n_chains + 63) / 64)), dim3(64), 0, st, a);
-    hipError_t e = hipGetLastError();
+    /* four waves per SIMD from 4096 chains on (below that the plain kernel's waves are spread thinner than one per SIMD
+     * anyway); MMCMC_DISCRETE_KERNEL=plain keeps the one-wave kernel (A/B and tests: the two are bit-identical) */
+    const char *force = getenv("MMCMC_DISCRETE_KERNEL");
+    hipError_t e = hipSuccess;
+    if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
+        static unsigned long long attr_set = 0;
+        if (h->device >= 64 || !((attr_set >> h->device) & 1ull)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(mm_discrete_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)DS_LDS_BYTES);
+            if (e == hipSuccess && h->device < 64)
+                attr_set |= 1ull << h->device;
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(mm_discrete_split_kernel, dim3((unsigned int)((h->n_chains + 255) / 256)), dim3(256 * (1 + DS_NN)),
+                               DS_LDS_BYTES, st, a);
+            e = hipGetLastError();
+        }
+    } else {
+        hipLaunchKernelGGL(mm_discrete_kernel, dim3((unsigned int)((h->n_chains + 63) / 64)), dim3(64), 0, st, a);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) {
         if (staged)
             (void)hipFree(d_out);
