@@ -29,13 +29,19 @@ MM_HD double mm_mixture_normal_pdf(double x, double mu, double sigma)
     return coeff * exp_val;
 }
 
-/* one full sweep of the state s = [x, z] */
-MM_HD void mm_gibbs_mixture_step(const mm_mixture_params &P, double *s, uint64_t seed, uint64_t chain, uint32_t iter)
+/* the two draws of a sweep: a pure function of (seed, chain, iteration) */
+MM_HD void mm_gibbs_mixture_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z0, double *u)
 {
     const mm_u32x4 b = mm_block(seed, chain, iter, 0u);
-    double z0, z1;
-    mm_box_muller_f64(mm_u53(b.w[0], b.w[1]), mm_u53(b.w[2], b.w[3]), &z0, &z1);
+    double z1;
+    mm_box_muller_f64(mm_u53(b.w[0], b.w[1]), mm_u53(b.w[2], b.w[3]), z0, &z1);
     (void)z1;
+    *u = mm_aux_u53(seed, chain, iter, 0u);
+}
+
+/* one full sweep of the state s = [x, z] given its draws */
+MM_HD void mm_gibbs_mixture_step_noise(const mm_mixture_params &P, double *s, double z0, double u)
+{
     /* i = 0: x given z */
     s[0] = (s[1] < 0.5) ? fma(P.sigma0, z0, P.mu0) : fma(P.sigma1, z0, P.mu1);
     /* i = 1: z given the new x */
@@ -43,8 +49,14 @@ MM_HD void mm_gibbs_mixture_step(const mm_mixture_params &P, double *s, uint64_t
     const double p1 = (1.0 - P.pi0) * mm_mixture_normal_pdf(s[0], P.mu1, P.sigma1);
     const double total = p0 + p1;
     const double prob_z1 = (total > 0.0) ? p1 / total : 0.5;
-    const double u = mm_aux_u53(seed, chain, iter, 0u);
     s[1] = (u < prob_z1) ? 1.0 : 0.0;
+}
+
+MM_HD void mm_gibbs_mixture_step(const mm_mixture_params &P, double *s, uint64_t seed, uint64_t chain, uint32_t iter)
+{
+    double z0, u;
+    mm_gibbs_mixture_noise(seed, chain, iter, &z0, &u);
+    mm_gibbs_mixture_step_noise(P, s, z0, u);
 }
 
 #endif /* MM_GIBBS_H */

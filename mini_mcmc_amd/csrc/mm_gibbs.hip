@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <new>
 
 #include "mm_gibbs.h"
@@ -72,6 +74,80 @@ __global__ __launch_bounds__(64) void mm_gibbs_mixture_kernel(const run_args a)
             }
         }
     }
+    if (active) {
+        a.state[2 * c] = s[0];
+        a.state[2 * c + 1] = s[1];
+    }
+}
+
+/* The same run with a chain's work spread over four waves of one SIMD, like the continuous samplers' (mm_split_kernels.h)
+ * and the integer-state MH (mm_discrete.hip): workgroup = 1024 threads = 4 transition waves (64 chains each) + 3 noise
+ * waves per transition wave.  A sweep is two Philox blocks + Box-Muller (log, sqrt, cos) on the noise side and two normal
+ * pdfs (exp, divisions) + the conditional draws on the transition side, about as many instructions each; one wave per
+ * SIMD (all that 65 536 chains give mm_gibbs_mixture_kernel) issues one every 4.4+ cycles.  (z0, u) of a sweep is a pure
+ * function of (seed, chain, iteration): noise wave r fills the sweeps r, r + 3, ... of a batch of GS_RB into an LDS ring
+ * (16 bytes per chain and sweep), one barrier per batch hands a filled half over.  Bit-identical to the plain kernel
+ * (same mm_gibbs_mixture_noise, same mm_gibbs_mixture_step_noise). */
+constexpr int GS_NN = 3, GS_RB = 6, GS_TILE_T = 24;
+using GsTile = mm_tile_t<double, 2, GS_TILE_T>;
+constexpr size_t GS_TILE_BYTES = (GsTile::lds_bytes_per_wave + 15) / 16 * 16;
+constexpr size_t GS_RING_BYTES = (size_t)2 * GS_RB * 64 * 16;
+constexpr size_t GS_LDS_BYTES = 4 * GS_TILE_BYTES + 4 * GS_RING_BYTES;
+static_assert(GS_LDS_BYTES <= 160 * 1024 && GS_RB % GS_NN == 0 && GS_TILE_T % GS_RB == 0, "LDS plan of the split Gibbs kernel");
+
+struct __attribute__((aligned(16))) gs_draw {
+    double z0, u;
+};
+
+__global__ __launch_bounds__(256 * (1 + GS_NN)) void mm_gibbs_mixture_split_kernel(const run_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave & 3, noise_rank = (wave >> 2) - 1;
+    double *tile = reinterpret_cast<double *>(gs_lds + (size_t)pair * GS_TILE_BYTES);
+    gs_draw *ring = reinterpret_cast<gs_draw *>(gs_lds + 4 * GS_TILE_BYTES + (size_t)pair * GS_RING_BYTES);
+    const unsigned long long c0 = (unsigned long long)blockIdx.x * 256ull + (unsigned long long)pair * 64ull, c = c0 + lane;
+    const unsigned long long chain = a.chain_offset + c;
+    const unsigned int total = a.n_discard + a.n_collect;
+    if (noise_rank >= 0) {
+        int half = 0;
+        for (unsigned int done = 0; done < total; done += GS_RB) {
+            const unsigned int nb = total - done < (unsigned int)GS_RB ? total - done : (unsigned int)GS_RB;
+            for (unsigned int j = (unsigned int)noise_rank; j < nb; j += GS_NN) {
+                gs_draw d;
+                mm_gibbs_mixture_noise(a.seed, chain, a.iter0 + done + j, &d.z0, &d.u);
+                ring[((size_t)half * GS_RB + j) * 64 + lane] = d;
+            }
+            half ^= 1;
+            __syncthreads();
+        }
+        __syncthreads();
+        return;
+    }
+    const bool active = c < a.n_chains;
+    double s[2] = {active ? a.state[2 * c] : 0.0, active ? a.state[2 * c + 1] : 0.0};
+    unsigned int col = 0, t0 = 0;
+    int half = 0;
+    for (unsigned int done = 0; done < total; done += GS_RB) {
+        const unsigned int nb = total - done < (unsigned int)GS_RB ? total - done : (unsigned int)GS_RB;
+        __syncthreads(); /* ring half `half` holds the draws of this batch */
+        for (unsigned int j = 0; j < nb; ++j) {
+            const gs_draw d = ring[((size_t)half * GS_RB + j) * 64 + lane];
+            mm_gibbs_mixture_step_noise(a.P, s, d.z0, d.u);
+            const unsigned int t = done + j;
+            if (t >= a.n_discard && a.out) {
+                tile[lane * GsTile::stride + 2 * col] = s[0];
+                tile[lane * GsTile::stride + 2 * col + 1] = s[1];
+                ++col;
+                if (col == (unsigned int)GS_TILE_T || t + 1 == total) {
+                    mm_flush_tile_raw<double, 2, GsTile>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
+                    t0 += col;
+                    col = 0;
+                }
+            }
+        }
+        half ^= 1;
+    }
+    __syncthreads();
     if (active) {
         a.state[2 * c] = s[0];
         a.state[2 * c + 1] = s[1];
@@ -170,8 +246,27 @@ int mmcmc_gibbs_mixture_run(mmcmc_gibbs_mixture *h, size_t n_collect, size_t n_d
     a.iter0 = h->iter;
     a.n_discard = (unsigned int)n_discard;
     a.n_collect = (unsigned int)n_collect;
-    hipLaunchKernelGGL(mm_gibbs_mixture_kernel, dim3((unsigned int)((h->n_chains + 63) / 64)), dim3(64), 0, st, a);
-    hipError_t e = hipGetLastError();
+    /* four waves per SIMD from 4096 chains on; MMCMC_GIBBS_KERNEL=plain keeps the one-wave kernel (A/B and tests: the two
+     * are bit-identical) */
+    const char *force = getenv("MMCMC_GIBBS_KERNEL");
+    hipError_t e = hipSuccess;
+    if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
+        static unsigned long long attr_set = 0;
+        if (h->device >= 64 || !((attr_set >> h->device) & 1ull)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(mm_gibbs_mixture_split_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS_BYTES);
+            if (e == hipSuccess && h->device < 64)
+                attr_set |= 1ull << h->device;
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(mm_gibbs_mixture_split_kernel, dim3((unsigned int)((h->n_chains + 255) / 256)),
+                               dim3(256 * (1 + GS_NN)), GS_LDS_BYTES, st, a);
+            e = hipGetLastError();
+        }
+    } else {
+        hipLaunchKernelGGL(mm_gibbs_mixture_kernel, dim3((unsigned int)((h->n_chains + 63) / 64)), dim3(64), 0, st, a);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) {
         if (staged)
             (void)hipFree(d_out);

@@ -88,3 +88,25 @@ def test_gpu_gibbs_bit_exact_and_moments(O, params):
     assert abs(x.mean() - mean) < 0.01 * np.sqrt(var) + 0.01 * abs(mean) and abs(x.var(ddof=1) - var) < 0.02 * var
     assert abs(sample[:, :, 1].mean() - (1 - params[4])) < 0.01
     assert 0.8 < stats.rhat.min <= stats.rhat.max <= 1.0 and stats.ess.min > 4096
+    # full size (the four-waves-per-SIMD kernel, mm_gibbs_mixture_split_kernel, from 4096 chains on): a sub-block equals the
+    # host build, the whole sample the one-wave kernel's, and sharding by chain offset reproduces the unsharded run; odd
+    # counts leave ragged batches and tiles
+    import os
+
+    C_ = 20000 + 37
+    init = init_with_seed(C_, 2, 3)
+    g = GibbsSampler(cond, init).set_seed(42)
+    out = g.run(131, 17)
+    ref, st = O.engine_host_gibbs_mixture_run(params, init[:300], 131, 17, seed=42)
+    assert np.array_equal(out[:300], ref) and np.array_equal(g.state()[:300], st)
+    os.environ["MMCMC_GIBBS_KERNEL"] = "plain"
+    try:
+        p = GibbsSampler(cond, init).set_seed(42)
+        assert np.array_equal(p.run(131, 17), out) and np.array_equal(p.state(), g.state())
+    finally:
+        del os.environ["MMCMC_GIBBS_KERNEL"]
+    hi = GibbsSampler(cond, init[9000:]).set_seed(42).set_chain_offset(9000).run(131, 17)
+    assert np.array_equal(hi, out[9000:])
+    out2 = g.run(7, 0)
+    ref2, _ = O.engine_host_gibbs_mixture_run(params, st, 7, 0, seed=42, iter0=148)
+    assert np.array_equal(out2[:300], ref2)
