@@ -204,13 +204,22 @@ def main() -> None:
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    # MMCMC_BENCH_DRYRUN_ONE_DEVICE=1: rehearsal of the N > 1 path on a box with ONE GPU (every rank on device 0, gloo for
+    # the barrier and the diagnostics' reductions, since RCCL refuses one device twice); the line it prints says so and is
+    # not a measurement
+    dryrun = distributed and os.environ.get("MMCMC_BENCH_DRYRUN_ONE_DEVICE") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if dryrun:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from mini_mcmc_amd.core import init_with_seed
     from mini_mcmc_amd.distributions import RosenbrockND
@@ -350,7 +359,7 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not dryrun else "synthetic; DRY RUN: all ranks on one device over gloo, not a measurement",
             "config": {
                 "workload": "BASELINE.json configs[2]: RosenbrockND D=3 HMC, 65536 chains/GPU, eps=0.032, L=10, f32, "
                             "run(n_collect=400, n_discard=50) per step, init_with_seed(C,3,42), seed 42",
