@@ -187,6 +187,25 @@ __device__ __forceinline__ void mm_flush_tile_raw(T *out, unsigned long long n_t
                 if (ok[gi])
                     wbase[off[gi]] = v[gi];
         }
+    } else if ((((int)nt * D) % EPL) == 0) {
+        /* short tile (the last one of a run, or a staggered first one) whose runs are whole 16-byte pieces: the same
+         * chain-linear cut with a run-time piece count per chain */
+        typedef T mm_vec16 __attribute__((ext_vector_type(EPL), aligned(sizeof(T))));
+        const unsigned int V = nt * (unsigned int)D / (unsigned int)EPL;
+        const float rV = 1.0f / (float)V;
+        for (unsigned int piece = (unsigned int)lane; piece < 64u * V; piece += 64u) {
+            unsigned int j = (unsigned int)((float)piece * rV); /* piece / V for piece < 2^16: off by at most one */
+            j -= (j * V > piece);
+            j += ((j + 1u) * V <= piece);
+            const unsigned int e = (piece - j * V) * (unsigned int)EPL;
+            const T *src = tile + j * STRIDE + e;
+            mm_vec16 v;
+            MM_UNROLL
+            for (int i = 0; i < EPL; ++i)
+                v[i] = src[i];
+            if (j < n_valid)
+                *reinterpret_cast<mm_vec16 *>(wbase + (unsigned long long)j * chain_stride + e) = v;
+        }
     } else {
         const int runv = (int)nt * D;
         for (unsigned int j = 0; j < n_valid; ++j)

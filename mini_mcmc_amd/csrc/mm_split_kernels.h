@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
         /* noise of iterations [it + QN, it + nb) of a batch into rows QN.. of the current ring half */
         /* PAIRS noise pairs are drawn back to back before any of them is stored: their Philox rounds and table reads
          * overlap (a lone pair waits out every LDS table read: the noise wave has no other work to cover it) */
+#ifndef MM_SPLIT_FLUSH_RANK
+#define MM_SPLIT_FLUSH_RANK (NN - 1) /* the noise wave that is dealt the fewest pairs of a batch writes the tiles out */
+#endif
 #ifndef MM_SPLIT_FILL_PAIRS
 #define MM_SPLIT_FILL_PAIRS 1 /* 2 and 4 measured: no difference (config 2: 0.273 / 0.280 / 0.272 ms) */
 #endif
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
             const unsigned int nb = min((unsigned int)RB, n_loud - done);
             fill(nb);
             MM_SPLIT_SYNC();
-            if (PFLUSH && pend && noise_rank == 0) {
+            if (PFLUSH && pend && noise_rank == MM_SPLIT_FLUSH_RANK) {
                 mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
                                               (unsigned long long)a.out_t0 + rows_out, pend);
                 rows_out += pend;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
             }
         }
         MM_SPLIT_SYNC(); /* the partner has finished its last batch */
-        if (PFLUSH && pend && noise_rank == 0)
+        if (PFLUSH && pend && noise_rank == MM_SPLIT_FLUSH_RANK)
             mm_flush_tile_raw<T, D, Tile>(a.out, a.n_total, a.n_chains, tiles + (size_t)pend_tb * TILE_ELEMS, lane, wave_c0,
                                           (unsigned long long)a.out_t0 + rows_out, pend);
         MM_SPLIT_PROF_END(0);
