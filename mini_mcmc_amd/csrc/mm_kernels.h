@@ -15,7 +15,7 @@
  *     one contiguous run of TILE_T*D elements with whole-wave coalesced stores
  *   - no inter-wave communication at all: a wave only synchronises with itself (wave-scope fences), so blocks
  *     are one wave (64 threads) and 65 536 chains give 1024 independent workgroups = 4 per CU, one per SIMD
- *   - accept decisions are tallied per lane and, through a wave ballot + popcount, per wave
+ *   - accept decisions are tallied per lane (one add under the accept mask) and summed over the wave once, at the end
  */
 #ifndef MM_KERNELS_H
 #define MM_KERNELS_H
@@ -237,7 +237,8 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
     Tab tab;
     if constexpr (sizeof(T) == 4) {
         mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, blockDim.x);
-        tab.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(mm_lds_raw);
+        mm_icdf_lds_check(mm_lds_raw);
+        tab.tab = mm_icdf_lds_at0();
         __syncthreads();
     }
 
@@ -259,7 +260,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
         lp = Tgt::logp(a.P, x);
 
     unsigned int it = a.iter0;
-    unsigned long long n_acc = 0, wave_acc = 0;
+    unsigned long long n_acc = 0;
     T zc[D], ln_uc = 0; /* PIPE: noise of the current transition, drawn one transition ahead */
     if (PIPE) {
         T u;
@@ -286,9 +287,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
         } else {
             acc = mm_mh_step<T, Tgt>(a.P, a.scale, x, &lp, a.seed, chain, it);
         }
-        acc = acc && active;
-        n_acc += (unsigned long long)acc;
-        wave_acc += (unsigned long long)__popcll(__ballot(acc)); /* wave-uniform: scalar add */
+        n_acc += (unsigned long long)acc; /* lanes past n_chains count too: their counters are dropped at the end */
         ++it;
     };
 
@@ -304,14 +303,12 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
         /* every lambda here MUST be inlined: an out-of-line call that captures x / g / lp by reference pins them (and the
          * kernel arguments) in scratch memory for the whole kernel -- what the compiler did for the larger targets */
         auto transition = [&](T *z, T ln_u) __attribute__((always_inline)) {
-            int acc;
+            /* accepts are counted inside the step (one add under the accept mask) and the wave's total is summed once at
+             * the end: a select, a ballot + s_bcnt1 and a 64-bit scalar add per transition were six issue slots */
             if (SAMPLER == MM_SAMPLER_HMC)
-                acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u);
+                (void)mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u, mm_no_hook(), &n_acc32);
             else
-                acc = mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u);
-            acc = acc && active;
-            n_acc32 += (unsigned int)acc;
-            wave_acc += (unsigned long long)__popcll(__ballot(acc));
+                (void)mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u, &n_acc32);
         };
         /* An odd count ends with half a pair: the second transition of the last pair is handed ln u = NaN, against which
          * both accept rules (`>`, `>=`) are false, so it leaves state and counters alone; then the noise is drawn afresh
@@ -405,8 +402,14 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
         if (a.accept)
             a.accept[c] += n_acc;
     }
-    if (a.accept_total && lane == 0 && wave_acc)
-        atomicAdd(a.accept_total, wave_acc);
+    if (a.accept_total) {
+        unsigned long long wave_acc = active ? n_acc : 0ull;
+        MM_UNROLL
+        for (int off = 32; off > 0; off >>= 1)
+            wave_acc += __shfl_xor(wave_acc, off);
+        if (lane == 0 && wave_acc)
+            atomicAdd(a.accept_total, wave_acc);
+    }
 }
 
 /* the kernel proper; the body is a device function so that a run-time compiled translation unit (user targets,

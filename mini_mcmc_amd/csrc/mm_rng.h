@@ -80,6 +80,11 @@ struct mm_icdf_global {
 
 #if defined(__HIPCC__)
 typedef __attribute__((address_space(3))) const mm_v4f *mm_lds_f4_ptr;
+/* The sampling kernels keep the tables at the very start of their (dynamic) LDS and have no static LDS, i.e. at LDS
+ * address 0: mm_icdf_lds_at0() hands out that address as a literal, so a row's address is its byte offset and nothing
+ * else.  With the array's symbol as the base every table read carried a `v_add_u32 v, <base>, v` (the base is resolved
+ * after instruction selection and cannot be folded): one instruction per normal and per logarithm.  The kernels check
+ * the assumption once (mm_icdf_lds_check) and trap if it does not hold. */
 struct mm_icdf_lds {
     mm_lds_f4_ptr tab; /* MM_ICDF_ROWS rows of the normal's table, then MM_LNM_ROWS of the logarithm's (mm_icdf_lds_fill) */
     __device__ __forceinline__ void row(uint32_t r, float *c) const
@@ -99,6 +104,12 @@ struct mm_icdf_lds {
         c[3] = v[3];
     }
 };
+__device__ __forceinline__ mm_lds_f4_ptr mm_icdf_lds_at0() { return (mm_lds_f4_ptr)(unsigned int)0u; }
+__device__ __forceinline__ void mm_icdf_lds_check(const void *lds_tab)
+{
+    if ((unsigned int)(unsigned long long)(__attribute__((address_space(3))) const void *)lds_tab != 0u)
+        __builtin_trap();
+}
 /* every thread of the block copies its share; the caller synchronises the block before the first draw */
 __device__ __forceinline__ void mm_icdf_lds_fill(float *lds_tab, unsigned int tid, unsigned int nthreads)
 {
@@ -110,6 +121,17 @@ __device__ __forceinline__ void mm_icdf_lds_fill(float *lds_tab, unsigned int ti
 #endif
 #define MM_NOISE_TABLE_BYTES ((MM_ICDF_ROWS + MM_LNM_ROWS) * 16)
 
+/* an opaque use-and-redefine of a value on the device: keeps the SLP vectoriser from fusing the scalar operations that
+ * produced it with a neighbour's (no instruction is emitted) */
+/* Only in translation units that ask for it (MM_NOISE_SCALAR_CUBICS: the MH / HMC sampling kernels, mm_inst.inc): in the
+ * NUTS kernels the same constraint sends this compiler into "Illegal instruction detected: Subtarget requires even
+ * aligned vector registers". */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MM_NOISE_SCALAR_CUBICS)
+#define MM_KEEP_SCALAR(v) asm volatile("" : "+v"(v))
+#else
+#define MM_KEEP_SCALAR(v) ((void)0)
+#endif
+
 template <class Tab> MM_HD float mm_icdf_f32(uint32_t w, const Tab &tab)
 {
     const uint32_t n = (w >> 8) | 1u;           /* odd, < 2^24: exact in f32 */
@@ -118,7 +140,12 @@ template <class Tab> MM_HD float mm_icdf_f32(uint32_t w, const Tab &tab)
     tab.row((b >> 19) & 511u, c);               /* low 5 exponent bits, top 4 mantissa bits */
     const float t = mm_u2f((b & 0x7ffffu) | 0x3f800000u) - 1.0f; /* [0, 1/16), exact */
     const float m = fmaf(fmaf(fmaf(c[3], t, c[2]), t, c[1]), t, c[0]);
-    return mm_u2f((mm_f2u(m) & 0x7fffffffu) | ((w << 23) & 0x80000000u)); /* magnitude of m, sign = bit 8 of w */
+    float z = mm_u2f((mm_f2u(m) & 0x7fffffffu) | ((w << 23) & 0x80000000u)); /* magnitude of m, sign = bit 8 of w */
+    /* On the device the result is made opaque (no instruction): otherwise the vectoriser evaluates the cubics of two
+     * neighbouring normals as three packed fmas and pays six register moves to pair the coefficients of the two table
+     * rows -- nine instructions and twelve issue slots where six scalar fmas take six. */
+    MM_KEEP_SCALAR(z);
+    return z;
 }
 
 /* ln u of the f32 accept uniform (u = (s + 1) 2^-24, any positive normal f32 works): e ln 2 + ln m with the mantissa's
@@ -132,7 +159,9 @@ template <class Tab> MM_HD float mm_lnu_f32(float u, const Tab &tab)
     tab.row_ln((b >> 18) & 31u, c); /* top five mantissa bits */
     const float t = mm_u2f((b & 0x3ffffu) | 0x3f800000u) - 1.0f; /* [0, 1/32), exact */
     const float lnm = fmaf(fmaf(fmaf(c[3], t, c[2]), t, c[1]), t, c[0]);
-    return fmaf(e, 0.6931471805599453f, lnm);
+    float r = fmaf(e, 0.6931471805599453f, lnm);
+    MM_KEEP_SCALAR(r); /* as in mm_icdf_f32: two logarithms side by side are not worth pairing */
+    return r;
 }
 /* the accept uniform's logarithm per element type: f32 the table above, f64 mm_log */
 template <class Tab> MM_HD float mm_ln_accept(float u, const Tab &tab) { return mm_lnu_f32(u, tab); }

@@ -95,7 +95,7 @@ MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, doub
 /* One Metropolis-Hastings transition with the isotropic Gaussian random-walk proposal, given its noise:
  * z[D] ~ N(0,1) and ln_u = log of the accept uniform.  x[D], lp = logp(x) are updated in place; returns 1 on accept. */
 template <class T, class Tgt>
-MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, T ln_u)
+MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, T ln_u, unsigned int *n_accepted = nullptr)
 {
     constexpr int D = Tgt::dim;
     T prop[D];
@@ -110,6 +110,8 @@ MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, cons
         for (int i = 0; i < D; ++i)
             x[i] = prop[i];
         *lp = lpp;
+        if (n_accepted)
+            ++*n_accepted; /* the kernels count here: one add under the accept mask instead of a select and an add */
     }
     return acc;
 }
@@ -134,7 +136,7 @@ struct mm_no_hook {
  * iterations' Philox rounds through here was measured (tools/hmc_split.hip) and is slower, DESIGN.md 5.1. */
 template <class T, class Tgt, int LCT = 0, class Red = mm_red_seq<T, Tgt::dim>, class Hook = mm_no_hook>
 MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x, T *lp, T *g, T *p, T ln_u,
-                            Hook &&hook = Hook())
+                            Hook &&hook = Hook(), unsigned int *n_accepted = nullptr)
 {
     /* Red: summation order of the two kinetic-energy dot products (mm_targets.h): sequential for one chain per lane,
      * grouped for the lane-group kernel (mm_hmc_lg.h), whose bit-exact host twin this then is */
@@ -193,6 +195,8 @@ MM_HD int mm_hmc_step_noise(const mm_tparams<T> &P, T eps, int n_leapfrog, T *x,
             g[i] = gn[i];
         }
         *lp = lpn;
+        if (n_accepted)
+            ++*n_accepted;
     }
     return acc;
 }

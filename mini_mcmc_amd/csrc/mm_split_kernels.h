@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
     Tab tab;
     if constexpr (sizeof(T) == 4) {
         mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, 256u * (1u + NN));
-        tab.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(mm_lds_raw);
+        mm_icdf_lds_check(mm_lds_raw);
+        tab.tab = mm_icdf_lds_at0();
     }
 #ifdef MM_SPLIT_PRIO_Q /* experiment hook of tools/split_probe.hip */
     if (!noise_wave)
@@ -256,7 +257,6 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
     MM_SPLIT_PROF_BEGIN();
 
     unsigned int n_acc32 = 0;
-    unsigned long long wave_acc = 0;
     unsigned int it = a.iter0;
     int half = 0;
     auto load_row = [&](const T *src, T *z, T *ln_u) __attribute__((always_inline)) {
@@ -274,14 +274,13 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
         *ln_u = row[D];
     };
     auto transition = [&](T *z, T ln_u) __attribute__((always_inline)) {
-        int acc;
         if (SAMPLER == MM_SAMPLER_HMC)
-            acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u);
+            (void)mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u, mm_no_hook(), &n_acc32);
         else
-            acc = mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u);
-        acc = acc && active;
-        n_acc32 += (unsigned int)acc;
-        wave_acc += (unsigned long long)__popcll(__ballot(acc));
+            (void)mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u, &n_acc32);
+        /* accepts are counted inside the step, one add under the accept mask; lanes past n_chains count too (their counters
+         * are dropped below) and the wave's total is summed once at the end -- a select, a ballot + s_bcnt1 and a 64-bit
+         * scalar add per transition were 6 of the transition wave's ~160 dependent-issue slots */
     };
     /* one batch: nb transitions; `stage` (null: silent) receives the states.  The first QN take noise drawn here, in
      * registers; the others the partner's rows, each requested one transition ahead */
@@ -291,35 +290,104 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
         for (int q = 0; q < QN; q += 2)
             mm_draw_noise_pair<D>(a.seed, chain, it_batch + q, zq[q], &lnq[q], zq[q + 1], &lnq[q + 1], tab);
     };
+    /* Collected states are staged two transitions at a time where that makes wider LDS writes (MM_SPLIT_STAGE_PAIRS): the
+     * state after the first transition of a pair waits in registers and both leave in 2 D sizeof(T) bytes cut into
+     * 16- or 8-byte pieces.  At D = 2 (f32) that is one ds_write_b128 per two transitions, conflict free at the tile's
+     * row stride, where the per-transition ds_write_b64 met a 2-way bank conflict that delayed the ring reads queued
+     * behind it.  Batches and tiles hold an even number of transitions, so a pair never straddles a tile. */
+#ifndef MM_SPLIT_STAGE_PAIRS
+#define MM_SPLIT_STAGE_PAIRS 1
+#endif
+    constexpr int PAIR_BYTES = 2 * D * (int)sizeof(T);
+    constexpr int PIECE_BYTES = (PAIR_BYTES % 16 == 0) ? 16 : ((PAIR_BYTES % 8 == 0) ? 8 : 4);
+    /* only where a pair is whole 16-byte pieces and a single state is not: D = 2 in f32 (config 2: 0.250 -> 0.236 ms), D = 1 in
+     * f64; at D = 3 (three 8-byte pieces per pair) it measured 1 % slower than ds_write2_b32 + ds_write_b32 per transition */
+    constexpr bool STAGE_PAIRS = MM_SPLIT_STAGE_PAIRS && (D * (int)sizeof(T)) % 16 != 0 && PIECE_BYTES == 16 &&
+                                 (STRIDE * (int)sizeof(T)) % PIECE_BYTES == 0 && RB % 2 == 0 && QN % 2 == 0;
+    constexpr int PE = PIECE_BYTES / (int)sizeof(T); /* elements per piece */
+    typedef T mm_piece __attribute__((ext_vector_type(PE > 1 ? PE : 2)));
+    auto put_one = [&](T *dst) __attribute__((always_inline)) {
+        MM_UNROLL
+        for (int k = 0; k < D; ++k)
+            dst[k] = x[k];
+    };
+    auto put_pair = [&](T *dst, const T *first) __attribute__((always_inline)) {
+        T both[2 * D];
+        MM_UNROLL
+        for (int k = 0; k < D; ++k) {
+            both[k] = first[k];
+            both[D + k] = x[k];
+        }
+        MM_UNROLL
+        for (int k = 0; k < 2 * D; k += PE) {
+            mm_piece v;
+            MM_UNROLL
+            for (int e = 0; e < PE; ++e)
+                v[e] = both[k + e];
+            *reinterpret_cast<mm_piece *>(dst + k) = v;
+        }
+    };
     auto batch = [&](unsigned int nb, T *stage) __attribute__((always_inline)) {
         const T *src = ring + (size_t)half * RB * 64 * NW + (size_t)lane * NW;
         T zc[D], lnc;
         if (QN < RB)
             load_row(src + (size_t)QN * 64 * NW, zc, &lnc);
-        MM_UNROLL
-        for (int q = 0; q < QN; ++q) {
-            if ((unsigned int)q < nb) {
-                transition(zq[q], lnq[q]);
-                if (stage) {
-                    MM_UNROLL
-                    for (int k = 0; k < D; ++k)
-                        stage[q * D + k] = x[k];
+        if constexpr (STAGE_PAIRS) {
+            T held[D];
+            MM_UNROLL
+            for (int q = 0; q < QN; q += 2) {
+                if ((unsigned int)q < nb) {
+                    transition(zq[q], lnq[q]);
+                    if ((unsigned int)q + 1u < nb) {
+                        MM_UNROLL
+                        for (int k = 0; k < D; ++k)
+                            held[k] = x[k];
+                        transition(zq[q + 1], lnq[q + 1]);
+                        if (stage)
+                            put_pair(stage + q * D, held);
+                    } else if (stage) {
+                        put_one(stage + q * D);
+                    }
                 }
             }
-        }
-        for (unsigned int j = QN; j < nb; ++j) {
-            T zn[D], lnn; /* rows past nb hold stale data: requested, never used */
-            load_row(src + (size_t)min(j + 1u, (unsigned int)RB - 1u) * 64 * NW, zn, &lnn);
-            transition(zc, lnc);
-            if (stage) {
+            unsigned int j = QN;
+            for (; j + 1u < nb; j += 2u) {
+                T zn[D], lnn; /* rows past nb hold stale data: requested, never used */
+                load_row(src + (size_t)(j + 1u) * 64 * NW, zn, &lnn);
+                transition(zc, lnc);
                 MM_UNROLL
                 for (int k = 0; k < D; ++k)
-                    stage[j * D + k] = x[k];
+                    held[k] = x[k];
+                load_row(src + (size_t)min(j + 2u, (unsigned int)RB - 1u) * 64 * NW, zc, &lnc);
+                transition(zn, lnn);
+                if (stage)
+                    put_pair(stage + j * D, held);
             }
+            if (j < nb) {
+                transition(zc, lnc);
+                if (stage)
+                    put_one(stage + j * D);
+            }
+        } else {
             MM_UNROLL
-            for (int k = 0; k < D; ++k)
-                zc[k] = zn[k];
-            lnc = lnn;
+            for (int q = 0; q < QN; ++q) {
+                if ((unsigned int)q < nb) {
+                    transition(zq[q], lnq[q]);
+                    if (stage)
+                        put_one(stage + q * D);
+                }
+            }
+            for (unsigned int j = QN; j < nb; ++j) {
+                T zn[D], lnn; /* rows past nb hold stale data: requested, never used */
+                load_row(src + (size_t)min(j + 1u, (unsigned int)RB - 1u) * 64 * NW, zn, &lnn);
+                transition(zc, lnc);
+                if (stage)
+                    put_one(stage + j * D);
+                MM_UNROLL
+                for (int k = 0; k < D; ++k)
+                    zc[k] = zn[k];
+                lnc = lnn;
+            }
         }
         it += nb;
         half ^= 1;
@@ -364,8 +432,14 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
         if (a.accept)
             a.accept[c] += (unsigned long long)n_acc32;
     }
-    if (a.accept_total && lane == 0 && wave_acc)
-        atomicAdd(a.accept_total, wave_acc);
+    if (a.accept_total) {
+        unsigned long long wave_acc = active ? (unsigned long long)n_acc32 : 0ull;
+        MM_UNROLL
+        for (int off = 32; off > 0; off >>= 1)
+            wave_acc += __shfl_xor(wave_acc, off);
+        if (lane == 0 && wave_acc)
+            atomicAdd(a.accept_total, wave_acc);
+    }
 }
 
 template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 [-DMM_SPLIT_PRIO_Q=3]
 //         [-DMM_SPLIT_MH_QP=0|1|2] tools/split_probe.hip -o /tmp/split_probe
 // config 3 (HMC RosenbrockND(3), 65 536 chains, run(400, 50)) and config 2 (MH Gaussian2D, run(1000, 100)).
+#define MM_NOISE_SCALAR_CUBICS 1 /* as mm_inst.inc */
 #include "../mini_mcmc_amd/csrc/mm_split_kernels.h"
 #include "../mini_mcmc_amd/csrc/mm_params.h"
 #include <cstdio>
