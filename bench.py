@@ -392,9 +392,9 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": k_ms,
                 "launches_per_step": 1,
-                "note": "the kernel is bound by VALU instruction issue, not by HBM (about 270 VALU instructions per 12 "
+                "note": "the kernel is bound by VALU instruction issue, not by HBM (about 260 VALU instructions per 12 "
                         "algorithmic bytes; tools/issue_rate.hip: 4.4 cycles per instruction for one wave, 5.85 for a dependent chain "
-                        "-- the transition wave's 165 instructions per transition; three noise waves share its SIMD): "
+                        "-- the transition wave's ~155 instructions per transition; three noise waves share its SIMD): "
                         "`frac` is the HBM fraction BASELINE.json asks for, `valu_issue` the SQ-counter view",
                 "valu": {"achieved_tflops": valu_tflops, "peak_tflops": FP32_VALU_PEAK_TFLOPS,
                          "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "flop_per_iteration": FLOP_PER_ITER},

@@ -127,7 +127,7 @@ __device__ __forceinline__ void mm_icdf_lds_fill(float *lds_tab, unsigned int ti
  * NUTS kernels the same constraint sends this compiler into "Illegal instruction detected: Subtarget requires even
  * aligned vector registers". */
 #if defined(__HIP_DEVICE_COMPILE__) && defined(MM_NOISE_SCALAR_CUBICS)
-#define MM_KEEP_SCALAR(v) asm volatile("" : "+v"(v))
+#define MM_KEEP_SCALAR(v) asm("" : "+v"(v)) /* not volatile: free to move, so neighbouring table reads still issue together */
 #else
 #define MM_KEEP_SCALAR(v) ((void)0)
 #endif
