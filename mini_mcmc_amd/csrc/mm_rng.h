@@ -64,6 +64,7 @@ struct mm_icdf_global {
         c[2] = v[2];
         c[3] = v[3];
     }
+    MM_HD void row_of_bits(uint32_t b, float *c) const { row((b >> 19) & 511u, c); }
     MM_HD void row_ln(uint32_t r, float *c) const /* the logarithm's table (mm_lnu_f32) */
     {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -90,6 +91,16 @@ struct mm_icdf_lds {
     __device__ __forceinline__ void row(uint32_t r, float *c) const
     {
         const mm_v4f v = tab[r];
+        c[0] = v[0];
+        c[1] = v[1];
+        c[2] = v[2];
+        c[3] = v[3];
+    }
+    __device__ __forceinline__ void row_of_bits(uint32_t b, float *c) const
+    {
+        /* the row's byte offset straight from the bits: (b >> 15) & 0x1ff0 (tab is LDS address 0, mm_icdf_lds_at0) */
+        const unsigned int off = (b >> 15) & 0x1ff0u;
+        const mm_v4f v = *(mm_lds_f4_ptr)((unsigned int)(unsigned long long)tab + off);
         c[0] = v[0];
         c[1] = v[1];
         c[2] = v[2];
@@ -137,10 +148,11 @@ template <class Tab> MM_HD float mm_icdf_f32(uint32_t w, const Tab &tab)
     const uint32_t n = (w >> 8) | 1u;           /* odd, < 2^24: exact in f32 */
     const uint32_t b = mm_f2u((float)n);
     float c[4];
-    tab.row((b >> 19) & 511u, c);               /* low 5 exponent bits, top 4 mantissa bits */
+    tab.row_of_bits(b, c);                      /* row (b >> 19) & 511: low 5 exponent bits, top 4 mantissa bits */
     const float t = mm_u2f((b & 0x7ffffu) | 0x3f800000u) - 1.0f; /* [0, 1/16), exact */
     const float m = fmaf(fmaf(fmaf(c[3], t, c[2]), t, c[1]), t, c[0]);
-    float z = mm_u2f((mm_f2u(m) & 0x7fffffffu) | ((w << 23) & 0x80000000u)); /* magnitude of m, sign = bit 8 of w */
+    /* magnitude of m, sign = bit 8 of w: (m & 0x7fffffff) | ((w << 23) & 0x80000000) written as a copysign -- one v_bfi_b32 */
+    float z = __builtin_copysignf(m, mm_u2f(w << 23));
     /* On the device the result is made opaque (no instruction): otherwise the vectoriser evaluates the cubics of two
      * neighbouring normals as three packed fmas and pays six register moves to pair the coefficients of the two table
      * rows -- nine instructions and twelve issue slots where six scalar fmas take six. */
@@ -228,10 +240,27 @@ MM_HD mm_u32x4 mm_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint3
                             (uint32_t)(seed >> 32));
 }
 
+/* s = low bytes of w0, w1, w2 side by side.  On the device two byte permutes (v_perm_b32: selector bytes 0-3 take bytes
+ * of the second operand, 4-7 of the first, 12 is the constant 0) instead of three masks, two shifts and two ors; and
+ * (float)(s + 1) 2^-24 as fma((float)s, 2^-24, 2^-24): s < 2^24 converts exactly and (s + 1) 2^-24 is representable, so the
+ * fma returns exactly the product of the plain form -- same bits, one instruction less. */
+MM_HD uint32_t mm_spare_bytes(uint32_t w0, uint32_t w1, uint32_t w2)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __builtin_amdgcn_perm(w1, w0, 0x0c0c0400u); /* [w0.b0, w1.b0, 0, 0] */
+    return __builtin_amdgcn_perm(w2, t, 0x0c040100u);               /* [t.b0, t.b1, w2.b0, 0] */
+#else
+    return (w0 & 255u) | ((w1 & 255u) << 8) | ((w2 & 255u) << 16);
+#endif
+}
 MM_HD float mm_spare_u24(mm_u32x4 b)
 {
-    uint32_t s = (b.w[0] & 255u) | ((b.w[1] & 255u) << 8) | ((b.w[2] & 255u) << 16);
+    const uint32_t s = mm_spare_bytes(b.w[0], b.w[1], b.w[2]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fmaf((float)s, 0x1.0p-24f, 0x1.0p-24f);
+#else
     return (float)(s + 1u) * 0x1.0p-24f;
+#endif
 }
 
 MM_HD double mm_u53(uint32_t hi, uint32_t lo)
@@ -313,8 +342,15 @@ MM_HD mm_u32x4x2 mm_block_pair(uint64_t seed, uint64_t chain, uint32_t iteration
 
 MM_HD mm_f2 mm_spare_u24x2(mm_u32x4x2 b)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mm_f2 r;
+    r[0] = fmaf((float)mm_spare_bytes(b.w[0][0], b.w[1][0], b.w[2][0]), 0x1.0p-24f, 0x1.0p-24f);
+    r[1] = fmaf((float)mm_spare_bytes(b.w[0][1], b.w[1][1], b.w[2][1]), 0x1.0p-24f, 0x1.0p-24f);
+    return r;
+#else
     mm_u2 s = (b.w[0] & 255u) | ((b.w[1] & 255u) << 8) | ((b.w[2] & 255u) << 16);
     return mm_u2_to_f2(s + 1u) * mm_splat2(0x1.0p-24f);
+#endif
 }
 
 /* auxiliary 53-bit uniform k of an iteration (NUTS; f64 accept uniform uses k = 0) */
