@@ -123,7 +123,7 @@ __device__ unsigned long long mm_split_prof[2][2];
 #endif
 
 /* NN noise waves per pair (1: the workgroup above; 2, 3: 768 / 1024 threads, three / four waves per SIMD -- the noise
- * pairs of a batch are dealt to the noise waves in turn, noise wave 0 writes the tiles out): more waves to cover each
+ * pairs of a batch are dealt to the noise waves in turn, the last noise wave -- dealt the fewest pairs -- writes the tiles out): more waves to cover each
  * other's LDS and issue latencies where the step is short (MH).  RBF: ring half (0 = the plan's choice). */
 template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
 __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_run_args<T> a)
