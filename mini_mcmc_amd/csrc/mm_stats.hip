@@ -69,6 +69,22 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+/* the same total, bit for bit ((r0 + r1) + (r2 + r3) with the sums commuted), with the rows combined by two row-broadcast
+ * adds and one readlane instead of four readlanes, two moves and three adds: lane 15 of rows 0 / 2 into rows 1 / 3, then
+ * lane 31 into rows 2 and 3; lane 63 holds (r3 + r2) + (r1 + r0) */
+__device__ __forceinline__ float wave_sum_dpp_bcast(float v)
+{
+#define MM_DPP_ADD(x, ctrl, rows) ((x) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), (rows), 0xf, false)))
+    v = MM_DPP_ADD(v, 0xB1, 0xf);  /* quad_perm [1, 0, 3, 2] */
+    v = MM_DPP_ADD(v, 0x4E, 0xf);  /* quad_perm [2, 3, 0, 1] */
+    v = MM_DPP_ADD(v, 0x141, 0xf); /* row_half_mirror */
+    v = MM_DPP_ADD(v, 0x140, 0xf); /* row_mirror */
+    v = MM_DPP_ADD(v, 0x142, 0xa); /* row_bcast:15 into rows 1 and 3 */
+    v = MM_DPP_ADD(v, 0x143, 0xc); /* row_bcast:31 into rows 2 and 3 */
+#undef MM_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 /* sample [C, n, D] of T (f32 or f64; converted to f32 on load like RunStats::from, stats.rs:365).
  * half-chain index hc in [0, 2C): hc < C -> rows [0, m) of chain hc ; else rows [n-m, n) of chain hc-C.
  * means / ssq: [2C, D];  slabs: [n_waves, D, m] un-normalised lag sums over the half-chains of each wave. */
@@ -465,6 +481,16 @@ __global__ __launch_bounds__(64) void mm_half_chain_tile_kernel(const T *__restr
             }
         }
     };
+#ifdef MM_STATS_DEPHASE /* experiment hook of tools/stats_probe.hip: which waves start late, and by how many 64-cycle units */
+    {
+        const unsigned int sel = MM_STATS_DEPHASE == 1 ? (blockIdx.x & 1u)
+                               : MM_STATS_DEPHASE == 2 ? (blockIdx.x >= gridDim.x / 2 ? 1u : 0u)
+                               : MM_STATS_DEPHASE == 3 ? ((blockIdx.x >> 8) & 1u)
+                               : ((blockIdx.x >> 2) & 1u);
+        if (sel)
+            __builtin_amdgcn_s_sleep(MM_STATS_DEPHASE_UNITS);
+    }
+#endif
     if (prefetch && blockIdx.x < n_half)
         request(blockIdx.x);
     for (unsigned long long hc = blockIdx.x; hc < n_half; hc += gridDim.x) {
@@ -627,6 +653,183 @@ __global__ __launch_bounds__(64) void mm_half_chain_tile_kernel(const T *__restr
     __builtin_amdgcn_wave_barrier();
     float *out = slabs + (size_t)blockIdx.x * D * m;
     for (unsigned int i = lane; i < D * m; i += 64)
+        out[i] = slab[i];
+}
+
+/* The register-tile kernel with ONE PARAMETER PER WAVE: wave (s, d) = block s D + d reduces parameter d of the half-chains
+ * s, s + S, s + 2 S, ... (S = gridDim.x / D) into row d of slab s.
+ *
+ * Why: the kernel above keeps all D x tiles(m) tiles of a half-chain in one wave -- 128 lag sums per lane at [., 400, 3],
+ * 250 registers, TWO waves per SIMD -- and two waves do not fill a SIMD: a lone wave issues one vector instruction per
+ * 4.4-5.5 cycles, so its 1024 FMAs alone take 4500+ cycles per half-chain and the SIMD's vector pipe sits at
+ * 57 % (SQ counters; de-phasing the two waves changed nothing).  One parameter's tiles(m) tiles are a third of that: TPL
+ * = 3 slots of 16 lag sums, the operands fetched per tile (no double buffer: other waves cover the LDS latency), ~110
+ * registers = FOUR waves per SIMD, and the half-chain's [m, D] block is read by D waves (the lines stay in L2; HBM traffic
+ * is unchanged).  Each (slab, parameter) accumulates the same half-chains in the same order as above; within a lag the
+ * time blocks' partial sums are folded in ascending order as above. */
+template <class T, int TPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n, unsigned int D, unsigned int m,
+                                float *__restrict__ means, float *__restrict__ ssq, float *__restrict__ slabs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr unsigned int RT = 8, SK = 16;
+    const unsigned int nbk = (m + SK - 1) / SK;
+    auto at = [](unsigned int t) -> unsigned int { return 12u * (t >> 3) + (t & 7u); };
+    const unsigned int pitch = 12u * ((m + RT + SK + 8 + 7) / 8) + 4u;
+    float *y = lds;              /* [pitch] */
+    float *slab = lds + pitch;   /* [m] */
+    float *scratch = slab + m;   /* [64][SK] */
+    const unsigned int lane = threadIdx.x;
+    const unsigned int dsel = blockIdx.x % D, bid = blockIdx.x / D, nblk = gridDim.x / D;
+    const unsigned long long n_half = 2ull * C;
+    auto cnt = [&](unsigned int kb) -> unsigned int { return (m - SK * kb + RT - 1) / RT; };
+    unsigned int n_tiles = 0;
+    for (unsigned int kb = 0; kb < nbk; ++kb)
+        n_tiles += cnt(kb);
+    unsigned int off_t[TPL], off_w[TPL];
+#pragma unroll
+    for (int sl = 0; sl < TPL; ++sl) {
+        const unsigned int e = lane + 64u * (unsigned int)sl;
+        off_t[sl] = 12u * ((m + 15) / 8); /* no tile in this slot: both operands from the zero tail of the row */
+        off_w[sl] = 12u * ((m + 15) / 8);
+        if (e < n_tiles) {
+            unsigned int r = e, kb = 0;
+            while (r >= cnt(kb)) {
+                r -= cnt(kb);
+                ++kb;
+            }
+            off_t[sl] = 12u * r;
+            off_w[sl] = 12u * (r + 2u * kb);
+        }
+    }
+    float acc[TPL][SK];
+#pragma unroll
+    for (int sl = 0; sl < TPL; ++sl)
+#pragma unroll
+        for (unsigned int j = 0; j < SK; ++j)
+            acc[sl][j] = 0.f;
+    for (unsigned int i = lane; i < pitch; i += 64)
+        y[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    /* the column of the NEXT half-chain is requested before the current one is reduced: element t of the column is
+     * src[t D] (a wave's 64 loads span 64 D elements: the D waves of a slab touch the same lines) */
+    constexpr unsigned int NPRE = 4; /* m <= 256 (the host checks) */
+    /* No branches in the loop: a lane's element t = lane + 64 i past the end of the column is loaded from the column's last
+     * element and masked to zero, and its centred value goes to a spare word behind the scratch area (the row's zero
+     * tail must stay zero).  src_idx / lds_off / live are loop invariants. */
+    unsigned int lds_off[NPRE], src_idx[NPRE];
+    bool live[NPRE];
+    float pre[NPRE];
+    const float inv_m = 1.0f / (float)m;
+#pragma unroll
+    for (unsigned int i = 0; i < NPRE; ++i) {
+        const unsigned int t = lane + 64u * i;
+        live[i] = t < m;
+        lds_off[i] = live[i] ? at(t) : pitch + m + 64u * SK + lane; /* the spare words: [64] behind scratch */
+        src_idx[i] = (live[i] ? t : m - 1u) * D;
+    }
+    auto column_of = [&](unsigned long long hc) -> const T * {
+        const unsigned long long chain = hc < C ? hc : hc - C;
+        const unsigned int row0 = hc < C ? 0u : n - m;
+        return sample + (chain * n + row0) * D + dsel;
+    };
+    auto request = [&](unsigned long long hc) {
+        const T *src = column_of(hc);
+#pragma unroll
+        for (unsigned int i = 0; i < NPRE; ++i)
+            pre[i] = (float)src[src_idx[i]];
+    };
+    if (bid < n_half)
+        request(bid);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (unsigned long long hc = bid; hc < n_half; hc += nblk) {
+        /* mean, centred sum of squares, centring: on the registers that hold the column (the row in LDS is written once,
+         * centred); the mean is sum x (1 / m) with the reciprocal formed once per wave */
+        float s0 = 0.f;
+#pragma unroll
+        for (unsigned int i = 0; i < NPRE; ++i) {
+            pre[i] = live[i] ? pre[i] : 0.f;
+            s0 += pre[i];
+        }
+        const float mean = wave_sum_dpp_bcast(s0) * inv_m;
+        float q = 0.f;
+#pragma unroll
+        for (unsigned int i = 0; i < NPRE; ++i) {
+            const float v = live[i] ? pre[i] - mean : 0.f;
+            y[lds_off[i]] = v;
+            q = fmaf(v, v, q);
+        }
+        q = wave_sum_dpp_bcast(q);
+        if (lane == 0) {
+            means[hc * D + dsel] = mean;
+            ssq[hc * D + dsel] = q;
+        }
+        if (hc + nblk < n_half)
+            request(hc + nblk);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sl = 0; sl < TPL; ++sl) {
+            float yt[RT], yw[RT + SK];
+            const f4 *pt = reinterpret_cast<const f4 *>(y + off_t[sl]);
+            const f4 *pw = reinterpret_cast<const f4 *>(y + off_w[sl]);
+#pragma unroll
+            for (unsigned int i = 0; i < RT / 4; ++i) {
+                const f4 v = pt[3 * (i >> 1) + (i & 1u)];
+                yt[4 * i] = v[0];
+                yt[4 * i + 1] = v[1];
+                yt[4 * i + 2] = v[2];
+                yt[4 * i + 3] = v[3];
+            }
+#pragma unroll
+            for (unsigned int i = 0; i < (RT + SK) / 4; ++i) {
+                const f4 v = pw[3 * (i >> 1) + (i & 1u)];
+                yw[4 * i] = v[0];
+                yw[4 * i + 1] = v[1];
+                yw[4 * i + 2] = v[2];
+                yw[4 * i + 3] = v[3];
+            }
+#pragma unroll
+            for (unsigned int r = 0; r < RT; ++r)
+#pragma unroll
+                for (unsigned int j = 0; j < SK; ++j)
+                    acc[sl][j] = fmaf(yt[r], yw[r + j], acc[sl][j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (unsigned int i = lane; i < m; i += 64)
+        slab[i] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < TPL; ++sl) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (unsigned int j = 0; j < SK; ++j)
+            scratch[lane * SK + j] = acc[sl][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned int e_lo = 64u * (unsigned int)sl, e_hi = e_lo + 64u;
+        for (unsigned int lag = lane; lag < m; lag += 64) {
+            const unsigned int kb = lag / SK, j = lag - kb * SK;
+            unsigned int first = 0;
+            for (unsigned int qq = 0; qq < kb; ++qq)
+                first += cnt(qq);
+            const unsigned int last = first + cnt(kb);
+            const unsigned int lo = first > e_lo ? first : e_lo, hi = last < e_hi ? last : e_hi;
+            float sum = slab[lag];
+            for (unsigned int e = lo; e < hi; ++e)
+                sum += scratch[(e - e_lo) * SK + j];
+            slab[lag] = sum;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float *out = slabs + ((size_t)bid * D + dsel) * m;
+    for (unsigned int i = lane; i < m; i += 64)
         out[i] = slab[i];
 }
 
@@ -808,6 +1011,35 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         !(force_kernel && !strcmp(force_kernel, "mfma"))) {
         if (!slabs)
             MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+        /* one parameter per wave (mm_half_chain_tile1_kernel: four waves per SIMD) where a parameter's tiles fit three
+         * slots per lane and the column four loads per lane: dim > 1, tiles(m) <= 192, m <= 256; MMCMC_STATS_KERNEL=tile
+         * keeps the all-parameters kernel */
+        const unsigned int tiles_1 = stats_tile_count(m);
+        const bool per_param = dim > 1 && tiles_1 <= 192 && m <= 256 && !(force_kernel && !strcmp(force_kernel, "tile"));
+        if (per_param) {
+            if (!getenv("MMCMC_STATS_WAVES"))
+                n_slabs = (unsigned int)std::min<size_t>(n_slabs, std::max<size_t>(1, 4096 / dim));
+            const size_t lds_1 = (pitch_t + m + 64 * 16 + 64) * sizeof(float);
+#define MM_TILE1_LAUNCH(TT, TPLV)                                                                                   \
+    hipLaunchKernelGGL((mm_half_chain_tile1_kernel<TT, TPLV>), dim3(n_slabs * (unsigned int)dim), dim3(64), lds_1, stream, \
+                       (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,        \
+                       (unsigned int)m, means, ssq, slabs)
+#define MM_TILE1_PICK(TT)                                                                                           \
+    do {                                                                                                            \
+        if (tiles_1 <= 64)                                                                                          \
+            MM_TILE1_LAUNCH(TT, 1);                                                                                 \
+        else if (tiles_1 <= 128)                                                                                    \
+            MM_TILE1_LAUNCH(TT, 2);                                                                                 \
+        else                                                                                                        \
+            MM_TILE1_LAUNCH(TT, 3);                                                                                 \
+    } while (0)
+            if (dtype == MMCMC_F32)
+                MM_TILE1_PICK(float);
+            else
+                MM_TILE1_PICK(double);
+#undef MM_TILE1_PICK
+#undef MM_TILE1_LAUNCH
+        } else {
         /* this kernel holds two waves per SIMD (250 registers): exactly the resident waves, each with a longer list of
          * half-chains (measured at [65 536, 400, 3]: 1024 waves 0.62 ms, 2048 0.39, 4096 0.43, 8192 0.54) */
         if (!getenv("MMCMC_STATS_WAVES"))
@@ -842,6 +1074,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
 #undef MM_TILE_PICK
 #undef MM_TILE_LAUNCH
 #undef MM_TILE_LAUNCH1
+        }
     } else if (lds_mfma <= 64 * 1024 && !(force_direct && force_direct[0] == '1')) {
         if (!slabs)
             MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));

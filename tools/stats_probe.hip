@@ -32,5 +32,20 @@ int main()
         }
         printf("tile<8> [65536, 400, 3], %u waves: %.4f ms\n", waves, best);
     }
+    /* one parameter per wave (mm_half_chain_tile1_kernel<float, 3>): blocks = slabs x D */
+    const size_t lds1 = (pitch + m + 64 * 16 + 64) * 4;
+    for (unsigned int slabs_n : {683u, 1024u, 1365u, 2048u, 2730u, 4096u}) {
+        float best = 1e9;
+        for (int r = 0; r < 6; ++r) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL((mm_half_chain_tile1_kernel<float, 3>), dim3(slabs_n * D), dim3(64), lds1, 0, x, C, n, D, m, means, ssq, slabs);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            best = ms < best ? ms : best;
+        }
+        printf("tile1<3> [65536, 400, 3], %u slabs x 3 waves: %.4f ms\n", slabs_n, best);
+    }
     return 0;
 }
