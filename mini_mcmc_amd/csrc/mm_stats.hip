@@ -667,10 +667,10 @@ __global__ __launch_bounds__(64) void mm_half_chain_tile_kernel(const T *__restr
  * registers = FOUR waves per SIMD, and the half-chain's [m, D] block is read by D waves (the lines stay in L2; HBM traffic
  * is unchanged).  Each (slab, parameter) accumulates the same half-chains in the same order as above; within a lag the
  * time blocks' partial sums are folded in ascending order as above. */
-template <class T, int TPL>
+template <class T, int TPL, int NPRE_>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n, unsigned int D, unsigned int m,
-                                float *__restrict__ means, float *__restrict__ ssq, float *__restrict__ slabs)
+                                unsigned int P, float *__restrict__ means, float *__restrict__ ssq, float *__restrict__ slabs)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr unsigned int RT = 8, SK = 16;
@@ -681,7 +681,10 @@ void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long
     float *slab = lds + pitch;   /* [m] */
     float *scratch = slab + m;   /* [64][SK] */
     const unsigned int lane = threadIdx.x;
-    const unsigned int dsel = blockIdx.x % D, bid = blockIdx.x / D, nblk = gridDim.x / D;
+    /* block = (slab, part, parameter): a parameter's tiles are dealt to P waves, 64 TPL consecutive tiles each (P = 1 up to
+     * 192 tiles, i.e. m <= 200; [., 1000, 3]: 1008 tiles, six parts); every part loads and centres the column itself */
+    const unsigned int dsel = blockIdx.x % D, part = (blockIdx.x / D) % P, bid = blockIdx.x / (D * P), nblk = gridDim.x / (D * P);
+    const unsigned int e0 = part * 64u * (unsigned int)TPL;
     const unsigned long long n_half = 2ull * C;
     auto cnt = [&](unsigned int kb) -> unsigned int { return (m - SK * kb + RT - 1) / RT; };
     unsigned int n_tiles = 0;
@@ -690,7 +693,7 @@ void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long
     unsigned int off_t[TPL], off_w[TPL];
 #pragma unroll
     for (int sl = 0; sl < TPL; ++sl) {
-        const unsigned int e = lane + 64u * (unsigned int)sl;
+        const unsigned int e = e0 + lane + 64u * (unsigned int)sl;
         off_t[sl] = 12u * ((m + 15) / 8); /* no tile in this slot: both operands from the zero tail of the row */
         off_w[sl] = 12u * ((m + 15) / 8);
         if (e < n_tiles) {
@@ -716,7 +719,7 @@ void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long
 
     /* the column of the NEXT half-chain is requested before the current one is reduced: element t of the column is
      * src[t D] (a wave's 64 loads span 64 D elements: the D waves of a slab touch the same lines) */
-    constexpr unsigned int NPRE = 4; /* m <= 256 (the host checks) */
+    constexpr unsigned int NPRE = NPRE_; /* m <= 64 NPRE (the host checks) */
     /* No branches in the loop: a lane's element t = lane + 64 i past the end of the column is loaded from the column's last
      * element and masked to zero, and its centred value goes to a spare word behind the scratch area (the row's zero
      * tail must stay zero).  src_idx / lds_off / live are loop invariants. */
@@ -763,7 +766,7 @@ void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long
             q = fmaf(v, v, q);
         }
         q = wave_sum_dpp_bcast(q);
-        if (lane == 0) {
+        if (lane == 0 && part == 0) {
             means[hc * D + dsel] = mean;
             ssq[hc * D + dsel] = q;
         }
@@ -812,7 +815,7 @@ void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long
             scratch[lane * SK + j] = acc[sl][j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const unsigned int e_lo = 64u * (unsigned int)sl, e_hi = e_lo + 64u;
+        const unsigned int e_lo = e0 + 64u * (unsigned int)sl, e_hi = e_lo + 64u;
         for (unsigned int lag = lane; lag < m; lag += 64) {
             const unsigned int kb = lag / SK, j = lag - kb * SK;
             unsigned int first = 0;
@@ -828,7 +831,7 @@ void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float *out = slabs + ((size_t)bid * D + dsel) * m;
+    float *out = slabs + (((size_t)bid * P + part) * D + dsel) * m;
     for (unsigned int i = lane; i < m; i += 64)
         out[i] = slab[i];
 }
@@ -1007,36 +1010,43 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
     const unsigned int tpl = (unsigned int)((tiles_total + 63) / 64);
     const size_t pitch_t = 12 * ((m + 8 + 16 + 8 + 7) / 8) + 4; /* the kernel's row pitch */
     const size_t lds_tile = (dim * pitch_t + dim * m + 64 * 16) * sizeof(float);
-    if (tpl <= 8 && lds_tile <= 40 * 1024 && /* 8 tiles = 128 lag sums + operands = 218 registers: two waves per SIMD */ !(force_direct && force_direct[0] == '1') &&
-        !(force_kernel && !strcmp(force_kernel, "mfma"))) {
+    /* one parameter per wave, a parameter's tiles dealt to `parts` waves of three slots (mm_half_chain_tile1_kernel: four
+     * waves per SIMD): half-chains up to 512 long -- eight column loads per lane, 16 waves' rows in a CU's LDS --;
+     * MMCMC_STATS_KERNEL=tile keeps the all-parameters kernel where that one applies */
+    const unsigned int tiles_1 = stats_tile_count(m);
+    const unsigned int tpl_1 = tiles_1 <= 64 ? 1u : tiles_1 <= 128 ? 2u : 3u;
+    const unsigned int parts = (tiles_1 + 64u * tpl_1 - 1u) / (64u * tpl_1);
+    const size_t lds_1 = (pitch_t + m + 64 * 16 + 64) * sizeof(float);
+    const bool no_force = !(force_direct && force_direct[0] == '1') && !(force_kernel && !strcmp(force_kernel, "mfma"));
+    const bool per_param = no_force && m <= 512 && 16 * lds_1 <= 160 * 1024 && (size_t)parts * dim <= n_slabs &&
+                           !(force_kernel && !strcmp(force_kernel, "tile"));
+    if (per_param || (tpl <= 8 && lds_tile <= 40 * 1024 && /* 8 tiles = 128 lag sums + operands = 218 registers: two waves per SIMD */ no_force)) {
         if (!slabs)
             MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
-        /* one parameter per wave (mm_half_chain_tile1_kernel: four waves per SIMD) where a parameter's tiles fit three
-         * slots per lane and the column four loads per lane: dim > 1, tiles(m) <= 192, m <= 256; MMCMC_STATS_KERNEL=tile
-         * keeps the all-parameters kernel */
-        const unsigned int tiles_1 = stats_tile_count(m);
-        const bool per_param = dim > 1 && tiles_1 <= 192 && m <= 256 && !(force_kernel && !strcmp(force_kernel, "tile"));
         if (per_param) {
-            if (!getenv("MMCMC_STATS_WAVES"))
-                n_slabs = (unsigned int)std::min<size_t>(n_slabs, std::max<size_t>(1, 4096 / dim));
-            const size_t lds_1 = (pitch_t + m + 64 * 16 + 64) * sizeof(float);
-#define MM_TILE1_LAUNCH(TT, TPLV)                                                                                   \
-    hipLaunchKernelGGL((mm_half_chain_tile1_kernel<TT, TPLV>), dim3(n_slabs * (unsigned int)dim), dim3(64), lds_1, stream, \
-                       (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,        \
-                       (unsigned int)m, means, ssq, slabs)
+            /* slabs x parts x parameters waves = the resident 16 per CU; the tail sums slabs x parts rows per (d, lag) */
+            const size_t cap = getenv("MMCMC_STATS_WAVES") ? (size_t)n_slabs : 4096 / dim;
+            n_slabs = (unsigned int)std::max<size_t>(1, std::min<size_t>(n_slabs, cap) / parts);
+#define MM_TILE1_LAUNCH(TT, TPLV, NPREV)                                                                            \
+    hipLaunchKernelGGL((mm_half_chain_tile1_kernel<TT, TPLV, NPREV>), dim3(n_slabs * parts * (unsigned int)dim), dim3(64), lds_1, \
+                       stream, (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, \
+                       (unsigned int)m, parts, means, ssq, slabs)
 #define MM_TILE1_PICK(TT)                                                                                           \
     do {                                                                                                            \
-        if (tiles_1 <= 64)                                                                                          \
-            MM_TILE1_LAUNCH(TT, 1);                                                                                 \
-        else if (tiles_1 <= 128)                                                                                    \
-            MM_TILE1_LAUNCH(TT, 2);                                                                                 \
+        if (m > 256)                                                                                                \
+            MM_TILE1_LAUNCH(TT, 3, 8);                                                                              \
+        else if (tpl_1 == 1)                                                                                        \
+            MM_TILE1_LAUNCH(TT, 1, 4);                                                                              \
+        else if (tpl_1 == 2)                                                                                        \
+            MM_TILE1_LAUNCH(TT, 2, 4);                                                                              \
         else                                                                                                        \
-            MM_TILE1_LAUNCH(TT, 3);                                                                                 \
+            MM_TILE1_LAUNCH(TT, 3, 4);                                                                              \
     } while (0)
             if (dtype == MMCMC_F32)
                 MM_TILE1_PICK(float);
             else
                 MM_TILE1_PICK(double);
+            n_slabs *= parts; /* rows the tail kernel sums */
 #undef MM_TILE1_PICK
 #undef MM_TILE1_LAUNCH
         } else {

@@ -390,7 +390,10 @@ def _ar1(rng, c, n, p, phi=0.6):
 
 
 @pytest.mark.parametrize("c,n,p", [(4, 60, 2), (3, 200, 3), (7, 201, 1), (16, 400, 3), (2, 1000, 2), (5, 2, 2), (1, 50, 4),
-                                   (64, 100, 32), (2, 6000, 3)])  # the last: too long for the MFMA kernel's LDS layout -> direct kernel
+                                   (64, 100, 32), (2, 6000, 3),  # the last: too long for the MFMA kernel's LDS layout -> direct kernel
+                                   # one parameter per wave (mm_half_chain_tile1_kernel) with enough chains for every path:
+                                   # six tile parts, eight column loads (m = 257, two parts), D = 1, ragged m, one slot
+                                   (300, 1000, 3), (200, 514, 2), (100, 402, 1), (50, 331, 5), (700, 64, 3)])
 def test_split_rhat_mean_ess_vs_oracle(M, O, c, n, p):
     from mini_mcmc_amd import stats as S
 
@@ -406,6 +409,37 @@ def test_split_rhat_mean_ess_vs_oracle(M, O, c, n, p):
     # f64 input is cast to f32 first, like RunStats::from (stats.rs:365)
     r2, e2 = S.split_rhat_mean_ess(x.astype(np.float64))
     assert np.array_equal(r1, r2) and np.array_equal(e1, e2)
+
+
+@pytest.mark.parametrize("c,n,p", [(2000, 400, 3), (300, 1000, 3), (500, 200, 2)])
+def test_stats_kernels_agree(M, O, c, n, p):
+    """The three lag-sum kernels -- one parameter per wave (default), all parameters in one wave ("tile"), matrix cores
+    ("mfma") -- on one sample: R-hat / ESS equal to 1e-5 / 1e-4, each bitwise reproducible from call to call."""
+    import os
+
+    from mini_mcmc_amd import stats as S
+
+    x = _ar1(np.random.default_rng(n + p), c, n, p)
+    x[:, :, -1] += 3.0
+    res = {}
+    for k in ("default", "tile", "mfma"):
+        if k == "default":
+            os.environ.pop("MMCMC_STATS_KERNEL", None)
+        else:
+            os.environ["MMCMC_STATS_KERNEL"] = k
+        try:
+            a = S.split_rhat_mean_ess(x)
+            b = S.split_rhat_mean_ess(x)
+        finally:
+            os.environ.pop("MMCMC_STATS_KERNEL", None)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), k
+        res[k] = a
+    for k in ("tile", "mfma"):
+        np.testing.assert_allclose(res[k][0], res["default"][0], rtol=1e-5)
+        np.testing.assert_allclose(res[k][1], res["default"][1], rtol=1e-4)
+    r0, e0 = O.split_rhat_mean_ess(x)
+    np.testing.assert_allclose(res["default"][0], r0, rtol=1e-4)
+    np.testing.assert_allclose(res["default"][1], e0, rtol=5e-3)
 
 
 def test_stats_kats_on_gpu(M, O, kats):

@@ -38,7 +38,7 @@ int main()
         float best = 1e9;
         for (int r = 0; r < 6; ++r) {
             (void)hipEventRecord(e0);
-            hipLaunchKernelGGL((mm_half_chain_tile1_kernel<float, 3>), dim3(slabs_n * D), dim3(64), lds1, 0, x, C, n, D, m, means, ssq, slabs);
+            hipLaunchKernelGGL((mm_half_chain_tile1_kernel<float, 3, 4>), dim3(slabs_n * D), dim3(64), lds1, 0, x, C, n, D, m, 1u, means, ssq, slabs);
             (void)hipEventRecord(e1);
             (void)hipEventSynchronize(e1);
             float ms;
