@@ -222,7 +222,8 @@ static bool launch_step_tiled(int D, unsigned int grid, hipStream_t st, const T 
 
 /* sequential replay of the last `len` <= kTail flags (time-major, chain-minor order).  One wave: lane l first loads
  * its contiguous share of the flags into registers (so the dependent chain below never waits for memory), then the
- * lanes fold their shares one after the other, handing p from lane to lane -- the reference's order exactly. */
+ * lanes fold their shares one after the other, handing p from lane to lane -- the reference's order exactly.  Most
+ * calls end after the last 4096 flags (the certificate below): 0.26 -> 0.07 ms. */
 __global__ __launch_bounds__(64) void tracker_paccept_kernel(const unsigned char *__restrict__ flags, size_t first,
                                                              size_t len, int restart, float *p_accept)
 {
@@ -241,6 +242,36 @@ __global__ __launch_bounds__(64) void tracker_paccept_kernel(const unsigned char
         bits[w] = v;
     }
     const unsigned int mine = lo < len ? (unsigned int)((len - lo) < per ? (len - lo) : per) : 0u;
+    /* A certificate first: one step, fl(fl((1 - a) p) + fl(a f)), is a monotone map of p, so is any run of steps, and the
+     * true value lies in [0, 1].  Replay only the last kCert flags from p = 0 and from p = 1 (two independent chains, the
+     * same latency as one): if the two arrive at the same number, every start in between does -- that number IS the
+     * sequential result over the whole history, bit for bit, whatever came before.  The map contracts by 0.99 per flag
+     * ((0.99)^4096 = 1e-18), so this succeeds in practice always; if it ever does not, the full replay below decides. */
+    {
+        constexpr unsigned int kCertLanes = 16; /* 16 x 256 = 4096 flags */
+        const unsigned int last_lane = len ? (unsigned int)((len - 1) / per) : 0u;
+        const unsigned int l0 = last_lane + 1u > kCertLanes ? last_lane + 1u - kCertLanes : 0u;
+        float plo = 0.0f, phi = 1.0f;
+        for (unsigned int l = l0; l <= last_lane; ++l) {
+            if (lane == l) {
+#pragma unroll
+                for (unsigned int w = 0; w < per / 32; ++w)
+                    for (unsigned int b = 0; b < 32; ++b)
+                        if (w * 32 + b < mine) {
+                            const float accepted = (float)((bits[w] >> b) & 1u);
+                            plo = (1.0f - kAlpha) * plo + kAlpha * accepted;
+                            phi = (1.0f - kAlpha) * phi + kAlpha * accepted;
+                        }
+            }
+            plo = __shfl(plo, (int)l, 64);
+            phi = __shfl(phi, (int)l, 64);
+        }
+        if (len && plo == phi) { /* wave-uniform */
+            if (lane == 0)
+                *p_accept = plo;
+            return;
+        }
+    }
     float p = restart ? 0.5f : *p_accept; /* restart: the sequence before `first` is forgotten anyway */
     for (unsigned int l = 0; l < 64; ++l) {
         if (lane == l) {

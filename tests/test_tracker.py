@@ -43,16 +43,30 @@ def test_tracker_matches_reference_semantics(O):
             assert tr.n == steps
             np.testing.assert_allclose(tr.rhat(), rhat_o, rtol=2e-5)
             assert abs(float(tr.max_rhat()) - float(rhat_o.max())) <= 2e-5 * float(rhat_o.max())
-            if chains * steps <= 16384:
-                assert tr.p_accept == p_o  # the same f32 operations in the same order: exact
-            else:
-                assert abs(float(tr.p_accept) - float(p_o)) < 1e-6  # start forgotten at rate 0.99^16384
-        assert ta.p_accept == tb.p_accept or chains * steps > 16384
+            # exact also where the history is longer than the kernel replays: the replay of the last 4096 flags from p = 0
+            # and from p = 1 meets in one number, and a step is a monotone map of p (tracker_paccept_kernel's certificate)
+            assert tr.p_accept == p_o
+        assert ta.p_accept == tb.p_accept
         # rows in tiles of 16 through the coalescing kernel (a) or lane by lane in short blocks (b): the same numbers
         assert np.array_equal(ta.rhat(), tb.rhat())
         ra, mxa, pa = ta.chain_stats()
         rb, mxb, pb = tb.chain_stats()
         assert np.array_equal(ra, rb) and mxa == mxb and pa == pb
+
+
+@pytest.mark.gpu
+def test_tracker_p_accept_when_the_certificate_fails(O):
+    """Every flag 1 (no state repeats): from p = 0 the rounded recurrence stalls a few ulps below 1, from p = 1 it stays at
+    1, so the two-sided replay does not meet and the kernel falls back to the sequential replay of the last 16 384 flags
+    from 0.5 -- still the oracle's number to 1e-6 (and in fact the same stalled value)."""
+    from mini_mcmc_amd import stats as S
+
+    rng = np.random.default_rng(3)
+    chains, steps, params = 5000, 9, 2
+    x = rng.standard_normal((steps, chains, params)).astype(np.float32)
+    _, p_o = O.multichain_tracker_rhat(x)
+    tr = S.MultiChainTracker(chains, params).step(np.ascontiguousarray(x.transpose(1, 0, 2)))
+    assert abs(float(tr.p_accept) - float(p_o)) < 1e-6 and float(p_o) > 0.999
 
 
 @pytest.mark.gpu
