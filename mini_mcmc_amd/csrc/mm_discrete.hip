@@ -103,31 +103,68 @@ using DsTile = mm_tile_t<int32_t, 1, DS_TILE_T>;
 constexpr size_t DS_TILE_BYTES = (DsTile::lds_bytes_per_wave + 15) / 16 * 16;
 constexpr size_t DS_RING_BYTES = (size_t)2 * DS_RB * 64 * 16;
 constexpr size_t DS_TABLE_BYTES = (size_t)MM_DISCRETE_POISSON_TABLE * sizeof(double);
-constexpr size_t DS_LDS_BYTES = DS_TABLE_BYTES + 4 * DS_TILE_BYTES + 4 * DS_RING_BYTES;
+constexpr size_t DS_LNM_BYTES = (size_t)MM_LNM_ROWS * 16; /* the f32 logarithm's table (mm_lnu_f32), read by the noise waves */
+constexpr size_t DS_LDS_BYTES = DS_TABLE_BYTES + DS_LNM_BYTES + 4 * DS_TILE_BYTES + 4 * DS_RING_BYTES;
 static_assert(DS_LDS_BYTES <= 160 * 1024 && DS_RB % DS_NN == 0 && DS_TILE_T % DS_RB == 0, "LDS plan of the split discrete kernel");
 
+/* what a noise wave hands over per transition (16 bytes): everything of the step that does not depend on the state --
+ * the direction, the accept uniform and the table logarithm the accept test filters with.  The transition wave is left
+ * with two look-ups of the log-density table, the ratio and the comparison (round 2, end: it used to convert the
+ * uniform and evaluate the table logarithm itself, from a table in global memory: a load per transition in the one
+ * dependent chain of the kernel). */
+struct __attribute__((aligned(16))) ds_draw {
+    int32_t step;
+    float lf;
+    double u;
+};
+struct ds_lnm_lds { /* Tab of mm_lnu_f32 with the logarithm's rows in LDS */
+    mm_lds_f4_ptr tab;
+    __device__ __forceinline__ void row_ln(uint32_t r, float *c) const
+    {
+        const mm_v4f v = tab[r];
+        c[0] = v[0];
+        c[1] = v[1];
+        c[2] = v[2];
+        c[3] = v[3];
+    }
+};
+
+/* KIND: the model (compile time: the proposal rule is a switch inside the transition) */
+template <int KIND>
 __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(const run_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ds_lds[];
     double *tab_lds = reinterpret_cast<double *>(ds_lds);
+    float *lnm_lds = reinterpret_cast<float *>(ds_lds + DS_TABLE_BYTES);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave & 3, noise_rank = (wave >> 2) - 1;
-    int32_t *tile = reinterpret_cast<int32_t *>(ds_lds + DS_TABLE_BYTES + (size_t)pair * DS_TILE_BYTES);
-    mm_u32x4 *ring = reinterpret_cast<mm_u32x4 *>(ds_lds + DS_TABLE_BYTES + 4 * DS_TILE_BYTES + (size_t)pair * DS_RING_BYTES);
+    int32_t *tile = reinterpret_cast<int32_t *>(ds_lds + DS_TABLE_BYTES + DS_LNM_BYTES + (size_t)pair * DS_TILE_BYTES);
+    ds_draw *ring = reinterpret_cast<ds_draw *>(ds_lds + DS_TABLE_BYTES + DS_LNM_BYTES + 4 * DS_TILE_BYTES + (size_t)pair * DS_RING_BYTES);
     mm_discrete_params P = a.P;
+    P.kind = KIND;
     for (int i = threadIdx.x; i < P.table_len && i < MM_DISCRETE_POISSON_TABLE; i += 256 * (1 + DS_NN))
         tab_lds[i] = a.P.logp[i];
+    for (int i = threadIdx.x; i < MM_LNM_ROWS; i += 256 * (1 + DS_NN))
+        reinterpret_cast<mm_v4f *>(lnm_lds)[i] = *reinterpret_cast<const mm_v4f *>(mm_lnm_tab_d + 4 * i);
     P.logp = tab_lds;
     P.table_len = P.table_len < MM_DISCRETE_POISSON_TABLE ? P.table_len : MM_DISCRETE_POISSON_TABLE;
     const unsigned long long c0 = (unsigned long long)blockIdx.x * 256ull + (unsigned long long)pair * 64ull, c = c0 + lane;
     const unsigned long long chain = a.chain_offset + c;
     const unsigned int total = a.n_discard + a.n_collect;
-    __syncthreads(); /* the table is complete */
+    __syncthreads(); /* the tables are complete */
     if (noise_rank >= 0) {
+        ds_lnm_lds lt;
+        lt.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(lnm_lds);
         int half = 0;
         for (unsigned int done = 0; done < total; done += DS_RB) {
             const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
-            for (unsigned int j = (unsigned int)noise_rank; j < nb; j += DS_NN)
-                ring[((size_t)half * DS_RB + j) * 64 + lane] = mm_block(a.seed, chain, a.iter0 + done + j, 0u);
+            for (unsigned int j = (unsigned int)noise_rank; j < nb; j += DS_NN) {
+                const mm_u32x4 b = mm_block(a.seed, chain, a.iter0 + done + j, 0u);
+                ds_draw d;
+                d.step = (b.w[0] >> 31) ? 1 : -1;
+                d.u = mm_u53(b.w[2], b.w[3]);
+                d.lf = mm_lnu_f32((float)d.u, lt);
+                ring[((size_t)half * DS_RB + j) * 64 + lane] = d;
+            }
             half ^= 1;
             __syncthreads();
         }
@@ -141,10 +178,10 @@ __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(co
     int half = 0;
     for (unsigned int done = 0; done < total; done += DS_RB) {
         const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
-        __syncthreads(); /* ring half `half` holds the blocks of this batch */
+        __syncthreads(); /* ring half `half` holds the draws of this batch */
         for (unsigned int j = 0; j < nb; ++j) {
-            const mm_u32x4 b = ring[((size_t)half * DS_RB + j) * 64 + lane];
-            n_acc += (unsigned long long)mm_discrete_step_block(P, &x, b);
+            const ds_draw d = ring[((size_t)half * DS_RB + j) * 64 + lane];
+            n_acc += (unsigned long long)mm_discrete_step_draws(P, &x, d.step, d.u, d.lf);
             const unsigned int t = done + j;
             if (t >= a.n_discard && a.out) {
                 tile[lane * DsTile::stride + col++] = x;
@@ -296,16 +333,24 @@ int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_disca
     const char *force = getenv("MMCMC_DISCRETE_KERNEL");
     hipError_t e = hipSuccess;
     if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
-        static unsigned long long attr_set = 0;
-        if (h->device >= 64 || !((attr_set >> h->device) & 1ull)) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(mm_discrete_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)DS_LDS_BYTES);
+        const void *fn = h->kind == MMCMC_POISSON_REFLECT  ? reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_POISSON_REFLECT>)
+                         : h->kind == MMCMC_BINOMIAL_CLAMP ? reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_BINOMIAL_CLAMP>)
+                                                           : reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_POISSON_NONNEG>);
+        const int slot = h->kind == MMCMC_POISSON_REFLECT ? 0 : h->kind == MMCMC_BINOMIAL_CLAMP ? 1 : 2;
+        static unsigned long long attr_set[3] = {0, 0, 0};
+        if (h->device >= 64 || !((attr_set[slot] >> h->device) & 1ull)) {
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DS_LDS_BYTES);
             if (e == hipSuccess && h->device < 64)
-                attr_set |= 1ull << h->device;
+                attr_set[slot] |= 1ull << h->device;
         }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(mm_discrete_split_kernel, dim3((unsigned int)((h->n_chains + 255) / 256)), dim3(256 * (1 + DS_NN)),
-                               DS_LDS_BYTES, st, a);
+            const dim3 grid((unsigned int)((h->n_chains + 255) / 256)), block(256 * (1 + DS_NN));
+            if (slot == 0)
+                hipLaunchKernelGGL(mm_discrete_split_kernel<MM_POISSON_REFLECT>, grid, block, DS_LDS_BYTES, st, a);
+            else if (slot == 1)
+                hipLaunchKernelGGL(mm_discrete_split_kernel<MM_BINOMIAL_CLAMP>, grid, block, DS_LDS_BYTES, st, a);
+            else
+                hipLaunchKernelGGL(mm_discrete_split_kernel<MM_POISSON_NONNEG>, grid, block, DS_LDS_BYTES, st, a);
             e = hipGetLastError();
         }
     } else {

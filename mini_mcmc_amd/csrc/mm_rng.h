@@ -185,15 +185,19 @@ template <class Tab> MM_HD double mm_ln_accept(double u, const Tab &) { return m
  * there and only a ratio inside the band -- one proposal in a million -- pays for mm_log.  The DECISION is the one of
  * the full comparison in every case (NaN falls through to it and rejects), only its cost changes: the f64 logarithm
  * with its division was a third of the integer-state MH step. */
-MM_HD bool mm_ratio_exceeds_ln_u(double ratio, double u)
+/* ... given lf = mm_lnu_f32((float)u): the integer-state kernel's noise waves compute it (a pure function of the draw) */
+MM_HD bool mm_ratio_exceeds_ln_u_given(double ratio, double u, float lf)
 {
-    const float lf = mm_lnu_f32((float)u, mm_icdf_global());
     const double mid = (double)lf, band = 1e-6 + 1e-6 * (mid < 0 ? -mid : mid);
     if (ratio > mid + band)
         return true;
     if (ratio <= mid - band)
         return false;
     return ratio > mm_log(u);
+}
+MM_HD bool mm_ratio_exceeds_ln_u(double ratio, double u)
+{
+    return mm_ratio_exceeds_ln_u_given(ratio, u, mm_lnu_f32((float)u, mm_icdf_global()));
 }
 
 typedef struct {
