@@ -246,6 +246,34 @@ MM_HD double mm_exp(double x)
     return (y * s1) * s2;
 }
 
+/* mm_exp with its three early returns as final selects: the same operations on every input that takes none of them, the
+ * same constants otherwise -- the same bits -- and no exec-mask regions.  Device code only (out of range the unused
+ * conversion to int would be undefined behaviour on the host; the GPU's saturates). */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double mm_exp_sel(double x)
+{
+    const double kf = rint(x * 1.44269504088896338700e+00);
+    const int k = (int)kf;
+    const double hi = fma(kf, -6.93147180369123816490e-01, x);
+    const double lo = kf * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * fma(t, fma(t, fma(t, fma(t, 4.13813679705723846039e-08, -1.65339022054652515390e-06),
+                                                6.61375632143793436117e-05),
+                                        -2.77777777770155933842e-03),
+                                 1.66666666666666019037e-01);
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const int k1 = k / 2, k2 = k - k1;
+    const double s1 = mm_u2d((uint64_t)(k1 + 1023) << 52);
+    const double s2 = mm_u2d((uint64_t)(k2 + 1023) << 52);
+    double e = (y * s1) * s2;
+    e = x < -745.1332191019411 ? 0.0 : e;
+    e = x > 709.782712893384 ? (double)MM_INFINITY_F : e;
+    e = x == x ? e : x;
+    return e;
+}
+#endif
+
 /* sin(2*pi*u), cos(2*pi*u) for u in [0,1], f64 */
 MM_HD void mm_sincos2pi(double u, double *s, double *c)
 {
