@@ -246,6 +246,33 @@ MM_HD double mm_exp(double x)
     return (y * s1) * s2;
 }
 
+/* mm_expf with its three early returns as final selects (see mm_exp_sel below): same bits, no exec-mask regions; device only */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float mm_expf_sel(float x)
+{
+    const float kf = rintf(x * 1.44269504088896341f);
+    const int k = (int)kf;
+    float r = fmaf(kf, -0.693359375f, x);
+    r = fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float rr = r * r;
+    const float y = fmaf(p, rr, r) + 1.0f;
+    const int k1 = k / 2, k2 = k - k1;
+    const float s1 = mm_u2f((uint32_t)(k1 + 127) << 23);
+    const float s2 = mm_u2f((uint32_t)(k2 + 127) << 23);
+    float e = (y * s1) * s2;
+    e = x < -103.97208f ? 0.0f : e;
+    e = x > 88.72283905206835f ? MM_INFINITY_F : e;
+    e = x == x ? e : x;
+    return e;
+}
+#endif
+
 /* mm_exp with its three early returns as final selects: the same operations on every input that takes none of them, the
  * same constants otherwise -- the same bits -- and no exec-mask regions.  Device code only (out of range the unused
  * conversion to int would be undefined behaviour on the host; the GPU's saturates). */

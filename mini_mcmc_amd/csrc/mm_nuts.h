@@ -286,7 +286,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
         S_level = 0;
         S_n = (logu < jointp) ? 1u : 0u;
         S_s = (logu - ST(1000)) < jointp;
-        S_alpha = mm_minT(ST(1), mm_expT(jointp - joint));
+        S_alpha = mm_minT(ST(1), mm_exp_hotT(jointp - joint));
         S_nalpha = 1;
         MM_UNROLL
         for (int i = 0; i < D; ++i) {

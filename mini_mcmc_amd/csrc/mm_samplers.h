@@ -24,6 +24,14 @@ MM_HD float mm_logT(float x) { return mm_logf(x); }
 MM_HD double mm_logT(double x) { return mm_log(x); }
 MM_HD float mm_expT(float x) { return mm_expf(x); }
 MM_HD double mm_expT(double x) { return mm_exp(x); }
+/* exp on a kernel's hot path (NUTS: once per leaf): on the device the branch-free forms of mm_math.h, same bits */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float mm_exp_hotT(float x) { return mm_expf_sel(x); }
+__device__ __forceinline__ double mm_exp_hotT(double x) { return mm_exp_sel(x); }
+#else
+inline float mm_exp_hotT(float x) { return mm_expf(x); }
+inline double mm_exp_hotT(double x) { return mm_exp(x); }
+#endif
 
 /* noise of (chain, iteration): z[0..D) ~ N(0,1) and the accept uniform u in (0,1]  (schedule: mm_rng.h).
  * Tab: where the f32 normal's table is read from (mm_icdf_global by default, mm_icdf_lds in the sampling kernel). */
