@@ -1,3 +1,5 @@
+"""MultiChainTracker.step on an HMC sample [65536, 400, 3] (realistic accept flags: the p_accept certificate applies):
+ms per call, back to back."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
