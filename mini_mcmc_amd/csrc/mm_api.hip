@@ -23,6 +23,8 @@
 #include "mm_params.h"
 #include "mm_rtc.h"
 
+size_t mm_split_lds_bytes_f32(int dim, int mh); /* mm_inst_f32.hip */
+
 #define MM_HIP(expr)                                                                                              \
     do {                                                                                                          \
         hipError_t _e = (expr);                                                                                   \
@@ -353,8 +355,18 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     const bool mh = s->sampler == MM_SAMPLER_MH, l10 = s->n_leapfrog == 10;
     if (s->variant == 7 && s->user) {
         /* the same skeleton (mm_run_kernel_body, PIPE = 2) around the user's functor, from the run-time compiled module */
-        const size_t lds = mm_tile_lds_bytes_rt(sizeof(T), s->dim);
-        e = mm_rtc_launch_run(s->user, mh ? 0 : 1, std::is_same<T, float>::value ? 0 : 1, &a, sizeof(a), grid, s->block, lds, stream);
+        /* f32 up to dim 8: the split-role skeleton (four waves per SIMD) where the module has it; else PIPE = 2, one wave per SIMD */
+        e = hipErrorNotFound;
+        const char *us = getenv("MMCMC_USER_SPLIT"); /* measurement aid: "0" keeps the one-wave-per-SIMD skeleton */
+        if (std::is_same<T, float>::value && s->dim <= 8 && !(us && us[0] == '0')) {
+            const size_t lds_split = mm_split_lds_bytes_f32(s->dim, mh ? 1 : 0);
+            if (lds_split)
+                e = mm_rtc_launch_run_split(s->user, mh ? 0 : 1, &a, sizeof(a), (unsigned int)((s->n_chains + 255) / 256), lds_split, stream);
+        }
+        if (e == hipErrorNotFound) {
+            const size_t lds = mm_tile_lds_bytes_rt(sizeof(T), s->dim);
+            e = mm_rtc_launch_run(s->user, mh ? 0 : 1, std::is_same<T, float>::value ? 0 : 1, &a, sizeof(a), grid, s->block, lds, stream);
+        }
     } else if (s->variant == 6) {
         mm_gen_args<T> q;
         q.P = P;

@@ -10,6 +10,8 @@ struct mm_user_target; /* opaque */
 const mm_user_target *mm_rtc_find(int kind);
 int mm_rtc_dim(const mm_user_target *t);
 /* kernels of a registered target: sampler 0 MH / 1 HMC, dtype 0 f32 / 1 f64; `args` = the mm_run_args<T> block */
+hipError_t mm_rtc_launch_run_split(const mm_user_target *t, int sampler, void *args, size_t args_bytes, unsigned int grid, size_t lds,
+                                   hipStream_t stream);
 hipError_t mm_rtc_launch_run(const mm_user_target *t, int sampler, int dtype, void *args, size_t args_bytes, unsigned int grid,
                              unsigned int block, size_t lds, hipStream_t stream);
 /* NUTS kernels of a registered target: mode 0 / 1 / 2 (mm_nuts_api.hip), init != 0: init_chain (`args` = mm_nuts_init_args<TT, ST>),

@@ -125,8 +125,10 @@ __device__ unsigned long long mm_split_prof[2][2];
 /* NN noise waves per pair (1: the workgroup above; 2, 3: 768 / 1024 threads, three / four waves per SIMD -- the noise
  * pairs of a batch are dealt to the noise waves in turn, the last noise wave -- dealt the fewest pairs -- writes the tiles out): more waves to cover each
  * other's LDS and issue latencies where the step is short (MH).  RBF: ring half (0 = the plan's choice). */
+/* the kernel proper is a device function so that a run-time compiled translation unit (user targets, csrc/mm_rtc.hip) can
+ * wrap it in an extern "C" kernel of its own, like mm_run_kernel_body */
 template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
-__global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_run_args<T> a)
+__device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
 {
     constexpr int D = Tgt::dim;
     using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH, RBF>;
@@ -443,6 +445,13 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
 }
 
 template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
+__global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_run_args<T> a)
+{
+    mm_run_split_body<T, Tgt, SAMPLER, LCT, QP, NN, RBF>(a);
+}
+
+#if !defined(__HIPCC_RTC__)
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
 hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
 {
     using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH, RBF>;
@@ -462,5 +471,6 @@ hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * (1 + NN)), Plan::lds_bytes, stream, a);
     return hipGetLastError();
 }
+#endif /* !__HIPCC_RTC__ */
 
 #endif /* MM_SPLIT_KERNELS_H */
