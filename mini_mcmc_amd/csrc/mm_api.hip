@@ -361,7 +361,7 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
         if (std::is_same<T, float>::value && s->dim <= 8 && !(us && us[0] == '0')) {
             const size_t lds_split = mm_split_lds_bytes_f32(s->dim, mh ? 1 : 0);
             if (lds_split)
-                e = mm_rtc_launch_run_split(s->user, mh ? 0 : 1, &a, sizeof(a), (unsigned int)((s->n_chains + 255) / 256), lds_split, stream);
+                e = mm_rtc_launch_run_split(s->user, mh ? 0 : (l10 ? 2 : 1), &a, sizeof(a), (unsigned int)((s->n_chains + 255) / 256), lds_split, stream);
         }
         if (e == hipErrorNotFound) {
             const size_t lds = mm_tile_lds_bytes_rt(sizeof(T), s->dim);
