@@ -310,6 +310,20 @@ int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_s
  * above.  Same arithmetic from there on (stats.rs:459-465, :425-427, :509-545). */
 int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float *acov_sum, size_t n_half_chains, size_t m,
                             size_t dim, float *rhat, float *ess);
+/* Which kernel computes the lag sums (process-wide; every one of them implements the same biased, mean-removed
+ * estimator of stats.rs:548-654 and they agree to f32 rounding -- tests/test_gpu_parity.py::test_stats_kernels_agree):
+ *   AUTO    what the reference does (stats.rs:549): direct sums for half-chains up to 100 draws (register tiles on the
+ *           vector ALU), the power spectrum above (one wave-level FFT per chain and parameter, one inverse for all);
+ *   FFT / TILE1 / TILE / MFMA / DIRECT   that kernel wherever its shape limits allow, AUTO's choice elsewhere
+ *           (FFT: 2 <= n/2 <= 1024; TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).
+ * For measurements and for the agreement test; results never depend on it beyond rounding. */
+#define MMCMC_STATS_KERNEL_AUTO 0
+#define MMCMC_STATS_KERNEL_FFT 1
+#define MMCMC_STATS_KERNEL_TILE1 2
+#define MMCMC_STATS_KERNEL_TILE 3
+#define MMCMC_STATS_KERNEL_MFMA 4
+#define MMCMC_STATS_KERNEL_DIRECT 5
+int mmcmc_stats_set_kernel(int kind);
 /* basic_stats stats.rs:310-336 (host) and RunStats::from stats.rs:360-371 */
 int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out);
 int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,

@@ -23,6 +23,8 @@
  * former, all-reduce of the latter; mini_mcmc_amd/stats.py).
  */
 #include "../../include/mmcmc.h"
+#include "mm_stats_fft.h"
+#include "mm_tuning.h"
 
 #include <hip/hip_runtime.h>
 
@@ -836,6 +838,217 @@ void mm_half_chain_tile1_kernel(const T *__restrict__ sample, unsigned long long
         out[i] = slab[i];
 }
 
+/* ---- lag sums through the power spectrum (mm_stats_fft.h; stats.rs:576-620) ---------------------------------------------
+ * mm_chain_fft_kernel<T, R1, DT>: a workgroup of four independent waves; wave w of workgroup g takes the chains 4 g + w,
+ * 4 g + w + W, ... (W waves per parameter tile) and DT consecutive parameters d0 .. d0 + DT - 1 of each (the last tile of
+ * a dimension that is not a multiple of DT starts at D - DT: the overlap is computed twice, bit-identically).
+ *   load      point t = 64 a + lane of BOTH half-chains, all DT parameters in one load per (half, a) (12 bytes per lane at
+ *             D = DT = 3: a wave's 64 loads are 768 contiguous bytes); the NEXT chain's points are requested before
+ *             the current one is reduced;
+ *   centre    mean and centred sum of squares per (half-chain, parameter) by DPP wave sums (the statistics withinvar
+ *             needs: means / ssq [2 C, D] in splitcat order, as every other kernel of this file writes them);
+ *   FFT       z = a + i b, three passes (mm_stats_fft.h), S[dt] += |Z|^2 on the lane's R1 bins.
+ * At the end the four waves fold their S into natural bin order in LDS one after the other (fixed order: bitwise
+ * reproducible) and the workgroup writes one slab [DT][N]; slabs: [workgroups][D][N]. */
+template <class T, int DT>
+__device__ __forceinline__ void mm_load_dt(const T *p, float (&out)[DT])
+{
+    if constexpr (std::is_same<T, float>::value && DT > 1) {
+        typedef float vt __attribute__((ext_vector_type(DT), aligned(4)));
+        const vt v = *reinterpret_cast<const vt *>(p);
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+            out[i] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+            out[i] = (float)p[i];
+    }
+}
+
+#define MM_WAVE_LDS_SYNC()                                                                                          \
+    do {                                                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                      \
+    } while (0)
+
+template <class T, int R1, int DT, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n, unsigned int D, unsigned int m,
+                         unsigned int n_pt, const mm_cx *__restrict__ tw, float *__restrict__ means,
+                         float *__restrict__ ssq, float *__restrict__ slabs)
+{
+    using pl = mm_fft_plan<R1>;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    const unsigned int lane = threadIdx.x & 63u;
+    const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    mm_cx *lds = reinterpret_cast<mm_cx *>(lds_raw) + wave * pl::LDS_CX;
+    const unsigned int pt = blockIdx.x % n_pt, wg = blockIdx.x / n_pt, n_wg = gridDim.x / n_pt;
+    const unsigned int d0 = pt * DT + DT <= D ? pt * DT : D - DT;
+    const unsigned long long Wt = 4ull * n_wg;
+
+    mm_cx tw1[R1], tw2[8];
+#pragma unroll
+    for (int b = 1; b < R1; ++b)
+        tw1[b] = tw[b * 64 + lane];
+    tw1[0] = mm_cx{1.f, 0.f};
+#pragma unroll
+    for (int g = 1; g < 8; ++g)
+        tw2[g] = tw[R1 * 64 + g * 8 + (lane & 7u)];
+    tw2[0] = mm_cx{1.f, 0.f};
+
+    unsigned int voff[pl::H];
+    bool valid[pl::H];
+#pragma unroll
+    for (int a = 0; a < pl::H; ++a) {
+        const unsigned int t = 64u * a + lane;
+        valid[a] = t < m;
+        voff[a] = (valid[a] ? t : m - 1u) * D;
+    }
+    const float inv_m = 1.0f / (float)m;
+    const size_t second = (size_t)(n - m) * D; /* the second half-chain: rows [n - m, n) */
+    float S[DT][pl::J][8];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int j = 0; j < pl::J; ++j)
+#pragma unroll
+            for (int h = 0; h < 8; ++h)
+                S[dt][j][h] = 0.f;
+
+    float pre[2][pl::H][DT];
+    auto request = [&](unsigned long long c) {
+        const T *base = sample + (size_t)c * n * D + d0;
+#pragma unroll
+        for (int a = 0; a < pl::H; ++a) {
+            mm_load_dt<T, DT>(base + voff[a], pre[0][a]);
+            mm_load_dt<T, DT>(base + second + voff[a], pre[1][a]);
+        }
+    };
+    unsigned long long c = 4ull * wg + wave;
+    if (c < C)
+        request(c);
+    for (; c < C; c += Wt) {
+        float y[2][pl::H][DT];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int a = 0; a < pl::H; ++a)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    y[hf][a][dt] = valid[a] ? pre[hf][a][dt] : 0.f;
+        /* the next chain of this wave (the last trip asks for its own chain again: no branch) */
+        request(c + Wt < C ? c + Wt : c);
+        float mu[2][DT], qq[2][DT];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                float s0 = y[hf][0][dt];
+#pragma unroll
+                for (int a = 1; a < pl::H; ++a)
+                    s0 += y[hf][a][dt];
+                mu[hf][dt] = wave_sum_dpp_bcast(s0) * inv_m;
+            }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                float q = 0.f;
+#pragma unroll
+                for (int a = 0; a < pl::H; ++a) {
+                    const float v = valid[a] ? y[hf][a][dt] - mu[hf][dt] : 0.f;
+                    y[hf][a][dt] = v;
+                    q = fmaf(v, v, q);
+                }
+                qq[hf][dt] = wave_sum_dpp_bcast(q);
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const size_t o = ((size_t)c + (hf ? (size_t)C : 0)) * D + d0 + dt;
+                    means[o] = mu[hf][dt];
+                    ssq[o] = qq[hf][dt];
+                }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            mm_cx z[pl::H];
+#pragma unroll
+            for (int a = 0; a < pl::H; ++a)
+                z[a] = mm_cx{y[0][a][dt], y[1][a][dt]};
+            mm_fft_pass1<R1>(z, tw1, lds, (int)lane);
+            MM_WAVE_LDS_SYNC();
+            mm_cx v[pl::J][8];
+            mm_fft_pass2_load<R1>(v, lds, (int)lane);
+            MM_WAVE_LDS_SYNC();
+            mm_fft_pass2_store<R1>(v, tw2, lds, (int)lane);
+            MM_WAVE_LDS_SYNC();
+            mm_fft_pass3<R1>(lds, (int)lane, S[dt]);
+            MM_WAVE_LDS_SYNC();
+        }
+    }
+    /* fold the four waves' spectra into natural bin order, one wave after the other */
+    float *acc = lds_raw;
+    for (unsigned int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int j = 0; j < pl::J; ++j)
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) {
+                        const unsigned int i = dt * pl::N + R1 * ((lane & 7u) + 8u * h) + (lane >> 3) + 8u * j;
+                        acc[i] = w == 0 ? S[dt][j][h] : acc[i] + S[dt][j][h];
+                    }
+        }
+    }
+    __syncthreads();
+    float *out = slabs + ((size_t)wg * D + d0) * pl::N;
+    for (unsigned int i = threadIdx.x; i < DT * pl::N; i += 256)
+        out[i] = acc[i];
+}
+
+/* The inverse of the accumulated spectrum, once per parameter for all chains: block (d, group of 64 lags) adds the
+ * partial totals parts[p][f D + d] of the tail kernel in f64 and evaluates
+ *     acov[lag D + d] = (1 / N) sum_f P[f] cos(2 pi f lag / N),   lag < m,
+ * four quarter-circles per lag combined in a fixed order. */
+__global__ __launch_bounds__(256) void mm_fft_finish_kernel(const float *__restrict__ parts, unsigned int n_parts,
+                                                            unsigned int D, unsigned int N, unsigned int m,
+                                                            float *__restrict__ acov)
+{
+    extern __shared__ __attribute__((aligned(16))) double shd[];
+    double *P = shd, *ct = shd + N, *red = shd + 2 * N; /* [N], [N], [4][64] */
+    const unsigned int d = blockIdx.x % D, lag0 = (blockIdx.x / D) * 64u, tid = threadIdx.x;
+    const size_t total = (size_t)N * D;
+    for (unsigned int f = tid; f < N; f += 256) {
+        double t = 0.0;
+        for (unsigned int p = 0; p < n_parts; ++p)
+            t += (double)parts[(size_t)p * total + (size_t)f * D + d];
+        P[f] = t;
+        ct[f] = cospi(2.0 * (double)f / (double)N);
+    }
+    __syncthreads();
+    const unsigned int lag = lag0 + (tid & 63u), q = tid >> 6;
+    double a0 = 0.0, a1 = 0.0;
+    const unsigned int f_lo = q * (N / 4), f_hi = f_lo + N / 4;
+    for (unsigned int f = f_lo; f < f_hi; f += 2) {
+        a0 = fma(P[f], ct[(f * lag) & (N - 1u)], a0);
+        a1 = fma(P[f + 1], ct[((f + 1u) * lag) & (N - 1u)], a1);
+    }
+    red[q * 64 + (tid & 63u)] = a0 + a1;
+    __syncthreads();
+    if (q == 0 && lag < m) {
+        const unsigned int l = tid & 63u;
+        const double r = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+        acov[(size_t)lag * D + d] = (float)(r / (double)N);
+    }
+}
+
 /* tiles of 8 time steps x 16 lags of one parameter's (t, lag) triangle (the kernel's own count) */
 static unsigned int stats_tile_count(size_t m)
 {
@@ -974,16 +1187,151 @@ static unsigned int stats_n_slabs(size_t n_chains)
 {
     /* 4 waves per SIMD hide the LDS / global latencies of the half-chain loop; more only lengthens the slab reduction
      * (measured at [65536, 400, 3]: 1024 waves 1.65 ms, 2048 0.96, 4096 0.69 + 0.08, 8192 0.82 + 0.21) */
-    const char *e = getenv("MMCMC_STATS_WAVES");
+    const char *e = mm_tuning_env("MMCMC_STATS_WAVES");
     const size_t w = e ? (size_t)atoi(e) : 4096;
     return (unsigned int)std::min<size_t>(2 * n_chains, w ? w : 4096);
+}
+
+/* ---- which kernel reduces a sample: mmcmc_stats_set_kernel (include/mmcmc.h) ---- */
+static std::atomic<int> g_stats_kernel{MMCMC_STATS_KERNEL_AUTO};
+
+/* the power-spectrum path (mm_chain_fft_kernel): half-chains longer than 100 draws, as stats.rs:549 switches */
+struct StatsFftPlan {
+    bool use = false;
+    int r1 = 0, dt = 0;
+    unsigned int n_pt = 0, n_wg = 0, N = 0;
+};
+
+static int stats_cu_count(int device)
+{
+    static std::atomic<int> cus[64];
+    int v = cus[device & 63].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0)
+            v = 256;
+        cus[device & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int device)
+{
+    StatsFftPlan p;
+    const size_t m = n / 2;
+    const int sel = g_stats_kernel.load(std::memory_order_relaxed);
+    if (sel != MMCMC_STATS_KERNEL_AUTO && sel != MMCMC_STATS_KERNEL_FFT)
+        return p;
+    if (m > 1024 || m < 2 || (sel == MMCMC_STATS_KERNEL_AUTO && m <= 100))
+        return p;
+    p.use = true;
+    p.r1 = m <= 256 ? 8 : m <= 512 ? 16 : 32;
+    p.N = 64u * (unsigned int)p.r1;
+    p.dt = p.r1 == 32 ? 1 : (int)std::min<size_t>(dim, 4);
+    p.n_pt = (unsigned int)((dim + p.dt - 1) / p.dt);
+    /* resident workgroups of four waves: waves per SIMD x CUs, shared between the parameter tiles */
+    const unsigned int wpe = p.r1 == 8 ? 3u : 2u;
+    const unsigned int resident = (unsigned int)stats_cu_count(device) * wpe;
+    p.n_wg = std::max(1u, resident / p.n_pt);
+    p.n_wg = (unsigned int)std::min<size_t>(p.n_wg, (n_chains + 3) / 4);
+    return p;
+}
+
+/* twiddles of the wave-level FFT: w_N^(lane b) as [R1][64], then w_64^(e g) as [8][8]; one table per device and
+ * length, computed in f64 on the host at first use, never freed */
+static const mm_cx *stats_fft_twiddles(int device, int r1)
+{
+    static std::atomic<const mm_cx *> tab[64][3];
+    const int k = r1 == 8 ? 0 : r1 == 16 ? 1 : 2;
+    const mm_cx *t = tab[device & 63][k].load(std::memory_order_acquire);
+    if (t)
+        return t;
+    const unsigned int N = 64u * (unsigned int)r1;
+    std::vector<mm_cx> h((size_t)r1 * 64 + 64);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int b = 0; b < r1; ++b)
+        for (int l = 0; l < 64; ++l) {
+            const double th = two_pi * (double)((unsigned int)(l * b) % N) / (double)N;
+            h[(size_t)b * 64 + l] = mm_cx{(float)std::cos(th), (float)-std::sin(th)};
+        }
+    for (int g = 0; g < 8; ++g)
+        for (int e = 0; e < 8; ++e) {
+            const double th = two_pi * (double)(e * g) / 64.0;
+            h[(size_t)r1 * 64 + g * 8 + e] = mm_cx{(float)std::cos(th), (float)-std::sin(th)};
+        }
+    mm_cx *d = nullptr;
+    if (hipMalloc((void **)&d, h.size() * sizeof(mm_cx)) != hipSuccess)
+        return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(mm_cx), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    const mm_cx *expected = nullptr;
+    if (!tab[device & 63][k].compare_exchange_strong(expected, d, std::memory_order_acq_rel)) {
+        (void)hipFree(d); /* another thread was first */
+        return expected;
+    }
+    return d;
+}
+
+template <class T, int R1, int DT, int WPE>
+static int stats_fft_launch1(const StatsFftPlan &p, const void *sample, size_t n_chains, size_t n, size_t dim, size_t m,
+                             const mm_cx *tw, float *means, float *ssq, float *slabs, hipStream_t stream)
+{
+    const size_t lds = (size_t)4 * mm_fft_plan<R1>::LDS_CX * sizeof(mm_cx);
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_set{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!(attr_set.load(std::memory_order_relaxed) >> (dev & 63) & 1ull)) {
+            MM_HIP(hipFuncSetAttribute((const void *)mm_chain_fft_kernel<T, R1, DT, WPE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL((mm_chain_fft_kernel<T, R1, DT, WPE>), dim3(p.n_wg * p.n_pt), dim3(256), lds, stream,
+                       (const T *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
+                       (unsigned int)m, p.n_pt, tw, means, ssq, slabs);
+    return MMCMC_OK;
+}
+
+template <class T>
+static int stats_fft_launch(const StatsFftPlan &p, const void *sample, size_t n_chains, size_t n, size_t dim, size_t m,
+                            const mm_cx *tw, float *means, float *ssq, float *slabs, hipStream_t stream)
+{
+#define MM_FFT_CASE(R1V, DTV, WPEV)                                                                                 \
+    if (p.r1 == R1V && p.dt == DTV)                                                                                 \
+    return stats_fft_launch1<T, R1V, DTV, WPEV>(p, sample, n_chains, n, dim, m, tw, means, ssq, slabs, stream)
+    MM_FFT_CASE(8, 1, 3);
+    MM_FFT_CASE(8, 2, 3);
+    MM_FFT_CASE(8, 3, 3);
+    MM_FFT_CASE(8, 4, 3);
+    MM_FFT_CASE(16, 1, 2);
+    MM_FFT_CASE(16, 2, 2);
+    MM_FFT_CASE(16, 3, 2);
+    MM_FFT_CASE(16, 4, 2);
+    MM_FFT_CASE(32, 1, 2);
+#undef MM_FFT_CASE
+    return MMCMC_ERR_UNSUPPORTED;
+}
+
+/* floats of device workspace stats_partials_impl wants behind `slabs_ws` */
+static size_t stats_ws_floats(size_t n_chains, size_t n, size_t dim, unsigned int n_parts, int device)
+{
+    const size_t m = n / 2;
+    size_t need = (size_t)stats_n_slabs(n_chains) * dim * m;
+    const StatsFftPlan p = stats_fft_plan(n_chains, n, dim, device);
+    if (p.use)
+        need = std::max(need, ((size_t)p.n_wg + n_parts) * dim * p.N);
+    return need;
 }
 
 /* wb_part: NULL, or [dim][MM_WB_CHUNKS][3] doubles for the cross-chain sums (single-GPU path) */
 static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
                                float *ssq, float *acov_sum, double *wb_part, float *slabs_ws, unsigned int n_parts,
-                               int device, void *stream_v)
+                               int device, void *stream_v, unsigned int *parts_out)
 {
+    if (parts_out)
+        *parts_out = n_parts;
     if (!sample || !means || !ssq || !acov_sum || n_chains == 0 || dim == 0 ||
         (dtype != MMCMC_F32 && dtype != MMCMC_F64))
         return MMCMC_ERR_INVALID_ARG;
@@ -995,6 +1343,40 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         return st;
     DevGuard g(device);
     hipStream_t stream = (hipStream_t)stream_v;
+    const StatsFftPlan fp = stats_fft_plan(n_chains, n, dim, device);
+    if (fp.use) {
+        /* power spectrum per workgroup -> bin totals in n_parts partial sums (the tail kernel, with bins for lags) ->
+         * one inverse per parameter: acov_sum[0] is the total, *parts_out = 1 */
+        const mm_cx *tw = stats_fft_twiddles(device, fp.r1);
+        if (!tw)
+            return (int)hipErrorOutOfMemory;
+        const size_t slab_floats = (size_t)fp.n_wg * dim * fp.N, part_floats = (size_t)n_parts * dim * fp.N;
+        float *ws = slabs_ws;
+        if (!ws)
+            MM_HIP(hipMallocAsync((void **)&ws, (slab_floats + part_floats) * sizeof(float), stream));
+        float *bins = ws + slab_floats;
+        st = dtype == MMCMC_F32
+                 ? stats_fft_launch<float>(fp, sample, n_chains, n, dim, m, tw, means, ssq, ws, stream)
+                 : stats_fft_launch<double>(fp, sample, n_chains, n, dim, m, tw, means, ssq, ws, stream);
+        if (st != MMCMC_OK)
+            return st;
+        MM_HIP(hipGetLastError());
+        const unsigned int total_b = (unsigned int)(dim * fp.N);
+        const unsigned int nb_red = (total_b + 63) / 64 * n_parts, nb_wb = wb_part ? (unsigned int)dim * MM_WB_CHUNKS : 0u;
+        hipLaunchKernelGGL(mm_stats_tail_kernel, dim3(nb_red + nb_wb), dim3(256), 0, stream, ws, fp.n_wg,
+                           (unsigned int)dim, fp.N, bins, nb_red, n_parts, means, ssq,
+                           (unsigned long long)(2 * n_chains), (float)m, wb_part);
+        MM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mm_fft_finish_kernel, dim3((unsigned int)dim * (unsigned int)((m + 63) / 64)), dim3(256),
+                           (2 * (size_t)fp.N + 256) * sizeof(double), stream, bins, n_parts, (unsigned int)dim, fp.N,
+                           (unsigned int)m, acov_sum);
+        MM_HIP(hipGetLastError());
+        if (!slabs_ws)
+            MM_HIP(hipFreeAsync(ws, stream));
+        if (parts_out)
+            *parts_out = 1;
+        return MMCMC_OK;
+    }
     unsigned int n_slabs = stats_n_slabs(n_chains);
     /* the per-wave lag sums: the caller's workspace (synchronous path) or a stream-ordered allocation */
     float *slabs = slabs_ws;
@@ -1002,8 +1384,9 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
     const unsigned int n_tiles = (unsigned int)((m + 255) / 256);
     const size_t row_len = 240 + 256 * (size_t)(n_tiles - 1) + m + 36, row_pitch = row_len + row_len / 16 + 1;
     const size_t lds_mfma = ((size_t)dim * row_pitch + (size_t)dim * m) * sizeof(float);
-    const char *force_direct = getenv("MMCMC_STATS_DIRECT"); /* measurement aid: the direct kernel */
-    const char *force_kernel = getenv("MMCMC_STATS_KERNEL"); /* measurement aid: "mfma" keeps the matrix-core kernel */
+    const int sel = g_stats_kernel.load(std::memory_order_relaxed); /* mmcmc_stats_set_kernel */
+    const bool force_direct = sel == MMCMC_STATS_KERNEL_DIRECT, force_mfma = sel == MMCMC_STATS_KERNEL_MFMA,
+               force_tile = sel == MMCMC_STATS_KERNEL_TILE;
     /* register tiles on the vector ALU where a lane's share of the D x tiles(m) tiles fits its registers (at most 8
      * tiles of 16 lag sums: [., 400, 3] just fits) */
     const size_t tiles_total = dim * (size_t)stats_tile_count(m);
@@ -1017,15 +1400,14 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
     const unsigned int tpl_1 = tiles_1 <= 64 ? 1u : tiles_1 <= 128 ? 2u : 3u;
     const unsigned int parts = (tiles_1 + 64u * tpl_1 - 1u) / (64u * tpl_1);
     const size_t lds_1 = (pitch_t + m + 64 * 16 + 64) * sizeof(float);
-    const bool no_force = !(force_direct && force_direct[0] == '1') && !(force_kernel && !strcmp(force_kernel, "mfma"));
-    const bool per_param = no_force && m <= 512 && 16 * lds_1 <= 160 * 1024 && (size_t)parts * dim <= n_slabs &&
-                           !(force_kernel && !strcmp(force_kernel, "tile"));
+    const bool no_force = !force_direct && !force_mfma;
+    const bool per_param = no_force && m <= 512 && 16 * lds_1 <= 160 * 1024 && (size_t)parts * dim <= n_slabs && !force_tile;
     if (per_param || (tpl <= 8 && lds_tile <= 40 * 1024 && /* 8 tiles = 128 lag sums + operands = 218 registers: two waves per SIMD */ no_force)) {
         if (!slabs)
             MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
         if (per_param) {
             /* slabs x parts x parameters waves = the resident 16 per CU; the tail sums slabs x parts rows per (d, lag) */
-            const size_t cap = getenv("MMCMC_STATS_WAVES") ? (size_t)n_slabs : 4096 / dim;
+            const size_t cap = mm_tuning_env("MMCMC_STATS_WAVES") ? (size_t)n_slabs : 4096 / dim;
             n_slabs = (unsigned int)std::max<size_t>(1, std::min<size_t>(n_slabs, cap) / parts);
 #define MM_TILE1_LAUNCH(TT, TPLV, NPREV)                                                                            \
     hipLaunchKernelGGL((mm_half_chain_tile1_kernel<TT, TPLV, NPREV>), dim3(n_slabs * parts * (unsigned int)dim), dim3(64), lds_1, \
@@ -1052,7 +1434,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         } else {
         /* this kernel holds two waves per SIMD (250 registers): exactly the resident waves, each with a longer list of
          * half-chains (measured at [65 536, 400, 3]: 1024 waves 0.62 ms, 2048 0.39, 4096 0.43, 8192 0.54) */
-        if (!getenv("MMCMC_STATS_WAVES"))
+        if (!mm_tuning_env("MMCMC_STATS_WAVES"))
             n_slabs = std::min(n_slabs, 2048u);
         /* 16-byte loads where every half-chain's [m, D] block starts on a 16-byte boundary and is whole vectors long */
         const bool vec_ok = dtype == MMCMC_F32 && (n * dim) % 4 == 0 && ((n - m) * dim) % 4 == 0 && (m * dim) % 4 == 0 &&
@@ -1085,7 +1467,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
 #undef MM_TILE_LAUNCH
 #undef MM_TILE_LAUNCH1
         }
-    } else if (lds_mfma <= 64 * 1024 && !(force_direct && force_direct[0] == '1')) {
+    } else if (lds_mfma <= 64 * 1024 && !force_direct) {
         if (!slabs)
             MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
         if (dtype == MMCMC_F32)
@@ -1189,6 +1571,14 @@ static float *stats_pinned(size_t n_floats)
 
 extern "C" {
 
+int mmcmc_stats_set_kernel(int kind)
+{
+    if (kind < MMCMC_STATS_KERNEL_AUTO || kind > MMCMC_STATS_KERNEL_DIRECT)
+        return MMCMC_ERR_INVALID_ARG;
+    g_stats_kernel.store(kind, std::memory_order_relaxed);
+    return MMCMC_OK;
+}
+
 int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
                          float *ssq, float *acov_sum, int device, void *stream_v)
 {
@@ -1211,7 +1601,7 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
         return st;
     DevGuard g(device);
     const size_t m = n / 2, total = m * dim;
-    const size_t need = (size_t)stats_n_slabs(n_chains) * total + (size_t)kParts * total;
+    const size_t need = stats_ws_floats(n_chains, n, dim, kParts, device) + (size_t)kParts * total;
     if (w.p && (w.device != device || w.stream != stream_v || need > w.cap)) {
         DevGuard gw(w.device);
         (void)hipDeviceSynchronize();
@@ -1228,11 +1618,13 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
     w.device = device;
     w.stream = stream_v;
     float *parts = w.p, *slabs = w.p + (size_t)kParts * total;
-    st = stats_partials_impl(sample, dtype, n_chains, n, dim, means, ssq, parts, nullptr, slabs, kParts, device, stream_v);
+    unsigned int n_written = kParts;
+    st = stats_partials_impl(sample, dtype, n_chains, n, dim, means, ssq, parts, nullptr, slabs, kParts, device, stream_v,
+                             &n_written);
     if (st != MMCMC_OK)
         return st;
     hipLaunchKernelGGL(mm_parts_sum_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream_v, parts, kParts, (unsigned int)total, acov_sum);
+                       (hipStream_t)stream_v, parts, n_written, (unsigned int)total, acov_sum);
     MM_HIP(hipGetLastError());
     return MMCMC_OK;
 }
@@ -1332,25 +1724,34 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
                 hipSuccess)
                 break;
         }
-        const size_t n_slab_floats = (size_t)stats_n_slabs(n_chains) * dim * m;
+        const size_t n_slab_floats = stats_ws_floats(n_chains, n, dim, kParts, device);
         if (!(d_buf = stats_workspace(device, nb + n_slab_floats))) {
             e = hipErrorOutOfMemory;
             break;
         }
         float *d_means = d_buf, *d_ssq = d_buf + c2 * dim, *d_acov = d_buf + 2 * c2 * dim;
         double *d_wb = reinterpret_cast<double *>(d_acov + n_acov);
+        unsigned int n_written = kParts;
         rc = stats_partials_impl(sample_is_device ? sample : d_sample, dtype, n_chains, n, dim, d_means, d_ssq, d_acov,
-                                 d_wb, d_buf + nb, kParts, device, stream_v);
+                                 d_wb, d_buf + nb, kParts, device, stream_v, &n_written);
         if (rc != MMCMC_OK)
             break;
-        if ((e = hipMemcpyAsync(h, d_acov, (n_acov + 2 * n_wb) * sizeof(float), hipMemcpyDeviceToHost, stream)) !=
-            hipSuccess)
-            break;
+        if (n_written == kParts) {
+            if ((e = hipMemcpyAsync(h, d_acov, (n_acov + 2 * n_wb) * sizeof(float), hipMemcpyDeviceToHost, stream)) !=
+                hipSuccess)
+                break;
+        } else { /* the power-spectrum path leaves the total in part 0: two small copies instead of sixteen parts */
+            if ((e = hipMemcpyAsync(h, d_acov, m * dim * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                break;
+            if ((e = hipMemcpyAsync(h + n_acov, d_acov + n_acov, 2 * n_wb * sizeof(float), hipMemcpyDeviceToHost,
+                                    stream)) != hipSuccess)
+                break;
+        }
         if ((e = stats_wait(stream)) != hipSuccess)
             break;
         for (size_t i = 0; i < m * dim; ++i) { /* lag sums: the partial totals in their fixed order */
             float t = h[i];
-            for (unsigned int part = 1; part < kParts; ++part)
+            for (unsigned int part = 1; part < n_written; ++part)
                 t += h[(size_t)part * m * dim + i];
             h[i] = t;
         }

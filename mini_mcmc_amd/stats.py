@@ -73,6 +73,15 @@ def _sample_args(sample):
     return a.ctypes.data, 0, L.F32 if a.dtype == np.float32 else L.F64, a.shape, 0, None, a
 
 
+STATS_KERNELS = {"auto": 0, "fft": 1, "tile1": 2, "tile": 3, "mfma": 4, "direct": 5}
+
+
+def set_kernel(kind: str = "auto") -> None:
+    """mmcmc_stats_set_kernel (include/mmcmc.h): which kernel computes the lag sums.  "auto" is the reference's own
+    rule (stats.rs:549): direct sums up to 100 draws per half-chain, the power spectrum above."""
+    L.check(L.lib().mmcmc_stats_set_kernel(STATS_KERNELS[kind]), "mmcmc_stats_set_kernel")
+
+
 def split_rhat_mean_ess(sample, device: int | None = None):
     """stats.rs:416-423: sample [chains, n, params] (numpy, or a torch tensor in HBM) -> (rhat[params], ess[params]).
     `rhat` is the reference's sqrt(W / var+) (quirk Q7)."""

@@ -637,3 +637,63 @@ extern "C" int eh_hmc_grouped_run(int dim, const double *matrix, double eps, int
         return -2;
     return 0;
 }
+
+/* ---- the statistics kernel's wave-level FFT (mm_stats_fft.h), its 64 lanes run one after another, phase by phase ---- */
+#include "../mini_mcmc_amd/csrc/mm_stats_fft.h"
+
+namespace {
+template <int R1>
+void fft_power_wave(const float *a, const float *b, int m, float *S_out)
+{
+    using pl = mm_fft_plan<R1>;
+    std::vector<mm_cx> lds(pl::LDS_CX, mm_cx{0.f, 0.f});
+    float S[64][pl::J][8];
+    memset(S, 0, sizeof S);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int lane = 0; lane < 64; ++lane) {
+        mm_cx z[pl::H], tw1[R1];
+        for (int s = 0; s < pl::H; ++s) {
+            const int t = 64 * s + lane;
+            z[s] = t < m ? mm_cx{a[t], b[t]} : mm_cx{0.f, 0.f};
+        }
+        for (int r = 0; r < R1; ++r) {
+            const double th = two_pi * (double)((lane * r) % pl::N) / (double)pl::N;
+            tw1[r] = mm_cx{(float)std::cos(th), (float)-std::sin(th)};
+        }
+        mm_fft_pass1<R1>(z, tw1, lds.data(), lane);
+    }
+    std::vector<mm_cx> held((size_t)64 * pl::J * 8);
+    for (int lane = 0; lane < 64; ++lane)
+        mm_fft_pass2_load<R1>(*reinterpret_cast<mm_cx(*)[pl::J][8]>(&held[(size_t)lane * pl::J * 8]), lds.data(), lane);
+    for (int lane = 0; lane < 64; ++lane) {
+        mm_cx tw2[8];
+        for (int g = 0; g < 8; ++g) {
+            const double th = two_pi * (double)((lane & 7) * g) / 64.0;
+            tw2[g] = mm_cx{(float)std::cos(th), (float)-std::sin(th)};
+        }
+        mm_fft_pass2_store<R1>(*reinterpret_cast<mm_cx(*)[pl::J][8]>(&held[(size_t)lane * pl::J * 8]), tw2, lds.data(), lane);
+    }
+    for (int lane = 0; lane < 64; ++lane)
+        mm_fft_pass3<R1>(lds.data(), lane, S[lane]);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < pl::J; ++j)
+            for (int h = 0; h < 8; ++h)
+                S_out[mm_fft_bin<R1>(lane, j, h)] = S[lane][j][h];
+}
+} // namespace
+
+/* |FFT_N(a + i b)|^2, N = 64 r1 bins in natural order, through the kernel's own per-lane code */
+extern "C" int eh_fft_power(int r1, const float *a, const float *b, int m, float *S_out)
+{
+    if (m < 1 || 2 * m > 64 * r1)
+        return -1;
+    if (r1 == 8)
+        fft_power_wave<8>(a, b, m, S_out);
+    else if (r1 == 16)
+        fft_power_wave<16>(a, b, m, S_out);
+    else if (r1 == 32)
+        fft_power_wave<32>(a, b, m, S_out);
+    else
+        return -1;
+    return 0;
+}

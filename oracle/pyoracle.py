@@ -487,9 +487,14 @@ def build_tree(target: Target, position, mom, grad, logu, v, j, epsilon, joint_0
 # ---------------------------------------------------------------- diagnostics
 
 
-def split_rhat_mean_ess(sample):
-    """stats.rs:416-423 on [chains, n, params] -> (rhat[params], ess[params]); 'rhat' is sqrt(W/var+) (Q7)."""
+def split_rhat_mean_ess(sample, n_threads: int = 0):
+    """stats.rs:416-423 on [chains, n, params] -> (rhat[params], ess[params]); 'rhat' is sqrt(W/var+) (Q7).
+    n_threads > 1 computes the per-chain autocovariances on that many threads (0: all cores for large samples) and adds
+    them up in chain order as the serial loop does: the result is bit-identical."""
     s = np.ascontiguousarray(sample, dtype=np.float32)
+    if n_threads == 0:
+        n_threads = (os.cpu_count() or 1) if s.size >= (1 << 22) else 1
+    lib().o_stats_set_threads(int(n_threads))
     c, n, p = s.shape
     rhat = np.zeros(p, dtype=np.float32)
     ess = np.zeros(p, dtype=np.float32)

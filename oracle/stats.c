@@ -14,6 +14,7 @@
 #include "oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -66,9 +67,50 @@ void o_autocov_bf(const float *data, size_t n, size_t d, float *out)
     free(col);
 }
 
+/* twiddles of the radix-2 FFT below: for every stage length len the factors (float)cos(ang k), (float)sin(ang k),
+ * k < len / 2, ang = sign 2 pi / len -- the values the loop used to evaluate in place, tabulated once per transform
+ * length (the table for length n holds all its stages back to back: n - 1 entries per sign). */
+typedef struct fft_tab {
+    size_t n;
+    float *wr[2], *wi[2]; /* [0] forward (sign -1), [1] inverse (sign +1) */
+    struct fft_tab *next;
+} fft_tab;
+static fft_tab *g_fft_tabs = NULL;
+static pthread_mutex_t g_fft_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static const fft_tab *fft_table(size_t n)
+{
+    pthread_mutex_lock(&g_fft_mu);
+    fft_tab *t = g_fft_tabs;
+    while (t && t->n != n)
+        t = t->next;
+    if (!t) {
+        t = (fft_tab *)malloc(sizeof(fft_tab));
+        t->n = n;
+        for (int sg = 0; sg < 2; ++sg) {
+            t->wr[sg] = (float *)malloc(sizeof(float) * (n ? n : 1));
+            t->wi[sg] = (float *)malloc(sizeof(float) * (n ? n : 1));
+            size_t o = 0;
+            for (size_t len = 2; len <= n; len <<= 1) {
+                double ang = (sg ? 1.0 : -1.0) * 2.0 * M_PI / (double)len;
+                for (size_t k = 0; k < len / 2; ++k, ++o) {
+                    t->wr[sg][o] = (float)cos(ang * (double)k);
+                    t->wi[sg][o] = (float)sin(ang * (double)k);
+                }
+            }
+        }
+        t->next = g_fft_tabs;
+        g_fft_tabs = t;
+    }
+    pthread_mutex_unlock(&g_fft_mu);
+    return t;
+}
+
 /* in-place iterative radix-2 FFT on interleaved complex f32; sign = -1 forward, +1 inverse (unnormalised) */
 static void fft_radix2(float *re, float *im, size_t n, int sign)
 {
+    const fft_tab *tab = fft_table(n);
+    const float *twr = tab->wr[sign > 0], *twi = tab->wi[sign > 0];
     for (size_t i = 1, j = 0; i < n; ++i) {
         size_t bit = n >> 1;
         for (; j & bit; bit >>= 1)
@@ -83,11 +125,11 @@ static void fft_radix2(float *re, float *im, size_t n, int sign)
             im[j] = t;
         }
     }
-    for (size_t len = 2; len <= n; len <<= 1) {
-        double ang = (double)sign * 2.0 * M_PI / (double)len;
+    size_t o = 0;
+    for (size_t len = 2; len <= n; o += len / 2, len <<= 1) {
         for (size_t i = 0; i < n; i += len) {
             for (size_t k = 0; k < len / 2; ++k) {
-                float wr = (float)cos(ang * (double)k), wi = (float)sin(ang * (double)k);
+                float wr = twr[o + k], wi = twi[o + k];
                 size_t a = i + k, b = i + k + len / 2;
                 float xr = re[b] * wr - im[b] * wi;
                 float xi = re[b] * wi + im[b] * wr;
@@ -138,6 +180,24 @@ static void autocov(const float *data, size_t n, size_t d, float *out)
         o_autocov_fft(data, n, d, out);
 }
 
+/* worker threads for the per-chain autocovariances of o_split_rhat_mean_ess (0 / 1: the plain serial loop); the result
+ * does not depend on it */
+static int g_stats_threads = 1;
+void o_stats_set_threads(int n) { g_stats_threads = n < 1 ? 1 : n; }
+
+typedef struct {
+    const float *sp;
+    float *out;
+    size_t half, p, lo, hi;
+} acov_job;
+static void *acov_worker(void *arg)
+{
+    acov_job *j = (acov_job *)arg;
+    for (size_t ch = j->lo; ch < j->hi; ++ch)
+        autocov(j->sp + ch * j->half * j->p, j->half, j->p, j->out + ch * j->half * j->p);
+    return NULL;
+}
+
 /* stats.rs:416-546 */
 void o_split_rhat_mean_ess(const float *sample, size_t c, size_t n, size_t p, float *rhat, float *ess)
 {
@@ -181,10 +241,38 @@ void o_split_rhat_mean_ess(const float *sample, size_t c, size_t n, size_t p, fl
     /* ess :496-546 */
     float *avg_rho = (float *)calloc(half * p + 1, sizeof(float));
     float *rho_c = (float *)malloc(sizeof(float) * (half * p + 1));
-    for (size_t ch = 0; ch < C; ++ch) {
-        autocov(sp + ch * half * p, half, p, rho_c);
-        for (size_t i = 0; i < half * p; ++i)
-            avg_rho[i] = avg_rho[i] + rho_c[i]; /* mean_axis(Axis(0)): sequential over chains */
+    if (g_stats_threads <= 1) {
+        for (size_t ch = 0; ch < C; ++ch) {
+            autocov(sp + ch * half * p, half, p, rho_c);
+            for (size_t i = 0; i < half * p; ++i)
+                avg_rho[i] = avg_rho[i] + rho_c[i]; /* mean_axis(Axis(0)): sequential over chains */
+        }
+    } else {
+        /* the same numbers with the per-chain autocovariances of a batch computed on several threads; they are added
+         * to the running sum one chain after the other, in chain order, as above: bit-identical */
+        const size_t batch = 64 * (size_t)g_stats_threads;
+        float *buf = (float *)malloc(sizeof(float) * batch * half * p);
+        for (size_t c0 = 0; c0 < C; c0 += batch) {
+            size_t nb = C - c0 < batch ? C - c0 : batch;
+            acov_job jobs[64];
+            pthread_t th[64];
+            int nt = g_stats_threads > 64 ? 64 : g_stats_threads;
+            for (int t = 0; t < nt; ++t) {
+                jobs[t].sp = sp + c0 * half * p;
+                jobs[t].out = buf;
+                jobs[t].half = half;
+                jobs[t].p = p;
+                jobs[t].lo = nb * (size_t)t / (size_t)nt;
+                jobs[t].hi = nb * (size_t)(t + 1) / (size_t)nt;
+                pthread_create(&th[t], NULL, acov_worker, &jobs[t]);
+            }
+            for (int t = 0; t < nt; ++t)
+                pthread_join(th[t], NULL);
+            for (size_t ch = 0; ch < nb; ++ch)
+                for (size_t i = 0; i < half * p; ++i)
+                    avg_rho[i] = avg_rho[i] + buf[ch * half * p + i];
+        }
+        free(buf);
     }
     for (size_t i = 0; i < half * p; ++i)
         avg_rho[i] = avg_rho[i] / (float)C;

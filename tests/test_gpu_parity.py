@@ -411,35 +411,82 @@ def test_split_rhat_mean_ess_vs_oracle(M, O, c, n, p):
     assert np.array_equal(r1, r2) and np.array_equal(e1, e2)
 
 
-@pytest.mark.parametrize("c,n,p", [(2000, 400, 3), (300, 1000, 3), (500, 200, 2)])
+@pytest.mark.parametrize("c,n,p", [(2000, 400, 3), (300, 1000, 3), (500, 200, 2), (200, 2048, 1), (64, 260, 5),
+                                   (33, 203, 7), (10, 1500, 2)])
 def test_stats_kernels_agree(M, O, c, n, p):
-    """The three lag-sum kernels -- one parameter per wave (default), all parameters in one wave ("tile"), matrix cores
-    ("mfma") -- on one sample: R-hat / ESS equal to 1e-5 / 1e-4, each bitwise reproducible from call to call."""
-    import os
-
+    """The lag-sum kernels -- power spectrum ("fft": the default above 100 draws per half-chain, like stats.rs:549), one
+    parameter per wave ("tile1": the default below), all parameters in one wave ("tile"), matrix cores ("mfma"), plain
+    sums ("direct") -- on one sample: R-hat / ESS equal to 1e-5 / 1e-4, each bitwise reproducible from call to call."""
     from mini_mcmc_amd import stats as S
 
     x = _ar1(np.random.default_rng(n + p), c, n, p)
     x[:, :, -1] += 3.0
     res = {}
-    for k in ("default", "tile", "mfma"):
-        if k == "default":
-            os.environ.pop("MMCMC_STATS_KERNEL", None)
-        else:
-            os.environ["MMCMC_STATS_KERNEL"] = k
-        try:
+    try:
+        for k in ("auto", "fft", "tile1", "tile", "mfma", "direct"):
+            S.set_kernel(k)
             a = S.split_rhat_mean_ess(x)
             b = S.split_rhat_mean_ess(x)
-        finally:
-            os.environ.pop("MMCMC_STATS_KERNEL", None)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), k
-        res[k] = a
-    for k in ("tile", "mfma"):
-        np.testing.assert_allclose(res[k][0], res["default"][0], rtol=1e-5)
-        np.testing.assert_allclose(res[k][1], res["default"][1], rtol=1e-4)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), k
+            res[k] = a
+    finally:
+        S.set_kernel("auto")
+    for k in ("fft", "tile1", "tile", "mfma", "direct"):
+        np.testing.assert_allclose(res[k][0], res["auto"][0], rtol=1e-5, err_msg=k)
+        np.testing.assert_allclose(res[k][1], res["auto"][1], rtol=1e-4, err_msg=k)
     r0, e0 = O.split_rhat_mean_ess(x)
-    np.testing.assert_allclose(res["default"][0], r0, rtol=1e-4)
-    np.testing.assert_allclose(res["default"][1], e0, rtol=5e-3)
+    np.testing.assert_allclose(res["auto"][0], r0, rtol=1e-4)
+    np.testing.assert_allclose(res["auto"][1], e0, rtol=5e-3)
+
+
+def test_stats_partials_fft_vs_direct_lag_sums(M, O):
+    """The power-spectrum kernel's lag sums themselves (not only the R-hat / ESS they feed): `stats_partials` of one sample
+    under "fft" and under "direct" -- means and centred sums of squares per half-chain to float rounding, every lag sum to
+    2e-6 of the lag-0 sum (the f32 transform's error is relative to the spectrum's largest bin)."""
+    import torch
+
+    from mini_mcmc_amd import stats as S
+
+    rng = np.random.default_rng(5)
+    for c, n, p in [(257, 400, 3), (100, 1000, 3), (31, 333, 4), (12, 2047, 1), (50, 250, 6)]:
+        x = _ar1(rng, c, n, p)
+        x[:, :, 0] += 100.0  # a mean far from zero: the centring happens before the transform
+        t = torch.from_numpy(x).cuda()
+        out = {}
+        try:
+            for k in ("fft", "direct"):
+                S.set_kernel(k)
+                out[k] = [v.cpu().numpy() for v in S.stats_partials(t)]
+        finally:
+            S.set_kernel("auto")
+        np.testing.assert_allclose(out["fft"][0], out["direct"][0], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(out["fft"][1], out["direct"][1], rtol=2e-5)
+        scale = out["direct"][2][0]  # lag 0, per parameter
+        assert np.max(np.abs(out["fft"][2] - out["direct"][2]) / scale) < 2e-6, (c, n, p)
+        # and against f64 sums on the host
+        m = n // 2
+        halves = np.concatenate([x[:, :m], x[:, n - m:]], axis=0).astype(np.float64)
+        y = halves - halves.mean(axis=1, keepdims=True)
+        ref = np.stack([(y[:, :m - k] * y[:, k:]).sum(axis=(0, 1)) for k in range(m)])
+        assert np.max(np.abs(out["fft"][2] - ref) / ref[0]) < 2e-6, (c, n, p)
+
+
+@pytest.mark.parametrize("n", [400, 1000])
+def test_split_rhat_mean_ess_full_size_vs_oracle(M, O, n):
+    """BASELINE's diagnostics shape [65 536, n, 3] against oracle/stats.c (stats.rs:416-546 with its FFT branch) -- not
+    kernel against kernel: an HMC sample of config 3 from the engine itself, R-hat / ESS to 1e-4 / 2e-3."""
+    from mini_mcmc_amd import stats as S
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import RosenbrockND
+    from mini_mcmc_amd.hmc import HMC
+
+    h = HMC(RosenbrockND(3), init_with_seed(65536, 3, 42, np.float32), 0.032, 10).set_seed(42)
+    t = h.run(n, 50, to="torch", accept_counts=False)
+    r1, e1 = S.split_rhat_mean_ess(t)
+    x = t.cpu().numpy()
+    r0, e0 = O.split_rhat_mean_ess(x)
+    np.testing.assert_allclose(r1, r0, rtol=1e-4)
+    np.testing.assert_allclose(e1, e0, rtol=2e-3)
 
 
 def test_stats_kats_on_gpu(M, O, kats):
