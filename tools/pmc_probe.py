@@ -19,7 +19,10 @@ if what == "nuts3":  # one-chain-per-lane NUTS on RosenbrockND(3): python3 tools
     sys.exit(0)
 if what == "stats":  # split-R-hat / ESS of a [65536, 400, 3] f32 sample in HBM
     from mini_mcmc_amd import stats as S
-    x = torch.randn(65536, 400, 3, device="cuda")
+    n = int(mode) if mode.isdigit() and int(mode) > 0 else 400  # python3 tools/pmc_probe.py stats <n> [kernel]
+    if len(sys.argv) > 3:
+        S.set_kernel(sys.argv[3])
+    x = torch.randn(65536, n, 3, device="cuda").cumsum(dim=1) * 0.1
     for _ in range(3):
         S.split_rhat_mean_ess(x)
     torch.cuda.synchronize()
