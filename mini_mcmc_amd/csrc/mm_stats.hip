@@ -873,7 +873,7 @@ __device__ __forceinline__ void mm_load_dt(const T *p, float (&out)[DT])
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                      \
     } while (0)
 
-template <class T, int R1, int DT, int WPE>
+template <class T, int R1, int DT, int WPE, bool TWL, bool TOP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n, unsigned int D, unsigned int m,
                          unsigned int n_pt, const mm_cx *__restrict__ tw, float *__restrict__ means,
@@ -888,22 +888,46 @@ void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, uns
     const unsigned int d0 = pt * DT + DT <= D ? pt * DT : D - DT;
     const unsigned long long Wt = 4ull * n_wg;
 
-    mm_cx tw1[R1], tw2[8];
+    /* twiddles: in registers (2 (R1 + 6) of them), or -- TWL -- one copy per workgroup in LDS behind the exchange blocks,
+     * read where they are used (R1 + 6 more ds_read_b64 per transform, conflict-free: lane-contiguous) */
+    mm_cx tw1[TWL ? 1 : R1], tw2[TWL ? 1 : 8];
+    const mm_cx *twl = reinterpret_cast<const mm_cx *>(lds_raw) + 4 * pl::LDS_CX;
+    if constexpr (TWL) {
+        mm_cx *twl_w = reinterpret_cast<mm_cx *>(lds_raw) + 4 * pl::LDS_CX;
+        for (unsigned int i = threadIdx.x; i < R1 * 64u + 64u; i += 256u)
+            twl_w[i] = tw[i];
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int b = 1; b < R1; ++b)
-        tw1[b] = tw[b * 64 + lane];
-    tw1[0] = mm_cx{1.f, 0.f};
+        for (int b = 1; b < R1; ++b)
+            tw1[b] = tw[b * 64 + lane];
+        tw1[0] = mm_cx{1.f, 0.f};
 #pragma unroll
-    for (int g = 1; g < 8; ++g)
-        tw2[g] = tw[R1 * 64 + g * 8 + (lane & 7u)];
-    tw2[0] = mm_cx{1.f, 0.f};
+        for (int g = 1; g < 8; ++g)
+            tw2[g] = tw[R1 * 64 + g * 8 + (lane & 7u)];
+        tw2[0] = mm_cx{1.f, 0.f};
+    }
+    auto tw1_of = [&](int b) -> mm_cx {
+        if constexpr (TWL)
+            return twl[b * 64 + lane];
+        else
+            return tw1[b];
+    };
+    auto tw2_of = [&](int g) -> mm_cx {
+        if constexpr (TWL)
+            return twl[R1 * 64 + g * 8 + (lane & 7u)];
+        else
+            return tw2[g];
+    };
 
+    /* TOP: the host found 64 (H - 1) < m, so only the last of a lane's H points can lie in the padding -- the others need
+     * no select (a select on a lane mask costs two issue slots: tools/xlane_rate.hip) */
     unsigned int voff[pl::H];
     bool valid[pl::H];
 #pragma unroll
     for (int a = 0; a < pl::H; ++a) {
         const unsigned int t = 64u * a + lane;
-        valid[a] = t < m;
+        valid[a] = (TOP && a < pl::H - 1) ? true : t < m;
         voff[a] = (valid[a] ? t : m - 1u) * D;
     }
     const float inv_m = 1.0f / (float)m;
@@ -980,12 +1004,12 @@ void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, uns
 #pragma unroll
             for (int a = 0; a < pl::H; ++a)
                 z[a] = mm_cx{y[0][a][dt], y[1][a][dt]};
-            mm_fft_pass1<R1>(z, tw1, lds, (int)lane);
+            mm_fft_pass1<R1>(z, tw1_of, lds, (int)lane);
             MM_WAVE_LDS_SYNC();
             mm_cx v[pl::J][8];
             mm_fft_pass2_load<R1>(v, lds, (int)lane);
             MM_WAVE_LDS_SYNC();
-            mm_fft_pass2_store<R1>(v, tw2, lds, (int)lane);
+            mm_fft_pass2_store<R1>(v, tw2_of, lds, (int)lane);
             MM_WAVE_LDS_SYNC();
             mm_fft_pass3<R1>(lds, (int)lane, S[dt]);
             MM_WAVE_LDS_SYNC();
@@ -1002,7 +1026,7 @@ void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, uns
                 for (int j = 0; j < pl::J; ++j)
 #pragma unroll
                     for (int h = 0; h < 8; ++h) {
-                        const unsigned int i = dt * pl::N + R1 * ((lane & 7u) + 8u * h) + (lane >> 3) + 8u * j;
+                        const unsigned int i = dt * pl::N + (unsigned int)mm_fft_bin<R1>((int)lane, j, h);
                         acc[i] = w == 0 ? S[dt][j][h] : acc[i] + S[dt][j][h];
                     }
         }
@@ -1013,38 +1037,44 @@ void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, uns
         out[i] = acc[i];
 }
 
-/* The inverse of the accumulated spectrum, once per parameter for all chains: block (d, group of 64 lags) adds the
+/* The inverse of the accumulated spectrum, once per parameter for all chains: block (d, group of 32 lags) adds the
  * partial totals parts[p][f D + d] of the tail kernel in f64 and evaluates
  *     acov[lag D + d] = (1 / N) sum_f P[f] cos(2 pi f lag / N),   lag < m,
- * four quarter-circles per lag combined in a fixed order. */
+ * the circle cut into eight arcs per lag that are combined in a fixed order.  cos_tab: cos(2 pi i / N), i < N, in f64
+ * (host-made, stats_fft_twiddles). */
 __global__ __launch_bounds__(256) void mm_fft_finish_kernel(const float *__restrict__ parts, unsigned int n_parts,
                                                             unsigned int D, unsigned int N, unsigned int m,
-                                                            float *__restrict__ acov)
+                                                            const double *__restrict__ cos_tab, float *__restrict__ acov)
 {
     extern __shared__ __attribute__((aligned(16))) double shd[];
-    double *P = shd, *ct = shd + N, *red = shd + 2 * N; /* [N], [N], [4][64] */
-    const unsigned int d = blockIdx.x % D, lag0 = (blockIdx.x / D) * 64u, tid = threadIdx.x;
+    double *P = shd, *ct = shd + N, *red = shd + 2 * N; /* [N], [N], [8][32] */
+    const unsigned int d = blockIdx.x % D, lag0 = (blockIdx.x / D) * 32u, tid = threadIdx.x;
     const size_t total = (size_t)N * D;
     for (unsigned int f = tid; f < N; f += 256) {
-        double t = 0.0;
-        for (unsigned int p = 0; p < n_parts; ++p)
-            t += (double)parts[(size_t)p * total + (size_t)f * D + d];
-        P[f] = t;
-        ct[f] = cospi(2.0 * (double)f / (double)N);
+        double t0 = 0.0, t1 = 0.0;
+        unsigned int p = 0;
+        for (; p + 1 < n_parts; p += 2) {
+            t0 += (double)parts[(size_t)p * total + (size_t)f * D + d];
+            t1 += (double)parts[(size_t)(p + 1) * total + (size_t)f * D + d];
+        }
+        if (p < n_parts)
+            t0 += (double)parts[(size_t)p * total + (size_t)f * D + d];
+        P[f] = t0 + t1;
+        ct[f] = cos_tab[f];
     }
     __syncthreads();
-    const unsigned int lag = lag0 + (tid & 63u), q = tid >> 6;
+    const unsigned int l = tid & 31u, q = tid >> 5, lag = lag0 + l;
     double a0 = 0.0, a1 = 0.0;
-    const unsigned int f_lo = q * (N / 4), f_hi = f_lo + N / 4;
+    const unsigned int f_lo = q * (N / 8), f_hi = f_lo + N / 8;
     for (unsigned int f = f_lo; f < f_hi; f += 2) {
         a0 = fma(P[f], ct[(f * lag) & (N - 1u)], a0);
         a1 = fma(P[f + 1], ct[((f + 1u) * lag) & (N - 1u)], a1);
     }
-    red[q * 64 + (tid & 63u)] = a0 + a1;
+    red[q * 32 + l] = a0 + a1;
     __syncthreads();
     if (q == 0 && lag < m) {
-        const unsigned int l = tid & 63u;
-        const double r = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+        const double r = ((red[l] + red[32 + l]) + (red[64 + l] + red[96 + l])) +
+                         ((red[128 + l] + red[160 + l]) + (red[192 + l] + red[224 + l]));
         acov[(size_t)lag * D + d] = (float)(r / (double)N);
     }
 }
@@ -1198,7 +1228,8 @@ static std::atomic<int> g_stats_kernel{MMCMC_STATS_KERNEL_AUTO};
 /* the power-spectrum path (mm_chain_fft_kernel): half-chains longer than 100 draws, as stats.rs:549 switches */
 struct StatsFftPlan {
     bool use = false;
-    int r1 = 0, dt = 0;
+    int r1 = 0, dt = 0, wpe = 0;
+    bool twl = false;
     unsigned int n_pt = 0, n_wg = 0, N = 0;
 };
 
@@ -1226,18 +1257,34 @@ static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int de
     p.use = true;
     p.r1 = m <= 256 ? 8 : m <= 512 ? 16 : 32;
     p.N = 64u * (unsigned int)p.r1;
-    p.dt = p.r1 == 32 ? 1 : (int)std::min<size_t>(dim, 4);
-    p.n_pt = (unsigned int)((dim + p.dt - 1) / p.dt);
+    /* parameters per wave: as many as the registers hold without spilling (R1 = 8: 4 at two waves per SIMD, 3 at three;
+     * R1 = 16: 3; R1 = 32: 1), the tiles of a larger dimension as even as possible */
+    const size_t dt_max = p.r1 == 8 ? 4 : p.r1 == 16 ? 3 : 1;
+    p.n_pt = (unsigned int)((dim + dt_max - 1) / dt_max);
+    p.dt = (int)((dim + p.n_pt - 1) / p.n_pt);
+    p.wpe = p.r1 == 8 && p.dt <= 3 ? 3 : 2;
+    p.twl = false;
+    if (const char *e = mm_tuning_env("MMCMC_FFT_WPE"))
+        p.wpe = atoi(e);
+    if (const char *e = mm_tuning_env("MMCMC_FFT_TWL"))
+        p.twl = atoi(e) != 0;
     /* resident workgroups of four waves: waves per SIMD x CUs, shared between the parameter tiles */
-    const unsigned int wpe = p.r1 == 8 ? 3u : 2u;
+    const unsigned int wpe = (unsigned int)p.wpe;
     const unsigned int resident = (unsigned int)stats_cu_count(device) * wpe;
     p.n_wg = std::max(1u, resident / p.n_pt);
+    if (const char *e = mm_tuning_env("MMCMC_FFT_NWG_MULT")) /* workgroups per resident slot (percent) */
+        p.n_wg = std::max(1u, (unsigned int)((unsigned long long)p.n_wg * (unsigned int)atoi(e) / 100u));
     p.n_wg = (unsigned int)std::min<size_t>(p.n_wg, (n_chains + 3) / 4);
     return p;
 }
 
 /* twiddles of the wave-level FFT: w_N^(lane b) as [R1][64], then w_64^(e g) as [8][8]; one table per device and
  * length, computed in f64 on the host at first use, never freed */
+static const double *stats_fft_cos_table(const mm_cx *tw, int r1)
+{
+    return reinterpret_cast<const double *>(tw + (size_t)r1 * 64 + 64); /* behind the twiddles, 8-byte aligned */
+}
+
 static const mm_cx *stats_fft_twiddles(int device, int r1)
 {
     static std::atomic<const mm_cx *> tab[64][3];
@@ -1246,7 +1293,13 @@ static const mm_cx *stats_fft_twiddles(int device, int r1)
     if (t)
         return t;
     const unsigned int N = 64u * (unsigned int)r1;
-    std::vector<mm_cx> h((size_t)r1 * 64 + 64);
+    /* [R1][64] + [8][8] complex, then cos(2 pi i / N), i < N, as doubles (two mm_cx slots... one double per slot) */
+    std::vector<mm_cx> h((size_t)r1 * 64 + 64 + N);
+    static_assert(sizeof(mm_cx) == sizeof(double), "the cosine table shares the allocation");
+    for (unsigned int i = 0; i < N; ++i) {
+        const double cv = std::cos(6.283185307179586476925286766559 * (double)i / (double)N);
+        memcpy(&h[(size_t)r1 * 64 + 64 + i], &cv, sizeof(double));
+    }
     const double two_pi = 6.283185307179586476925286766559;
     for (int b = 0; b < r1; ++b)
         for (int l = 0; l < 64; ++l) {
@@ -1273,22 +1326,22 @@ static const mm_cx *stats_fft_twiddles(int device, int r1)
     return d;
 }
 
-template <class T, int R1, int DT, int WPE>
+template <class T, int R1, int DT, int WPE, bool TWL, bool TOP>
 static int stats_fft_launch1(const StatsFftPlan &p, const void *sample, size_t n_chains, size_t n, size_t dim, size_t m,
                              const mm_cx *tw, float *means, float *ssq, float *slabs, hipStream_t stream)
 {
-    const size_t lds = (size_t)4 * mm_fft_plan<R1>::LDS_CX * sizeof(mm_cx);
+    const size_t lds = ((size_t)4 * mm_fft_plan<R1>::LDS_CX + (TWL ? R1 * 64 + 64 : 0)) * sizeof(mm_cx);
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> attr_set{0};
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!(attr_set.load(std::memory_order_relaxed) >> (dev & 63) & 1ull)) {
-            MM_HIP(hipFuncSetAttribute((const void *)mm_chain_fft_kernel<T, R1, DT, WPE>,
+            MM_HIP(hipFuncSetAttribute((const void *)mm_chain_fft_kernel<T, R1, DT, WPE, TWL, TOP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((mm_chain_fft_kernel<T, R1, DT, WPE>), dim3(p.n_wg * p.n_pt), dim3(256), lds, stream,
+    hipLaunchKernelGGL((mm_chain_fft_kernel<T, R1, DT, WPE, TWL, TOP>), dim3(p.n_wg * p.n_pt), dim3(256), lds, stream,
                        (const T *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
                        (unsigned int)m, p.n_pt, tw, means, ssq, slabs);
     return MMCMC_OK;
@@ -1298,18 +1351,26 @@ template <class T>
 static int stats_fft_launch(const StatsFftPlan &p, const void *sample, size_t n_chains, size_t n, size_t dim, size_t m,
                             const mm_cx *tw, float *means, float *ssq, float *slabs, hipStream_t stream)
 {
-#define MM_FFT_CASE(R1V, DTV, WPEV)                                                                                 \
-    if (p.r1 == R1V && p.dt == DTV)                                                                                 \
-    return stats_fft_launch1<T, R1V, DTV, WPEV>(p, sample, n_chains, n, dim, m, tw, means, ssq, slabs, stream)
-    MM_FFT_CASE(8, 1, 3);
-    MM_FFT_CASE(8, 2, 3);
-    MM_FFT_CASE(8, 3, 3);
-    MM_FFT_CASE(8, 4, 3);
-    MM_FFT_CASE(16, 1, 2);
-    MM_FFT_CASE(16, 2, 2);
-    MM_FFT_CASE(16, 3, 2);
-    MM_FFT_CASE(16, 4, 2);
-    MM_FFT_CASE(32, 1, 2);
+    const bool top = m > 64 * (size_t)(p.r1 / 2 - 1); /* only a lane's last point can be padding */
+#define MM_FFT_CASE(R1V, DTV, WPEV, TWLV)                                                                           \
+    if (p.r1 == R1V && p.dt == DTV && p.wpe == WPEV && p.twl == TWLV)                                               \
+    return top ? stats_fft_launch1<T, R1V, DTV, WPEV, TWLV, true>(p, sample, n_chains, n, dim, m, tw, means, ssq, slabs, stream) \
+               : stats_fft_launch1<T, R1V, DTV, WPEV, TWLV, false>(p, sample, n_chains, n, dim, m, tw, means, ssq, slabs, stream)
+    MM_FFT_CASE(8, 1, 3, false);
+    MM_FFT_CASE(8, 2, 3, false);
+    MM_FFT_CASE(8, 3, 3, false);
+    MM_FFT_CASE(8, 4, 2, false);
+    MM_FFT_CASE(16, 1, 2, false);
+    MM_FFT_CASE(16, 2, 2, false);
+    MM_FFT_CASE(16, 3, 2, false);
+    MM_FFT_CASE(32, 1, 2, false);
+#ifdef MMCMC_TUNING /* experiments: MMCMC_FFT_WPE, MMCMC_FFT_TWL */
+    MM_FFT_CASE(8, 3, 4, false);
+    MM_FFT_CASE(8, 3, 4, true);
+    MM_FFT_CASE(8, 3, 3, true);
+    MM_FFT_CASE(16, 3, 3, true);
+    MM_FFT_CASE(16, 3, 2, true);
+#endif
 #undef MM_FFT_CASE
     return MMCMC_ERR_UNSUPPORTED;
 }
@@ -1328,8 +1389,9 @@ static size_t stats_ws_floats(size_t n_chains, size_t n, size_t dim, unsigned in
 /* wb_part: NULL, or [dim][MM_WB_CHUNKS][3] doubles for the cross-chain sums (single-GPU path) */
 static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, size_t n, size_t dim, float *means,
                                float *ssq, float *acov_sum, double *wb_part, float *slabs_ws, unsigned int n_parts,
-                               int device, void *stream_v, unsigned int *parts_out)
+                               int device, void *stream_v, unsigned int *parts_out, float *final_out = nullptr)
 {
+    /* final_out (may be NULL): where a path that produces the total itself writes it; *parts_out = 0 then */
     if (parts_out)
         *parts_out = n_parts;
     if (!sample || !means || !ssq || !acov_sum || n_chains == 0 || dim == 0 ||
@@ -1367,14 +1429,14 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
                            (unsigned int)dim, fp.N, bins, nb_red, n_parts, means, ssq,
                            (unsigned long long)(2 * n_chains), (float)m, wb_part);
         MM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(mm_fft_finish_kernel, dim3((unsigned int)dim * (unsigned int)((m + 63) / 64)), dim3(256),
+        hipLaunchKernelGGL(mm_fft_finish_kernel, dim3((unsigned int)dim * (unsigned int)((m + 31) / 32)), dim3(256),
                            (2 * (size_t)fp.N + 256) * sizeof(double), stream, bins, n_parts, (unsigned int)dim, fp.N,
-                           (unsigned int)m, acov_sum);
+                           (unsigned int)m, stats_fft_cos_table(tw, fp.r1), final_out ? final_out : acov_sum);
         MM_HIP(hipGetLastError());
         if (!slabs_ws)
             MM_HIP(hipFreeAsync(ws, stream));
         if (parts_out)
-            *parts_out = 1;
+            *parts_out = final_out ? 0 : 1;
         return MMCMC_OK;
     }
     unsigned int n_slabs = stats_n_slabs(n_chains);
@@ -1620,9 +1682,11 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
     float *parts = w.p, *slabs = w.p + (size_t)kParts * total;
     unsigned int n_written = kParts;
     st = stats_partials_impl(sample, dtype, n_chains, n, dim, means, ssq, parts, nullptr, slabs, kParts, device, stream_v,
-                             &n_written);
+                             &n_written, acov_sum);
     if (st != MMCMC_OK)
         return st;
+    if (n_written == 0) /* the power-spectrum path wrote acov_sum itself */
+        return MMCMC_OK;
     hipLaunchKernelGGL(mm_parts_sum_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream_v, parts, n_written, (unsigned int)total, acov_sum);
     MM_HIP(hipGetLastError());

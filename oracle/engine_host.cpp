@@ -660,7 +660,7 @@ void fft_power_wave(const float *a, const float *b, int m, float *S_out)
             const double th = two_pi * (double)((lane * r) % pl::N) / (double)pl::N;
             tw1[r] = mm_cx{(float)std::cos(th), (float)-std::sin(th)};
         }
-        mm_fft_pass1<R1>(z, tw1, lds.data(), lane);
+        mm_fft_pass1<R1>(z, [&](int r) { return tw1[r]; }, lds.data(), lane);
     }
     std::vector<mm_cx> held((size_t)64 * pl::J * 8);
     for (int lane = 0; lane < 64; ++lane)
@@ -671,7 +671,7 @@ void fft_power_wave(const float *a, const float *b, int m, float *S_out)
             const double th = two_pi * (double)((lane & 7) * g) / 64.0;
             tw2[g] = mm_cx{(float)std::cos(th), (float)-std::sin(th)};
         }
-        mm_fft_pass2_store<R1>(*reinterpret_cast<mm_cx(*)[pl::J][8]>(&held[(size_t)lane * pl::J * 8]), tw2, lds.data(), lane);
+        mm_fft_pass2_store<R1>(*reinterpret_cast<mm_cx(*)[pl::J][8]>(&held[(size_t)lane * pl::J * 8]), [&](int g) { return tw2[g]; }, lds.data(), lane);
     }
     for (int lane = 0; lane < 64; ++lane)
         mm_fft_pass3<R1>(lds.data(), lane, S[lane]);

@@ -18,17 +18,22 @@
  *   pass 1   radix R1 over a in registers (decimation in frequency; the upper half of the inputs is the zero padding, so
  *            it is two DFTs of R1 / 2 points: even outputs from z, odd outputs from z[a] w_R1^a), twiddle w_N^(l b);
  *            what is left are R1 FFTs of 64 points over the lanes, one per residue b = f mod R1;
- *   pass 2   l = 8 c + e: exchange through LDS so that lane (beta, e) holds u_b[8 c + e], c = 0..7, for the rows
- *            b = beta + 8 j; radix 8 over c, twiddle w_64^(e g);
- *   pass 3   exchange inside the groups of 8 lanes (LDS again: 16 LDS instructions where a register transpose is 100
- *            vector instructions), radix 8 over e.  Lane (beta, g), register (j, h) ends with bin
- *            f = R1 (g + 8 h) + beta + 8 j; bins are never reordered: S is indexed by (lane, register) until the
+ *   pass 2   l = 8 c + e: a transposition through LDS (eight lanes x eight registers, over c) so that lane (beta, e) holds
+ *            u_b[8 c + e], c = 0..7, for the rows b = beta + 8 j; radix 8 over c, twiddle w_64^(e g);
+ *   pass 3   the same transposition over e, in registers: e sits in the lane bits v_permlane32_swap / v_permlane16_swap /
+ *            a quad permute exchange (48 vector instructions); radix 8 over e.  Lane (beta, g), register (j, h) ends with
+ *            bin f = R1 (g + 8 h) + beta + 8 j; bins are never reordered: S is indexed by (lane, register) until the
  *            workgroup folds its waves' S into natural order once, at the end of the launch.
- * Vector instructions per FFT of 512 points: about 240 (two DFT-4, 7 + 7 twiddles, two DFT-8, |Z|^2), against 935 per
- * chain and parameter in the register-tile kernel's direct sums at m = 200 -- and O(m log m) instead of O(m^2) beyond.
+ * Vector instructions per FFT of 512 points: about 290 (two DFT-4, 7 + 7 twiddles, two DFT-8, the transposition,
+ * |Z|^2), against 935 per chain and parameter in the register-tile kernel's direct sums at m = 200 -- and O(m log m)
+ * instead of O(m^2) beyond.
  *
- * LDS per wave: R1 rows of 72 complex numbers (a row = the 64 points of one residue; pitch 72 = 64 + 8 makes both
- * exchanges conflict-free: pass 2 reads unit 72 b + 8 c + e, pass 3's data sits at 72 b + 9 g + e).
+ * Why only ONE of the two transpositions goes through LDS (tools/fft_probe.hip): with both there, a transform is 860
+ * cycles per SIMD at any occupancy, of which the LDS traffic alone is 710 (16 KB per transform through a write path of
+ * ~90 bytes per clock per CU) and the arithmetic alone 500: the kernel was LDS-bandwidth bound.
+ *
+ * LDS per wave: R1 rows of 66 complex numbers (a row = the 64 points of one residue, stored at the writer's lane;
+ * pitch 66 = 2 mod 32 makes pass 2's gather conflict-free).
  *
  * Everything below the kernel is written per lane (MM_FD) so that a host build can run the 64 lanes of a wave one
  * after another, phase by phase, against a plain DFT (oracle/engine_host.cpp, tests/test_stats_fft_host.py).
@@ -41,7 +46,9 @@
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 #define MM_FD __device__ __forceinline__
+#define MM_HDC __host__ __device__ constexpr
 #else
+#define MM_HDC constexpr
 #include <cmath>
 #define MM_FD static inline
 #endif
@@ -57,51 +64,6 @@ MM_FD mm_cx mm_cx_mul(mm_cx a, float wr, float wi)
 {
     return mm_cx{fmaf(-a.im, wi, a.re * wr), fmaf(a.re, wi, a.im * wr)};
 }
-
-/* Eight complex numbers from LDS at p + STRIDE k, k = 0..7.  The compiler pairs neighbouring reads into ds_read2_b64,
- * which the LDS serves at 128 bytes per clock -- half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table) -- and the
- * transform is LDS-bound (tools/fft_probe.hip: 672 of its 860 cycles per SIMD are LDS time).  -DMM_FFT_ASM_LDS_LOADS
- * issues eight ds_read_b64 from a volatile asm instead: in the probe the transform drops to 763-789 cycles, in the kernel
- * the wait inside the asm (the compiler cannot count these loads) costs what the faster reads gain -- [65536, 400, 3]
- * 0.154 ms either way, [65536, 1000, 3] 0.32 against 0.29 ms -- so the plain form is the default. */
-#if defined(__HIPCC__) && defined(MM_FFT_ASM_LDS_LOADS)
-template <int STRIDE, class P>
-MM_FD void mm_lds_load8(P p, mm_cx (&out)[8])
-{
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const unsigned int a = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) const void *)(const void *)p;
-    f2 r0, r1, r2, r3, r4, r5, r6, r7;
-    asm volatile("ds_read_b64 %0, %8 offset:%9\n\t"
-                 "ds_read_b64 %1, %8 offset:%10\n\t"
-                 "ds_read_b64 %2, %8 offset:%11\n\t"
-                 "ds_read_b64 %3, %8 offset:%12\n\t"
-                 "ds_read_b64 %4, %8 offset:%13\n\t"
-                 "ds_read_b64 %5, %8 offset:%14\n\t"
-                 "ds_read_b64 %6, %8 offset:%15\n\t"
-                 "ds_read_b64 %7, %8 offset:%16\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-                 : "v"(a), "n"(0), "n"(8 * STRIDE), "n"(16 * STRIDE), "n"(24 * STRIDE), "n"(32 * STRIDE), "n"(40 * STRIDE),
-                   "n"(48 * STRIDE), "n"(56 * STRIDE)
-                 : "memory");
-    out[0] = mm_cx{r0[0], r0[1]};
-    out[1] = mm_cx{r1[0], r1[1]};
-    out[2] = mm_cx{r2[0], r2[1]};
-    out[3] = mm_cx{r3[0], r3[1]};
-    out[4] = mm_cx{r4[0], r4[1]};
-    out[5] = mm_cx{r5[0], r5[1]};
-    out[6] = mm_cx{r6[0], r6[1]};
-    out[7] = mm_cx{r7[0], r7[1]};
-}
-#else
-template <int STRIDE, class P>
-MM_FD void mm_lds_load8(P p, mm_cx (&out)[8])
-{
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        out[k] = p[STRIDE * k];
-}
-#endif
 
 /* cos(2 pi k / 32) for any k from its first octant */
 constexpr float mm_cos32(int k)
@@ -187,16 +149,24 @@ struct mm_fft_plan {
     static constexpr int H = R1 / 2;      /* non-zero inputs per lane */
     static constexpr int N = 64 * R1;     /* transform length */
     static constexpr int J = R1 / 8;      /* rows (residues b) per lane in passes 2 and 3 */
-    static constexpr int PITCH = 72;      /* complex numbers per LDS row */
+    static constexpr int PITCH = 66;      /* complex numbers per LDS row */
     static constexpr int LDS_CX = R1 * PITCH; /* complex numbers of LDS per wave */
     static constexpr int HB = mm_log2i(H);
 };
 
-/* bin held by lane (beta = lane >> 3, g = lane & 7), register (j, h) after pass 3 */
+/* The two 3-bit fields of a lane.  Position l = 8 c + e inside a block of 64 points: c sits in lane bits 3..1, e in lane
+ * bits 5, 4 and 0 -- the bits v_permlane32_swap, v_permlane16_swap and a quad permute exchange, which is what lets the
+ * second transposition (over e) stay in registers.  After the first transposition the field of c holds beta (the residue
+ * b mod 8 of the lane's rows), after the second the field of e holds g. */
+MM_HDC int mm_fft_lane_c(int lane) { return (lane >> 1) & 7; }
+MM_HDC int mm_fft_lane_e(int lane) { return ((lane >> 5) & 1) << 2 | ((lane >> 4) & 1) << 1 | (lane & 1); }
+MM_HDC int mm_fft_lane_pos(int lane) { return 8 * mm_fft_lane_c(lane) + mm_fft_lane_e(lane); }
+
+/* bin held by lane (beta, g), register (j, h) after pass 3 */
 template <int R1>
-constexpr int mm_fft_bin(int lane, int j, int h)
+MM_HDC int mm_fft_bin(int lane, int j, int h)
 {
-    return R1 * ((lane & 7) + 8 * h) + (lane >> 3) + 8 * j;
+    return R1 * (mm_fft_lane_e(lane) + 8 * h) + mm_fft_lane_c(lane) + 8 * j;
 }
 
 template <int R1, int... A>
@@ -205,9 +175,9 @@ MM_FD void mm_fft_turn(const mm_cx (&z)[R1 / 2], mm_cx (&od)[R1 / 2], std::integ
     ((od[A] = mm_cx_rot<R1, A>(z[A])), ...);
 }
 
-/* pass 1: z[a] = point 64 a + lane (a < R1 / 2, the rest is padding); tw1(b) = w_N^(lane b) (a callable: the kernel
- * keeps the factors in registers or reads them from LDS).  Row b of the wave's LDS
- * block receives u_b[lane]. */
+/* pass 1: z[a] = point 64 a + mm_fft_lane_pos(lane) (a < R1 / 2, the rest is padding); tw1(b) = w_N^(pos b) (a callable:
+ * the kernel keeps the factors in registers or reads them from LDS).  Row b of the wave's LDS block receives u_b[pos] at
+ * the writer's LANE (unit b PITCH + lane: a wave's store is 64 contiguous units). */
 template <int R1, class P, class TW>
 MM_FD void mm_fft_pass1(const mm_cx (&z)[R1 / 2], TW tw1, P lds, int lane)
 {
@@ -234,24 +204,20 @@ MM_FD void mm_fft_pass1(const mm_cx (&z)[R1 / 2], TW tw1, P lds, int lane)
     }
 }
 
-/* pass 2: lane (beta, e) takes u_b[8 c + e] of its rows b = beta + 8 j, radix 8 over c, twiddle tw2[g] = w_64^(e g),
- * and leaves V_b[g][e] at unit 72 b + 9 g + e of the same row (the row's other readers are the lanes of this group, and
- * a wave's LDS instructions execute in order: every lane's loads are issued before any lane's stores -- two functions so
- * that a host build can run them as two phases). */
-template <int R1, class P>
-MM_FD void mm_fft_pass2_load(mm_cx (&v)[R1 / 8][8], P lds, int lane)
+/* pass 2: lane (beta, e) takes u_b[8 c + e], c = 0..7, of its rows b = beta + 8 j -- written by the lanes (c, e), i.e. at
+ * units (lane & 0x31) + 2 c of the row; with PITCH = 66 = 2 mod 32 the 32 lanes of a half-wave meet 32 different banks
+ * (2 beta + e0 + 16 e1) --, radix 8 over c, twiddle tw2(g) = w_64^(e g); V[j][g] in natural order of g. */
+template <int R1, class P, class TW>
+MM_FD void mm_fft_pass2(mm_cx (&V)[R1 / 8][8], TW tw2, P lds, int lane)
 {
     using pl = mm_fft_plan<R1>;
-    const int beta = lane >> 3, e = lane & 7;
+    const int beta = mm_fft_lane_c(lane), eb = lane & 0x31;
+    mm_cx v[pl::J][8];
 #pragma unroll
     for (int j = 0; j < pl::J; ++j)
-        mm_lds_load8<8>(lds + (beta + 8 * j) * pl::PITCH + e, v[j]);
-}
-template <int R1, class P, class TW>
-MM_FD void mm_fft_pass2_store(mm_cx (&v)[R1 / 8][8], TW tw2, P lds, int lane)
-{
-    using pl = mm_fft_plan<R1>;
-    const int beta = lane >> 3, e = lane & 7;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            v[j][c] = lds[(beta + 8 * j) * pl::PITCH + eb + 2 * c];
 #pragma unroll
     for (int j = 0; j < pl::J; ++j) {
         mm_dft_dif<8>(v[j]);
@@ -263,28 +229,93 @@ MM_FD void mm_fft_pass2_store(mm_cx (&v)[R1 / 8][8], TW tw2, P lds, int lane)
                 const mm_cx w = tw2(g);
                 t = mm_cx_mul(v[j][p], w.re, w.im);
             }
-            lds[(beta + 8 * j) * pl::PITCH + 9 * g + e] = t;
+            V[j][g] = t;
         }
     }
 }
 
-/* pass 3: lane (beta, g) takes V_b[g][e], e = 0..7, radix 8 over e, and adds |X|^2 of its R1 bins to S[j][h] */
-template <int R1, class P>
-MM_FD void mm_fft_pass3(P lds, int lane, float (&S)[R1 / 8][8])
+/* The second transposition, in registers: inside every group of eight lanes that share beta, lane e register g
+ * becomes lane g register e.  Three steps, one per bit: bit 2 of (e, g) by v_permlane32_swap (lane bit 5), bit 1 by
+ * v_permlane16_swap (lane bit 4) -- one instruction exchanges the upper lanes of one register with the lower lanes of
+ * another, i.e. a whole step for a register pair --, bit 0 (lane bit 0) by a quad permute and three selects. */
+#ifdef __HIPCC__
+MM_FD void mm_fft_swap_hi_lo32(float &x0, float &x1)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+    x0 = __uint_as_float(r[0]);
+    x1 = __uint_as_float(r[1]);
+}
+MM_FD void mm_fft_swap_hi_lo16(float &x0, float &x1)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+    x0 = __uint_as_float(r[0]);
+    x1 = __uint_as_float(r[1]);
+}
+MM_FD void mm_fft_swap_odd_even(float &x0, float &x1, bool odd)
+{
+    const float send = odd ? x0 : x1;
+    const float got = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+    x0 = odd ? got : x0;
+    x1 = odd ? x1 : got;
+}
+template <int JJ>
+MM_FD void mm_fft_xpose(mm_cx (&V)[JJ][8], int lane)
+{
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < JJ; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { /* bit 2 */
+            mm_fft_swap_hi_lo32(V[j][g].re, V[j][g | 4].re);
+            mm_fft_swap_hi_lo32(V[j][g].im, V[j][g | 4].im);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { /* bit 1 */
+            const int g = (k & 1) | (k & 2) << 1;
+            mm_fft_swap_hi_lo16(V[j][g].re, V[j][g | 2].re);
+            mm_fft_swap_hi_lo16(V[j][g].im, V[j][g | 2].im);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { /* bit 0 */
+            const int g = 2 * k;
+            mm_fft_swap_odd_even(V[j][g].re, V[j][g | 1].re, odd);
+            mm_fft_swap_odd_even(V[j][g].im, V[j][g | 1].im, odd);
+        }
+    }
+}
+#else
+/* host twin of the above on the 64 lanes of a wave at once (test harness): element (lane field e, register g) <-> (g, e) */
+template <int JJ>
+static inline void mm_fft_xpose_wave(mm_cx (*V)[JJ][8])
+{
+    for (int j = 0; j < JJ; ++j)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int g = 0; g < 8; ++g) {
+                const int e = mm_fft_lane_e(lane);
+                if (e < g) { /* each pair once */
+                    const int partner = (lane & ~0x31) | ((g >> 2) & 1) << 5 | ((g >> 1) & 1) << 4 | (g & 1);
+                    const mm_cx t = V[lane][j][g];
+                    V[lane][j][g] = V[partner][j][e];
+                    V[partner][j][e] = t;
+                }
+            }
+}
+#endif
+
+/* pass 3: lane (beta, g) holds W[j][e] = V_b[g][e], e = 0..7: radix 8 over e, |X|^2 of its R1 bins added to S[j][h] */
+template <int R1>
+MM_FD void mm_fft_pass3(mm_cx (&W)[R1 / 8][8], float (&S)[R1 / 8][8])
 {
     using pl = mm_fft_plan<R1>;
-    const int beta = lane >> 3, g = lane & 7;
-    mm_cx w[pl::J][8];
-#pragma unroll
-    for (int j = 0; j < pl::J; ++j)
-        mm_lds_load8<1>(lds + (beta + 8 * j) * pl::PITCH + 9 * g, w[j]);
 #pragma unroll
     for (int j = 0; j < pl::J; ++j) {
-        mm_dft_dif<8>(w[j]);
+        mm_dft_dif<8>(W[j]);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int h = mm_bitrev(p, 3);
-            S[j][h] = fmaf(w[j][p].im, w[j][p].im, fmaf(w[j][p].re, w[j][p].re, S[j][h]));
+            S[j][h] = fmaf(W[j][p].im, W[j][p].im, fmaf(W[j][p].re, W[j][p].re, S[j][h]));
         }
     }
 }
