@@ -167,7 +167,9 @@ int mmcmc_nuts_set_chain_offset(mmcmc_nuts *h, uint64_t chain_offset);
 int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
 /* Kernel mapping (not in the reference).  0 = one chain per lane, the lanes of a wave taking their transitions in step
  * (every target / mode); 4 = one chain per lane, every lane advancing through its transitions on its own, one leaf per
- * tick (dim <= 8; the default there; results identical to 0).  6 = one chain per lane at RUN-TIME dimension, the
+ * tick (dim <= 8; results identical to 0); 5 = the same with the leaves taken in pairs, level 0 of the pending-subtree
+ * stack in registers and the auxiliary uniforms in an LDS ring (dim <= 8; the default there; results identical to 0
+ * and 4).  6 = one chain per lane at RUN-TIME dimension, the
  * transition's vectors in an HBM store (csrc/mm_nuts_generic.h): the N-dimensional built-in targets (isotropic / standard
  * / dense Gaussian, RosenbrockND) at ANY dimension, all three modes; the default where there is no compiled instance of
  * 0 (those exist for every dim <= 8 and 10, 16, 20, 24 / 32 for the dense Gaussian), selectable everywhere, results
@@ -179,7 +181,7 @@ int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
  * work units from per-level queues, chains advancing independently of each other (the fastest from a few thousand
  * chains on; below 2048 chains it runs as 1).
  * 1..3 exist for mode 2 + MMCMC_GAUSSIAN_ND with dim 16 or 32, where 3 is the default; elsewhere setting them returns
- * MMCMC_ERR_UNSUPPORTED (so does 4 above dim 8).  1, 2 and 3 give bit-identical results.  They sum the D-term dot products in a different
+ * MMCMC_ERR_UNSUPPORTED (so do 4 and 5 above dim 8).  1, 2 and 3 give bit-identical results.  They sum the D-term dot products in a different
  * order than 0 (four interleaved partial sums vs sequential), so their samples differ from 0's in the last bits and,
  * over long trajectories of a stiff target, visibly; each is bit-exact against its own host build
  * (oracle/engine_host.cpp modes 3 and 2).  With variant 3 mmcmc_nuts_run returns after the kernel has finished.

@@ -236,11 +236,17 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
         aux_b = 0;
         aux_load(seed, chain, 0, aux_q);
         aux_load(seed, chain, 1, aux_q + 2);
+        begin_with(P, x, seed, chain, aux(seed, chain));
+    }
+    /* the same with the transition's first auxiliary uniform handed in (m already set): kernels that keep the uniforms
+     * somewhere else than in aux_q (mm_nuts_pair_kernel: a ring in LDS) */
+    MM_HD void begin_with(const mm_tparams<TT> &P, const TT *x, uint64_t seed, uint64_t chain, double u0)
+    {
         TT mom0[D], grad[D];
         mm_nuts_momentum<D>(seed, chain, m, mom0);
         const TT ulogp = Tgt::logp_grad(P, x, grad);
         joint = (ST)(double)(ulogp - Red::dot(mom0, mom0) * TT(0.5));
-        const ST exp1_obs = (ST)(-mm_log(aux(seed, chain))); /* Exp(1) by inversion of the first auxiliary uniform */
+        const ST exp1_obs = (ST)(-mm_log(u0)); /* Exp(1) by inversion of the first auxiliary uniform */
         logu = joint - exp1_obs;
         MM_UNROLL
         for (int i = 0; i < D; ++i) {
@@ -259,7 +265,11 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
 
     template <bool PRE = false> MM_HD void double_begin(const mm_nuts_adapt<ST> &ad, uint64_t seed, uint64_t chain)
     {
-        const ST u_run_1 = (ST)aux<PRE>(seed, chain);
+        double_begin_with(ad.epsilon, aux<PRE>(seed, chain));
+    }
+    MM_HD void double_begin_with(ST epsilon, double u)
+    {
+        const ST u_run_1 = (ST)u;
         v = (u_run_1 < ST(0.5)) ? 1 : -1;
         const bool neg = v == -1;
         MM_UNROLL
@@ -268,7 +278,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
             cp[i] = neg ? pm[i] : pp[i];
             cg[i] = neg ? gm[i] : gp[i];
         }
-        eps_signed = (TT)((ST)v * ad.epsilon);
+        eps_signed = (TT)((ST)v * epsilon);
         sp = 0; /* pending first children on the stack */
         S_level = 0;
         S_n = 0;
@@ -301,13 +311,24 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
     template <bool PRE = false>
     MM_HD int hand_up(uint64_t seed, uint64_t chain, const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
     {
+        return hand_up_with(stk, [&]() -> double { return this->template aux<PRE>(seed, chain); });
+    }
+    /* is S the second child of a pair whose first child waits on the stack? (then the next hand_up step is a merge) */
+    MM_HD bool sibling_waits(const mm_nuts_stack<TT, ST, Tgt::dim> &stk) const
+    {
+        return sp > 0 && stk.c(sp - 1, 0) == S_level;
+    }
+    /* draw(): the next auxiliary uniform, called only when a merge takes place */
+    template <class Draw>
+    MM_HD int hand_up_with(const mm_nuts_stack<TT, ST, Tgt::dim> &stk, Draw &&draw)
+    {
         if (S_level == (uint32_t)j)
             return HAND_DONE;
         if (sp > 0 && stk.c(sp - 1, 0) == S_level) {
             /* S is the second child: merge with its sibling T1 (nuts.rs:900-928) */
             const int e = sp - 1;
             const uint32_t n1 = stk.c(e, 1);
-            const double u = aux<PRE>(seed, chain); /* always f64 (nuts.rs:910) */
+            const double u = draw(); /* always f64 (nuts.rs:910) */
             uint32_t den = n1 + S_n;
             if (den < 1)
                 den = 1;
@@ -354,6 +375,80 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
         return (S_level == (uint32_t)j) ? HAND_DONE : HAND_MORE;
     }
 
+    /* ---- leaves taken in pairs (mm_nuts_pair_kernel): level 0 of the pending-subtree stack in registers ----
+     * A first child at level 0 is a single leaf: its first-leaf state and its proposal are the leaf itself, so what waits
+     * for the sibling is (x, p) of that leaf, its alpha and its n' -- no trip to the stack.  pair_first() is hand_up's
+     * decision for a level-0 subtree, pair_second() its merge branch with the sibling read from L0_* instead of the stack:
+     * the same operations in the same order, so the chain's numbers do not change. */
+    TT L0_x[D], L0_p[D];
+    ST L0_alpha;
+    uint32_t L0_n;
+    MM_HD int pair_first()
+    {
+        if (j == 0)
+            return HAND_DONE; /* a doubling of one leaf */
+        if (S_s) {
+            MM_UNROLL
+            for (int i = 0; i < D; ++i) {
+                L0_x[i] = cx[i];
+                L0_p[i] = cp[i];
+            }
+            L0_alpha = S_alpha;
+            L0_n = S_n;
+            return HAND_NEXT_LEAF;
+        }
+        S_level = 1; /* first child with s' = 0: handed up unmerged, its sibling is never built */
+        return (S_level == (uint32_t)j) ? HAND_DONE : HAND_MORE;
+    }
+    MM_HD int pair_second(double u)
+    {
+        const uint32_t n1 = L0_n;
+        uint32_t den = n1 + S_n;
+        if (den < 1)
+            den = 1;
+        const bool take2 = u < ((double)S_n / (double)den);
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            if (!take2)
+                S_prime[i] = L0_x[i];
+        S_n += n1;
+        const bool crit = (v == -1) ? mm_stop_criterion<TT, D, Red>(cx, L0_x, cp, L0_p)
+                                    : mm_stop_criterion<TT, D, Red>(L0_x, cx, L0_p, cp);
+        S_s = S_s && crit;
+        S_alpha = L0_alpha + S_alpha;
+        S_nalpha += 1u;
+        MM_UNROLL
+        for (int i = 0; i < D; ++i) {
+            S_first_x[i] = L0_x[i];
+            S_first_p[i] = L0_p[i];
+        }
+        S_level = 1;
+        return (S_level == (uint32_t)j) ? HAND_DONE : HAND_MORE;
+    }
+    /* the hand_up steps that need no uniform (a push, or a first child with s' = 0 moving up): false when the next step
+     * is a merge */
+    MM_HD int hand_up_free(const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
+    {
+        if (S_level == (uint32_t)j)
+            return HAND_DONE;
+        if (S_s) {
+            MM_UNROLL
+            for (int i = 0; i < D; ++i) {
+                stk.v(sp, 0, i) = S_first_x[i];
+                stk.v(sp, 1, i) = S_first_p[i];
+                stk.v(sp, 2, i) = S_prime[i];
+            }
+            stk.a(sp) = S_alpha;
+            stk.c(sp, 0) = S_level;
+            stk.c(sp, 1) = S_n;
+            stk.c(sp, 2) = S_nalpha;
+            sp += 1;
+            return HAND_NEXT_LEAF;
+        }
+        S_level += 1;
+        return (S_level == (uint32_t)j) ? HAND_DONE : HAND_MORE;
+    }
+
     /* one leaf and the merges it completes; true when the doubling is complete (or was cut short) */
     MM_HD bool leaf_step(const mm_tparams<TT> &P, uint64_t seed, uint64_t chain,
                          const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
@@ -368,6 +463,10 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
 
     /* x[D]: the chain's position, replaced by the doubling's proposal when it is accepted */
     template <bool PRE = false> MM_HD void double_end(TT *x, uint64_t seed, uint64_t chain, int max_depth)
+    {
+        double_end_with(x, max_depth, aux<PRE>(seed, chain));
+    }
+    MM_HD void double_end_with(TT *x, int max_depth, double u)
     {
         const bool neg = v == -1;
         MM_UNROLL
@@ -385,7 +484,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
         alpha = S_alpha; /* from the LAST doubling only (nuts.rs:614-615, 649-650) */
         n_alpha = S_nalpha;
         const ST tmp = mm_minT(ST(1), (ST)S_n / (ST)n);
-        const ST u_run_2 = (ST)aux<PRE>(seed, chain);
+        const ST u_run_2 = (ST)u;
         if (S_s && (u_run_2 < tmp)) {
             MM_UNROLL
             for (int i = 0; i < D; ++i)
@@ -426,6 +525,38 @@ MM_HD mm_nuts_info mm_nuts_step(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST
     while (t.s) {
         t.double_begin(*ad, seed, chain);
         while (!t.leaf_step(P, seed, chain, stk)) {
+        }
+        t.double_end(x, seed, chain, max_depth);
+    }
+    t.finish(ad, n_discard, target_accept_p);
+    return t.info;
+}
+
+/* The same transition with the leaves taken in pairs (pair_first / pair_second / hand_up_free): the order in which
+ * mm_nuts_pair_kernel walks a tree, run here back to back.  Bit-identical to mm_nuts_step by construction; the host
+ * build compares the two (tests/test_nuts_parity_cpu.py). */
+template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
+MM_HD mm_nuts_info mm_nuts_step_pairs(const mm_tparams<TT> &P, TT *x, mm_nuts_adapt<ST> *ad, uint32_t m, uint32_t n_discard,
+                                      ST target_accept_p, int max_depth, uint64_t seed, uint64_t chain,
+                                      const mm_nuts_stack<TT, ST, Tgt::dim> &stk)
+{
+    using Tree = mm_nuts_tree<TT, ST, Tgt, Red>;
+    Tree t;
+    t.begin(P, x, m, seed, chain);
+    auto draw = [&]() -> double { return t.aux(seed, chain); };
+    while (t.s) {
+        t.double_begin(*ad, seed, chain);
+        for (;;) {
+            t.leaf(P);
+            int r = t.pair_first();
+            if (r == Tree::HAND_NEXT_LEAF) {
+                t.leaf(P);
+                r = t.pair_second(draw());
+            }
+            while (r == Tree::HAND_MORE)
+                r = t.sibling_waits(stk) ? t.hand_up_with(stk, draw) : t.hand_up_free(stk);
+            if (r == Tree::HAND_DONE)
+                break;
         }
         t.double_end(x, seed, chain, max_depth);
     }

@@ -211,7 +211,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
             stack_in_lds = (k->tile_bytes_per_wave + k->stack_bytes_per_wave) <= 40 * 1024;
             /* the scratch area also serves the asynchronous-lane kernel when ITS stack (max_depth levels, no tile) is
              * over the LDS limit; max_depth can change after create, so allocate whenever the full stack is */
-            if (!stack_in_lds || k->stack_bytes_per_wave > 40 * 1024) {
+            if (!stack_in_lds || k->stack_bytes_per_wave + 4096 > 40 * 1024) { /* + the pair kernel's ring of uniforms */
                 const size_t waves = (n_chains + 63) / 64;
                 MM_HIP(hipMalloc((void **)&d_scratch, waves * k->stack_bytes_per_wave));
             }
@@ -245,7 +245,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
             }
         }
         if (!lg && k && k->run_async)
-            variant = 4; /* asynchronous lanes: the default for the one-chain-per-lane kernels */
+            variant = 4; /* asynchronous lanes */
+        if (!lg && k && k->run_pair)
+            variant = 5; /* asynchronous lanes, leaves in pairs: the default for the one-chain-per-lane kernels */
         MM_HIP(hipStreamCreateWithFlags(&stream, hipStreamDefault));
         MM_HIP(hipEventCreate(&ev0));
         MM_HIP(hipEventCreate(&ev1));
@@ -254,11 +256,12 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int set_variant(int v) override
     {
-        if ((v == 0 && k) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 6 && generic_ok) || (v == 7 && user)) {
+        if ((v == 0 && k) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 5 && k && k->run_pair) ||
+            (v == 6 && generic_ok) || (v == 7 && user)) {
             variant = v;
             return MMCMC_OK;
         }
-        return (v >= 0 && v <= 7 && v != 5) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
+        return (v >= 0 && v <= 7) ? MMCMC_ERR_UNSUPPORTED : MMCMC_ERR_INVALID_ARG;
     }
 
     /* the lane-group launch exists for <double, double> only; the other instantiations never reach it */
@@ -592,7 +595,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
             ga.write_initial = a.write_initial;
             e = launch_generic(ga, 0, st);
         } else {
-            e = use_lg ? run_lg(a, st) : (variant == 4 && k->run_async) ? k->run_async(a, st) : k->run(a, st);
+            e = use_lg ? run_lg(a, st)
+                       : (variant == 5 && k->run_pair) ? k->run_pair(a, st)
+                       : (variant == 4 && k->run_async) ? k->run_async(a, st) : k->run(a, st);
         }
         if (e != hipSuccess)
             return (int)e;

@@ -328,7 +328,197 @@ __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT
     }
 }
 
+/* Asynchronous lanes, LEAVES IN PAIRS (kernel variant 5, the default for D <= 8).
+ *
+ * What the kernel above pays per leaf (SQ counters on RosenbrockND(3), 65 536 chains: ~700 vector + 210 scalar instructions
+ * per tick, TWO ticks per leaf): a tick gives a lane one leaf and ONE step of handing the subtree up, and a leaf needs
+ * (trailing ones of its index) + 1 such steps -- two on average, the second a mere push onto the stack --, while the wave
+ * executes every section (leaf, merge, doubling begin / end, the uniforms' Philox block) in every tick because some lane
+ * always wants it.  Here a tick is a PAIR of leaves:
+ *   * the first leaf of a pair waits for its sibling in registers (a one-leaf subtree is its own first leaf and its own
+ *     proposal: (x, p), alpha, n'), the level-0 merge runs on registers (mm_nuts_tree::pair_first / pair_second): level 0
+ *     of the pending-subtree stack, half of all pushes and merges, never touches LDS;
+ *   * after the pair one merge at level >= 1 (the step that draws a uniform) and then every step that draws none -- the
+ *     push, a first child with s' = 0 moving up -- in the same tick (hand_up_free): 0.75 ticks per leaf instead of 2;
+ *   * the auxiliary uniforms come from a ring of eight per lane in LDS, refilled for all lanes that have room whenever one
+ *     lane runs low (a Philox block = two uniforms serves most of the wave each time it is evaluated, where the two-block
+ *     register window above is advanced for the few lanes that ran dry), three are fetched per tick and handed to the
+ *     tree's steps in order (double_begin_with / pair_second / hand_up_with / double_end_with: at most three per tick).
+ * A chain goes through exactly the operations of mm_nuts_step in the same order (mm_nuts_step_pairs is this walk on the
+ * host, compared bit for bit in tests/test_nuts_parity_cpu.py): samples, adaptation state, leapfrog counts and depth
+ * histogram are identical to variants 0 and 4 and to the host build. */
+#define MM_NUTS_RING 8 /* auxiliary uniforms per lane in LDS */
+template <class TT, class ST, class Tgt, bool LDS_STACK>
+__global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT, ST> a)
+{
+    constexpr int D = Tgt::dim;
+    using Lay = mm_nuts_stack_layout<TT, ST, D>;
+    using Tree = mm_nuts_tree<TT, ST, Tgt>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
+    const int lane = threadIdx.x & 63;
+    __shared__ unsigned int hist_lds[MM_NUTS_JMAX + 1]; /* see mm_nuts_run_kernel */
+    if (lane <= MM_NUTS_JMAX)
+        hist_lds[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long c = (unsigned long long)blockIdx.x * 64 + lane;
+    const bool active = c < a.n_chains;
+    const unsigned long long chain = a.chain_offset + c;
+    double *const ring = reinterpret_cast<double *>(mm_lds_raw) + lane; /* slot s of this lane: ring[64 s] */
+    constexpr size_t ring_bytes = (size_t)MM_NUTS_RING * 64 * sizeof(double);
+    const mm_nuts_stack<TT, ST, D> stk = LDS_STACK ? Lay::make_levels(mm_lds_raw + ring_bytes, lane, a.max_depth)
+                                                   : Lay::make(a.scratch + (size_t)blockIdx.x * Lay::bytes, lane);
+
+    TT x[D];
+    MM_UNROLL
+    for (int i = 0; i < D; ++i)
+        x[i] = active ? a.state[c * D + i] : TT(0);
+    mm_nuts_adapt<ST> ad;
+    if (active) {
+        ad = a.adapt[c];
+    } else {
+        ad.epsilon = ST(0.1);
+        ad.epsilon_bar = ST(1);
+        ad.h_bar = ST(0);
+        ad.mu = ST(0);
+    }
+    const unsigned int total = a.n_pre + a.n_rec;
+    TT *const rows = a.out ? a.out + (c * a.n_total + a.out_t0) * D : nullptr; /* this chain's first row */
+    if (a.write_initial && rows && active) {
+        MM_UNROLL
+        for (int k = 0; k < D; ++k)
+            rows[k] = x[k];
+    }
+    const unsigned int first = a.write_initial ? 1u : 0u;
+
+    Tree T;
+    unsigned long long n_lf = 0;
+    unsigned int m = a.m0, done = 0;
+    unsigned int aux_p = 0; /* uniforms of transition T.m produced so far (even); T.aux_k: consumed */
+    T.aux_k = 0;
+    int phase = 0; /* 0: between transitions, 1: begin a doubling, 2: next pair of leaves, 4: hand the subtree up */
+    bool live = active && total > 0;
+    bool closing = false;
+    const unsigned int batch = a.async_batch ? a.async_batch : (D <= 4 ? 8u : 1u);
+    while (__ballot(live) != 0ull) {
+        const bool turn = live && phase == 0;
+        const unsigned long long turn_mask = __ballot(turn);
+        if ((unsigned int)__popcll(turn_mask) >= batch || __ballot(live && phase != 0) == 0ull) {
+            if (turn) {
+                if (closing) {
+                    T.finish(&ad, a.n_discard, a.target_accept_p);
+                    n_lf += T.info.n_leapfrog;
+                    if (a.depth_hist)
+                        atomicAdd(&hist_lds[T.info.depth < MM_NUTS_JMAX ? T.info.depth : MM_NUTS_JMAX], 1u);
+                    if (done >= a.n_pre && rows) {
+                        TT *r = rows + (size_t)(first + (done - a.n_pre)) * D;
+                        MM_UNROLL
+                        for (int k = 0; k < D; ++k)
+                            r[k] = x[k];
+                    }
+                    ++done;
+                    closing = false;
+                    live = done < total;
+                }
+                if (live) {
+                    ++m;
+                    T.m = m;
+                    double q[4];
+                    T.aux_load(a.seed, chain, 0, q);
+                    T.aux_load(a.seed, chain, 1, q + 2);
+                    ring[64 * 1] = q[1];
+                    ring[64 * 2] = q[2];
+                    ring[64 * 3] = q[3];
+                    aux_p = 4;
+                    T.aux_k = 1; /* the transition's first uniform is the slice variable's Exp(1) */
+                    T.begin_with(a.P, x, a.seed, chain, q[0]);
+                    phase = 1;
+                }
+            }
+        }
+        const bool work = live && phase != 0;
+        /* keep three uniforms ahead of every working lane; whoever has room for a block takes one along */
+        while (__ballot(work && aux_p - T.aux_k < 3u) != 0ull) {
+            if (work && aux_p - T.aux_k <= (unsigned int)MM_NUTS_RING - 2u) {
+                double q[2];
+                T.aux_load(a.seed, chain, aux_p >> 1, q);
+                ring[64 * (aux_p & (MM_NUTS_RING - 1u))] = q[0];
+                ring[64 * ((aux_p + 1u) & (MM_NUTS_RING - 1u))] = q[1];
+                aux_p += 2u;
+            }
+        }
+        if (work) {
+            const unsigned int k0 = T.aux_k;
+            const double d0 = ring[64 * (k0 & (MM_NUTS_RING - 1u))];
+            const double d1 = ring[64 * ((k0 + 1u) & (MM_NUTS_RING - 1u))];
+            const double d2 = ring[64 * ((k0 + 2u) & (MM_NUTS_RING - 1u))];
+            unsigned int used = 0;
+            auto draw = [&]() -> double {
+                const double r = used == 0u ? d0 : (used == 1u ? d1 : d2);
+                ++used;
+                return r;
+            };
+            if (phase == 1) {
+                T.double_begin_with(ad.epsilon, draw());
+                phase = 2;
+            }
+            int r = Tree::HAND_MORE; /* phase 4: a subtree on its way up */
+            bool second = false;
+            if (phase == 2) {
+                T.leaf(a.P);
+                r = T.pair_first();
+                second = r == Tree::HAND_NEXT_LEAF;
+            }
+            if (second) {
+                T.leaf(a.P);
+                r = T.pair_second(draw());
+            }
+            if (r == Tree::HAND_MORE && T.sibling_waits(stk))
+                r = T.hand_up_with(stk, draw);
+            while (__ballot(r == Tree::HAND_MORE && !T.sibling_waits(stk)) != 0ull) {
+                if (r == Tree::HAND_MORE && !T.sibling_waits(stk))
+                    r = T.hand_up_free(stk);
+            }
+            phase = r == Tree::HAND_MORE ? 4 : 2;
+            if (r == Tree::HAND_DONE) {
+                T.double_end_with(x, a.max_depth, draw());
+                phase = 1;
+                if (!T.s) {
+                    phase = 0;
+                    closing = true;
+                }
+            }
+            T.aux_k = k0 + used;
+        }
+    }
+
+    __builtin_amdgcn_wave_barrier();
+    if (a.depth_hist && lane <= MM_NUTS_JMAX && hist_lds[lane] != 0u)
+        atomicAdd(&a.depth_hist[lane], hist_lds[lane]);
+    if (active) {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            a.state[c * D + i] = x[i];
+        a.adapt[c] = ad;
+        if (a.n_leapfrog)
+            a.n_leapfrog[c] += n_lf;
+    }
+}
+
 #if !defined(__HIPCC_RTC__) /* host side: not part of the run-time compiled kernels of user targets (mm_rtc.hip) */
+template <class TT, class ST, class Tgt>
+hipError_t mm_launch_nuts_run_pair(const mm_nuts_args<TT, ST> &a, hipStream_t stream)
+{
+    using Lay = mm_nuts_stack_layout<TT, ST, Tgt::dim>;
+    const unsigned int grid = (unsigned int)((a.n_chains + 63) / 64);
+    const size_t ring = (size_t)MM_NUTS_RING * 64 * sizeof(double);
+    const size_t need = ring + Lay::bytes_for(a.max_depth);
+    if (need <= MM_NUTS_ASYNC_LDS_LIMIT)
+        hipLaunchKernelGGL((mm_nuts_pair_kernel<TT, ST, Tgt, true>), dim3(grid), dim3(64), need, stream, a);
+    else
+        hipLaunchKernelGGL((mm_nuts_pair_kernel<TT, ST, Tgt, false>), dim3(grid), dim3(64), ring, stream, a);
+    return hipGetLastError();
+}
+
 template <class TT, class ST, class Tgt>
 hipError_t mm_launch_nuts_run_async(const mm_nuts_args<TT, ST> &a, hipStream_t stream)
 {
@@ -375,6 +565,7 @@ template <class TT, class ST> struct mm_nuts_entry {
                        unsigned long long, unsigned long long, hipStream_t);
     hipError_t (*run)(const mm_nuts_args<TT, ST> &, hipStream_t);
     hipError_t (*run_async)(const mm_nuts_args<TT, ST> &, hipStream_t); /* asynchronous lanes; NULL for dim > 8 */
+    hipError_t (*run_pair)(const mm_nuts_args<TT, ST> &, hipStream_t);  /* asynchronous lanes, leaves in pairs; NULL for dim > 8 */
     size_t stack_bytes_per_wave, tile_bytes_per_wave;
 };
 

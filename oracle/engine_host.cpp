@@ -200,6 +200,10 @@ int eh_run(int sampler, int dtype, int kind, int dim, const double params[8], co
  * init_chain, then n_pre unrecorded and n_rec recorded transitions, row 0 = initial position for run() with
  * n_discard == 0.  positions [n, dim] doubles in/out (converted to the tensor type on entry like the C ABI does),
  * adapt [n, 4] doubles in/out (epsilon, epsilon_bar, h_bar, mu), out [n, n_collect, dim] of the tensor type. */
+/* eh_nuts_set_pairs: walk the trees leaf pair by leaf pair (mm_nuts_step_pairs, the order of mm_nuts_pair_kernel) */
+static int g_nuts_pairs = 0;
+extern "C" void eh_nuts_set_pairs(int on) { g_nuts_pairs = on; }
+
 template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>>
 static void nuts_chains(const mm_tparams<TT> &P, double *positions, size_t n, double tap, uint64_t seed, uint64_t off,
                         uint32_t m0, size_t n_collect, size_t n_discard, int progress, int max_depth, double *adapt,
@@ -233,7 +237,9 @@ static void nuts_chains(const mm_tparams<TT> &P, double *positions, size_t n, do
             if (write_initial) rec();
             for (unsigned t = 0; t < n_pre + n_rec; ++t) {
                 ++m;
-                mm_nuts_info inf = mm_nuts_step<TT, ST, Tgt, Red>(P, x, &ad, m, (uint32_t)n_discard, (ST)tap, max_depth, seed, off + c, stk);
+                mm_nuts_info inf = g_nuts_pairs
+                                       ? mm_nuts_step_pairs<TT, ST, Tgt, Red>(P, x, &ad, m, (uint32_t)n_discard, (ST)tap, max_depth, seed, off + c, stk)
+                                       : mm_nuts_step<TT, ST, Tgt, Red>(P, x, &ad, m, (uint32_t)n_discard, (ST)tap, max_depth, seed, off + c, stk);
                 lf += inf.n_leapfrog;
                 if (t >= n_pre) rec();
             }

@@ -610,7 +610,8 @@ def test_nuts_bit_exact_vs_host_build(M, O, mode):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_nuts_asynchronous_lanes_equal_synchronous_lanes(M, O, mode):
-    """Kernel variant 4 (every lane advances through ITS transitions, one leaf per tick; the default for dim <= 8)
+    """Kernel variants 4 (every lane advances through ITS transitions, one leaf per tick) and 5 (the same with the leaves
+    in pairs, level 0 of the stack in registers, uniforms in an LDS ring; the default for dim <= 8)
     against variant 0 (the wave waits for its deepest tree) and against the host build: samples, positions, adaptation
     state, leapfrog counts and the depth histogram are identical, with ragged waves, chain offsets, run / run_progress,
     a continued handle and a depth cap that bites."""
@@ -626,9 +627,9 @@ def test_nuts_asynchronous_lanes_equal_synchronous_lanes(M, O, mode):
     for tgt, kind, params, C, nc, nd, progress, off, max_depth in cases:
         init = M.core.init_with_seed(C, tgt.dim, 17) * 0.7
         res = {}
-        for variant in (4, 0):
+        for variant in (5, 4, 0):
             s = NUTS(tgt, init, 0.8, mode=mode).set_seed(23).set_max_depth(max_depth)
-            assert s.kernel_variant == 4  # the default
+            assert s.kernel_variant == 5  # the default: asynchronous lanes, leaves in pairs
             s.set_kernel_variant(variant)
             if off:
                 s.set_chain_offset(off)
@@ -636,10 +637,11 @@ def test_nuts_asynchronous_lanes_equal_synchronous_lanes(M, O, mode):
             out2 = s._run(5, 0, True, "numpy")  # continue the handle
             res[variant] = (out, out2, s.positions(), s.leapfrog_counts(), s.depth_histogram(), s.adapt_state())
         name = f"{type(tgt).__name__} D={tgt.dim} mode={mode} C={C}"
-        for i in range(5):
-            assert np.array_equal(res[4][i], res[0][i]), (name, i)
-        for key in ("epsilon", "epsilon_bar", "h_bar", "mu"):
-            assert np.array_equal(res[4][5][key], res[0][5][key]), (name, key)
+        for v in (4, 5):
+            for i in range(5):
+                assert np.array_equal(res[v][i], res[0][i]), (name, v, i)
+            for key in ("epsilon", "epsilon_bar", "h_bar", "mu"):
+                assert np.array_equal(res[v][5][key], res[0][5][key]), (name, v, key)
         ref, pos, ad, nlf = O.engine_host_nuts_run(mode, kind, tgt.dim, params, init, 0.8, nc, nd, seed=23,
                                                    progress=progress, max_depth=max_depth, chain_offset=off)
         assert np.array_equal(res[4][0], ref), name

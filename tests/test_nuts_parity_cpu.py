@@ -107,3 +107,26 @@ def test_engine_nuts_posterior_moments(O, kats):
     assert np.all(np.abs(flat.mean(axis=0) - [0.0, 1.0]) < 0.1)
     assert np.all(np.abs(np.cov(flat.T) - np.array([[4.0, 2.0], [2.0, 3.0]])) < 0.25)
     assert np.all(ad[:, 0] == ad[:, 1])  # after warm-up epsilon is frozen at epsilon_bar (nuts.rs:688-690)
+
+
+def test_leaf_pairs_walk_the_same_trees_bit_for_bit(O):
+    """mm_nuts_step_pairs (leaves in pairs, level 0 of the pending-subtree stack in registers, pushes folded into the step
+    that precedes them: the order in which mm_nuts_pair_kernel walks a tree) against mm_nuts_step, host build, every type
+    mode: samples, positions, adaptation state and leapfrog counts equal bit for bit -- including depth-capped trees and
+    a stiff target whose trees are cut short by divergences."""
+    E = O.engine_host_lib()
+    for kind, dim, params, mat, _ in _cases(O):
+        for mode in (0, 1, 2):
+            for max_depth, scale in ((10, 0.8), (3, 0.8), (10, 6.0)):
+                init = O.init_with_seed(24, dim, 23) * scale
+                res = []
+                try:
+                    for pairs in (0, 1):
+                        E.eh_nuts_set_pairs(pairs)
+                        res.append(O.engine_host_nuts_run(mode, kind, dim, params, init, 0.8, 12, 10, seed=9, matrix=mat,
+                                                          max_depth=max_depth, n_threads=2))
+                finally:
+                    E.eh_nuts_set_pairs(0)
+                for a, b in zip(res[0], res[1]):
+                    assert np.array_equal(a, b), (kind, dim, mode, max_depth, scale)
+                assert res[0][3].sum() > 0
