@@ -348,6 +348,16 @@ __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT
  * host, compared bit for bit in tests/test_nuts_parity_cpu.py): samples, adaptation state, leapfrog counts and depth
  * histogram are identical to variants 0 and 4 and to the host build. */
 #define MM_NUTS_RING 8 /* auxiliary uniforms per lane in LDS */
+/* -DMM_NUTS_PROFILE (tools/nuts_pair_probe.hip): per-wave event counters, written over the first lanes' leapfrog totals */
+#ifdef MM_NUTS_PROFILE
+#define MM_NP_DECL unsigned long long np_[16] = {}
+#define MM_NP_ADD(i, v) (np_[i] += (unsigned long long)(v))
+#define MM_NP_LANES(i, cond) (np_[i] += (unsigned long long)__popcll(__ballot(cond)))
+#else
+#define MM_NP_DECL
+#define MM_NP_ADD(i, v) ((void)0)
+#define MM_NP_LANES(i, cond) ((void)0)
+#endif
 template <class TT, class ST, class Tgt, bool LDS_STACK>
 __global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT, ST> a)
 {
@@ -399,10 +409,16 @@ __global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT,
     bool live = active && total > 0;
     bool closing = false;
     const unsigned int batch = a.async_batch ? a.async_batch : (D <= 4 ? 8u : 1u);
+    MM_NP_DECL;
     while (__ballot(live) != 0ull) {
         const bool turn = live && phase == 0;
         const unsigned long long turn_mask = __ballot(turn);
+        MM_NP_ADD(0, 1);            /* ticks */
+        MM_NP_LANES(1, turn);       /* lane-ticks spent waiting between transitions */
+        MM_NP_LANES(2, live);       /* lane-ticks alive */
         if ((unsigned int)__popcll(turn_mask) >= batch || __ballot(live && phase != 0) == 0ull) {
+            MM_NP_ADD(3, 1);        /* transition sections executed */
+            MM_NP_LANES(4, turn);   /* lanes served by them */
             if (turn) {
                 if (closing) {
                     T.finish(&ad, a.n_discard, a.target_accept_p);
@@ -438,6 +454,8 @@ __global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT,
         const bool work = live && phase != 0;
         /* keep three uniforms ahead of every working lane; whoever has room for a block takes one along */
         while (__ballot(work && aux_p - T.aux_k < 3u) != 0ull) {
+            MM_NP_ADD(5, 1);        /* Philox blocks evaluated for the ring */
+            MM_NP_LANES(6, work && aux_p - T.aux_k <= (unsigned int)MM_NUTS_RING - 2u); /* lanes that took one */
             if (work && aux_p - T.aux_k <= (unsigned int)MM_NUTS_RING - 2u) {
                 double q[2];
                 T.aux_load(a.seed, chain, aux_p >> 1, q);
@@ -457,28 +475,35 @@ __global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT,
                 ++used;
                 return r;
             };
+            MM_NP_LANES(7, phase == 1); /* doublings begun */
             if (phase == 1) {
                 T.double_begin_with(ad.epsilon, draw());
                 phase = 2;
             }
             int r = Tree::HAND_MORE; /* phase 4: a subtree on its way up */
             bool second = false;
+            MM_NP_LANES(8, phase == 2); /* first leaves */
             if (phase == 2) {
                 T.leaf(a.P);
                 r = T.pair_first();
                 second = r == Tree::HAND_NEXT_LEAF;
             }
+            MM_NP_LANES(9, second);     /* second leaves */
             if (second) {
                 T.leaf(a.P);
                 r = T.pair_second(draw());
             }
+            MM_NP_LANES(10, r == Tree::HAND_MORE && T.sibling_waits(stk)); /* merges at level >= 1 */
             if (r == Tree::HAND_MORE && T.sibling_waits(stk))
                 r = T.hand_up_with(stk, draw);
             while (__ballot(r == Tree::HAND_MORE && !T.sibling_waits(stk)) != 0ull) {
+                MM_NP_ADD(11, 1);       /* trips of the free-step loop */
+                MM_NP_LANES(12, r == Tree::HAND_MORE && !T.sibling_waits(stk));
                 if (r == Tree::HAND_MORE && !T.sibling_waits(stk))
                     r = T.hand_up_free(stk);
             }
             phase = r == Tree::HAND_MORE ? 4 : 2;
+            MM_NP_LANES(13, r == Tree::HAND_DONE); /* doublings ended */
             if (r == Tree::HAND_DONE) {
                 T.double_end_with(x, a.max_depth, draw());
                 phase = 1;
@@ -502,6 +527,10 @@ __global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT,
         if (a.n_leapfrog)
             a.n_leapfrog[c] += n_lf;
     }
+#ifdef MM_NUTS_PROFILE
+    if (a.n_leapfrog && lane < 16)
+        a.n_leapfrog[c] = np_[lane];
+#endif
 }
 
 #if !defined(__HIPCC_RTC__) /* host side: not part of the run-time compiled kernels of user targets (mm_rtc.hip) */
