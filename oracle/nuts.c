@@ -271,6 +271,24 @@ void o_nuts_chain_state(o_nuts *s, int chain, double out[7])
 #undef FILL
 }
 
+/* transitions of all chains by tree depth (diagnostic, not in the reference); also every chain's epsilon / epsilon_bar */
+void o_nuts_depth_hist(o_nuts *s, unsigned long long out[16], double *eps, double *eps_bar)
+{
+    memset(out, 0, 16 * sizeof(unsigned long long));
+#define ACC(TYPE)                                                                                            \
+    for (int i = 0; i < s->n_chains; ++i) {                                                                  \
+        const TYPE *c = &((const TYPE *)s->chains)[i];                                                       \
+        for (int k = 0; k < 16; ++k)                                                                         \
+            out[k] += c->depth_hist[k];                                                                      \
+        if (eps)                                                                                             \
+            eps[i] = (double)c->epsilon;                                                                     \
+        if (eps_bar)                                                                                         \
+            eps_bar[i] = (double)c->epsilon_bar;                                                             \
+    }
+    DISPATCH(s, ACC(nuts_chain_m0), ACC(nuts_chain_m1), ACC(nuts_chain_m2));
+#undef ACC
+}
+
 /* nuts.rs:695-761, for the known-answer test nuts.rs:1050-1055 */
 double o_nuts_find_reasonable_epsilon(const ot_target *target, const double *position, const double *mom,
                                       int mode)

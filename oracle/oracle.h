@@ -74,6 +74,7 @@ void o_nuts_use_engine_stream(o_nuts *s, uint64_t seed, uint64_t chain_offset);
 void o_nuts_set_max_depth(o_nuts *s, int max_depth);
 void o_nuts_run(o_nuts *s, size_t n_collect, size_t n_discard, int progress, int n_threads, double *out);
 void o_nuts_chain_state(o_nuts *s, int chain, double out[7]);
+void o_nuts_depth_hist(o_nuts *s, unsigned long long out[16], double *eps, double *eps_bar);
 double o_nuts_find_reasonable_epsilon(const ot_target *target, const double *position, const double *mom,
                                       int mode);
 void o_nuts_build_tree(const ot_target *target, const double *position, const double *mom, const double *grad,

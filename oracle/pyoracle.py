@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
         "o_nuts_set_max_depth": (None, [C.c_void_p, C.c_int]),
         "o_nuts_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _dp]),
         "o_nuts_chain_state": (None, [C.c_void_p, C.c_int, _dp]),
+        "o_nuts_depth_hist": (None, [C.c_void_p, C.POINTER(C.c_ulonglong), _dp, _dp]),
         "o_nuts_find_reasonable_epsilon": (C.c_double, [tp, _dp, _dp, C.c_int]),
         "o_nuts_build_tree": (
             None,
@@ -453,6 +454,14 @@ class NUTS:
         lib().o_nuts_chain_state(self._h, chain, _d(out))
         keys = ["epsilon", "epsilon_bar", "h_bar", "mu", "m", "last_depth", "n_leapfrog_total"]
         return dict(zip(keys, out.tolist()))
+
+    def depth_histogram(self):
+        """(transitions of all chains by tree depth [16], epsilon [C], epsilon_bar [C]) -- diagnostics, not in the reference."""
+        h = np.zeros(16, dtype=np.uint64)
+        eps = np.zeros(self.n_chains)
+        ebar = np.zeros(self.n_chains)
+        lib().o_nuts_depth_hist(self._h, h.ctypes.data_as(C.POINTER(C.c_ulonglong)), _d(eps), _d(ebar))
+        return h, eps, ebar
 
     def __del__(self):
         if getattr(self, "_h", None):
