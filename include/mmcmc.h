@@ -68,8 +68,11 @@ typedef struct mmcmc_target_desc {
     const double *matrix; /* host pointer, only for MMCMC_GAUSSIAN_ND */
 } mmcmc_target_desc;
 
-/* `impl Proposal`: only the reference's IsotropicGaussian (distributions.rs:344-392) */
+/* `impl Proposal` (distributions.rs:92-101): the reference's IsotropicGaussian (distributions.rs:344-392), or a kind
+ * handed out by mmcmc_proposal_register_source (>= MMCMC_USER_PROPOSAL_BASE): a proposal of the caller's own, `std` = its
+ * one run-time parameter */
 #define MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN 0
+#define MMCMC_USER_PROPOSAL_BASE 1000
 typedef struct mmcmc_proposal_desc {
     int32_t kind;
     int32_t reserved;
@@ -245,6 +248,26 @@ int mmcmc_hmc_kernel_variant(mmcmc_hmc *h); /* the variant in use (>= 0) or a ne
  * MMCMC_ERR_INVALID_ARG: the source does not compile (see log); MMCMC_ERR_UNSUPPORTED: no libhiprtc on this machine. */
 #define MMCMC_USER_KIND_BASE 1000
 int mmcmc_target_register_source(const char *name, int dim, const char *hip_source, int *kind_out, char *log, size_t log_len);
+
+/* ---- user-defined proposals (csrc/mm_rtc.hip) --------------------------------------------------------------------
+ * `Proposal` is an open trait too (distributions.rs:92-101), and the reference keeps BOTH q-terms in the acceptance
+ * ratio because a proposal may be asymmetric (metropolis_hastings.rs:303-315; its own integration tests define custom
+ * proposals, tests/metrohast_poisson_test.rs:50-85).  The GPU analogue of `impl Proposal for MyProposal`: the HIP source of
+ *     template <class T> struct mmcmc_user_proposal {
+ *         MM_HD static void sample(T sigma, const T *x, const T *z, T *out);   // x' ~ q(. | x) from z[dim] i.i.d. N(0, 1)
+ *         MM_HD static T logp(T sigma, const T *from, const T *to);            // log q(to | from)
+ *     };
+ * (sigma = `std` of the mmcmc_proposal_desc the sampler is created with; MM_USER_DIM = dim; the engine's headers are in
+ * scope) is compiled for ONE target -- `target_kind` a built-in kind at dimension `dim`, or a kind handed out by
+ * mmcmc_target_register_source -- into the engine's MH skeletons for f32 and f64, whose transition then is
+ * MHMarkovChain::step with both q-terms in the reference's order:
+ *     log_accept_ratio = (lp(x') + log q(x | x')) - (lp(x) + log q(x' | x));   accept iff log_accept_ratio > ln u
+ * The noise z and u are the engine's stream (mm_rng.h), so a run is reproducible and independent of launch partition
+ * and sharding like every other.  *proposal_kind_out (>= MMCMC_USER_PROPOSAL_BASE) goes into mmcmc_proposal_desc.kind;
+ * mmcmc_mh_create accepts it together with a description of exactly that target kind and dimension
+ * (MMCMC_ERR_UNSUPPORTED / MMCMC_ERR_SHAPE otherwise).  Status codes as for mmcmc_target_register_source. */
+int mmcmc_proposal_register_source(const char *name, int target_kind, int dim, const char *hip_source, int *proposal_kind_out,
+                                   char *log, size_t log_len);
 
 /* ---- device groups: one call runs every chain on N GPUs (csrc/mm_group.hip) ------------------------------------
  * `run` of the reference executes ALL chains of the sampler (ChainRunner::run core.rs:176-186, HMC::run hmc.rs:137-158).

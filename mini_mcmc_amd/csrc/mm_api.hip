@@ -78,6 +78,9 @@ template <class T> const mm_kernel_entry<T> *find_kernel(int kind, int dim)
     return nullptr;
 }
 
+/* set by mmcmc_mh_create while it creates the sampler of a target + proposal model */
+static thread_local bool g_allow_model = false;
+
 int validate_target(const mmcmc_target_desc *t)
 {
     if (!t || t->dim <= 0)
@@ -107,6 +110,12 @@ int validate_target(const mmcmc_target_desc *t)
             return MMCMC_ERR_UNSUPPORTED;
         if (mm_rtc_dim(u) != t->dim)
             return MMCMC_ERR_SHAPE;
+        /* a target + proposal model (mmcmc_proposal_register_source) is reached through mmcmc_mh_create's proposal
+         * description only, which checks its base target itself */
+        if (mm_rtc_is_model(u) && !g_allow_model)
+            return MMCMC_ERR_UNSUPPORTED;
+        if (mm_rtc_is_model(u) && mm_rtc_base_kind(u) == MMCMC_GAUSSIAN_ND && !t->matrix)
+            return MMCMC_ERR_INVALID_ARG;
         break;
     }
     }
@@ -117,12 +126,14 @@ int validate_target(const mmcmc_target_desc *t)
 template <class T> int make_params(const mmcmc_target_desc *t, mm_tparams<T> *P, T **d_mat)
 {
     *d_mat = nullptr;
-    if (t->kind >= MM_USER_KIND_BASE) {
+    /* a model over a BUILT-IN target derives its parameter block like that target (Sigma^-1, 1 / sigma^2, ...) */
+    const int base = t->kind >= MM_USER_KIND_BASE ? mm_rtc_base_kind(mm_rtc_find(t->kind)) : t->kind;
+    if (t->kind >= MM_USER_KIND_BASE && !(base >= 0 && base < MM_USER_KIND_BASE)) {
         /* user target: the description's parameters as they are; `matrix`, if given, is dim x dim */
         std::memset(P, 0, sizeof *P);
         for (int i = 0; i < 8; ++i)
             P->p[i] = (T)t->params[i];
-    } else if (mm_fill_params<T>(t->kind, t->params, P) != 0)
+    } else if (mm_fill_params<T>(base, t->params, P) != 0)
         return MMCMC_ERR_INVALID_ARG;
     if (t->kind == MMCMC_GAUSSIAN_ND || (t->kind >= MM_USER_KIND_BASE && t->matrix)) {
         size_t n = (size_t)t->dim * t->dim;
@@ -362,6 +373,10 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
             const size_t lds_split = mm_split_lds_bytes_f32(s->dim, mh ? 1 : 0);
             if (lds_split)
                 e = mm_rtc_launch_run_split(s->user, mh ? 0 : (l10 ? 2 : 1), &a, sizeof(a), (unsigned int)((s->n_chains + 255) / 256), lds_split, stream);
+        }
+        if (e != hipSuccess && e != hipErrorNotFound) {
+            (void)hipGetLastError(); /* a runtime that refuses the launch (e.g. the dynamic LDS size): the one-wave skeleton */
+            e = hipErrorNotFound;
         }
         if (e == hipErrorNotFound) {
             const size_t lds = mm_tile_lds_bytes_rt(sizeof(T), s->dim);
@@ -734,10 +749,33 @@ int mmcmc_mh_create(mmcmc_mh **out, const mmcmc_target_desc *target, const mmcmc
     if (!out || !proposal)
         return MMCMC_ERR_INVALID_ARG;
     *out = nullptr;
-    if (proposal->kind != MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN)
-        return MMCMC_ERR_UNSUPPORTED;
     Sampler *s = nullptr;
-    int st = sampler_create(&s, MM_SAMPLER_MH, target, proposal->std, 0, init, n_chains, dtype, device);
+    int st;
+    if (proposal->kind >= MMCMC_USER_PROPOSAL_BASE) {
+        /* a proposal compiled from source (mmcmc_proposal_register_source): the target + proposal model stands in for the
+         * target; it was compiled for exactly one target kind and dimension */
+        const mm_user_target *model = mm_rtc_find(proposal->kind);
+        if (!model || !mm_rtc_is_model(model) || !target)
+            return MMCMC_ERR_UNSUPPORTED;
+        if (mm_rtc_base_kind(model) != target->kind)
+            return MMCMC_ERR_UNSUPPORTED;
+        if (mm_rtc_dim(model) != target->dim)
+            return MMCMC_ERR_SHAPE;
+        if (target->kind < MM_USER_KIND_BASE) { /* the built-in target's own description must be valid */
+            st = validate_target(target);
+            if (st != MMCMC_OK)
+                return st;
+        }
+        mmcmc_target_desc as_model = *target;
+        as_model.kind = proposal->kind;
+        g_allow_model = true;
+        st = sampler_create(&s, MM_SAMPLER_MH, &as_model, proposal->std, 0, init, n_chains, dtype, device);
+        g_allow_model = false;
+    } else if (proposal->kind != MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN) {
+        return MMCMC_ERR_UNSUPPORTED;
+    } else {
+        st = sampler_create(&s, MM_SAMPLER_MH, target, proposal->std, 0, init, n_chains, dtype, device);
+    }
     if (st != MMCMC_OK)
         return st;
     mmcmc_mh *h = new (std::nothrow) mmcmc_mh{s};

@@ -9,6 +9,10 @@
 struct mm_user_target; /* opaque */
 const mm_user_target *mm_rtc_find(int kind);
 int mm_rtc_dim(const mm_user_target *t);
+/* a MODEL (target + user proposal, mmcmc_proposal_register_source): MH kernels only; base kind = the target it wraps
+ * (a built-in kind, or a user kind); -1 for a plain user target */
+int mm_rtc_base_kind(const mm_user_target *t);
+int mm_rtc_is_model(const mm_user_target *t);
 /* kernels of a registered target: sampler 0 MH / 1 HMC, dtype 0 f32 / 1 f64; `args` = the mm_run_args<T> block */
 hipError_t mm_rtc_launch_run_split(const mm_user_target *t, int sampler, void *args, size_t args_bytes, unsigned int grid, size_t lds,
                                    hipStream_t stream);

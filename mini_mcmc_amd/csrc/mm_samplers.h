@@ -100,18 +100,46 @@ MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, doub
     *lnb = mm_log(u);
 }
 
-/* One Metropolis-Hastings transition with the isotropic Gaussian random-walk proposal, given its noise:
- * z[D] ~ N(0,1) and ln_u = log of the accept uniform.  x[D], lp = logp(x) are updated in place; returns 1 on accept. */
+/* A target class may carry a proposal of its own: `typedef <functor> proposal;` with
+ *     static void sample(T sigma, const T *x, const T *z, T *out);   // x' ~ q(. | x) from z[dim] i.i.d. N(0, 1)
+ *     static T logp(T sigma, const T *from, const T *to);            // log q(to | from)
+ * -- the open `Proposal` trait (distributions.rs:92-101) as a device functor (mm_rtc.hip: mmcmc_proposal_register_source).
+ * No <type_traits>: this header also compiles under hipRTC. */
+template <class...> struct mm_void_t {
+    typedef void type;
+};
+template <class Tgt, class = void> struct mm_has_proposal {
+    static constexpr bool value = false;
+};
+template <class Tgt> struct mm_has_proposal<Tgt, typename mm_void_t<typename Tgt::proposal>::type> {
+    static constexpr bool value = true;
+};
+
+/* One Metropolis-Hastings transition, given its noise: z[D] ~ N(0,1) and ln_u = log of the accept uniform.  x[D],
+ * lp = logp(x) are updated in place; returns 1 on accept.
+ * Built-in proposal: the isotropic Gaussian random walk x' = x + sigma z, whose q-terms cancel and are dropped (Q4).
+ * A target with a `proposal` of its own: MHMarkovChain::step with BOTH q-terms, in the reference's order
+ * (metropolis_hastings.rs:303-315): log_accept_ratio = (lp' + log q(x | x')) - (lp + log q(x' | x)). */
 template <class T, class Tgt>
 MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, T ln_u, unsigned int *n_accepted = nullptr)
 {
     constexpr int D = Tgt::dim;
     T prop[D];
-    MM_UNROLL
-    for (int i = 0; i < D; ++i)
-        prop[i] = mm_fma(prop_std, z[i], x[i]);
-    T lpp = Tgt::logp(P, prop);
-    T log_accept_ratio = lpp - *lp;
+    T lpp, log_accept_ratio;
+    if constexpr (mm_has_proposal<Tgt>::value) {
+        Tgt::proposal::sample(prop_std, x, z, prop);
+        const T current_lp = *lp; /* carried instead of recomputed: the same value (Q3) */
+        lpp = Tgt::logp(P, prop);
+        const T log_q_forward = Tgt::proposal::logp(prop_std, x, prop);
+        const T log_q_backward = Tgt::proposal::logp(prop_std, prop, x);
+        log_accept_ratio = (lpp + log_q_backward) - (current_lp + log_q_forward);
+    } else {
+        MM_UNROLL
+        for (int i = 0; i < D; ++i)
+            prop[i] = mm_fma(prop_std, z[i], x[i]);
+        lpp = Tgt::logp(P, prop);
+        log_accept_ratio = lpp - *lp;
+    }
     int acc = log_accept_ratio > ln_u;
     if (acc) {
         MM_UNROLL

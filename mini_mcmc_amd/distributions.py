@@ -167,6 +167,37 @@ class UserTarget(Target):
         self.name = name
 
 
+class UserProposal:
+    """A proposal of the user's own: the GPU analogue of `impl Proposal for MyProposal` (distributions.rs:92-101).
+
+    `source` is HIP C++ defining `template <class T> struct mmcmc_user_proposal` with `sample(sigma, x, z, out)` (the
+    proposed state from the current one and `dim` standard normals) and `logp(sigma, from, to)` = log q(to | from)
+    (include/mmcmc.h: mmcmc_proposal_register_source).  It is compiled at run time for ONE target (a built-in one at its
+    dimension, or a `UserTarget`); MetropolisHastings then keeps both q-terms of the acceptance ratio as
+    metropolis_hastings.rs:303-315 does.  `std` is the proposal's one run-time parameter (`sigma`)."""
+
+    def __init__(self, name: str, target: Target, source: str, std: float = 1.0):
+        kind = C.c_int(0)
+        log = C.create_string_buffer(1 << 16)
+        st = L.lib().mmcmc_proposal_register_source(name.encode(), int(target.kind), int(target.dim), source.encode(),
+                                                    C.byref(kind), log, len(log))
+        self.compile_log = log.value.decode(errors="replace")
+        if st != L.OK:
+            raise L.MmcmcError(st, "mmcmc_proposal_register_source" + (": " + self.compile_log[-2000:] if self.compile_log else ""))
+        self.kind, self.name, self.std, self.target = kind.value, name, float(std), target
+
+    def set_seed(self, seed: int) -> "UserProposal":
+        """Proposal::set_seed: no effect, as for IsotropicGaussian (the noise is the sampler's counter-based stream)."""
+        self._seed = int(seed)
+        return self
+
+    def proposal_desc(self) -> L.ProposalDesc:
+        p = L.ProposalDesc()
+        p.kind = self.kind
+        p.std = self.std
+        return p
+
+
 class Categorical:
     """distributions.rs:421-477 `Categorical::new(probs)` (`Discrete` + `Target<usize>`): host-side utility, not on the
     GPU path.  Probabilities are normalised on construction; `sample` walks the cumulative sums with `r <= cum` and

@@ -86,6 +86,12 @@ typedef struct {
 struct o_mh {
     ot_target target;
     int dim, n_chains, is_f32, engine;
+    /* 0: IsotropicGaussian (distributions.rs:344-392).  1: a custom `impl Proposal` of the kind the reference's own tests
+     * write (tests/metrohast_poisson_test.rs:50-85), ASYMMETRIC, so that both q-terms of metropolis_hastings.rs:308-309
+     * matter: the multiplicative log-normal random walk on positive states,
+     *     sample: x'_i = x_i exp(std z_i);   logp(from, to) = sum_i [ -ln to_i - d_i^2 / (2 std^2) ] - dim (ln std + ln sqrt(2 pi)),
+     *     d_i = ln to_i - ln from_i                                   (tests/test_user_proposal.py holds the same as HIP source) */
+    int prop_kind;
     double std;
     mh_chain *chains;
 };
@@ -138,6 +144,8 @@ void o_mh_seed(o_mh *s, uint64_t seed)
         o_rng_init_rand_compat(&s->chains[i].rng, 1 + seed + (uint64_t)i);
 }
 
+void o_mh_set_proposal(o_mh *s, int kind) { s->prop_kind = kind; }
+
 void o_mh_use_engine_stream(o_mh *s, uint64_t seed, uint64_t chain_offset)
 {
     s->engine = 1;
@@ -147,7 +155,24 @@ void o_mh_use_engine_stream(o_mh *s, uint64_t seed, uint64_t chain_offset)
     }
 }
 
-#define MH_STEP(REAL, SUF, LOGP, LN)                                                                         \
+/* the custom proposal's log q(to | from) (prop_kind 1); engine stream: the engine's log, like everything else there */
+#define MH_LOGNORMAL_LOGQ(REAL, SUF, LN)                                                                     \
+    static REAL lognormal_logq_##SUF(const o_mh *s, const REAL *from, const REAL *to)                        \
+    {                                                                                                        \
+        REAL std = (REAL)s->std, two = (REAL)2, var = std * std, acc = 0;                                    \
+        for (int i = 0; i < s->dim; ++i) {                                                                   \
+            REAL lt = s->engine ? mm_##LN(to[i]) : LN(to[i]);                                                \
+            REAL lf = s->engine ? mm_##LN(from[i]) : LN(from[i]);                                            \
+            REAL dd = lt - lf;                                                                               \
+            acc += -lt - (dd * dd) / (two * var);                                                            \
+        }                                                                                                    \
+        REAL ls = s->engine ? mm_##LN(std) : LN(std);                                                        \
+        return acc - (REAL)s->dim * (ls + (REAL)0.91893853320467274178);                                     \
+    }
+MH_LOGNORMAL_LOGQ(float, f32, logf)
+MH_LOGNORMAL_LOGQ(double, f64, log)
+
+#define MH_STEP(REAL, SUF, LOGP, LN, EXP)                                                                    \
     static void mh_step_##SUF(o_mh *s, mh_chain *c)                                                          \
     {                                                                                                        \
         int d = s->dim;                                                                                      \
@@ -157,6 +182,28 @@ void o_mh_use_engine_stream(o_mh *s, uint64_t seed, uint64_t chain_offset)
         c->prop_rng.begin_iter(&c->prop_rng, c->iter);                                                       \
         c->rng.begin_iter(&c->rng, c->iter);                                                                 \
         REAL std = (REAL)s->std;                                                                             \
+        if (s->prop_kind == 1) {                                                                             \
+            /* MHMarkovChain::step metropolis_hastings.rs:303-315 with the custom proposal above */          \
+            for (int i = 0; i < d; ++i) {                                                                    \
+                REAL z = (REAL)c->prop_rng.normal_f64(&c->prop_rng);                                         \
+                REAL e = s->engine ? mm_##EXP(std * z) : EXP(std * z);                                       \
+                prop[i] = cur[i] * e;                                                                        \
+            }                                                                                                \
+            REAL current_lp = LOGP(&s->target, cur);                                                         \
+            REAL proposed_lp = LOGP(&s->target, prop);                                                       \
+            REAL lqf = lognormal_logq_##SUF(s, cur, prop);                                                   \
+            REAL lqb = lognormal_logq_##SUF(s, prop, cur);                                                   \
+            REAL log_accept_ratio = (proposed_lp + lqb) - (current_lp + lqf);                                \
+            REAL u = (REAL)c->rng.accept_uniform(&c->rng);                                                   \
+            REAL ln_u = s->engine ? mm_##LN(u) : LN(u);                                                      \
+            if (log_accept_ratio > ln_u) {                                                                   \
+                for (int i = 0; i < d; ++i)                                                                  \
+                    c->state[i] = (double)prop[i];                                                           \
+                c->n_accept += 1;                                                                            \
+            }                                                                                                \
+            c->iter += 1;                                                                                    \
+            return;                                                                                          \
+        }                                                                                                    \
         /* IsotropicGaussian::sample distributions.rs:364-372 : Normal(0,std).sample = 0 + std*z ; + current */ \
         for (int i = 0; i < d; ++i) {                                                                        \
             REAL z = (REAL)c->prop_rng.normal_f64(&c->prop_rng);                                             \
@@ -192,8 +239,8 @@ void o_mh_use_engine_stream(o_mh *s, uint64_t seed, uint64_t chain_offset)
         c->iter += 1;                                                                                        \
     }
 
-MH_STEP(float, f32, ot_logp_f32, logf)
-MH_STEP(double, f64, ot_logp_f64, log)
+MH_STEP(float, f32, ot_logp_f32, logf, expf)
+MH_STEP(double, f64, ot_logp_f64, log, exp)
 
 typedef struct {
     o_mh *s;

@@ -41,6 +41,8 @@ void o_mh_proposal_seed(o_mh *s, uint64_t seed);
 void o_mh_seed(o_mh *s, uint64_t seed);
 /* run every chain on the GPU engine's counter-based stream instead (independent proposal noise per chain,
  * no extra normal per proposal, symmetric q-terms kept as the reference computes them) */
+/* 0: IsotropicGaussian; 1: the asymmetric custom proposal (multiplicative log-normal random walk, mh_hmc.c) */
+void o_mh_set_proposal(o_mh *s, int kind);
 void o_mh_use_engine_stream(o_mh *s, uint64_t seed, uint64_t chain_offset);
 /* ChainRunner::run (core.rs:176-186).  out [n_chains, n_collect, dim] (double = exact widening of T);
  * accept_counts[n_chains] (may be NULL) counts accepted proposals over all n_discard + n_collect steps. */

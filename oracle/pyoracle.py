@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         "o_mh_proposal_seed": (None, [C.c_void_p, C.c_uint64]),
         "o_mh_seed": (None, [C.c_void_p, C.c_uint64]),
         "o_mh_use_engine_stream": (None, [C.c_void_p, C.c_uint64, C.c_uint64]),
+        "o_mh_set_proposal": (None, [C.c_void_p, C.c_int]),
         "o_mh_run": (None, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, _dp, _u64p]),
         "o_mh_state": (None, [C.c_void_p, _dp]),
         "o_hmc_create": (C.c_void_p, [tp, _dp, C.c_int, C.c_double, C.c_int, C.c_int]),
@@ -340,6 +341,12 @@ class MetropolisHastings:
 
     def use_engine_stream(self, seed, chain_offset=0):
         lib().o_mh_use_engine_stream(self._h, seed, chain_offset)
+        return self
+
+    def set_proposal(self, kind):
+        """0: IsotropicGaussian (the reference's); 1: the asymmetric custom proposal of oracle/mh_hmc.c (multiplicative
+        log-normal random walk), for the parity test of user-defined proposals."""
+        lib().o_mh_set_proposal(self._h, int(kind))
         return self
 
     def run(self, n_collect, n_discard, n_threads=None, want_out=True):
