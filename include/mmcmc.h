@@ -394,6 +394,18 @@ int mmcmc_tracker_destroy(mmcmc_tracker *h);
 #define MMCMC_POISSON_REFLECT 16
 #define MMCMC_BINOMIAL_CLAMP 17
 #define MMCMC_POISSON_NONNEG 18
+/* An integer-state model of the caller's own (csrc/mm_rtc.hip, csrc/mm_discrete_kernels.h): `impl Target<i32, f64>` +
+ * `impl Proposal<i32, f64>` as the reference's own tests write them (tests/metrohast_poisson_test.rs:18-85), as HIP source
+ *     struct mmcmc_user_discrete {
+ *         MM_HD static double logp(const double *params, int k);                  // Target::unnorm_logp
+ *         MM_HD static int sample(const double *params, int current, int step);   // Proposal::sample; step = +1 / -1, p = 1/2 each
+ *         MM_HD static double logq(const double *params, int from, int to);       // Proposal::logp = log q(to | from)
+ *     };
+ * (mm_log, mm_ln_factorial, MM_NEG_INF, ... of the engine's headers in scope).  *kind_out (>= MMCMC_USER_KIND_BASE) is a `kind` for
+ * mmcmc_mh_discrete_create, whose `params` (eight doubles) reach the functor unchanged; the transition is
+ * MHMarkovChain::step with both q-terms on the built-in models' stream, so a restatement of a built-in model reproduces
+ * it bit for bit (tests/test_user_proposal.py). */
+int mmcmc_discrete_register_source(const char *name, const char *hip_source, int *kind_out, char *log, size_t log_len);
 typedef struct mmcmc_mh_discrete mmcmc_mh_discrete;
 int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *params, const int32_t *init,
                              size_t n_chains, int device);

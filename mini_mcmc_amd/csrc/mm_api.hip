@@ -114,6 +114,8 @@ int validate_target(const mmcmc_target_desc *t)
          * description only, which checks its base target itself */
         if (mm_rtc_is_model(u) && !g_allow_model)
             return MMCMC_ERR_UNSUPPORTED;
+        if (mm_rtc_is_discrete(u))
+            return MMCMC_ERR_UNSUPPORTED; /* an integer-state model belongs to mmcmc_mh_discrete_create */
         if (mm_rtc_is_model(u) && mm_rtc_base_kind(u) == MMCMC_GAUSSIAN_ND && !t->matrix)
             return MMCMC_ERR_INVALID_ARG;
         break;

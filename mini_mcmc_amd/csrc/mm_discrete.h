@@ -21,6 +21,9 @@
 #define MM_BINOMIAL_CLAMP 17
 #define MM_POISSON_NONNEG 18
 
+/* -inf as a double without <cmath> (this header also compiles under hipRTC) */
+#define MM_NEG_INF (-(double)MM_INFINITY_F)
+
 #define MM_DISCRETE_POISSON_TABLE 1024 /* states >= this have log-density -inf (lambda must be far below) */
 
 struct mm_discrete_params {
@@ -74,15 +77,15 @@ MM_HD int mm_discrete_fill_table(int kind, const double *params, double *tab, in
 
 MM_HD double mm_discrete_logp(const mm_discrete_params &P, int k)
 {
-    return (k >= 0 && k < P.table_len) ? P.logp[k] : -(double)INFINITY;
+    return (k >= 0 && k < P.table_len) ? P.logp[k] : MM_NEG_INF;
 }
 
 /* NonnegativeProposal::logp (poisson_mh.rs:52-70) */
 MM_HD double mm_nonneg_logq(const mm_discrete_params &P, int x, int y)
 {
     if (x == 0)
-        return y == 1 ? 0.0 : -(double)INFINITY;
-    return (y == x + 1 || y + 1 == x) ? P.ln_half : -(double)INFINITY;
+        return y == 1 ? 0.0 : MM_NEG_INF;
+    return (y == x + 1 || y + 1 == x) ? P.ln_half : MM_NEG_INF;
 }
 
 /* one transition; returns 1 iff the proposal was accepted */

@@ -12,7 +12,9 @@
 #include <vector>
 
 #include "mm_discrete.h"
+#include "mm_discrete_kernels.h"
 #include "mm_kernels.h"
+#include "mm_rtc.h"
 
 #define MM_HIP(expr)                                                                                              \
     do {                                                                                                          \
@@ -209,6 +211,8 @@ struct mmcmc_mh_discrete {
     uint64_t seed = 0, chain_offset = 0;
     uint32_t iter = 0;
     mm_discrete_params P{};
+    const mm_user_target *user = nullptr; /* a model compiled from source (mmcmc_discrete_register_source) */
+    double user_params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double *d_table = nullptr;
     int32_t *d_state = nullptr;
     unsigned long long *d_accept = nullptr;
@@ -225,9 +229,14 @@ int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *pa
     *out = nullptr;
     if (!params || !init || n_chains == 0)
         return MMCMC_ERR_INVALID_ARG;
-    if (kind != MMCMC_POISSON_REFLECT && kind != MMCMC_BINOMIAL_CLAMP && kind != MMCMC_POISSON_NONNEG)
+    const mm_user_target *user = kind >= MM_USER_KIND_BASE ? mm_rtc_find(kind) : nullptr;
+    if (user && !mm_rtc_is_discrete(user))
         return MMCMC_ERR_UNSUPPORTED;
-    if (kind == MMCMC_BINOMIAL_CLAMP) {
+    if (!user && kind != MMCMC_POISSON_REFLECT && kind != MMCMC_BINOMIAL_CLAMP && kind != MMCMC_POISSON_NONNEG)
+        return MMCMC_ERR_UNSUPPORTED;
+    if (user) {
+        /* params: eight doubles, handed to the functor as they are */
+    } else if (kind == MMCMC_BINOMIAL_CLAMP) {
         if (!(params[0] >= 1.0 && params[0] < 1e6) || !(params[1] > 0.0 && params[1] < 1.0))
             return MMCMC_ERR_INVALID_ARG;
     } else if (!(params[0] > 0.0 && params[0] <= 256.0)) {
@@ -245,14 +254,18 @@ int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *pa
     h->kind = kind;
     h->n_chains = n_chains;
     DevGuard g(device);
+    h->user = user;
+    if (user)
+        for (int i = 0; i < 8; ++i)
+            h->user_params[i] = params[i];
     /* the kernel keeps the log-density table in LDS: at most MM_DISCRETE_POISSON_TABLE states */
     if (kind == MMCMC_BINOMIAL_CLAMP && !(params[0] >= 0 && params[0] < (double)MM_DISCRETE_POISSON_TABLE)) {
         delete h;
         return MMCMC_ERR_UNSUPPORTED;
     }
-    const int cap = kind == MMCMC_BINOMIAL_CLAMP ? (int)params[0] + 1 : MM_DISCRETE_POISSON_TABLE;
-    std::vector<double> tab((size_t)cap);
-    const int len = mm_discrete_fill_table(kind, params, tab.data(), cap);
+    const int cap = user ? 1 : kind == MMCMC_BINOMIAL_CLAMP ? (int)params[0] + 1 : MM_DISCRETE_POISSON_TABLE;
+    std::vector<double> tab((size_t)cap, 0.0);
+    const int len = user ? 1 : mm_discrete_fill_table(kind, params, tab.data(), cap);
     h->P.kind = kind;
     h->P.n = kind == MMCMC_BINOMIAL_CLAMP ? (int)params[0] : 0;
     h->P.table_len = len;
@@ -332,7 +345,21 @@ int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_disca
      * anyway); MMCMC_DISCRETE_KERNEL=plain keeps the one-wave kernel (A/B and tests: the two are bit-identical) */
     const char *force = getenv("MMCMC_DISCRETE_KERNEL");
     hipError_t e = hipSuccess;
-    if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
+    if (h->user) {
+        mm_discrete_user_args ua;
+        for (int i = 0; i < 8; ++i)
+            ua.params[i] = h->user_params[i];
+        ua.state = a.state;
+        ua.out = a.out;
+        ua.accept = a.accept;
+        ua.n_chains = a.n_chains;
+        ua.seed = a.seed;
+        ua.chain_offset = a.chain_offset;
+        ua.iter0 = a.iter0;
+        ua.n_discard = a.n_discard;
+        ua.n_collect = a.n_collect;
+        e = mm_rtc_launch_discrete(h->user, &ua, sizeof(ua), (unsigned int)((h->n_chains + 63) / 64), st);
+    } else if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
         const void *fn = h->kind == MMCMC_POISSON_REFLECT  ? reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_POISSON_REFLECT>)
                          : h->kind == MMCMC_BINOMIAL_CLAMP ? reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_BINOMIAL_CLAMP>)
                                                            : reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_POISSON_NONNEG>);

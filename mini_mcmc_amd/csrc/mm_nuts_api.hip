@@ -154,6 +154,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
             user = mm_rtc_find(t->kind);
             if (!user)
                 return MMCMC_ERR_INVALID_ARG;
+            if (mm_rtc_is_model(user) || mm_rtc_is_discrete(user))
+                return MMCMC_ERR_UNSUPPORTED; /* a target + proposal model / an integer-state model has no NUTS kernels */
             if (mm_rtc_dim(user) != t->dim)
                 return MMCMC_ERR_SHAPE;
             /* mm_nuts_stack_layout<TT, ST, D>::bytes and the output tile of mm_tile<TT, D>, for a run-time D */

@@ -13,6 +13,9 @@ int mm_rtc_dim(const mm_user_target *t);
  * (a built-in kind, or a user kind); -1 for a plain user target */
 int mm_rtc_base_kind(const mm_user_target *t);
 int mm_rtc_is_model(const mm_user_target *t);
+/* an integer-state model (mmcmc_discrete_register_source); `args` = mm_discrete_user_args, one wave per workgroup */
+int mm_rtc_is_discrete(const mm_user_target *t);
+hipError_t mm_rtc_launch_discrete(const mm_user_target *t, void *args, size_t args_bytes, unsigned int grid, hipStream_t stream);
 /* kernels of a registered target: sampler 0 MH / 1 HMC, dtype 0 f32 / 1 f64; `args` = the mm_run_args<T> block */
 hipError_t mm_rtc_launch_run_split(const mm_user_target *t, int sampler, void *args, size_t args_bytes, unsigned int grid, size_t lds,
                                    hipStream_t stream);

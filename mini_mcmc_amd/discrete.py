@@ -48,6 +48,25 @@ class PoissonNonneg:
         return [float(self.lam)]
 
 
+class UserDiscreteModel:
+    """An integer-state model of the user's own: `impl Target<i32, f64>` + `impl Proposal<i32, f64>` as HIP source defining
+    `struct mmcmc_user_discrete` with `logp(params, k)`, `sample(params, current, step)`, `logq(params, from, to)`
+    (include/mmcmc.h: mmcmc_discrete_register_source), compiled at run time.  `params`: up to eight numbers."""
+
+    def __init__(self, name: str, source: str, params=()):
+        kind = C.c_int(0)
+        log = C.create_string_buffer(1 << 16)
+        st = L.lib().mmcmc_discrete_register_source(name.encode(), source.encode(), C.byref(kind), log, len(log))
+        self.compile_log = log.value.decode(errors="replace")
+        if st != L.OK:
+            raise L.MmcmcError(st, "mmcmc_discrete_register_source" + (": " + self.compile_log[-2000:] if self.compile_log else ""))
+        self.kind, self.name = kind.value, name
+        self._params = [float(v) for v in params] + [0.0] * (8 - len(params))
+
+    def params(self):
+        return self._params
+
+
 class DiscreteMetropolisHastings:
     """MetropolisHastings::new(target, proposal, initial_states) for the models above; one chain per GPU lane.
 

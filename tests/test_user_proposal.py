@@ -182,3 +182,104 @@ def test_user_proposal_error_paths():
     fake.kind = prop.kind
     with pytest.raises(Exception):
         HMC(fake, init_with_seed(64, 2, 1, np.float32), 0.1, 3)
+
+
+# ---- integer states: the reference's own custom Target + Proposal pairs as user source -------------------------------
+# tests/metrohast_poisson_test.rs:18-85: PoissonDist + PoissonRandomWalk
+POISSON_REFLECT = r"""
+struct mmcmc_user_discrete {
+    MM_HD static double logp(const double *p, int k) {
+        if (k < 0) return MM_NEG_INF;
+        const double kf = (double)k;
+        return kf * mm_log(p[0]) - p[0] - mm_ln_factorial(k);      /* :31 */
+    }
+    MM_HD static int sample(const double *, int current, int step) {
+        const int n = current + step;
+        return n < 0 ? 0 : n;                                       /* "reflect instead of going negative" :70-76 */
+    }
+    MM_HD static double logq(const double *, int, int) { return mm_log(0.5); }   /* :79-82 */
+};
+"""
+# tests/metrohast_poisson_test.rs:150-212: BinomialDist + BinomialRandomWalk (p[0] = n, p[1] = p)
+BINOMIAL_CLAMP = r"""
+struct mmcmc_user_discrete {
+    MM_HD static double logp(const double *p, int k) {
+        const int n = (int)p[0];
+        if (k < 0 || k > n) return MM_NEG_INF;
+        const double kf = (double)k, nf = (double)n;
+        const double bc = mm_ln_factorial(n) - mm_ln_factorial(k) - mm_ln_factorial(n - k);
+        return bc + kf * mm_log(p[1]) + (nf - kf) * mm_log(1.0 - p[1]);
+    }
+    MM_HD static int sample(const double *p, int current, int step) {
+        const int n = (int)p[0], v = current + step;
+        return v < 0 ? 0 : (v > n ? n : v);
+    }
+    MM_HD static double logq(const double *, int, int) { return mm_log(0.5); }
+};
+"""
+# examples/poisson_mh.rs:8-76: PoissonTarget + NonnegativeProposal (asymmetric at 0)
+POISSON_NONNEG = r"""
+struct mmcmc_user_discrete {
+    MM_HD static double logp(const double *p, int k) {
+        if (k < 0) return MM_NEG_INF;
+        const double kf = (double)k;
+        return -p[0] + kf * mm_log(p[0]) - mm_ln_factorial(k);      /* poisson_mh.rs:25 */
+    }
+    MM_HD static int sample(const double *, int current, int step) { return current == 0 ? 1 : current + step; }
+    MM_HD static double logq(const double *, int x, int y) {
+        if (x == 0) return y == 1 ? 0.0 : MM_NEG_INF;
+        return (y == x + 1 || y + 1 == x) ? mm_log(0.5) : MM_NEG_INF;
+    }
+};
+"""
+# a model the library does not have: geometric pmf (1 - r) r^k on k >= 0 under a walk that reflects at 0
+GEOMETRIC = r"""
+struct mmcmc_user_discrete {
+    MM_HD static double logp(const double *p, int k) { return k < 0 ? MM_NEG_INF : (double)k * mm_log(p[0]); }
+    MM_HD static int sample(const double *, int current, int step) { const int n = current + step; return n < 0 ? 0 : n; }
+    MM_HD static double logq(const double *, int, int) { return mm_log(0.5); }
+};
+"""
+
+
+@pytest.mark.gpu
+def test_user_restatements_of_the_discrete_models_are_bit_identical():
+    """The reference's three hand-written Target + Proposal pairs as user source against the built-in integer-state models
+    (whose log-densities are tables filled on the host in the reference's operation order): samples, final states and
+    accept counts equal bit for bit -- ragged chain counts, a chain offset, a continued handle."""
+    from mini_mcmc_amd.discrete import (BinomialClamp, DiscreteMetropolisHastings, PoissonNonneg, PoissonReflect,
+                                        UserDiscreteModel)
+
+    cases = [(PoissonReflect(4.0), UserDiscreteModel("poisson_reflect", POISSON_REFLECT, [4.0])),
+             (BinomialClamp(10, 0.3), UserDiscreteModel("binomial_clamp", BINOMIAL_CLAMP, [10.0, 0.3])),
+             (PoissonNonneg(4.0), UserDiscreteModel("poisson_nonneg", POISSON_NONNEG, [4.0]))]
+    rng = np.random.default_rng(4)
+    for builtin, user in cases:
+        assert user.kind >= 1000
+        for C_, off in ((5000, 0), (130, 1 << 33)):  # four-waves-per-SIMD kernel / one-wave kernel of the built-in model
+            init = rng.integers(0, 9, size=C_).astype(np.int32)
+            a = DiscreteMetropolisHastings(builtin, init).seed(11).set_chain_offset(off)
+            b = DiscreteMetropolisHastings(user, init).seed(11).set_chain_offset(off)
+            for nc, nd in ((70, 13), (25, 0)):
+                assert np.array_equal(a.run(nc, nd), b.run(nc, nd)), (user.name, C_, nc)
+            assert np.array_equal(a.state(), b.state()) and np.array_equal(a.accept_counts(), b.accept_counts()), user.name
+
+
+@pytest.mark.gpu
+def test_new_discrete_model_samples_its_pmf():
+    from mini_mcmc_amd.discrete import DiscreteMetropolisHastings, UserDiscreteModel
+
+    r = 0.6
+    m = UserDiscreteModel("geometric", GEOMETRIC, [r])
+    s = DiscreteMetropolisHastings(m, np.zeros(65536, dtype=np.int32)).seed(3)
+    out = s.run(100, 400).reshape(-1)
+    k = np.arange(12)
+    emp = np.array([(out == i).mean() for i in k])
+    np.testing.assert_allclose(emp, (1 - r) * r**k, atol=2e-3)
+    with pytest.raises(Exception):  # an integer-state model is not a continuous target
+        from mini_mcmc_amd.distributions import IsotropicGaussian, RosenbrockND
+        from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+
+        fake = RosenbrockND(1)
+        fake.kind = m.kind
+        MetropolisHastings(fake, IsotropicGaussian(1.0), np.zeros((8, 1), dtype=np.float32))
