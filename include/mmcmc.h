@@ -224,7 +224,13 @@ int mmcmc_nuts_destroy(mmcmc_nuts *h);
  *   f32, where it is the default (elsewhere MMCMC_ERR_UNSUPPORTED).  Like the NUTS mappings it sums the D-term dot
  *   products as four partial sums (f64: interleaved coordinates, f32: blocks of four), so its samples differ from
  *   variants 0 / 2 by rounding; it is bit-exact against its own host build (oracle/engine_host.cpp:
- *   eh_hmc_grouped_run, eh_hmc_grouped_run_f32). */
+ *   eh_hmc_grouped_run, eh_hmc_grouped_run_f32);
+ *   6 = one chain per lane at RUN-TIME dimension (csrc/mm_generic.h), the default for a dimension without a compiled
+ *   instance; HMC only: 8 = one chain per WORKGROUP, the coordinates across up to 1024 threads (csrc/mm_wide.hip) -- few
+ *   chains of a huge dimension, the shape of the reference's own timing tests (hmc.rs:882-916: 6 chains, D = 10 000) --
+ *   for RosenbrockND / IsotropicGaussian / StandardNormal at 4 <= dim <= 32 768, the default there from dim 128 on with
+ *   fewer than 1024 chains.  It reduces the three sums of a transition across the workgroup, so its samples differ from
+ *   variant 6's by rounding (same stream, same transition). */
 int mmcmc_mh_set_iters_per_launch(mmcmc_mh *h, uint32_t iters);
 int mmcmc_hmc_set_iters_per_launch(mmcmc_hmc *h, uint32_t iters);
 int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant);

@@ -21,6 +21,7 @@
 #include "mm_kernels.h"
 #include "mm_host_rng.h"
 #include "mm_params.h"
+#include "mm_wide.h"
 #include "mm_rtc.h"
 
 size_t mm_split_lds_bytes_f32(int dim, int mh); /* mm_inst_f32.hip */
@@ -169,6 +170,7 @@ struct Sampler {
     const mm_user_target *user = nullptr; /* run-time compiled target (mm_rtc.hip), variant 7 */
     bool generic = false;      /* no fixed-dimension kernel: the run-time-dimension path (mm_generic.h), variant 6 */
     bool generic_ok = false;   /* the target kind has a run-time-dimension form */
+    bool wide_ok = false;      /* HMC with one chain per workgroup (mm_wide.hip): a huge dimension, variant 8 */
     void *d_gscratch = nullptr; /* its HBM store when the chain vectors do not fit LDS */
     size_t c_pad = 0;
     unsigned int block = 64;
@@ -247,6 +249,10 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         s->variant = 3;
     if (s->user)
         s->variant = 7;
+    /* few chains of a huge dimension (hmc.rs:882-916: 6 x 10 000): the coordinates of a chain across a workgroup */
+    s->wide_ok = sampler == MM_SAMPLER_HMC && !s->user && mm_wide_kind_ok(s->kind) && s->dim >= 4 && s->dim <= MM_WIDE_MAX_DIM;
+    if (s->wide_ok && s->generic && s->dim >= 128 && n_chains < 1024)
+        s->variant = 8;
     DeviceGuard g(device);
     auto fail = [&](int code) {
         if (s->d_state)
@@ -384,6 +390,29 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
             const size_t lds = mm_tile_lds_bytes_rt(sizeof(T), s->dim);
             e = mm_rtc_launch_run(s->user, mh ? 0 : 1, std::is_same<T, float>::value ? 0 : 1, &a, sizeof(a), grid, s->block, lds, stream);
         }
+    } else if (s->variant == 8 && s->wide_ok) {
+        mm_wide_args<T> q;
+        q.P = P;
+        q.kind = s->kind;
+        q.dim = s->dim;
+        q.eps = (T)s->scale;
+        q.n_leapfrog = s->n_leapfrog;
+        q.state = (T *)s->d_state;
+        q.out = d_out;
+        q.accept = a.accept;
+        q.accept_total = a.accept_total;
+        q.n_chains = a.n_chains;
+        q.seed = a.seed;
+        q.chain_offset = a.chain_offset;
+        q.n_total = n_total;
+        q.iter0 = a.iter0;
+        q.n_discard = n_discard;
+        q.n_collect = n_collect;
+        q.out_t0 = out_t0;
+        if constexpr (std::is_same<T, float>::value)
+            e = mm_launch_hmc_wide_f32(q, stream);
+        else
+            e = mm_launch_hmc_wide_f64(q, stream);
     } else if (s->variant == 6) {
         mm_gen_args<T> q;
         q.P = P;
@@ -813,8 +842,18 @@ static int set_variant_common(Sampler *s, int variant)
 {
     if (s->user)
         return variant == 7 ? MMCMC_OK : MMCMC_ERR_UNSUPPORTED;
-    if (s->generic)
-        return variant == 6 ? MMCMC_OK : MMCMC_ERR_UNSUPPORTED;
+    if (variant == 8) {
+        if (!s->wide_ok)
+            return MMCMC_ERR_UNSUPPORTED;
+        s->variant = 8;
+        return MMCMC_OK;
+    }
+    if (s->generic) {
+        if (variant != 6)
+            return MMCMC_ERR_UNSUPPORTED;
+        s->variant = 6;
+        return MMCMC_OK;
+    }
     if (variant == 6) {
         const size_t lds = s->dtype == MMCMC_F32 ? mm_generic_store_bytes<float>(s->sampler, s->dim)
                                                  : mm_generic_store_bytes<double>(s->sampler, s->dim);
@@ -839,7 +878,7 @@ int mmcmc_mh_set_kernel_variant(mmcmc_mh *h, int variant)
 }
 int mmcmc_hmc_set_kernel_variant(mmcmc_hmc *h, int variant)
 {
-    if (!h || variant < 0 || (variant > 3 && variant != 5 && variant != 6 && variant != 7))
+    if (!h || variant < 0 || (variant > 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8))
         return MMCMC_ERR_INVALID_ARG;
     if (const int st = set_variant_common(h->s, variant); st <= 0)
         return st;

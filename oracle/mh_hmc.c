@@ -22,6 +22,8 @@
 #include <string.h>
 
 #define MAXD 512 /* the reference has no limit; the GPU parity tests go up to 257 */
+/* HMC: the reference's own timing test runs D = 10 000 (hmc.rs:882-916); its row buffers live on the stack here */
+#define HMC_MAXD 16384
 
 /* ------------------------------------------------------------------ init */
 
@@ -307,7 +309,7 @@ struct o_hmc {
 o_hmc *o_hmc_create(const ot_target *target, const double *init, int n_chains, double step_size, int n_leapfrog,
                     int is_f32)
 {
-    if (!target || !init || n_chains <= 0 || target->dim <= 0 || target->dim > MAXD || n_leapfrog < 0)
+    if (!target || !init || n_chains <= 0 || target->dim <= 0 || target->dim > HMC_MAXD || n_leapfrog < 0)
         return NULL;
     o_hmc *s = (o_hmc *)calloc(1, sizeof *s);
     s->target = *target;
@@ -374,7 +376,7 @@ void o_hmc_use_engine_stream(o_hmc *s, uint64_t seed, uint64_t chain_offset)
     {                                                                                                        \
         int d = s->dim;                                                                                      \
         REAL eps = (REAL)s->step_size, half = (REAL)0.5;                                                     \
-        REAL pos0[MAXD], pos[MAXD], mom[MAXD], g[MAXD], gs[MAXD];                                            \
+        REAL pos0[HMC_MAXD], pos[HMC_MAXD], mom[HMC_MAXD], g[HMC_MAXD], gs[HMC_MAXD];                        \
         for (int i = 0; i < d; ++i) {                                                                        \
             pos0[i] = (REAL)s->positions[(size_t)ci * d + i];                                                \
             pos[i] = pos0[i];                                                                                \
