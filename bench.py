@@ -205,6 +205,75 @@ def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
     return out
 
 
+def main_group(args) -> None:
+    """--group: the same headline through the in-library device group -- one process, N devices (MMCMC_BENCH_GROUP_DEVICES =
+    comma-separated device list overrides 0..N-1, e.g. "0,0" rehearses two shards on one GPU through the host exchange).
+    A step = mmcmc_hmc_group_run of all N x 65 536 chains (every shard's kernel on its own device and stream, the call
+    returns when all have finished); the diagnostics afterwards go through ncclAllGather / ncclAllReduce inside the
+    library, and the line says which path they took."""
+    import numpy as np
+    import torch
+
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import RosenbrockND
+    from mini_mcmc_amd.group import HMCGroup
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    devs = os.environ.get("MMCMC_BENCH_GROUP_DEVICES")
+    devices = [int(d) for d in devs.split(",")] if devs else list(range(args.gpus))
+    n = len(devices)
+    init = init_with_seed(C_PER_GPU * n, DIM, SEED, np.float32)
+    g = HMCGroup(RosenbrockND(DIM), init, STEP_SIZE, N_LEAPFROG, devices=devices).set_seed(SEED)
+
+    def step():
+        g.run(N_COLLECT, N_DISCARD, to_host=False)
+
+    t_pre, pre = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < args.preroll_seconds:
+        for _ in range(20):
+            step()
+        pre += 20
+    for _ in range(args.warmup):
+        step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    dt = time.perf_counter() - t0
+    g.split_rhat_mean_ess()
+    ts = time.perf_counter()
+    for _ in range(5):
+        rhat, ess = g.split_rhat_mean_ess()
+    stats_s = (time.perf_counter() - ts) / 5
+    samples = float(args.steps) * C_PER_GPU * n * N_COLLECT
+    ms = dt / args.steps * 1e3
+    alg_bytes = C_PER_GPU * DIM * 4 * (N_COLLECT + 2)
+    res = {
+        "metric": "samples/sec (all chains), 3D Rosenbrock HMC", "value": samples / dt, "unit": "samples/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2] per device (configs[3] at 8): RosenbrockND D=3 HMC, 65536 chains/GPU, "
+                               "eps=0.032, L=10, f32, run(400, 50) per step", "chains_per_gpu": C_PER_GPU, "dim": DIM,
+                   "n_leapfrog": N_LEAPFROG, "n_collect": N_COLLECT, "n_discard": N_DISCARD, "devices": devices,
+                   "parallelism": f"in-library device group x{n}: one process, one host thread + stream per device, no data-path collective"},
+        "leapfrog_steps_per_s": float(args.steps) * C_PER_GPU * n * (N_COLLECT + N_DISCARD) * N_LEAPFROG / dt,
+        "ess_min": float(ess.min()), "ess_per_s": float(ess.min()) * args.steps / (dt + stats_s * args.steps),
+        "stats_ms": stats_s * 1e3,
+        "diagnostics_exchange": {1: "rccl (ncclAllGather + ncclAllReduce inside libmmcmc.so)", 0: "host (a device is listed twice)",
+                                 -1: "host FALLBACK: no RCCL library could be loaded", -2: "host FALLBACK: ncclCommInitAll failed"}[g.exchange_status],
+        "preroll": {"seconds": args.preroll_seconds, "steps": pre},
+        # a group step includes the host's fan-out to N device threads and their join: per-device kernel time is not separated
+        "roofline": {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G vector-issue slots/s", "frac": None, "traffic": None,
+                     "hbm": {"achieved": alg_bytes * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * n, "unit": "GB/s",
+                             "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "from ms_per_step (host fan-out included)"}},
+    }
+    print(json.dumps(res))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +285,10 @@ def main() -> None:
     ap.add_argument("--preroll-seconds", type=float, default=1.0,
                     help="untimed pre-roll of step() before the counted warm-up (clock ramp); 0 disables it")
     ap.add_argument("--variant", type=int, default=5, help="kernel variant: 5 noise waves + transition waves, four waves per SIMD (default), 2 one wave per SIMD with paired + pipelined noise, 0 plain")
+    ap.add_argument("--group", action="store_true",
+                    help="ONE process drives all --gpus N devices through the library's device group (mmcmc_hmc_group_*: one "
+                         "host thread and stream per device, RCCL inside the library for the diagnostics) instead of one "
+                         "process per GPU under torch.distributed.run; same workload, same JSON line")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time sampler and diagnostics as a two-stream pipeline (a measured negative result, DESIGN.md 5.2: "
                          "slower than back to back; off by default so that a profiled run holds only undisturbed launches of the sampling kernel)")
@@ -224,6 +297,8 @@ def main() -> None:
     import numpy as np
     import torch
 
+    if args.group:
+        return main_group(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

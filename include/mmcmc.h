@@ -282,7 +282,9 @@ int mmcmc_proposal_register_source(const char *name, int target_kind, int dim, c
  * device with no data-path collective, and reduces split-R-hat / ESS (stats.rs:416-546) over all chains: per-device
  * sufficient statistics, RCCL ncclAllGather of the per-half-chain means / sums of squares + ncclAllReduce of the lag
  * sums over xGMI, host finish in the single-GPU summation order.  (RCCL is bound at run time; if it is missing, or a
- * device is listed twice -- several shards on one GPU --, the statistics travel through the host; *used_rccl says which.)
+ * device is listed twice -- several shards on one GPU --, the statistics travel through the host; *used_rccl says which:
+ * 1 = RCCL; 0 = the host by design (a device listed twice); -1 = the host as a FALLBACK because no RCCL library could be
+ * loaded; -2 = the host because ncclCommInitAll failed -- check it in a scaling run.)
  *   init: host [n_chains, dim] of dtype.  run: the sample stays on the devices (mmcmc_hmc_group_shard gives each shard's
  *   device pointer [n_i, n_collect, dim]); out_host, if not NULL, also receives [n_chains, n_collect, dim];
  *   accept_counts: host [n_chains] or NULL.  A second run continues the chains. */

@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <new>
 #include <vector>
 
@@ -364,11 +366,11 @@ int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_disca
                          : h->kind == MMCMC_BINOMIAL_CLAMP ? reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_BINOMIAL_CLAMP>)
                                                            : reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_POISSON_NONNEG>);
         const int slot = h->kind == MMCMC_POISSON_REFLECT ? 0 : h->kind == MMCMC_BINOMIAL_CLAMP ? 1 : 2;
-        static unsigned long long attr_set[3] = {0, 0, 0};
-        if (h->device >= 64 || !((attr_set[slot] >> h->device) & 1ull)) {
+        static std::atomic<unsigned long long> attr_set[3];
+        if (h->device >= 64 || !((attr_set[slot].load(std::memory_order_relaxed) >> h->device) & 1ull)) {
             e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DS_LDS_BYTES);
             if (e == hipSuccess && h->device < 64)
-                attr_set[slot] |= 1ull << h->device;
+                attr_set[slot].fetch_or(1ull << h->device, std::memory_order_relaxed);
         }
         if (e == hipSuccess) {
             const dim3 grid((unsigned int)((h->n_chains + 255) / 256)), block(256 * (1 + DS_NN));

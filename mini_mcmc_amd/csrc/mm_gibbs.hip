@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -251,12 +253,12 @@ int mmcmc_gibbs_mixture_run(mmcmc_gibbs_mixture *h, size_t n_collect, size_t n_d
     const char *force = getenv("MMCMC_GIBBS_KERNEL");
     hipError_t e = hipSuccess;
     if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
-        static unsigned long long attr_set = 0;
-        if (h->device >= 64 || !((attr_set >> h->device) & 1ull)) {
+        static std::atomic<unsigned long long> attr_set{0};
+        if (h->device >= 64 || !((attr_set.load(std::memory_order_relaxed) >> h->device) & 1ull)) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(mm_gibbs_mixture_split_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS_BYTES);
             if (e == hipSuccess && h->device < 64)
-                attr_set |= 1ull << h->device;
+                attr_set.fetch_or(1ull << h->device, std::memory_order_relaxed);
         }
         if (e == hipSuccess) {
             hipLaunchKernelGGL(mm_gibbs_mixture_split_kernel, dim3((unsigned int)((h->n_chains + 255) / 256)),

@@ -146,6 +146,10 @@ struct Group {
     size_t n_chains = 0, cmax = 0;
     size_t last_collect = 0;
     bool use_rccl = false, comm_ready = false;
+    /* why the statistics travel as they do (reported through *used_rccl): 1 RCCL; 0 the host BY DESIGN (a device listed
+     * twice: RCCL refuses two ranks on one GPU); -1 the host as a FALLBACK: libnccl / librccl not found; -2: ncclCommInitAll
+     * failed (e.g. no peer access) -- a scaling run must not take the host path silently */
+    int exchange_status = 0;
     uint64_t user_offset = 0;
     std::vector<Shard> sh;
     size_t esize() const { return dtype == MMCMC_F32 ? 4 : 8; }
@@ -220,6 +224,7 @@ int group_create(Group **out, int sampler, const mmcmc_target_desc *target, cons
     g->dim = target->dim;
     g->n_chains = n_chains;
     g->use_rccl = !dup && rccl().ok();
+    g->exchange_status = g->use_rccl ? 1 : dup ? 0 : -1;
     g->sh.resize((size_t)n_devices);
     const size_t esz = g->esize(), base = n_chains / (size_t)n_devices, rem = n_chains % (size_t)n_devices;
     size_t first = 0;
@@ -352,7 +357,8 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
         for (size_t i = 0; i < N; ++i)
             devs[i] = g->sh[i].device;
         if (rccl().CommInitAll(comms.data(), (int)N, devs.data()) != 0) {
-            g->use_rccl = false; /* e.g. no peer access: exchange through the host */
+            g->use_rccl = false; /* e.g. no peer access: exchange through the host, and say so */
+            g->exchange_status = -2;
         } else {
             for (size_t i = 0; i < N; ++i)
                 g->sh[i].comm = comms[i];
@@ -360,9 +366,11 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
         }
     }
     if (used_rccl)
-        *used_rccl = g->use_rccl ? 1 : 0;
+        *used_rccl = g->exchange_status;
     std::vector<float> h_own(g->use_rccl ? 0 : N * own);
-    int st = for_each_shard(g, [&](Shard &s, int i) -> int {
+    /* phase 1: every shard's local statistics, finished and checked BEFORE any rank enters a collective -- a shard that
+     * failed here would otherwise leave the others waiting in ncclAllGather for good */
+    int st = for_each_shard(g, [&](Shard &s, int) -> int {
         if (hipSetDevice(s.device) != hipSuccess)
             return MMCMC_ERR_NO_DEVICE;
         hipError_t e;
@@ -375,7 +383,7 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
                 return (int)e;
             s.stats_cap = total;
         }
-        float *means = s.d_stats, *ssq = means + part, *acov = ssq + part, *gathered = acov + m * D, *acov_all = gathered + N * 2 * part;
+        float *means = s.d_stats, *ssq = means + part, *acov = ssq + part;
         if ((e = hipMemsetAsync(s.d_stats, 0, own * sizeof(float), s.stream)) != hipSuccess)
             return (int)e;
         /* the local statistics are [2][n_i][D] (first halves of the local chains, then their second halves); every
@@ -383,6 +391,18 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
         int rc = mmcmc_stats_partials(s.d_sample, g->dtype, s.n, n, D, means, ssq, acov, s.device, s.stream);
         if (rc != MMCMC_OK)
             return rc;
+        e = hipStreamSynchronize(s.stream);
+        return e == hipSuccess ? MMCMC_OK : (int)e;
+    });
+    if (st != MMCMC_OK)
+        return st;
+    /* phase 2: the exchange */
+    st = for_each_shard(g, [&](Shard &s, int i) -> int {
+        if (hipSetDevice(s.device) != hipSuccess)
+            return MMCMC_ERR_NO_DEVICE;
+        hipError_t e;
+        float *means = s.d_stats, *ssq = means + part, *acov = ssq + part, *gathered = acov + m * D, *acov_all = gathered + N * 2 * part;
+        (void)ssq;
         if (g->use_rccl) {
             /* means and ssq are adjacent: one all-gather of 2 * part floats per rank; lag sums: one all-reduce */
             if (rccl().AllGather(means, gathered, 2 * part, kNcclFloat32, s.comm, s.stream) != 0)

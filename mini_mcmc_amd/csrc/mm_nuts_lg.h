@@ -64,6 +64,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "mm_nuts.h"
 
 /* Section timers for tools/lg_profile.hip (s_memtime deltas of lane 0 per wave); compiled out of the product. */
@@ -1755,7 +1757,7 @@ template <int D> hipError_t mm_launch_nuts_lgq(const mm_nuts_lg_args &a, unsigne
     if (occ == 2) {
         /* workgroups of 8 waves: n_waves is rounded down to whole workgroups (the caller asks for two per SIMD) */
         const size_t lds2 = ((size_t)(D / 16) * (D / 4) * 64 + 8 * (size_t)Cfg2::lds_slots * 64) * sizeof(double);
-        static unsigned long long attr_set = 0;
+        static std::atomic<unsigned long long> attr_set{0};
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev >= 64 || !((attr_set >> dev) & 1ull)) {

@@ -451,11 +451,12 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
 }
 
 #if !defined(__HIPCC_RTC__)
+#include <atomic>
 template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
 hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
 {
     using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH, RBF>;
-    static unsigned long long attr_set = 0; /* > 64 KB of dynamic LDS has to be allowed once per kernel and device */
+    static std::atomic<unsigned long long> attr_set{0}; /* > 64 KB of dynamic LDS has to be allowed once per kernel and device */
     auto kern = mm_run_split_kernel<T, Tgt, SAMPLER, LCT, QP, NN, RBF>;
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -49,7 +49,8 @@ class _Group:
         st = self._fn("split_rhat_mean_ess")(self._h, rhat.ctypes.data_as(C.POINTER(C.c_float)),
                                              ess.ctypes.data_as(C.POINTER(C.c_float)), C.byref(used))
         L.check(st, "group_split_rhat_mean_ess")
-        self.used_rccl = bool(used.value)
+        self.exchange_status = used.value  # 1 RCCL; 0 host by design (a device listed twice); -1 / -2 host as a fallback
+        self.used_rccl = used.value == 1
         return rhat, ess
 
     def close(self):
