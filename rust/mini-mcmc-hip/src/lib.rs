@@ -310,3 +310,200 @@ pub fn split_rhat_mean_ess(sample: ArrayView3<f32>) -> Result<(Array1<f32>, Arra
     })?;
     Ok((rhat, ess))
 }
+
+/// `RunStats` (stats.rs:338-342): summaries of ESS and split R-hat over the parameters.
+pub type RunStats = sys::mmcmc_run_stats;
+
+/// `RunStats::from(sample.view())` (stats.rs:360-371)
+pub fn run_stats<T: GpuFloat>(sample: &Array3<T>) -> Result<RunStats, MmcmcError> {
+    let (c, n, p) = sample.dim();
+    let owned = sample.as_standard_layout();
+    let mut out = RunStats::default();
+    check(unsafe { sys::mmcmc_run_stats_from(owned.as_ptr() as *const c_void, 0, T::DTYPE, c, n, p, &mut out, 0, null_mut()) })?;
+    Ok(out)
+}
+
+impl<T: GpuFloat> GpuMetropolisHastings<T> {
+    /// `ChainRunner::run_progress(n_collect, n_discard)` (core.rs:208-360): the sample and its `RunStats`.  The
+    /// reference's progress bars (one OS thread per chain feeding indicatif) have no analogue at 65 536 chains; the
+    /// running diagnostics they display are `GpuTracker`.
+    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<T>, RunStats), Box<dyn std::error::Error>> {
+        let sample = self.run(n_collect, n_discard)?;
+        let stats = run_stats(&sample)?;
+        Ok((sample, stats))
+    }
+}
+impl<T: GpuFloat> GpuHmc<T> {
+    /// `HMC::run_progress(n_collect, n_discard)` (hmc.rs:222-294): `(sample, RunStats)`
+    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<T>, RunStats), Box<dyn std::error::Error>> {
+        let sample = self.run(n_collect, n_discard)?;
+        let stats = run_stats(&sample)?;
+        Ok((sample, stats))
+    }
+}
+impl GpuNuts {
+    /// `NUTS::run_progress(n_collect, n_discard)` (nuts.rs:194-338): all N transitions (`run` performs N - 1), `(sample, RunStats)`
+    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<f32>, RunStats), Box<dyn std::error::Error>> {
+        let mut out = Array3::<f32>::default((self.n_chains, n_collect, self.dim));
+        check(unsafe { sys::mmcmc_nuts_run(self.h, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, 0, 1, null_mut()) })?;
+        check(unsafe { sys::mmcmc_nuts_sync(self.h) })?;
+        let stats = run_stats(&out)?;
+        Ok((out, stats))
+    }
+}
+
+/// `MultiChainTracker` (stats.rs:189-306) on the GPU: running R-hat and the acceptance EMA of all chains.
+pub struct GpuTracker {
+    h: *mut sys::mmcmc_tracker,
+    dim: usize,
+    n_chains: usize,
+}
+unsafe impl Send for GpuTracker {}
+impl GpuTracker {
+    /// `MultiChainTracker::new(n_chains, n_params)` (stats.rs:207-226)
+    pub fn new(n_chains: usize, n_params: usize) -> Result<Self, MmcmcError> {
+        let mut h = null_mut();
+        check(unsafe { sys::mmcmc_tracker_create(&mut h, n_chains, n_params, 0) })?;
+        Ok(Self { h, dim: n_params, n_chains })
+    }
+    /// `MultiChainTracker::step` (stats.rs:236-262) for every row of `states [n_chains, k, dim]`
+    pub fn steps<T: GpuFloat>(&mut self, states: &Array3<T>) -> Result<(), MmcmcError> {
+        let (c, k, d) = states.dim();
+        assert!(c == self.n_chains && d == self.dim);
+        let owned = states.as_standard_layout();
+        check(unsafe { sys::mmcmc_tracker_steps(self.h, owned.as_ptr() as *const c_void, 0, T::DTYPE, k, 0, k, null_mut()) })
+    }
+    /// `(rhat per parameter, max_rhat, p_accept)` (stats.rs:264-286)
+    pub fn stats(&mut self) -> Result<(Array1<f32>, f32, f32), MmcmcError> {
+        let mut rhat = Array1::<f32>::zeros(self.dim);
+        let (mut mx, mut pa) = (0f32, 0f32);
+        check(unsafe { sys::mmcmc_tracker_stats(self.h, rhat.as_mut_ptr(), &mut mx, &mut pa, null_mut()) })?;
+        Ok((rhat, mx, pa))
+    }
+}
+impl Drop for GpuTracker {
+    fn drop(&mut self) {
+        unsafe { sys::mmcmc_tracker_destroy(self.h) };
+    }
+}
+
+/// How a device group exchanged its diagnostics (`*used_rccl` of `mmcmc_*_group_split_rhat_mean_ess`).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum GroupExchange {
+    Rccl,
+    HostByDesign,
+    HostFallbackNoLibrary,
+    HostFallbackInitFailed,
+}
+fn exchange_of(code: c_int) -> GroupExchange {
+    match code {
+        1 => GroupExchange::Rccl,
+        0 => GroupExchange::HostByDesign,
+        -1 => GroupExchange::HostFallbackNoLibrary,
+        _ => GroupExchange::HostFallbackInitFailed,
+    }
+}
+
+/// `HMC` over several GPUs from one call (`mmcmc_hmc_group_*`): contiguous shards, the stream keyed by the global chain index.
+pub struct GpuHmcGroup<T: GpuFloat> {
+    g: *mut sys::mmcmc_hmc_group,
+    n_chains: usize,
+    dim: usize,
+    pub accept_counts: Vec<u64>,
+    _t: PhantomData<T>,
+}
+unsafe impl<T: GpuFloat> Send for GpuHmcGroup<T> {}
+impl<T: GpuFloat> GpuHmcGroup<T> {
+    pub fn new_on(devices: &[i32], target: GpuTarget, initial_positions: Vec<Vec<T>>, step_size: f64, n_leapfrog: usize) -> Result<Self, MmcmcError> {
+        let (flat, n, d) = flatten(&initial_positions);
+        let desc = target.desc(d);
+        let mut g = null_mut();
+        check(unsafe {
+            sys::mmcmc_hmc_group_create(&mut g, &desc, flat.as_ptr() as *const c_void, n, step_size, n_leapfrog as c_int, T::DTYPE, devices.as_ptr(), devices.len() as c_int)
+        })?;
+        Ok(Self { g, n_chains: n, dim: d, accept_counts: vec![0; n], _t: PhantomData })
+    }
+    pub fn set_seed(self, seed: u64) -> Self {
+        unsafe { sys::mmcmc_hmc_group_seed(self.g, seed) };
+        self
+    }
+    /// `HMC::run(n_collect, n_discard)` of every chain on every device
+    pub fn run(&mut self, n_collect: usize, n_discard: usize) -> Result<Array3<T>, ShapeError> {
+        let mut out = Array3::<T>::default((self.n_chains, n_collect, self.dim));
+        let st = unsafe { sys::mmcmc_hmc_group_run(self.g, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, self.accept_counts.as_mut_ptr()) };
+        if st == sys::MMCMC_OK { Ok(out) } else { Err(shape_error(st)) }
+    }
+    /// `(rhat, ess)` of the last run over the chains of all devices, and how the statistics travelled
+    pub fn split_rhat_mean_ess(&mut self) -> Result<(Array1<f32>, Array1<f32>, GroupExchange), MmcmcError> {
+        let (mut rhat, mut ess) = (Array1::<f32>::zeros(self.dim), Array1::<f32>::zeros(self.dim));
+        let mut how: c_int = 0;
+        check(unsafe { sys::mmcmc_hmc_group_split_rhat_mean_ess(self.g, rhat.as_mut_ptr(), ess.as_mut_ptr(), &mut how) })?;
+        Ok((rhat, ess, exchange_of(how)))
+    }
+}
+impl<T: GpuFloat> Drop for GpuHmcGroup<T> {
+    fn drop(&mut self) {
+        unsafe { sys::mmcmc_hmc_group_destroy(self.g) };
+    }
+}
+
+/// `MetropolisHastings` over several GPUs from one call (`mmcmc_mh_group_*`).
+pub struct GpuMhGroup<T: GpuFloat> {
+    g: *mut sys::mmcmc_mh_group,
+    n_chains: usize,
+    dim: usize,
+    pub accept_counts: Vec<u64>,
+    _t: PhantomData<T>,
+}
+unsafe impl<T: GpuFloat> Send for GpuMhGroup<T> {}
+impl<T: GpuFloat> GpuMhGroup<T> {
+    pub fn new_on(devices: &[i32], target: GpuTarget, proposal_std: f64, initial_states: Vec<Vec<T>>) -> Result<Self, MmcmcError> {
+        let (flat, n, d) = flatten(&initial_states);
+        let desc = target.desc(d);
+        let prop = sys::mmcmc_proposal_desc { kind: sys::MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN, reserved: 0, std: proposal_std };
+        let mut g = null_mut();
+        check(unsafe {
+            sys::mmcmc_mh_group_create(&mut g, &desc, &prop, flat.as_ptr() as *const c_void, n, T::DTYPE, devices.as_ptr(), devices.len() as c_int)
+        })?;
+        Ok(Self { g, n_chains: n, dim: d, accept_counts: vec![0; n], _t: PhantomData })
+    }
+    pub fn seed(self, seed: u64) -> Self {
+        unsafe { sys::mmcmc_mh_group_seed(self.g, seed) };
+        self
+    }
+    /// `ChainRunner::run` of every chain on every device
+    pub fn run(&mut self, n_collect: usize, n_discard: usize) -> Result<Array3<T>, ShapeError> {
+        let mut out = Array3::<T>::default((self.n_chains, n_collect, self.dim));
+        let st = unsafe { sys::mmcmc_mh_group_run(self.g, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, self.accept_counts.as_mut_ptr()) };
+        if st == sys::MMCMC_OK { Ok(out) } else { Err(shape_error(st)) }
+    }
+    pub fn split_rhat_mean_ess(&mut self) -> Result<(Array1<f32>, Array1<f32>, GroupExchange), MmcmcError> {
+        let (mut rhat, mut ess) = (Array1::<f32>::zeros(self.dim), Array1::<f32>::zeros(self.dim));
+        let mut how: c_int = 0;
+        check(unsafe { sys::mmcmc_mh_group_split_rhat_mean_ess(self.g, rhat.as_mut_ptr(), ess.as_mut_ptr(), &mut how) })?;
+        Ok((rhat, ess, exchange_of(how)))
+    }
+}
+impl<T: GpuFloat> Drop for GpuMhGroup<T> {
+    fn drop(&mut self) {
+        unsafe { sys::mmcmc_mh_group_destroy(self.g) };
+    }
+}
+
+/// A target or proposal written as HIP source (`mmcmc_target_register_source` / `mmcmc_proposal_register_source`): the
+/// GPU analogue of implementing `Target` / `GradientTarget` / `Proposal` (distributions.rs:65-108) oneself.  Returns the
+/// kind to put into a target / proposal description, or the compiler's log.
+pub fn register_target_source(name: &str, dim: usize, hip_source: &str) -> Result<i32, String> {
+    let (n, s) = (std::ffi::CString::new(name).unwrap(), std::ffi::CString::new(hip_source).unwrap());
+    let mut kind: c_int = 0;
+    let mut log = vec![0 as std::os::raw::c_char; 1 << 16];
+    let st = unsafe { sys::mmcmc_target_register_source(n.as_ptr(), dim as c_int, s.as_ptr(), &mut kind, log.as_mut_ptr(), log.len()) };
+    if st == sys::MMCMC_OK { Ok(kind) } else { Err(unsafe { CStr::from_ptr(log.as_ptr()) }.to_string_lossy().into_owned()) }
+}
+pub fn register_proposal_source(name: &str, target_kind: i32, dim: usize, hip_source: &str) -> Result<i32, String> {
+    let (n, s) = (std::ffi::CString::new(name).unwrap(), std::ffi::CString::new(hip_source).unwrap());
+    let mut kind: c_int = 0;
+    let mut log = vec![0 as std::os::raw::c_char; 1 << 16];
+    let st = unsafe { sys::mmcmc_proposal_register_source(n.as_ptr(), target_kind, dim as c_int, s.as_ptr(), &mut kind, log.as_mut_ptr(), log.len()) };
+    if st == sys::MMCMC_OK { Ok(kind) } else { Err(unsafe { CStr::from_ptr(log.as_ptr()) }.to_string_lossy().into_owned()) }
+}

@@ -47,16 +47,27 @@ def test_c_sequence_runs_on_gpu(tmp_path):
     assert r.returncode == 0 and "abi sequence ok" in r.stdout, r.stdout + r.stderr
 
 
-def test_rust_sources_declare_what_the_header_exports():
-    """Every `pub fn mmcmc_*` of the -sys crate is an entry point of the header (a typo would only show at link time on
-    a machine with a Rust toolchain)."""
+def test_rust_sys_crate_is_the_header_in_both_directions():
+    """rust/mini-mcmc-hip-sys/src/lib.rs is GENERATED from include/mmcmc.h (tools/gen_rust_sys.py): the committed file must
+    equal a fresh generation, every exported function of the header must be declared, and nothing else; every `sys::`
+    item the safe wrappers use must exist in it."""
     import re
 
-    sys_rs = open(os.path.join(ROOT, "rust", "mini-mcmc-hip-sys", "src", "lib.rs")).read()
-    header = open(os.path.join(ROOT, "include", "mmcmc.h")).read()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_sys
+
+    path = os.path.join(ROOT, "rust", "mini-mcmc-hip-sys", "src", "lib.rs")
+    sys_rs = open(path).read()
+    assert sys_rs == gen_rust_sys.generate(), "run python tools/gen_rust_sys.py"
+    header = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "mmcmc.h")).read(), flags=re.S)
     declared = set(re.findall(r"pub fn (mmcmc_\w+)\s*\(", sys_rs))
-    exported = set(re.findall(r"\b(mmcmc_\w+)\s*\(", header))
-    assert len(declared) > 30 and declared <= exported, sorted(declared - exported)
+    exported = set(re.findall(r"^(?:int|const char \*|void)\s*(mmcmc_\w+)\s*\(", header, flags=re.M))
+    assert len(exported) >= 100 and declared == exported, (sorted(declared - exported), sorted(exported - declared))
+    wrappers = open(os.path.join(ROOT, "rust", "mini-mcmc-hip", "src", "lib.rs")).read()
+    used = set(re.findall(r"sys::(\w+)", wrappers))
+    known = declared | set(re.findall(r"pub (?:const|struct) (\w+)", sys_rs))
+    assert used <= known, sorted(used - known)
+    for name in ("run_progress", "GpuHmcGroup", "GpuMhGroup", "GpuNutsGroup", "GpuTracker", "RunStats"):
+        assert name in wrappers, name
     for f in ("Cargo.toml", "build.rs"):
         assert os.path.exists(os.path.join(ROOT, "rust", "mini-mcmc-hip-sys", f))
-    assert os.path.exists(os.path.join(ROOT, "rust", "mini-mcmc-hip", "src", "lib.rs"))
