@@ -417,6 +417,9 @@ int mmcmc_discrete_register_source(const char *name, const char *hip_source, int
 typedef struct mmcmc_mh_discrete mmcmc_mh_discrete;
 int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *params, const int32_t *init,
                              size_t n_chains, int device);
+/* kernel mapping: 1 = noise waves + transition waves, four waves per SIMD (default; used from 4096 chains on), 0 = one wave per
+ * SIMD; bit-identical */
+int mmcmc_mh_discrete_set_kernel_variant(mmcmc_mh_discrete *h, int variant);
 int mmcmc_mh_discrete_seed(mmcmc_mh_discrete *h, uint64_t seed);                 /* MetropolisHastings::seed :187-193 */
 int mmcmc_mh_discrete_set_chain_offset(mmcmc_mh_discrete *h, uint64_t chain_offset);
 /* ChainRunner::run core.rs:176-186: n_discard + n_collect transitions, the last n_collect states kept */
@@ -435,6 +438,7 @@ int mmcmc_mh_discrete_destroy(mmcmc_mh_discrete *h);
 typedef struct mmcmc_gibbs_mixture mmcmc_gibbs_mixture;
 int mmcmc_gibbs_mixture_create(mmcmc_gibbs_mixture **out, const double *params, const double *init, size_t n_chains,
                                int device);
+int mmcmc_gibbs_mixture_set_kernel_variant(mmcmc_gibbs_mixture *h, int variant); /* as mmcmc_mh_discrete_set_kernel_variant */
 int mmcmc_gibbs_mixture_seed(mmcmc_gibbs_mixture *h, uint64_t seed);            /* GibbsSampler::set_seed gibbs.rs:179-187 */
 int mmcmc_gibbs_mixture_set_chain_offset(mmcmc_gibbs_mixture *h, uint64_t chain_offset);
 int mmcmc_gibbs_mixture_run(mmcmc_gibbs_mixture *h, size_t n_collect, size_t n_discard, double *out, int out_is_device,

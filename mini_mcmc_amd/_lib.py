@@ -122,6 +122,8 @@ SIGNATURES = {
     "mmcmc_tracker_n": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "mmcmc_tracker_destroy": (C.c_int, [_vp]),
     "mmcmc_mh_discrete_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_size_t, C.c_int]),
+    "mmcmc_mh_discrete_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+    "mmcmc_gibbs_mixture_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "mmcmc_mh_discrete_seed": (C.c_int, [_vp, C.c_uint64]),
     "mmcmc_mh_discrete_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
     "mmcmc_mh_discrete_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp]),

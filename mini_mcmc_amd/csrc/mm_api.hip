@@ -22,6 +22,7 @@
 #include "mm_host_rng.h"
 #include "mm_params.h"
 #include "mm_wide.h"
+#include "mm_tuning.h"
 #include "mm_rtc.h"
 
 size_t mm_split_lds_bytes_f32(int dim, int mh); /* mm_inst_f32.hip */
@@ -376,7 +377,7 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
         /* the same skeleton (mm_run_kernel_body, PIPE = 2) around the user's functor, from the run-time compiled module */
         /* f32 up to dim 8: the split-role skeleton (four waves per SIMD) where the module has it; else PIPE = 2, one wave per SIMD */
         e = hipErrorNotFound;
-        const char *us = getenv("MMCMC_USER_SPLIT"); /* measurement aid: "0" keeps the one-wave-per-SIMD skeleton */
+        const char *us = mm_tuning_env("MMCMC_USER_SPLIT"); /* measurement aid: "0" keeps the one-wave-per-SIMD skeleton */
         if (std::is_same<T, float>::value && s->dim <= 8 && !(us && us[0] == '0')) {
             const size_t lds_split = mm_split_lds_bytes_f32(s->dim, mh ? 1 : 0);
             if (lds_split)

@@ -212,6 +212,7 @@ struct mmcmc_mh_discrete {
     size_t n_chains = 0;
     uint64_t seed = 0, chain_offset = 0;
     uint32_t iter = 0;
+    int variant = 1; /* 1: noise waves + transition waves (from 4096 chains on); 0: one wave per SIMD */
     mm_discrete_params P{};
     const mm_user_target *user = nullptr; /* a model compiled from source (mmcmc_discrete_register_source) */
     double user_params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -296,6 +297,14 @@ int mmcmc_mh_discrete_create(mmcmc_mh_discrete **out, int kind, const double *pa
     return MMCMC_OK;
 }
 
+int mmcmc_mh_discrete_set_kernel_variant(mmcmc_mh_discrete *h, int variant)
+{
+    if (!h || (variant != 0 && variant != 1))
+        return MMCMC_ERR_INVALID_ARG;
+    h->variant = variant;
+    return MMCMC_OK;
+}
+
 int mmcmc_mh_discrete_seed(mmcmc_mh_discrete *h, uint64_t seed)
 {
     if (!h)
@@ -344,8 +353,7 @@ int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_disca
     a.n_discard = (unsigned int)n_discard;
     a.n_collect = (unsigned int)n_collect;
     /* four waves per SIMD from 4096 chains on (below that the plain kernel's waves are spread thinner than one per SIMD
-     * anyway); MMCMC_DISCRETE_KERNEL=plain keeps the one-wave kernel (A/B and tests: the two are bit-identical) */
-    const char *force = getenv("MMCMC_DISCRETE_KERNEL");
+     * anyway); variant 0 keeps the one-wave kernel (A/B and tests: the two are bit-identical) */
     hipError_t e = hipSuccess;
     if (h->user) {
         mm_discrete_user_args ua;
@@ -361,7 +369,7 @@ int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_disca
         ua.n_discard = a.n_discard;
         ua.n_collect = a.n_collect;
         e = mm_rtc_launch_discrete(h->user, &ua, sizeof(ua), (unsigned int)((h->n_chains + 63) / 64), st);
-    } else if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
+    } else if (h->n_chains >= 4096 && h->variant == 1) {
         const void *fn = h->kind == MMCMC_POISSON_REFLECT  ? reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_POISSON_REFLECT>)
                          : h->kind == MMCMC_BINOMIAL_CLAMP ? reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_BINOMIAL_CLAMP>)
                                                            : reinterpret_cast<const void *>(mm_discrete_split_kernel<MM_POISSON_NONNEG>);

@@ -163,6 +163,7 @@ struct mmcmc_gibbs_mixture {
     size_t n_chains = 0;
     uint64_t seed = 0, chain_offset = 0;
     uint32_t iter = 0;
+    int variant = 1; /* 1: noise waves + transition waves (from 4096 chains on); 0: one wave per SIMD (mmcmc_gibbs_mixture_set_kernel_variant) */
     mm_mixture_params P{};
     double *d_state = nullptr;
     hipStream_t stream = nullptr;
@@ -199,6 +200,14 @@ int mmcmc_gibbs_mixture_create(mmcmc_gibbs_mixture **out, const double *params, 
         return (int)e;
     }
     *out = h;
+    return MMCMC_OK;
+}
+
+int mmcmc_gibbs_mixture_set_kernel_variant(mmcmc_gibbs_mixture *h, int variant)
+{
+    if (!h || (variant != 0 && variant != 1))
+        return MMCMC_ERR_INVALID_ARG;
+    h->variant = variant;
     return MMCMC_OK;
 }
 
@@ -248,11 +257,9 @@ int mmcmc_gibbs_mixture_run(mmcmc_gibbs_mixture *h, size_t n_collect, size_t n_d
     a.iter0 = h->iter;
     a.n_discard = (unsigned int)n_discard;
     a.n_collect = (unsigned int)n_collect;
-    /* four waves per SIMD from 4096 chains on; MMCMC_GIBBS_KERNEL=plain keeps the one-wave kernel (A/B and tests: the two
-     * are bit-identical) */
-    const char *force = getenv("MMCMC_GIBBS_KERNEL");
+    /* four waves per SIMD from 4096 chains on; variant 0 keeps the one-wave kernel (A/B and tests: the two are bit-identical) */
     hipError_t e = hipSuccess;
-    if (h->n_chains >= 4096 && !(force && !strcmp(force, "plain"))) {
+    if (h->n_chains >= 4096 && h->variant == 1) {
         static std::atomic<unsigned long long> attr_set{0};
         if (h->device >= 64 || !((attr_set.load(std::memory_order_relaxed) >> h->device) & 1ull)) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(mm_gibbs_mixture_split_kernel),

@@ -18,6 +18,7 @@
 #include "mm_nuts_kernels.h"
 #include "mm_nuts_lg.h"
 #include "mm_nuts_generic.h"
+#include "mm_tuning.h"
 #include "mm_rtc.h"
 #include "mm_params.h"
 
@@ -309,18 +310,18 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 g.ctrl = d_lg_ctrl;
                 g.slots = d_lg_lists;
                 g.patience = 8u; /* 65 536 chains: 4 -> 516.5 ms, 16 -> 518.5, 64 -> 520.9, 256 -> 530.3 */
-                if (const char *ev = getenv("MMCMC_LGQ_PATIENCE"))
+                if (const char *ev = mm_tuning_env("MMCMC_LGQ_PATIENCE"))
                     g.patience = (unsigned int)atoi(ev);
                 const unsigned int groups16 = (unsigned int)(c_pad / 16);
                 /* waves per SIMD the scheduler is built for (mm_lg_cfg): 2 wherever two per SIMD can be filled */
                 int occ = lgq_occ;
-                if (const char *ev = getenv("MMCMC_LGQ_OCC"))
+                if (const char *ev = mm_tuning_env("MMCMC_LGQ_OCC"))
                     occ = atoi(ev) == 2 ? 2 : 1;
                 if (groups16 < 2u * n_resident_waves)
                     occ = 1;
                 const unsigned int resident = n_resident_waves * (unsigned int)occ;
                 unsigned int nw = groups16 < resident ? groups16 : resident;
-                if (const char *ev = getenv("MMCMC_LGQ_WAVES")) {
+                if (const char *ev = mm_tuning_env("MMCMC_LGQ_WAVES")) {
                     const unsigned int w = (unsigned int)atoi(ev);
                     if (w >= 1 && w < nw)
                         nw = w;
@@ -336,7 +337,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
                         return e;
                     if ((e = hipStreamSynchronize(st)) != hipSuccess)
                         return e;
-                    if (getenv("MMCMC_LGQ_STATS"))
+                    if (mm_tuning_env("MMCMC_LGQ_STATS"))
                         fprintf(stderr, "lgq: first level %d units %llu chains %llu (%.2f per unit) leaf iterations %llu idle polls %llu error %u ticks pick %.3g fetch %.3g work %.3g handover %.3g\n",
                                 gq.j0, hc.stat_units, hc.stat_chains,
                                 (double)hc.stat_chains / (double)(hc.stat_units ? hc.stat_units : 1), hc.stat_leaf_iters,
@@ -565,7 +566,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
         a.target_accept_p = (ST)target_accept_p;
         a.stack_in_lds = stack_in_lds ? 1 : 0;
         a.async_batch = 0;
-        if (const char *e = getenv("MMCMC_NUTS_ASYNC_BATCH")) /* tuning aid; no result depends on it */
+        if (const char *e = mm_tuning_env("MMCMC_NUTS_ASYNC_BATCH")) /* tuning aid; no result depends on it */
             a.async_batch = (unsigned int)atoi(e);
         a.scratch = d_scratch;
         const size_t total = n_collect + n_discard;

@@ -97,6 +97,11 @@ class DiscreteMetropolisHastings:
         L.check(L.lib().mmcmc_mh_discrete_seed(self._h, int(seed)), "mmcmc_mh_discrete_seed")
         return self
 
+    def set_kernel_variant(self, variant: int) -> "DiscreteMetropolisHastings":
+        """1: noise waves + transition waves (default), 0: one wave per SIMD; bit-identical."""
+        L.check(L.lib().mmcmc_mh_discrete_set_kernel_variant(self._h, int(variant)), "mmcmc_mh_discrete_set_kernel_variant")
+        return self
+
     def set_chain_offset(self, first_global_chain: int) -> "DiscreteMetropolisHastings":
         L.check(L.lib().mmcmc_mh_discrete_set_chain_offset(self._h, int(first_global_chain)), "set_chain_offset")
         return self

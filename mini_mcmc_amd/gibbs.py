@@ -55,6 +55,11 @@ class GibbsSampler:
         L.check(L.lib().mmcmc_gibbs_mixture_seed(self._h, int(seed)), "mmcmc_gibbs_mixture_seed")
         return self
 
+    def set_kernel_variant(self, variant: int) -> "GibbsSampler":
+        """1: noise waves + transition waves (default), 0: one wave per SIMD; bit-identical."""
+        L.check(L.lib().mmcmc_gibbs_mixture_set_kernel_variant(self._h, int(variant)), "mmcmc_gibbs_mixture_set_kernel_variant")
+        return self
+
     def set_chain_offset(self, first_global_chain: int) -> "GibbsSampler":
         L.check(L.lib().mmcmc_gibbs_mixture_set_chain_offset(self._h, int(first_global_chain)), "set_chain_offset")
         return self
