@@ -235,6 +235,14 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         }
         s->generic = true;
         s->variant = 6;
+        /* up to dimension 32 the target's own functor is compiled into the register-resident skeletons on first use
+         * (hipRTC, mm_rtc_builtin): variant 7 then, with the run-time-D kernel (6) still selectable */
+        if (s->dim <= 32) {
+            DeviceGuard gb(device);
+            s->user = mm_rtc_builtin(s->kind, s->dim);
+            if (s->user)
+                s->variant = 7;
+        }
     }
     /* dense Gaussian at dim 16 / 32 under HMC (f64 and f32): the lane-group / MFMA kernels, and the default there */
     s->lg_ok = sampler == MM_SAMPLER_HMC && s->kind == MMCMC_GAUSSIAN_ND && (s->dim == 16 || s->dim == 32);
@@ -248,7 +256,7 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         s->variant = 5;
     if (s->lg_ok)
         s->variant = 3;
-    if (s->user)
+    if (s->user && !s->generic)
         s->variant = 7;
     /* few chains of a huge dimension (hmc.rs:882-916: 6 x 10 000): the coordinates of a chain across a workgroup */
     s->wide_ok = sampler == MM_SAMPLER_HMC && !s->user && mm_wide_kind_ok(s->kind) && s->dim >= 4 && s->dim <= MM_WIDE_MAX_DIM;
@@ -841,6 +849,12 @@ static bool split_ok(const Sampler *s)
  * request wherever the target kind has one and the chain vectors fit LDS (what the bit-identity tests use) */
 static int set_variant_common(Sampler *s, int variant)
 {
+    if (s->user && s->generic) { /* a built-in target on its run-time compiled register kernels (7) or the run-time-D kernel (6) */
+        if (variant != 6 && variant != 7)
+            return MMCMC_ERR_UNSUPPORTED;
+        s->variant = variant;
+        return MMCMC_OK;
+    }
     if (s->user)
         return variant == 7 ? MMCMC_OK : MMCMC_ERR_UNSUPPORTED;
     if (variant == 8) {
