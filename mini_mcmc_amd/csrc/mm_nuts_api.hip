@@ -151,8 +151,17 @@ template <class TT, class ST> struct Nuts : NutsBase {
             if (tab[i].kind == t->kind && tab[i].dim == t->dim)
                 k = &tab[i];
         generic_ok = mm_generic_kind_ok(t->kind) && t->dim >= 1;
-        if (t->kind >= MM_USER_KIND_BASE) {
-            user = mm_rtc_find(t->kind);
+        bool builtin_user = false;
+        if (t->kind < MM_USER_KIND_BASE && !k && generic_ok && t->dim <= 32) {
+            /* a built-in target at a dimension without a compiled instance: its functor compiled into the one-chain-per-lane
+             * kernels on first use (hipRTC, mm_rtc_builtin_nuts); NULL keeps the run-time-D kernel */
+            DevGuard gb(device);
+            user = mm_rtc_builtin_nuts(t->kind, t->dim);
+            builtin_user = user != nullptr;
+        }
+        if (t->kind >= MM_USER_KIND_BASE || builtin_user) {
+            if (!builtin_user)
+                user = mm_rtc_find(t->kind);
             if (!user)
                 return MMCMC_ERR_INVALID_ARG;
             if (mm_rtc_is_model(user) || mm_rtc_is_discrete(user))
@@ -172,7 +181,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
         } else if (!k && !generic_ok) {
             return MMCMC_ERR_UNSUPPORTED;
         }
-        if (user) {
+        if (user && !builtin_user) {
             for (int i = 0; i < 8; ++i) /* P.p[0..8) = the description's params (mm_rtc.hip) */
                 P.p[i] = (TT)t->params[i];
             P.mat = nullptr;

@@ -18,6 +18,7 @@ int mm_rtc_is_discrete(const mm_user_target *t);
 /* a built-in target's register-resident MH / HMC kernels for a dimension <= 32 without a compiled instance, built on first
  * use (NULL: no hipRTC, or the unit failed to build) */
 const mm_user_target *mm_rtc_builtin(int kind, int dim);
+const mm_user_target *mm_rtc_builtin_nuts(int kind, int dim); /* the same for NUTS: init + run, three type modes */
 hipError_t mm_rtc_launch_discrete(const mm_user_target *t, void *args, size_t args_bytes, unsigned int grid, hipStream_t stream);
 /* kernels of a registered target: sampler 0 MH / 1 HMC, dtype 0 f32 / 1 f64; `args` = the mm_run_args<T> block */
 hipError_t mm_rtc_launch_run_split(const mm_user_target *t, int sampler, void *args, size_t args_bytes, unsigned int grid, size_t lds,

@@ -267,7 +267,13 @@ def test_gpu_nuts_any_dimension_bit_exact_vs_host_build(M, O, mode):
                                    (M.dist.StandardNormal(33), O.STANDARD_NORMAL, [], None), (M.dist.GaussianND(A40), O.GAUSSIAN_ND, [], A40)):
         init = M.core.init_with_seed(70, tgt.dim, 31) * 0.5
         s = NUTS(tgt, init, 0.8, mode=mode).set_seed(77)
-        assert s.kernel_variant == 6
+        # up to dimension 32 the functor is compiled into the one-chain-per-lane kernel on first use (variant 7), beyond
+        # that the run-time-D kernel runs (6); both must equal the host build
+        assert s.kernel_variant == (7 if tgt.dim <= 32 else 6)
+        if tgt.dim <= 32:
+            g6 = NUTS(tgt, init, 0.8, mode=mode).set_seed(77).set_kernel_variant(6)
+            assert np.array_equal(g6._run(7, 6, False, "numpy"), s._run(7, 6, False, "numpy")) and np.array_equal(g6.positions(), s.positions())
+            s = NUTS(tgt, init, 0.8, mode=mode).set_seed(77)
         out = s._run(7, 6, False, "numpy")
         ref, pos, ad, nlf = O.engine_host_nuts_run(mode, kind, tgt.dim, params, init, 0.8, 7, 6, seed=77, matrix=mat)
         name = f"{type(tgt).__name__} D={tgt.dim} mode={mode}"
