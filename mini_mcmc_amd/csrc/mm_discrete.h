@@ -88,58 +88,40 @@ MM_HD double mm_nonneg_logq(const mm_discrete_params &P, int x, int y)
     return (y == x + 1 || y + 1 == x) ? P.ln_half : MM_NEG_INF;
 }
 
-/* one transition; returns 1 iff the proposal was accepted */
-/* the transition given its noise block b = mm_block(seed, chain, iteration, 0): direction = top bit of word 0, accept
- * uniform = u53 of words 2, 3 */
-/* ... given its draws in the form the kernel's noise waves hand them over: direction, accept uniform, and the table
- * logarithm of (float)u that the accept test filters with (mm_ratio_exceeds_ln_u) */
-MM_HD int mm_discrete_step_draws(const mm_discrete_params &P, int32_t *x, int step, double u, float lf)
+/* the proposal of a chain at `cur` for direction `step` (+1 / -1) */
+MM_HD int mm_discrete_propose(const mm_discrete_params &P, int cur, int step)
 {
-    const int cur = *x;
-    int prop;
-    double qf = P.ln_half, qb = P.ln_half;
     if (P.kind == MM_POISSON_REFLECT) {
-        prop = cur + step;
-        if (prop < 0)
-            prop = 0; /* "reflect instead of going negative" = stay at 0 (:70-76) */
-    } else if (P.kind == MM_BINOMIAL_CLAMP) {
-        prop = cur + step;
-        prop = prop < 0 ? 0 : (prop > P.n ? P.n : prop);
-    } else {
-        prop = cur == 0 ? 1 : cur + step;
+        const int prop = cur + step;
+        return prop < 0 ? 0 : prop; /* "reflect instead of going negative" = stay at 0 (:70-76) */
+    }
+    if (P.kind == MM_BINOMIAL_CLAMP) {
+        const int prop = cur + step;
+        return prop < 0 ? 0 : (prop > P.n ? P.n : prop);
+    }
+    return cur == 0 ? 1 : cur + step;
+}
+/* ... and its log accept ratio (metropolis_hastings.rs:303-310): a function of the state and the direction only, so
+ * the split kernel tabulates it per state (mm_discrete.hip) */
+MM_HD double mm_discrete_log_ratio(const mm_discrete_params &P, int cur, int step, int *prop_out)
+{
+    const int prop = mm_discrete_propose(P, cur, step);
+    double qf = P.ln_half, qb = P.ln_half;
+    if (P.kind != MM_POISSON_REFLECT && P.kind != MM_BINOMIAL_CLAMP) {
         qf = mm_nonneg_logq(P, cur, prop);
         qb = mm_nonneg_logq(P, prop, cur);
     }
     const double current_lp = mm_discrete_logp(P, cur);
     const double proposed_lp = mm_discrete_logp(P, prop);
-    const double log_accept_ratio = (proposed_lp + qb) - (current_lp + qf);
-    if (mm_ratio_exceeds_ln_u_given(log_accept_ratio, u, lf)) { /* log_accept_ratio > ln u (metropolis_hastings.rs:311) */
-        *x = prop;
-        return 1;
-    }
-    return 0;
+    *prop_out = prop;
+    return (proposed_lp + qb) - (current_lp + qf);
 }
+/* one transition given its noise block b = mm_block(seed, chain, iteration, 0): direction = top bit of word 0, accept
+ * uniform = u53 of words 2, 3; returns 1 iff the proposal was accepted */
 MM_HD int mm_discrete_step_block(const mm_discrete_params &P, int32_t *x, const mm_u32x4 &b)
 {
-    const int step = (b.w[0] >> 31) ? 1 : -1;
-    const int cur = *x;
     int prop;
-    double qf = P.ln_half, qb = P.ln_half;
-    if (P.kind == MM_POISSON_REFLECT) {
-        prop = cur + step;
-        if (prop < 0)
-            prop = 0; /* "reflect instead of going negative" = stay at 0 (:70-76) */
-    } else if (P.kind == MM_BINOMIAL_CLAMP) {
-        prop = cur + step;
-        prop = prop < 0 ? 0 : (prop > P.n ? P.n : prop);
-    } else {
-        prop = cur == 0 ? 1 : cur + step;
-        qf = mm_nonneg_logq(P, cur, prop);
-        qb = mm_nonneg_logq(P, prop, cur);
-    }
-    const double current_lp = mm_discrete_logp(P, cur);
-    const double proposed_lp = mm_discrete_logp(P, prop);
-    const double log_accept_ratio = (proposed_lp + qb) - (current_lp + qf);
+    const double log_accept_ratio = mm_discrete_log_ratio(P, *x, (b.w[0] >> 31) ? 1 : -1, &prop);
     const double u = mm_u53(b.w[2], b.w[3]);
     if (mm_ratio_exceeds_ln_u(log_accept_ratio, u)) { /* log_accept_ratio > ln u (metropolis_hastings.rs:311) */
         *x = prop;

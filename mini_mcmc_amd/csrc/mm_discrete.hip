@@ -97,30 +97,34 @@ __global__ __launch_bounds__(64) void mm_discrete_kernel(const run_args a)
 
 /* The same run with the work of a chain spread over four waves of one SIMD, like the continuous samplers'
  * (mm_split_kernels.h): workgroup = 1024 threads = 4 transition waves (64 chains each) + 3 noise waves per transition
- * wave.  A transition is ~65 instructions of Philox and ~40 of table look-ups and accept test; one wave per SIMD (all
- * that 65 536 chains give mm_discrete_kernel) issues an instruction every 4.4+ cycles and waits out every LDS look-up.
- * The noise block is a pure function of (seed, chain, iteration): noise wave r draws the blocks of iterations
- * r, r + 3, ... of a batch of RB into an LDS ring (16 bytes per chain and iteration), one barrier per batch hands a
- * filled half over.  Bit-identical to mm_discrete_kernel (same blocks, same mm_discrete_step_block). */
+ * wave.  The noise block is a pure function of (seed, chain, iteration): noise wave r draws the blocks of iterations
+ * r, r + 3, ... of a batch of RB into an LDS ring, one barrier per batch hands a filled half over.  Bit-identical to
+ * mm_discrete_kernel (same blocks, same accept decisions).
+ *
+ * Round 3 (tools/experiments/ds_probe.py, cycle stamps in the transition wave): the transition wave never waited at the
+ * barrier -- it spent 627 cycles per transition on ~30 instructions: an LDS round trip for the draw, two dependent
+ * look-ups of the log-density with their bounds checks as exec-mask branches, six dependent f64 operations; and the
+ * bare skeleton (no Philox, no transition, no output) still took 240 cycles per transition, the LDS pipe of the CU
+ * moving 16 bytes per chain and transition through the ring twice.  Now:
+ *   - the ring carries 4 bytes per draw: the f32 table logarithm of the accept uniform with the direction in its sign
+ *     bit (ln u <= 0).  The uniform itself is needed only inside the filter's band (one transition in ~10^5) and is
+ *     drawn again there;
+ *   - a transition reads no log-density: the workgroup tabulates, per state, the log accept ratio of the move down
+ *     and of the move up (the expression of mm_discrete_step_draws, evaluated once), the chain carries the pair of its
+ *     state, and the pair of the PROPOSED state is fetched while the accept test runs (its address depends on the state
+ *     and the direction, not on the decision);
+ *   - a batch's draws are read from the ring in one go and its transitions are unrolled.
+ * A wave with a chain outside the table (only possible with such an initial state) keeps the plain transition. */
 constexpr int DS_NN = 3, DS_RB = 12, DS_TILE_T = 48;
 using DsTile = mm_tile_t<int32_t, 1, DS_TILE_T>;
 constexpr size_t DS_TILE_BYTES = (DsTile::lds_bytes_per_wave + 15) / 16 * 16;
-constexpr size_t DS_RING_BYTES = (size_t)2 * DS_RB * 64 * 16;
+constexpr size_t DS_RING_BYTES = (size_t)2 * DS_RB * 64 * 4;
 constexpr size_t DS_TABLE_BYTES = (size_t)MM_DISCRETE_POISSON_TABLE * sizeof(double);
+constexpr size_t DS_RATIO_BYTES = (size_t)(MM_DISCRETE_POISSON_TABLE + 1) * 16; /* {down, up} per state + one row past the end */
 constexpr size_t DS_LNM_BYTES = (size_t)MM_LNM_ROWS * 16; /* the f32 logarithm's table (mm_lnu_f32), read by the noise waves */
-constexpr size_t DS_LDS_BYTES = DS_TABLE_BYTES + DS_LNM_BYTES + 4 * DS_TILE_BYTES + 4 * DS_RING_BYTES;
+constexpr size_t DS_LDS_BYTES = DS_RATIO_BYTES + DS_TABLE_BYTES + DS_LNM_BYTES + 4 * DS_TILE_BYTES + 4 * DS_RING_BYTES;
 static_assert(DS_LDS_BYTES <= 160 * 1024 && DS_RB % DS_NN == 0 && DS_TILE_T % DS_RB == 0, "LDS plan of the split discrete kernel");
 
-/* what a noise wave hands over per transition (16 bytes): everything of the step that does not depend on the state --
- * the direction, the accept uniform and the table logarithm the accept test filters with.  The transition wave is left
- * with two look-ups of the log-density table, the ratio and the comparison (round 2, end: it used to convert the
- * uniform and evaluate the table logarithm itself, from a table in global memory: a load per transition in the one
- * dependent chain of the kernel). */
-struct __attribute__((aligned(16))) ds_draw {
-    int32_t step;
-    float lf;
-    double u;
-};
 struct ds_lnm_lds { /* Tab of mm_lnu_f32 with the logarithm's rows in LDS */
     mm_lds_f4_ptr tab;
     __device__ __forceinline__ void row_ln(uint32_t r, float *c) const
@@ -132,42 +136,66 @@ struct ds_lnm_lds { /* Tab of mm_lnu_f32 with the logarithm's rows in LDS */
         c[3] = v[3];
     }
 };
+typedef double ds_ratio_pair __attribute__((ext_vector_type(2))); /* log accept ratio of the move down, of the move up */
+
+/* what a noise wave hands over per transition: -|table logarithm of (float)u| with the sign bit replaced by the
+ * direction (set = up).  Any value within the filter's band of ln u yields the exact decision, ln u <= 0, so dropping
+ * a positive sign the table's rounding may produce next to u = 1 moves the value towards ln u. */
+__device__ __forceinline__ uint32_t ds_draw_pack(const mm_u32x4 &b, const ds_lnm_lds &lt)
+{
+    const double u = mm_u53(b.w[2], b.w[3]);
+    return (mm_f2u(mm_lnu_f32((float)u, lt)) & 0x7fffffffu) | (b.w[0] & 0x80000000u);
+}
 
 /* KIND: the model (compile time: the proposal rule is a switch inside the transition) */
 template <int KIND>
 __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(const run_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ds_lds[];
-    double *tab_lds = reinterpret_cast<double *>(ds_lds);
-    float *lnm_lds = reinterpret_cast<float *>(ds_lds + DS_TABLE_BYTES);
+    ds_ratio_pair *ratio_lds = reinterpret_cast<ds_ratio_pair *>(ds_lds);
+    double *tab_lds = reinterpret_cast<double *>(ds_lds + DS_RATIO_BYTES);
+    float *lnm_lds = reinterpret_cast<float *>(ds_lds + DS_RATIO_BYTES + DS_TABLE_BYTES);
+    unsigned char *const per_pair = ds_lds + DS_RATIO_BYTES + DS_TABLE_BYTES + DS_LNM_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave & 3, noise_rank = (wave >> 2) - 1;
-    int32_t *tile = reinterpret_cast<int32_t *>(ds_lds + DS_TABLE_BYTES + DS_LNM_BYTES + (size_t)pair * DS_TILE_BYTES);
-    ds_draw *ring = reinterpret_cast<ds_draw *>(ds_lds + DS_TABLE_BYTES + DS_LNM_BYTES + 4 * DS_TILE_BYTES + (size_t)pair * DS_RING_BYTES);
+    int32_t *tile = reinterpret_cast<int32_t *>(per_pair + (size_t)pair * DS_TILE_BYTES);
+    uint32_t *ring = reinterpret_cast<uint32_t *>(per_pair + 4 * DS_TILE_BYTES + (size_t)pair * DS_RING_BYTES);
     mm_discrete_params P = a.P;
     P.kind = KIND;
-    for (int i = threadIdx.x; i < P.table_len && i < MM_DISCRETE_POISSON_TABLE; i += 256 * (1 + DS_NN))
+    constexpr int NT = 256 * (1 + DS_NN);
+    for (int i = threadIdx.x; i < P.table_len && i < MM_DISCRETE_POISSON_TABLE; i += NT)
         tab_lds[i] = a.P.logp[i];
-    for (int i = threadIdx.x; i < MM_LNM_ROWS; i += 256 * (1 + DS_NN))
+    for (int i = threadIdx.x; i < MM_LNM_ROWS; i += NT)
         reinterpret_cast<mm_v4f *>(lnm_lds)[i] = *reinterpret_cast<const mm_v4f *>(mm_lnm_tab_d + 4 * i);
     P.logp = tab_lds;
     P.table_len = P.table_len < MM_DISCRETE_POISSON_TABLE ? P.table_len : MM_DISCRETE_POISSON_TABLE;
+    __syncthreads(); /* the log-density table is complete */
+    for (int i = threadIdx.x; i <= P.table_len; i += NT) {
+        int prop;
+        ds_ratio_pair r;
+        r.x = mm_discrete_log_ratio(P, i, -1, &prop);
+        r.y = mm_discrete_log_ratio(P, i, 1, &prop);
+        ratio_lds[i] = r;
+    }
     const unsigned long long c0 = (unsigned long long)blockIdx.x * 256ull + (unsigned long long)pair * 64ull, c = c0 + lane;
     const unsigned long long chain = a.chain_offset + c;
     const unsigned int total = a.n_discard + a.n_collect;
-    __syncthreads(); /* the tables are complete */
+    __syncthreads(); /* ... and the table of the ratios */
     if (noise_rank >= 0) {
         ds_lnm_lds lt;
         lt.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(lnm_lds);
         int half = 0;
         for (unsigned int done = 0; done < total; done += DS_RB) {
             const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
-            for (unsigned int j = (unsigned int)noise_rank; j < nb; j += DS_NN) {
-                const mm_u32x4 b = mm_block(a.seed, chain, a.iter0 + done + j, 0u);
-                ds_draw d;
-                d.step = (b.w[0] >> 31) ? 1 : -1;
-                d.u = mm_u53(b.w[2], b.w[3]);
-                d.lf = mm_lnu_f32((float)d.u, lt);
-                ring[((size_t)half * DS_RB + j) * 64 + lane] = d;
+            uint32_t *const batch = ring + (size_t)half * DS_RB * 64 + lane;
+            if (nb == (unsigned int)DS_RB) {
+                MM_UNROLL
+                for (int k = 0; k < DS_RB / DS_NN; ++k) { /* independent blocks: their Philox rounds interleave */
+                    const unsigned int j = (unsigned int)(noise_rank + k * DS_NN);
+                    batch[(size_t)j * 64] = ds_draw_pack(mm_block(a.seed, chain, a.iter0 + done + j, 0u), lt);
+                }
+            } else {
+                for (unsigned int j = (unsigned int)noise_rank; j < nb; j += DS_NN)
+                    batch[(size_t)j * 64] = ds_draw_pack(mm_block(a.seed, chain, a.iter0 + done + j, 0u), lt);
             }
             half ^= 1;
             __syncthreads();
@@ -177,23 +205,63 @@ __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(co
     }
     const bool active = c < a.n_chains;
     int32_t x = active ? a.state[c] : 0;
+    /* wave-uniform: every chain inside the table (and then for good: a move out of it has ratio -inf) */
+    const bool tabulated = __all(x >= 0 && x < P.table_len) != 0;
+    ds_ratio_pair rx = tabulated ? ratio_lds[x] : ds_ratio_pair{0.0, 0.0};
     unsigned long long n_acc = 0;
     unsigned int col = 0, t0 = 0;
     int half = 0;
+    /* one transition of a tabulated chain given its packed draw */
+    auto step_tabulated = [&](uint32_t draw, unsigned int t) {
+        const bool up = (draw >> 31) != 0u;
+        const int prop = mm_discrete_propose(P, x, up ? 1 : -1);
+        const ds_ratio_pair rp = ratio_lds[prop]; /* in flight during the accept test */
+        const double ratio = up ? rx.y : rx.x;
+        const double mid = (double)mm_u2f(draw | 0x80000000u), band = 1e-6 + 1e-6 * -mid; /* mm_ratio_exceeds_ln_u_given */
+        bool accept = ratio > mid + band;
+        if (!accept && !(ratio <= mid - band)) { /* inside the band: the uniform again, and its f64 logarithm */
+            const mm_u32x4 b = mm_block(a.seed, chain, a.iter0 + t, 0u);
+            accept = ratio > mm_log(mm_u53(b.w[2], b.w[3]));
+        }
+        if (accept) {
+            x = prop;
+            rx = rp;
+            ++n_acc;
+        }
+    };
+    auto stage = [&](unsigned int t) { /* the sample of iteration t into the tile, the tile out when it is full */
+        if (t >= a.n_discard && a.out) {
+            tile[lane * DsTile::stride + col++] = x;
+            if (col == (unsigned int)DS_TILE_T || t + 1 == total) {
+                mm_flush_tile_raw<int32_t, 1, DsTile>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
+                t0 += col;
+                col = 0;
+            }
+        }
+    };
     for (unsigned int done = 0; done < total; done += DS_RB) {
         const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
         __syncthreads(); /* ring half `half` holds the draws of this batch */
-        for (unsigned int j = 0; j < nb; ++j) {
-            const ds_draw d = ring[((size_t)half * DS_RB + j) * 64 + lane];
-            n_acc += (unsigned long long)mm_discrete_step_draws(P, &x, d.step, d.u, d.lf);
-            const unsigned int t = done + j;
-            if (t >= a.n_discard && a.out) {
-                tile[lane * DsTile::stride + col++] = x;
-                if (col == (unsigned int)DS_TILE_T || t + 1 == total) {
-                    mm_flush_tile_raw<int32_t, 1, DsTile>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
-                    t0 += col;
-                    col = 0;
-                }
+        const uint32_t *const batch = ring + (size_t)half * DS_RB * 64 + lane;
+        if (!tabulated) {
+            for (unsigned int j = 0; j < nb; ++j) {
+                n_acc += (unsigned long long)mm_discrete_step(P, &x, a.seed, chain, a.iter0 + done + j);
+                stage(done + j);
+            }
+        } else if (nb == (unsigned int)DS_RB) {
+            uint32_t d[DS_RB];
+            MM_UNROLL
+            for (int j = 0; j < DS_RB; ++j)
+                d[j] = batch[(size_t)j * 64];
+            MM_UNROLL
+            for (int j = 0; j < DS_RB; ++j) {
+                step_tabulated(d[j], done + (unsigned int)j);
+                stage(done + (unsigned int)j);
+            }
+        } else {
+            for (unsigned int j = 0; j < nb; ++j) {
+                step_tabulated(batch[(size_t)j * 64], done + j);
+                stage(done + j);
             }
         }
         half ^= 1;
