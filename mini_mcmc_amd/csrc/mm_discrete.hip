@@ -115,7 +115,13 @@ __global__ __launch_bounds__(64) void mm_discrete_kernel(const run_args a)
  *     and the direction, not on the decision);
  *   - a batch's draws are read from the ring in one go and its transitions are unrolled.
  * A wave with a chain outside the table (only possible with such an initial state) keeps the plain transition. */
-constexpr int DS_NN = 3, DS_RB = 12, DS_TILE_T = 48;
+#ifndef MM_DS_NN /* measurement knobs (tools/experiments/ds_knobs.sh) */
+#define MM_DS_NN 3
+#endif
+#ifndef MM_DS_RB
+#define MM_DS_RB 12
+#endif
+constexpr int DS_NN = MM_DS_NN, DS_RB = MM_DS_RB, DS_TILE_T = 48;
 using DsTile = mm_tile_t<int32_t, 1, DS_TILE_T>;
 constexpr size_t DS_TILE_BYTES = (DsTile::lds_bytes_per_wave + 15) / 16 * 16;
 constexpr size_t DS_RING_BYTES = (size_t)2 * DS_RB * 64 * 4;
@@ -145,6 +151,15 @@ __device__ __forceinline__ uint32_t ds_draw_pack(const mm_u32x4 &b, const ds_lnm
 {
     const double u = mm_u53(b.w[2], b.w[3]);
     return (mm_f2u(mm_lnu_f32((float)u, lt)) & 0x7fffffffu) | (b.w[0] & 0x80000000u);
+}
+
+/* the batches of a run: DS_RB transitions, cut at n_discard -- so that the collected samples of a batch fill whole
+ * columns k * DS_RB .. of the tile and the tile is full exactly at the end of a batch (DS_TILE_T % DS_RB == 0) -- and at
+ * the end of the run.  Both roles walk the same sequence. */
+__device__ __forceinline__ unsigned int ds_batch(unsigned int done, unsigned int n_discard, unsigned int total)
+{
+    const unsigned int left = (done < n_discard ? n_discard : total) - done;
+    return left < (unsigned int)DS_RB ? left : (unsigned int)DS_RB;
 }
 
 /* KIND: the model (compile time: the proposal rule is a switch inside the transition) */
@@ -184,8 +199,8 @@ __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(co
         ds_lnm_lds lt;
         lt.tab = (mm_lds_f4_ptr)reinterpret_cast<const mm_v4f *>(lnm_lds);
         int half = 0;
-        for (unsigned int done = 0; done < total; done += DS_RB) {
-            const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
+        for (unsigned int done = 0, nb; done < total; done += nb) {
+            nb = ds_batch(done, a.n_discard, total);
             uint32_t *const batch = ring + (size_t)half * DS_RB * 64 + lane;
             if (nb == (unsigned int)DS_RB) {
                 MM_UNROLL
@@ -208,60 +223,91 @@ __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(co
     /* wave-uniform: every chain inside the table (and then for good: a move out of it has ratio -inf) */
     const bool tabulated = __all(x >= 0 && x < P.table_len) != 0;
     ds_ratio_pair rx = tabulated ? ratio_lds[x] : ds_ratio_pair{0.0, 0.0};
-    unsigned long long n_acc = 0;
-    unsigned int col = 0, t0 = 0;
+    unsigned int n_acc = 0, col = 0, t0 = 0;
     int half = 0;
-    /* one transition of a tabulated chain given its packed draw */
-    auto step_tabulated = [&](uint32_t draw, unsigned int t) {
-        const bool up = (draw >> 31) != 0u;
-        const int prop = mm_discrete_propose(P, x, up ? 1 : -1);
-        const ds_ratio_pair rp = ratio_lds[prop]; /* in flight during the accept test */
-        const double ratio = up ? rx.y : rx.x;
-        const double mid = (double)mm_u2f(draw | 0x80000000u), band = 1e-6 + 1e-6 * -mid; /* mm_ratio_exceeds_ln_u_given */
-        bool accept = ratio > mid + band;
-        if (!accept && !(ratio <= mid - band)) { /* inside the band: the uniform again, and its f64 logarithm */
-            const mm_u32x4 b = mm_block(a.seed, chain, a.iter0 + t, 0u);
-            accept = ratio > mm_log(mm_u53(b.w[2], b.w[3]));
+    for (unsigned int done = 0, nb; done < total; done += nb) {
+        nb = ds_batch(done, a.n_discard, total);
+        __syncthreads(); /* ring half `half` holds the draws of this batch */
+        const uint32_t *const batch = ring + (size_t)half * DS_RB * 64 + lane;
+        const bool collecting = done >= a.n_discard && a.out; /* a batch lies on one side of n_discard (ds_batch) */
+        int32_t *const row = tile + lane * DsTile::stride + col;
+        unsigned int j = 0;
+        if (tabulated && nb == (unsigned int)DS_RB) {
+            /* the common case, unrolled and free of branches: the batch's draws come out of the ring in one go and the
+             * filter's bounds are formed ahead of the chain of transitions.  A transition that finds its ratio inside
+             * the band (about 4e-6 of them) is decided provisionally; the batch is then run again, from the state it
+             * started in, by the loop below. */
+            double hi[DS_RB], lo[DS_RB];
+            bool up[DS_RB];
+            MM_UNROLL
+            for (int k = 0; k < DS_RB; ++k) {
+                const uint32_t d = batch[(size_t)k * 64];
+                const double mid = (double)mm_u2f(d | 0x80000000u), band = 1e-6 + 1e-6 * -mid; /* mm_ratio_exceeds_ln_u_given */
+                up[k] = (d >> 31) != 0u;
+                hi[k] = mid + band;
+                lo[k] = mid - band;
+            }
+            const int32_t x0 = x;
+            const ds_ratio_pair rx0 = rx;
+            const unsigned int n_acc0 = n_acc;
+            bool in_band = false, accept = false;
+            ds_ratio_pair rp = rx;
+            MM_UNROLL
+            for (int k = 0; k < DS_RB; ++k) {
+                /* the pair of the proposed state is asked for first and used by the NEXT transition: a look-up has a
+                 * whole transition to come back (two transitions share one LDS latency) */
+                const int prop = mm_discrete_propose(P, x, up[k] ? 1 : -1);
+                const ds_ratio_pair rp_next = ratio_lds[prop];
+                __builtin_amdgcn_sched_barrier(0);
+                rx = accept ? rp : rx; /* the previous transition's move, now that its look-up is back */
+                rp = rp_next;
+                const double ratio = up[k] ? rx.y : rx.x;
+                accept = ratio > hi[k];
+                in_band |= !accept && !(ratio <= lo[k]);
+                x = accept ? prop : x;
+                n_acc += accept ? 1u : 0u;
+                if (collecting)
+                    row[k] = x;
+            }
+            rx = accept ? rp : rx;
+            if (__any(in_band)) {
+                x = x0;
+                rx = rx0;
+                n_acc = n_acc0;
+            } else {
+                j = nb;
+            }
         }
-        if (accept) {
-            x = prop;
-            rx = rp;
-            ++n_acc;
+        for (; j < nb; ++j) {
+            const unsigned int t = done + j;
+            if (tabulated) {
+                const uint32_t draw = batch[(size_t)j * 64];
+                const bool up = (draw >> 31) != 0u;
+                const int prop = mm_discrete_propose(P, x, up ? 1 : -1);
+                const double ratio = up ? rx.y : rx.x;
+                const double mid = (double)mm_u2f(draw | 0x80000000u), band = 1e-6 + 1e-6 * -mid; /* mm_ratio_exceeds_ln_u_given */
+                bool accept = ratio > mid + band;
+                if (!accept && !(ratio <= mid - band)) { /* inside the band: the uniform again, and its f64 logarithm */
+                    const mm_u32x4 b = mm_block(a.seed, chain, a.iter0 + t, 0u);
+                    accept = ratio > mm_log(mm_u53(b.w[2], b.w[3]));
+                }
+                if (accept) {
+                    x = prop;
+                    rx = ratio_lds[prop];
+                    ++n_acc;
+                }
+            } else {
+                n_acc += (unsigned int)mm_discrete_step(P, &x, a.seed, chain, a.iter0 + t);
+            }
+            if (collecting)
+                row[j] = x;
         }
-    };
-    auto stage = [&](unsigned int t) { /* the sample of iteration t into the tile, the tile out when it is full */
-        if (t >= a.n_discard && a.out) {
-            tile[lane * DsTile::stride + col++] = x;
-            if (col == (unsigned int)DS_TILE_T || t + 1 == total) {
+        if (collecting) {
+            col += nb;
+            if (col == (unsigned int)DS_TILE_T || done + nb == total) {
                 mm_flush_tile_raw<int32_t, 1, DsTile>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
                 t0 += col;
                 col = 0;
-            }
-        }
-    };
-    for (unsigned int done = 0; done < total; done += DS_RB) {
-        const unsigned int nb = total - done < (unsigned int)DS_RB ? total - done : (unsigned int)DS_RB;
-        __syncthreads(); /* ring half `half` holds the draws of this batch */
-        const uint32_t *const batch = ring + (size_t)half * DS_RB * 64 + lane;
-        if (!tabulated) {
-            for (unsigned int j = 0; j < nb; ++j) {
-                n_acc += (unsigned long long)mm_discrete_step(P, &x, a.seed, chain, a.iter0 + done + j);
-                stage(done + j);
-            }
-        } else if (nb == (unsigned int)DS_RB) {
-            uint32_t d[DS_RB];
-            MM_UNROLL
-            for (int j = 0; j < DS_RB; ++j)
-                d[j] = batch[(size_t)j * 64];
-            MM_UNROLL
-            for (int j = 0; j < DS_RB; ++j) {
-                step_tabulated(d[j], done + (unsigned int)j);
-                stage(done + (unsigned int)j);
-            }
-        } else {
-            for (unsigned int j = 0; j < nb; ++j) {
-                step_tabulated(batch[(size_t)j * 64], done + j);
-                stage(done + j);
             }
         }
         half ^= 1;
