@@ -104,3 +104,46 @@ def test_gpu_discrete_bit_exact_and_pmf(O, name, params, init, pmf):
     assert np.array_equal(out[:512, :, 0].cpu().numpy(), ref) and np.array_equal(s.accept_counts()[:512], acc)
     hi = D.DiscreteMetropolisHastings(model, start[40000:]).seed(42).set_chain_offset(40000).run(200, 300)
     assert np.array_equal(hi, out[40000:].cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,params,init,pmf", CASES)
+def test_gpu_discrete_split_kernel_batches_tiles_and_band(O, name, params, init, pmf):
+    """The four-waves-per-SIMD kernel (from 4096 chains on; round 3: tabulated accept ratios, 4-byte draws, batches of
+    12 transitions cut at n_discard, tiles of 48 samples) against the one-wave kernel and the host build: run lengths
+    around every batch / tile boundary, a ragged last workgroup, continued runs, chains that start outside the table
+    (their wave keeps the plain transition), and -- over all 65 536 chains -- the transitions whose ratio falls inside
+    the accept filter's band (about 4 in 10^6: the batch is run again by the exact loop)."""
+    from mini_mcmc_amd import discrete as D
+
+    model = {"POISSON_REFLECT": D.PoissonReflect(4.0), "BINOMIAL_CLAMP": D.BinomialClamp(10, 0.3),
+             "POISSON_NONNEG": D.PoissonNonneg(4.0)}[name]
+    kind = getattr(O, name)
+    rng = np.random.default_rng(11)
+    C_ = 4096 + 77
+    start = rng.integers(0, 9, size=C_).astype(np.int32)
+    start[4000:4003] = 5000  # beyond the table: log-density -inf
+    if name != "BINOMIAL_CLAMP":
+        start[130] = 1023  # the last tabulated state
+    for nc, nd in ((1, 0), (11, 1), (12, 12), (13, 11), (47, 13), (48, 0), (49, 24), (100, 5), (96, 36), (7, 100)):
+        a = D.DiscreteMetropolisHastings(model, start).seed(3)
+        b = D.DiscreteMetropolisHastings(model, start).seed(3).set_kernel_variant(0)
+        oa, ob = a.run(nc, nd), b.run(nc, nd)
+        assert np.array_equal(oa, ob), (name, nc, nd)
+        assert np.array_equal(a.state(), b.state()) and np.array_equal(a.accept_counts(), b.accept_counts()), (name, nc, nd)
+        ref, st, acc = O.engine_host_discrete_run(kind, params, start[3900:4200], nc, nd, seed=3, chain_offset=3900)
+        assert np.array_equal(oa[3900:4200, :, 0], ref) and np.array_equal(a.accept_counts()[3900:4200], acc), (name, nc, nd)
+        oa2, ob2 = a.run(50, 3), b.run(50, 3)  # continued: stream position and state carry over
+        assert np.array_equal(oa2, ob2) and np.array_equal(a.accept_counts(), b.accept_counts()), (name, nc, nd)
+    # no output buffer: states and counts only
+    a = D.DiscreteMetropolisHastings(model, start).seed(3)
+    b = D.DiscreteMetropolisHastings(model, start).seed(3).set_kernel_variant(0)
+    a.run(0, 77), b.run(0, 77)
+    assert np.array_equal(a.state(), b.state()) and np.array_equal(a.accept_counts(), b.accept_counts())
+    # every chain of the full-size run, both kernels (3e7 transitions: ~100 of them inside the band)
+    C_ = 65536
+    start = np.full(C_, init, dtype=np.int32)
+    a = D.DiscreteMetropolisHastings(model, start).seed(42)
+    b = D.DiscreteMetropolisHastings(model, start).seed(42).set_kernel_variant(0)
+    oa, ob = a.run(400, 100, to="torch"), b.run(400, 100, to="torch")
+    assert bool((oa == ob).all()) and np.array_equal(a.accept_counts(), b.accept_counts())
