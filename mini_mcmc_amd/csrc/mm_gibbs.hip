@@ -101,6 +101,15 @@ struct __attribute__((aligned(16))) gs_draw {
     double z0, u;
 };
 
+/* the batches of a run: GS_RB sweeps, cut at n_discard (the collected sweeps of a batch fill whole columns of the tile and
+ * the tile is full exactly at the end of a batch: GS_TILE_T % GS_RB == 0) and at the end of the run; both roles walk the
+ * same sequence (as in mm_discrete.hip) */
+__device__ __forceinline__ unsigned int gs_batch(unsigned int done, unsigned int n_discard, unsigned int total)
+{
+    const unsigned int left = (done < n_discard ? n_discard : total) - done;
+    return left < (unsigned int)GS_RB ? left : (unsigned int)GS_RB;
+}
+
 __global__ __launch_bounds__(256 * (1 + GS_NN)) void mm_gibbs_mixture_split_kernel(const run_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
@@ -112,12 +121,13 @@ __global__ __launch_bounds__(256 * (1 + GS_NN)) void mm_gibbs_mixture_split_kern
     const unsigned int total = a.n_discard + a.n_collect;
     if (noise_rank >= 0) {
         int half = 0;
-        for (unsigned int done = 0; done < total; done += GS_RB) {
-            const unsigned int nb = total - done < (unsigned int)GS_RB ? total - done : (unsigned int)GS_RB;
+        for (unsigned int done = 0, nb; done < total; done += nb) {
+            nb = gs_batch(done, a.n_discard, total);
+            gs_draw *const batch = ring + (size_t)half * GS_RB * 64 + lane;
             for (unsigned int j = (unsigned int)noise_rank; j < nb; j += GS_NN) {
                 gs_draw d;
                 mm_gibbs_mixture_noise(a.seed, chain, a.iter0 + done + j, &d.z0, &d.u);
-                ring[((size_t)half * GS_RB + j) * 64 + lane] = d;
+                batch[(size_t)j * 64] = d;
             }
             half ^= 1;
             __syncthreads();
@@ -129,22 +139,43 @@ __global__ __launch_bounds__(256 * (1 + GS_NN)) void mm_gibbs_mixture_split_kern
     double s[2] = {active ? a.state[2 * c] : 0.0, active ? a.state[2 * c + 1] : 0.0};
     unsigned int col = 0, t0 = 0;
     int half = 0;
-    for (unsigned int done = 0; done < total; done += GS_RB) {
-        const unsigned int nb = total - done < (unsigned int)GS_RB ? total - done : (unsigned int)GS_RB;
+    for (unsigned int done = 0, nb; done < total; done += nb) {
+        nb = gs_batch(done, a.n_discard, total);
         __syncthreads(); /* ring half `half` holds the draws of this batch */
-        for (unsigned int j = 0; j < nb; ++j) {
-            const gs_draw d = ring[((size_t)half * GS_RB + j) * 64 + lane];
-            mm_gibbs_mixture_step_noise(a.P, s, d.z0, d.u);
-            const unsigned int t = done + j;
-            if (t >= a.n_discard && a.out) {
-                tile[lane * GsTile::stride + 2 * col] = s[0];
-                tile[lane * GsTile::stride + 2 * col + 1] = s[1];
-                ++col;
-                if (col == (unsigned int)GS_TILE_T || t + 1 == total) {
-                    mm_flush_tile_raw<double, 2, GsTile>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
-                    t0 += col;
-                    col = 0;
+        const gs_draw *const batch = ring + (size_t)half * GS_RB * 64 + lane;
+        const bool collecting = done >= a.n_discard && a.out; /* a batch lies on one side of n_discard */
+        double *const row = tile + lane * GsTile::stride + 2 * col;
+        if (nb == (unsigned int)GS_RB) {
+            /* a full batch: its draws come out of the ring in one go (one LDS latency per batch, not one per sweep, in
+             * the kernel's one dependent chain), the sweeps are unrolled */
+            gs_draw d[GS_RB];
+            MM_UNROLL
+            for (int k = 0; k < GS_RB; ++k)
+                d[k] = batch[(size_t)k * 64];
+            MM_UNROLL
+            for (int k = 0; k < GS_RB; ++k) {
+                mm_gibbs_mixture_step_noise(a.P, s, d[k].z0, d[k].u);
+                if (collecting) {
+                    row[2 * k] = s[0];
+                    row[2 * k + 1] = s[1];
                 }
+            }
+        } else {
+            for (unsigned int k = 0; k < nb; ++k) {
+                const gs_draw d = batch[(size_t)k * 64];
+                mm_gibbs_mixture_step_noise(a.P, s, d.z0, d.u);
+                if (collecting) {
+                    row[2 * k] = s[0];
+                    row[2 * k + 1] = s[1];
+                }
+            }
+        }
+        if (collecting) {
+            col += nb;
+            if (col == (unsigned int)GS_TILE_T || done + nb == total) {
+                mm_flush_tile_raw<double, 2, GsTile>(a.out, a.n_collect, a.n_chains, tile, lane, c0, t0, col);
+                t0 += col;
+                col = 0;
             }
         }
         half ^= 1;
