@@ -448,8 +448,12 @@ def test_stats_partials_fft_vs_direct_lag_sums(M, O):
     from mini_mcmc_amd import stats as S
 
     rng = np.random.default_rng(5)
-    for c, n, p in [(257, 400, 3), (100, 1000, 3), (31, 333, 4), (12, 2047, 1), (50, 250, 6)]:
+    # the last rows: half-chain lengths around the transform sizes 512 / 1024 / 2048 (m = 101 is the shortest, 1024 the longest)
+    for c, n, p in [(257, 400, 3), (100, 1000, 3), (31, 333, 4), (12, 2047, 1), (50, 250, 6), (8, 202, 2), (9, 512, 3),
+                    (9, 514, 1), (5, 1024, 2), (5, 1026, 3), (3, 2046, 1), (3, 2048, 2), (20, 400, 3)]:
         x = _ar1(rng, c, n, p)
+        if (c, n) == (20, 400):
+            x = x.astype(np.float64)  # f64 samples take the same kernel (converted on load)
         x[:, :, 0] += 100.0  # a mean far from zero: the centring happens before the transform
         t = torch.from_numpy(x).cuda()
         out = {}
