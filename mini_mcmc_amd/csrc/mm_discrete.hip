@@ -162,6 +162,16 @@ __device__ __forceinline__ unsigned int ds_batch(unsigned int done, unsigned int
     return left < (unsigned int)DS_RB ? left : (unsigned int)DS_RB;
 }
 
+__device__ __forceinline__ void ds_setprio(int p)
+{
+    switch (p) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 /* KIND: the model (compile time: the proposal rule is a switch inside the transition) */
 template <int KIND>
 __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(const run_args a)
@@ -205,6 +215,10 @@ __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(co
             if (nb == (unsigned int)DS_RB) {
                 MM_UNROLL
                 for (int k = 0; k < DS_RB / DS_NN; ++k) { /* independent blocks: their Philox rounds interleave */
+                    /* the arbiter serves the highest priority first, then the oldest wave: a noise wave lowers its priority
+                     * with every draw of the batch it has made, so that the three end their shares together instead of one
+                     * after the other (the last one alone on the SIMD at a lone wave's issue rate): -3 % */
+                    ds_setprio(3 - k > 0 ? 3 - k : 0);
                     const unsigned int j = (unsigned int)(noise_rank + k * DS_NN);
                     batch[(size_t)j * 64] = ds_draw_pack(mm_block(a.seed, chain, a.iter0 + done + j, 0u), lt);
                 }
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(256 * (1 + DS_NN)) void mm_discrete_split_kernel(co
         __syncthreads();
         return;
     }
+    __builtin_amdgcn_s_setprio(3); /* the transition wave's dependent chain is the longer leg of a batch */
     const bool active = c < a.n_chains;
     int32_t x = active ? a.state[c] : 0;
     /* wave-uniform: every chain inside the table (and then for good: a move out of it has ratio -inf) */

@@ -14,7 +14,7 @@ for _ in range(3):
     s.run(1000, 100, to="torch")
 torch.cuda.synchronize()
 ts = []
-for _ in range(9):
+for _ in range(25):
     t0 = time.perf_counter(); s.run(1000, 100, to="torch"); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 print(f"{sys.argv[1].split('/')[-1]}: median {np.median(ts) * 1e3:.4f} ms  min {min(ts) * 1e3:.4f}", flush=True)
 '''
