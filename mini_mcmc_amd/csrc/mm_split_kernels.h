@@ -167,6 +167,19 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     if (!noise_wave)
         __builtin_amdgcn_s_setprio(MM_SPLIT_PRIO_Q);
 #endif
+#ifdef MM_SPLIT_PRIO_N /* experiment hook: 1 = younger noise waves first (against the arbiter's oldest-first), 2 = older first */
+    if (noise_wave) {
+        const int pr = MM_SPLIT_PRIO_N == 1 ? noise_rank : MM_SPLIT_PRIO_N == 2 ? 2 - noise_rank : MM_SPLIT_PRIO_N == 3 ? 1 : MM_SPLIT_PRIO_N == 4 ? noise_rank + 1 : (noise_rank == 2 ? 2 : 0);
+        if (pr <= 0)
+            __builtin_amdgcn_s_setprio(0);
+        else if (pr == 1)
+            __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2)
+            __builtin_amdgcn_s_setprio(2);
+        else
+            __builtin_amdgcn_s_setprio(3);
+    }
+#endif
 
     if (noise_wave) {
         __syncthreads(); /* the table is complete */
