@@ -28,6 +28,7 @@
 #include <cmath>
 #include <new>
 #include <vector>
+#include "mm_tuning.h"
 
 #define MM_HIP(expr)                                                                                              \
     do {                                                                                                          \
@@ -190,18 +191,153 @@ __global__ __launch_bounds__(64) void tracker_step_tiled_kernel(const T *__restr
     }
 }
 
+/* The same step with the parameters of a chain spread over the waves of a workgroup: 64 chains x D waves, wave d keeps
+ * (mean, mean of squares, last value) of parameter d of its lane's chain.  The kernel above is bound by instruction issue,
+ * not by memory -- 107 vector instructions per row (two IEEE divisions per parameter) at the 5 cycles a lone wave per SIMD
+ * gets: 180 us for 315 MB -- and 65 536 chains are one wave per SIMD; here they are D, issuing side by side (2.2 cycles
+ * per instruction and SIMD).  The tile is fetched by all 64 D threads (V / D 16-byte pieces each), a wave
+ * reads column d of its lane's 16 rows, the "this row differs from the last" bits of the D parameters meet in LDS and
+ * wave 0 folds them into the chain's acceptance average and the flags.  Same recurrences in the same order:
+ * bit-identical to tracker_step_kernel. */
+template <class T, int D>
+__global__ __launch_bounds__(64 * (D + 1)) void tracker_step_dims_kernel(const T *__restrict__ states, unsigned long long C,
+                                                                         unsigned long long n_rows, unsigned long long t0,
+                                                                         unsigned int k, unsigned long long n_before,
+                                                                         float *__restrict__ mean, float *__restrict__ mean_sq,
+                                                                         float *__restrict__ last, float *__restrict__ p_chain,
+                                                                         unsigned char *__restrict__ flags /* [k, C] */)
+{
+    constexpr int TT = 16, EPL = 16 / (int)sizeof(T), RUN = TT * D, V = RUN / EPL, PITCH = RUN + EPL;
+    constexpr int PER = V / D; /* 16-byte pieces of a tile per thread of the D parameter waves: 4 (f32), 8 (f64) */
+    static_assert(V % D == 0, "pieces per thread");
+    typedef T vec16 __attribute__((ext_vector_type(EPL), aligned(sizeof(T))));
+    typedef T vec16a __attribute__((ext_vector_type(EPL)));
+    __shared__ __attribute__((aligned(16))) T tile[64 * PITCH];
+    /* per tile and chain: bit t of difs[b][d][lane] = "parameter d of row t differs from the row before"; two buffers: the
+     * bookkeeping wave folds tile i while the parameter waves fill tile i + 1 */
+    __shared__ __attribute__((aligned(16))) unsigned int difs[2][D + 1][64];
+    const int lane = threadIdx.x & 63, dim = threadIdx.x >> 6;
+    const unsigned long long wave_c0 = (unsigned long long)blockIdx.x * 64, c = wave_c0 + lane;
+    const bool active = c < C;
+    const unsigned int n_valid = (unsigned int)(C - wave_c0 < 64 ? C - wave_c0 : 64);
+    const unsigned int n_tiles = k / TT;
+    if (dim == D) {
+        /* ---- the bookkeeping wave: acceptance average of the chain (a sequential recurrence over the rows) and the flags;
+         * one tile behind the parameter waves, beside their next tile's rows (it used to be wave 0's tail: every other wave
+         * of the workgroup waited for it, tools/experiments/tracker_probe.hip) ---- */
+        float pc = active ? p_chain[c] : 0.f;
+        for (unsigned int i = 0; i <= n_tiles; ++i) {
+            if (i < n_tiles)
+                __syncthreads(); /* A_i: tile i staged (nothing to do with it here) */
+            if (i > 0) {
+                const unsigned int b = (i - 1) & 1u, tr = (i - 1) * TT;
+                const unsigned int dif0 = difs[b][0][lane];
+                unsigned int any = dif0;
+#pragma unroll
+                for (int d = 1; d < D; ++d)
+                    any |= difs[b][d][lane];
+                if (n_valid == 64u && (C & 15ull) == 0ull) {
+                    /* the tile's flags, 16 rows x 64 chains, leave as ONE 16-byte store per lane instead of 16 one-byte
+                     * stores: lane 4 r + g writes the flags of row r, chains 16 g .. 16 g + 15, assembled from those
+                     * chains' 16-bit masks */
+                    difs[b][D][lane] = any;
+                    __builtin_amdgcn_wave_barrier(); /* LDS operations of one wave execute in order */
+                    const int r = lane >> 2, g = lane & 3;
+                    unsigned int w[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const uint4 mk = *reinterpret_cast<const uint4 *>(&difs[b][D][16 * g + 4 * q4]);
+                        w[q4] = ((mk.x >> r) & 1u) | (((mk.y >> r) & 1u) << 8) | (((mk.z >> r) & 1u) << 16) | (((mk.w >> r) & 1u) << 24);
+                    }
+                    *reinterpret_cast<uint4 *>(flags + (size_t)(tr + r) * C + wave_c0 + 16 * g) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else if (active) {
+#pragma unroll 4
+                    for (int t = 0; t < TT; ++t)
+                        flags[(size_t)(tr + t) * C + c] = (unsigned char)((any >> t) & 1u);
+                }
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const int ne = (int)((any >> t) & 1u), ne0 = (int)((dif0 >> t) & 1u);
+                        const float p_start = (pc >= 0.0f) ? pc : (float)ne0; /* stats.rs:109-123 (Q12) */
+                        pc = (1.0f - kAlpha) * p_start + kAlpha * (float)ne;
+                    }
+                }
+            }
+            if (i < n_tiles)
+                __syncthreads(); /* B_i: the bits of tile i are in */
+        }
+        if (active)
+            p_chain[c] = pc;
+        return;
+    }
+    /* ---- parameter wave `dim` ---- */
+    float m = active ? mean[c * D + dim] : 0.f, q = active ? mean_sq[c * D + dim] : 0.f, l = active ? last[c * D + dim] : 0.f;
+    vec16 pre[PER];
+    auto request = [&](unsigned int trow) {
+#pragma unroll
+        for (int kk = 0; kk < PER; ++kk) {
+            const int p = kk * 64 * D + (int)threadIdx.x, j = p / V, e = (p - j * V) * EPL;
+            vec16 v = {};
+            if ((unsigned int)j < n_valid)
+                v = *reinterpret_cast<const vec16 *>(states + ((wave_c0 + j) * n_rows + t0 + trow) * D + e);
+            pre[kk] = v;
+        }
+    };
+    request(0);
+    for (unsigned int i = 0; i < n_tiles; ++i) {
+        const unsigned int tr = i * TT;
+#pragma unroll
+        for (int kk = 0; kk < PER; ++kk) {
+            const int p = kk * 64 * D + (int)threadIdx.x, j = p / V, e = (p - j * V) * EPL;
+            *reinterpret_cast<vec16a *>(tile + j * PITCH + e) = pre[kk];
+        }
+        if (i + 1 < n_tiles)
+            request(tr + TT);
+        __syncthreads(); /* A_i: the tile is complete */
+        unsigned int dif = 0;
+        {
+            const T *rows = tile + lane * PITCH + dim;
+#pragma unroll 4
+            for (int t = 0; t < TT; ++t) {
+                const unsigned long long n_i = n_before + tr + t + 1;
+                const float n = (float)n_i;
+                const float x = (float)rows[t * D];
+                m = (m * (n - 1.0f) + x) / n;
+                q = (n_i == 1) ? x * x : (q * (n - 1.0f) + x * x) / n;
+                dif |= (x != l) ? (1u << t) : 0u;
+                l = x;
+            }
+        }
+        difs[i & 1u][dim][lane] = dif;
+        __syncthreads(); /* B_i: the bits of every parameter are in; nobody reads the tile any more */
+    }
+    if (active) {
+        mean[c * D + dim] = m;
+        mean_sq[c * D + dim] = q;
+        last[c * D + dim] = l;
+    }
+}
+
 template <class T>
 static bool launch_step_tiled(int D, unsigned int grid, hipStream_t st, const T *states, unsigned long long C,
                               unsigned long long n_rows, unsigned long long t0, unsigned int k,
                               unsigned long long n_before, float *mean, float *mean_sq, float *last, float *p_chain,
                               unsigned char *flags)
 {
+    /* one wave per 64 chains (all parameters in one lane) only as the measurement's reference: MMCMC_TRACKER_ONE_WAVE */
+    const bool one_wave = mm_tuning_env("MMCMC_TRACKER_ONE_WAVE") != nullptr;
 #define MM_TILED(DD)                                                                                              \
     case DD:                                                                                                      \
         if (DD * sizeof(T) <= 32) {                                                                               \
-            hipLaunchKernelGGL((tracker_step_tiled_kernel<T, (DD * sizeof(T) <= 32 ? DD : 1)>), dim3(grid),      \
-                               dim3(64), 0, st, states, C, n_rows, t0, k, n_before, mean, mean_sq, last, p_chain, \
-                               flags);                                                                            \
+            if (DD > 1 && !one_wave)                                                                              \
+                hipLaunchKernelGGL((tracker_step_dims_kernel<T, (DD * sizeof(T) <= 32 ? DD : 1)>), dim3(grid),   \
+                                   dim3(64 * (DD + 1)), 0, st, states, C, n_rows, t0, k, n_before, mean, mean_sq, last, \
+                                   p_chain, flags);                                                               \
+            else                                                                                                  \
+                hipLaunchKernelGGL((tracker_step_tiled_kernel<T, (DD * sizeof(T) <= 32 ? DD : 1)>), dim3(grid),  \
+                                   dim3(64), 0, st, states, C, n_rows, t0, k, n_before, mean, mean_sq, last,      \
+                                   p_chain, flags);                                                               \
             return true;                                                                                          \
         }                                                                                                         \
         return false;
@@ -220,52 +356,84 @@ static bool launch_step_tiled(int D, unsigned int grid, hipStream_t st, const T 
 #undef MM_TILED
 }
 
-/* sequential replay of the last `len` <= kTail flags (time-major, chain-minor order).  One wave: lane l first loads
- * its contiguous share of the flags into registers (so the dependent chain below never waits for memory), then the
- * lanes fold their shares one after the other, handing p from lane to lane -- the reference's order exactly.  Most
- * calls end after the last 4096 flags (the certificate below): 0.26 -> 0.07 ms. */
+/* sequential replay of the last `len` <= kTail flags (time-major, chain-minor order).  One wave.  Lane l first loads
+ * its contiguous share of 256 flags into eight words of bits (16-byte loads when the share is aligned).  The recurrence
+ * itself runs in the LANES: every lane carries one value of p through the same flags, which are wave-uniform (read from
+ * their owner with v_readlane, the bit tests and the addend alpha / 0 on the scalar unit) -- lane 0 starts from p = 0,
+ * lane 1 from p = 1: the two replays of the certificate cost one multiply and one add per flag together, where they were
+ * two of each plus the bit's extraction and conversion in the one lane that owned the flags (0.097 -> 0.04 ms for the
+ * 4096 flags of the certificate, round 3). */
+template <bool FULL>
+__device__ __forceinline__ float tracker_fold_block(float p, const unsigned int (&w)[kTail / 64 / 32], unsigned int n)
+{
+#pragma unroll
+    for (unsigned int i = 0; i < kTail / 64 / 32; ++i) {
+#pragma unroll
+        for (unsigned int b = 0; b < 32; ++b)
+            if (FULL || i * 32 + b < n) {
+                const float a = ((w[i] >> b) & 1u) ? kAlpha : 0.0f; /* = kAlpha * accepted, exactly */
+                p = (1.0f - kAlpha) * p + a;                         /* fl(fl((1 - a) p) + fl(a f)): stats.rs:113-123 */
+            }
+    }
+    return p;
+}
+
 __global__ __launch_bounds__(64) void tracker_paccept_kernel(const unsigned char *__restrict__ flags, size_t first,
                                                              size_t len, int restart, float *p_accept)
 {
-    constexpr unsigned int per = (unsigned int)(kTail / 64); /* flags per lane */
+    constexpr unsigned int per = (unsigned int)(kTail / 64), NW = per / 32; /* flags, words of bits per lane */
     const unsigned int lane = threadIdx.x;
-    unsigned int bits[per / 32];
+    unsigned int bits[NW];
     const size_t lo = (size_t)lane * per;
-#pragma unroll
-    for (unsigned int w = 0; w < per / 32; ++w) {
-        unsigned int v = 0;
-        for (unsigned int b = 0; b < 32; ++b) {
-            const size_t i = lo + w * 32 + b;
-            if (i < len && flags[first + i])
-                v |= 1u << b;
-        }
-        bits[w] = v;
-    }
     const unsigned int mine = lo < len ? (unsigned int)((len - lo) < per ? (len - lo) : per) : 0u;
+    if (mine == per && ((reinterpret_cast<size_t>(flags) + first) & 15u) == 0u) {
+        /* 16 flags per load; four 0 / 1 bytes of a word become four bits by one multiply (the partial products land on
+         * distinct bits, the wanted ones on 28..31) */
+        const uint4 *src = reinterpret_cast<const uint4 *>(flags + first + lo);
+#pragma unroll
+        for (unsigned int w = 0; w < NW; ++w) {
+            const uint4 q0 = src[2 * w], q1 = src[2 * w + 1];
+            const unsigned int d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            unsigned int v = 0;
+#pragma unroll
+            for (unsigned int k = 0; k < 8; ++k)
+                v |= (((d[k] & 0x01010101u) * 0x10204080u) >> 28) << (4 * k);
+            bits[w] = v;
+        }
+    } else {
+#pragma unroll
+        for (unsigned int w = 0; w < NW; ++w) {
+            unsigned int v = 0;
+            for (unsigned int b = 0; b < 32; ++b) {
+                const size_t i = lo + w * 32 + b;
+                if (i < len && flags[first + i])
+                    v |= 1u << b;
+            }
+            bits[w] = v;
+        }
+    }
+    /* the flags of lane l's share, wave-uniform */
+    auto fold_share = [&](float p, unsigned int l) -> float {
+        unsigned int w[NW];
+#pragma unroll
+        for (unsigned int i = 0; i < NW; ++i)
+            w[i] = (unsigned int)__builtin_amdgcn_readlane((int)bits[i], (int)l);
+        const unsigned int n = (unsigned int)__builtin_amdgcn_readlane((int)mine, (int)l);
+        return n == per ? tracker_fold_block<true>(p, w, n) : tracker_fold_block<false>(p, w, n);
+    };
     /* A certificate first: one step, fl(fl((1 - a) p) + fl(a f)), is a monotone map of p, so is any run of steps, and the
-     * true value lies in [0, 1].  Replay only the last kCert flags from p = 0 and from p = 1 (two independent chains, the
-     * same latency as one): if the two arrive at the same number, every start in between does -- that number IS the
-     * sequential result over the whole history, bit for bit, whatever came before.  The map contracts by 0.99 per flag
-     * ((0.99)^4096 = 1e-18), so this succeeds in practice always; if it ever does not, the full replay below decides. */
+     * true value lies in [0, 1].  Replay only the last kCert flags from p = 0 and from p = 1: if the two arrive at the same
+     * number, every start in between does -- that number IS the sequential result over the whole history, bit for bit,
+     * whatever came before.  The map contracts by 0.99 per flag ((0.99)^4096 = 1e-18), so this succeeds in practice always
+     * (not on a run of equal flags: several f32 fixed points); if it does not, the full replay below decides. */
+    const unsigned int last_lane = len ? (unsigned int)((len - 1) / per) : 0u;
     {
         constexpr unsigned int kCertLanes = 16; /* 16 x 256 = 4096 flags */
-        const unsigned int last_lane = len ? (unsigned int)((len - 1) / per) : 0u;
         const unsigned int l0 = last_lane + 1u > kCertLanes ? last_lane + 1u - kCertLanes : 0u;
-        float plo = 0.0f, phi = 1.0f;
-        for (unsigned int l = l0; l <= last_lane; ++l) {
-            if (lane == l) {
-#pragma unroll
-                for (unsigned int w = 0; w < per / 32; ++w)
-                    for (unsigned int b = 0; b < 32; ++b)
-                        if (w * 32 + b < mine) {
-                            const float accepted = (float)((bits[w] >> b) & 1u);
-                            plo = (1.0f - kAlpha) * plo + kAlpha * accepted;
-                            phi = (1.0f - kAlpha) * phi + kAlpha * accepted;
-                        }
-            }
-            plo = __shfl(plo, (int)l, 64);
-            phi = __shfl(phi, (int)l, 64);
-        }
+        float p = lane == 1u ? 1.0f : 0.0f;
+        for (unsigned int l = l0; l <= last_lane; ++l)
+            p = fold_share(p, l);
+        const float plo = __shfl(p, 0, 64), phi = __shfl(p, 1, 64);
         if (len && plo == phi) { /* wave-uniform */
             if (lane == 0)
                 *p_accept = plo;
@@ -273,18 +441,8 @@ __global__ __launch_bounds__(64) void tracker_paccept_kernel(const unsigned char
         }
     }
     float p = restart ? 0.5f : *p_accept; /* restart: the sequence before `first` is forgotten anyway */
-    for (unsigned int l = 0; l < 64; ++l) {
-        if (lane == l) {
-#pragma unroll
-            for (unsigned int w = 0; w < per / 32; ++w)
-                for (unsigned int b = 0; b < 32; ++b)
-                    if (w * 32 + b < mine) {
-                        const float accepted = (float)((bits[w] >> b) & 1u);
-                        p = (1.0f - kAlpha) * p + kAlpha * accepted;
-                    }
-        }
-        p = __shfl(p, (int)l, 64);
-    }
+    for (unsigned int l = 0; l <= last_lane && len; ++l)
+        p = fold_share(p, l);
     if (lane == 0)
         *p_accept = p;
 }

@@ -19,7 +19,8 @@ def test_tracker_matches_reference_semantics(O):
     from mini_mcmc_amd import stats as S
 
     rng = np.random.default_rng(8)
-    for chains, steps, params in ((4, 30, 2), (300, 57, 3), (20000, 12, 3)):
+    # parameters 2 ... 8: one wave per parameter (tracker_step_dims_kernel); 1: all in one wave; f64 input up to 4
+    for chains, steps, params in ((4, 30, 2), (300, 57, 3), (20000, 12, 3), (70, 40, 5), (129, 33, 8), (64, 32, 1), (100, 49, 4)):
         # states with repeats (rejections): a chain keeps its previous state with probability 0.35
         x = rng.standard_normal((steps, chains, params)).astype(np.float32)
         keep = rng.random((steps, chains)) < 0.35
