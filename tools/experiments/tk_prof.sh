@@ -1,3 +1,6 @@
+# Kernel times of the tracker (rocprofv3 --kernel-trace) for every library build copied to tools/experiments/tk/lib_*.so
+# (e.g. cp mini_mcmc_amd/libmmcmc.so tools/experiments/tk/lib_new.so), on an HMC sample [65536, 400, 3]:
+#   bash tools/experiments/tk_prof.sh      (on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for l in $R/tools/experiments/tk/lib_*.so; do
