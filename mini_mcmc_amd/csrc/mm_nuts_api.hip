@@ -268,7 +268,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int set_variant(int v) override
     {
-        if ((v == 0 && k) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 5 && k && k->run_pair) ||
+        if ((v == 0 && (k || user)) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 5 && k && k->run_pair) ||
             (v == 6 && generic_ok) || (v == 7 && user)) {
             variant = v;
             return MMCMC_OK;
@@ -542,7 +542,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
         const int type_mode = std::is_same<TT, double>::value ? 2 : (std::is_same<ST, double>::value ? 0 : 1);
         const unsigned int grid64 = (unsigned int)((n_chains + 63) / 64);
         hipError_t e;
-        if (variant == 7) {
+        const bool rtc_target = user && (variant == 7 || (variant == 0 && !k)); /* kernels of a run-time compiled unit */
+        if (rtc_target) {
             mm_nuts_init_args<TT, ST> ia;
             ia.P = P;
             ia.state = d_state;
@@ -598,8 +599,15 @@ template <class TT, class ST> struct Nuts : NutsBase {
             a.n_rec = (unsigned int)n_collect;
         }
         MM_HIP(hipEventRecord(ev0, st));
-        if (variant == 7) {
-            e = mm_rtc_launch_nuts(user, type_mode, 0, &a, sizeof(a), grid64, user_lds, st);
+        if (rtc_target) {
+            /* a run-time compiled target: asynchronous lanes with the leaves in pairs (mm_nuts_pair_body; dynamic LDS = the
+             * ring of uniforms, stack in the scratch area) up to MM_RTC_NUTS_PAIR_MAX_DIM dimensions, else -- and as
+             * variant 0 -- the lanes in step (mm_nuts_run_body); bit-identical */
+            e = hipErrorNotFound;
+            if (variant == 7 && dim <= MM_RTC_NUTS_PAIR_MAX_DIM)
+                e = mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
+            if (e == hipErrorNotFound)
+                e = mm_rtc_launch_nuts(user, type_mode, 0, &a, sizeof(a), grid64, user_lds, st);
         } else if (use_generic) {
             ga.out = d_out;
             ga.n_pre = a.n_pre;

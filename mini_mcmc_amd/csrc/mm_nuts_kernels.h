@@ -358,8 +358,10 @@ __global__ __launch_bounds__(64) void mm_nuts_async_kernel(const mm_nuts_args<TT
 #define MM_NP_ADD(i, v) ((void)0)
 #define MM_NP_LANES(i, cond) ((void)0)
 #endif
+/* the kernel proper is a device function so that a run-time compiled unit (csrc/mm_rtc.hip: user targets, built-in targets
+ * at dimensions without a compiled instance) can wrap it in an extern "C" kernel of its own, like mm_nuts_run_body */
 template <class TT, class ST, class Tgt, bool LDS_STACK>
-__global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT, ST> a)
+__device__ __forceinline__ void mm_nuts_pair_body(const mm_nuts_args<TT, ST> &a)
 {
     constexpr int D = Tgt::dim;
     using Lay = mm_nuts_stack_layout<TT, ST, D>;
@@ -531,6 +533,12 @@ __global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT,
     if (a.n_leapfrog && lane < 16)
         a.n_leapfrog[c] = np_[lane];
 #endif
+}
+
+template <class TT, class ST, class Tgt, bool LDS_STACK>
+__global__ __launch_bounds__(64) void mm_nuts_pair_kernel(const mm_nuts_args<TT, ST> a)
+{
+    mm_nuts_pair_body<TT, ST, Tgt, LDS_STACK>(a);
 }
 
 #if !defined(__HIPCC_RTC__) /* host side: not part of the run-time compiled kernels of user targets (mm_rtc.hip) */
