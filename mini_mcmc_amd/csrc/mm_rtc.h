@@ -27,9 +27,9 @@ hipError_t mm_rtc_launch_run(const mm_user_target *t, int sampler, int dtype, vo
                              unsigned int block, size_t lds, hipStream_t stream);
 /* NUTS kernels of a registered target: mode 0 / 1 / 2 (mm_nuts_api.hip), init = 1: init_chain (`args` = mm_nuts_init_args<TT, ST>),
  * 0: the run with the lanes in step (`args` = mm_nuts_args<TT, ST>, stack in the HBM scratch area), 2: the run with asynchronous
- * lanes and leaves in pairs (mm_nuts_pair_body; dynamic LDS = the ring of uniforms; hipErrorNotFound above
- * MM_RTC_NUTS_PAIR_MAX_DIM or if the unit lacks it); one wave per workgroup */
-#define MM_RTC_NUTS_PAIR_MAX_DIM 16
+ * lanes and leaves in pairs (mm_nuts_pair_body; dynamic LDS = the ring of uniforms; hipErrorNotFound if the unit lacks it: it is
+ * compiled up to MM_RTC_NUTS_PAIR_MAX_DIM; the caller decides by the size of a chain's vectors); one wave per workgroup */
+#define MM_RTC_NUTS_PAIR_MAX_DIM 32
 hipError_t mm_rtc_launch_nuts(const mm_user_target *t, int mode, int init, void *args, size_t args_bytes, unsigned int grid, size_t lds,
                               hipStream_t stream);
 /* unnorm_logp / unnorm_logp_and_grad of n rows; `args` = {mm_tparams<T> P, const T *x, T *logp, T *grad, u64 n} packed */
