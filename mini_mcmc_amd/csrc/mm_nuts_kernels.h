@@ -602,7 +602,7 @@ template <class TT, class ST> struct mm_nuts_entry {
                        unsigned long long, unsigned long long, hipStream_t);
     hipError_t (*run)(const mm_nuts_args<TT, ST> &, hipStream_t);
     hipError_t (*run_async)(const mm_nuts_args<TT, ST> &, hipStream_t); /* asynchronous lanes; NULL for dim > 8 */
-    hipError_t (*run_pair)(const mm_nuts_args<TT, ST> &, hipStream_t);  /* asynchronous lanes, leaves in pairs; NULL for dim > 8 */
+    hipError_t (*run_pair)(const mm_nuts_args<TT, ST> &, hipStream_t);  /* asynchronous lanes, leaves in pairs; NULL where MM_NUTS_PAIR_AT(dim) is false (mm_nuts_inst.inc) */
     size_t stack_bytes_per_wave, tile_bytes_per_wave;
 };
 
