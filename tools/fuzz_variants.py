@@ -1,6 +1,7 @@
 """Differential fuzz on the GPU: kernels that must give the same bits are run on random shapes and compared.
   - integer-state MH: the four-waves-per-SIMD kernel against the one-wave kernel (random chain counts, run lengths, starts
     inside and outside the table, continued runs);
+  - Gibbs mixture: likewise;
   - tracker: whole blocks (one wave per parameter, tiles of 16 rows) against step-by-step feeding (the plain kernel);
   - NUTS: asynchronous-lane pair kernel against the lanes in step, compiled and run-time compiled dimensions.
 usage: python tools/fuzz_variants.py [seconds per family, default 40]"""
@@ -34,6 +35,21 @@ while time.time() - t0 < budget:
         assert np.array_equal(oa, ob) and np.array_equal(a.state(), b.state()) and np.array_equal(a.accept_counts(), b.accept_counts()), (type(model).__name__, C, nc, nd, seed)
     n += 1
 print(f"integer-state MH: {n} random cases, split kernel == one-wave kernel")
+
+from mini_mcmc_amd.core import init_det
+from mini_mcmc_amd.gibbs import GibbsSampler, MixtureConditional
+t0, n = time.time(), 0
+while time.time() - t0 < budget / 2:
+    C = int(rng.integers(4096, 9000))
+    cond = MixtureConditional(float(rng.uniform(-3, 0)), float(rng.uniform(0.5, 2)), float(rng.uniform(0, 4)), float(rng.uniform(0.5, 2)), float(rng.uniform(0.05, 0.95)))
+    seed = int(rng.integers(1 << 30))
+    a = GibbsSampler(cond, init_det(C, 2)).set_seed(seed)
+    b = GibbsSampler(cond, init_det(C, 2)).set_seed(seed).set_kernel_variant(0)
+    for _ in range(2):
+        nc, nd = int(rng.integers(0, 80)), int(rng.integers(0, 40))
+        assert np.array_equal(a.run(nc, nd), b.run(nc, nd)), (C, nc, nd, seed)
+    n += 1
+print(f"Gibbs mixture: {n} random cases, split kernel == one-wave kernel")
 
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
