@@ -101,25 +101,33 @@ template <class T, int D, int NN = 1> struct mm_split_mh_qp {
 /* Role timing for tools/split_probe.hip (-DMM_SPLIT_PROFILE): s_memtime ticks each role spends at the batch barrier
  * and in total, summed over waves into mm_split_prof[role][0 / 1]; compiled out of the product. */
 #ifdef MM_SPLIT_PROFILE
-__device__ unsigned long long mm_split_prof[2][2];
+__device__ unsigned long long mm_split_prof[2][3]; /* [role][barrier wait / total / the transition wave's own draws] */
 #define MM_SPLIT_SYNC()                                                                                           \
     do {                                                                                                          \
         const unsigned long long _t0 = __builtin_amdgcn_s_memtime();                                              \
         __syncthreads();                                                                                          \
         prof_wait += __builtin_amdgcn_s_memtime() - _t0;                                                          \
     } while (0)
-#define MM_SPLIT_PROF_BEGIN() unsigned long long prof_wait = 0; const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime()
+#define MM_SPLIT_PROF_BEGIN() unsigned long long prof_wait = 0, prof_draw = 0; const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime()
+#define MM_SPLIT_PROF_DRAW(stmt)                                                                                  \
+    do {                                                                                                          \
+        const unsigned long long _d0 = __builtin_amdgcn_s_memtime();                                              \
+        stmt;                                                                                                     \
+        prof_draw += __builtin_amdgcn_s_memtime() - _d0;                                                          \
+    } while (0)
 #define MM_SPLIT_PROF_END(role)                                                                                   \
     do {                                                                                                          \
         if ((threadIdx.x & 63) == 0) {                                                                            \
             atomicAdd(&mm_split_prof[role][0], prof_wait);                                                        \
             atomicAdd(&mm_split_prof[role][1], __builtin_amdgcn_s_memtime() - prof_t0);                           \
+            atomicAdd(&mm_split_prof[role][2], prof_draw);                                                        \
         }                                                                                                         \
     } while (0)
 #else
 #define MM_SPLIT_SYNC() __syncthreads()
 #define MM_SPLIT_PROF_BEGIN() ((void)0)
 #define MM_SPLIT_PROF_END(role) ((void)0)
+#define MM_SPLIT_PROF_DRAW(stmt) stmt
 #endif
 
 /* NN noise waves per pair (1: the workgroup above; 2, 3: 768 / 1024 threads, three / four waves per SIMD -- the noise
@@ -414,7 +422,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
         MM_SPLIT_SYNC(); /* ring half `half` is full; the other one is free again */
         batch(min((unsigned int)RB, n_silent - done), nullptr);
         if (QN)
-            draw_own(it); /* for the next batch (a batch past the end of the run: drawn, never used) */
+            MM_SPLIT_PROF_DRAW(draw_own(it)); /* for the next batch (a batch past the end of the run: drawn, never used) */
     }
     unsigned int tcol = 0, rows_out = 0;
     int tb = 0;
@@ -423,7 +431,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
         MM_SPLIT_SYNC(); /* ... and (PFLUSH) the tile this batch may be the first to write into has been flushed */
         batch(nb, tiles + (size_t)tb * TILE_ELEMS + lane * STRIDE + tcol * D);
         if (QN)
-            draw_own(it);
+            MM_SPLIT_PROF_DRAW(draw_own(it));
         tcol += nb;
         if (PFLUSH) {
             if (tcol == (unsigned int)TILE_T) {

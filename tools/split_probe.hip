@@ -78,11 +78,11 @@ template <class Tgt, int SAMPLER, int LCT> static void bench(const char *name, i
             printf("%-10s %-14s %s: %.4f ms   checksum %.6f\n", name, kern ? "split" : "mm_run_kernel", mode ? "no output " : "with output", best, s);
 #ifdef MM_SPLIT_PROFILE
             if (kern == 1) {
-                unsigned long long hp[2][2], zero[2][2] = {{0, 0}, {0, 0}};
+                unsigned long long hp[2][3], zero[2][3] = {{0, 0, 0}, {0, 0, 0}};
                 (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(mm_split_prof), sizeof(hp));
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(mm_split_prof), zero, sizeof(zero));
-                printf("    noise waves: %.1f %% of their time at the barrier   transition waves: %.1f %%   (ticks per wave and launch: %.0f)\n",
-                       100.0 * (double)hp[0][0] / (double)hp[0][1], 100.0 * (double)hp[1][0] / (double)hp[1][1], (double)hp[1][1] / 1024.0 / 8.0);
+                printf("    noise waves: %.1f %% of their time at the barrier   transition waves: %.1f %%, %.1f %% in their own draws   (ticks per wave and launch: %.0f)\n",
+                       100.0 * (double)hp[0][0] / (double)hp[0][1], 100.0 * (double)hp[1][0] / (double)hp[1][1], 100.0 * (double)hp[1][2] / (double)hp[1][1], (double)hp[1][1] / 1024.0 / 8.0);
             }
 #endif
         }
