@@ -606,7 +606,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
             e = hipErrorNotFound;
             /* ... while a chain's vectors stay in registers: f32 to 128 bytes (dimension 32), f64 to 96 (dimension 12);
              * measured at D = 24: f32 15 ms against 29 in step, f64 79 against 39; at D = 16 f64 62 against 46 */
-            if (variant == 7 && dim <= MM_RTC_NUTS_PAIR_MAX_DIM && (size_t)dim * sizeof(TT) <= (sizeof(TT) == 4 ? 128u : 96u))
+            const size_t pair_bytes = kind == MMCMC_GAUSSIAN_ND ? (sizeof(TT) == 4 ? 64u : 80u) /* the dense gradient's registers */
+                                                                : (sizeof(TT) == 4 ? 128u : 96u);
+            if (variant == 7 && dim <= MM_RTC_NUTS_PAIR_MAX_DIM && (size_t)dim * sizeof(TT) <= pair_bytes)
                 e = mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
             if (e == hipErrorNotFound)
                 e = mm_rtc_launch_nuts(user, type_mode, 0, &a, sizeof(a), grid64, user_lds, st);
