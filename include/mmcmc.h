@@ -189,10 +189,9 @@ int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
  * over long trajectories of a stiff target, visibly; each is bit-exact against its own host build
  * (oracle/engine_host.cpp modes 3 and 2).  With variant 3 mmcmc_nuts_run returns after the kernel has finished.
  * 7 (the default of targets compiled at run time: mmcmc_target_register_source, and built-in targets at dimensions 9 .. 31
- * without a compiled instance): the asynchronous-lane kernel with the leaves in pairs (as 5) where a chain's vectors are at
- * most 128 bytes in f32 (every dimension up to 32), 96 in f64 (up to 12) -- the dense Gaussian: 64 / 80 --, else the lanes in
- * step; 0 selects the lanes-in-step kernel
- * there too.  Bit-identical to each other.
+ * without a compiled instance): the asynchronous-lane kernel with the leaves in pairs (as 5), compiled with the target's functor
+ * on first use.  A unit is checked once against the run-time-dimension kernel (6), bit for bit, before a handle relies on
+ * it; if that fails a built-in target runs 6 and a user target is refused (MMCMC_ERR_UNSUPPORTED).
  * mmcmc_nuts_kernel_variant returns the mapping in use (>= 0) or a negative status.
  * mmcmc_nuts_set_compaction (variants 2, 3): doublings below `first_level` run before the first re-packing (default 5;
  * variant 3, until this is called, picks the mode of the depths seen so far minus one, after a 16-transition pilot on a

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
+#include <map>
 #include <vector>
 
 #include <type_traits>
@@ -46,6 +48,9 @@ struct DevGuard {
     }
 };
 
+/* 0: normal; 1: inside the self-test of a run-time compiled unit; 2: create without run-time compiled built-in units */
+thread_local int g_rtc_create_mode = 0;
+
 struct NutsBase {
     virtual ~NutsBase() {}
     virtual int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream) = 0;
@@ -61,6 +66,7 @@ struct NutsBase {
     bool compaction_auto = true; /* variant 3: choose it from the depths seen so far (until set_compaction is called) */
     int compaction_groups = 0; /* variant 2: chain groups with their own launch sequence (0 = choose) */
     int device = 0, mode = 0, kind = 0, dim = 0;
+    const void *rtc_unit = nullptr; /* the run-time compiled unit whose kernels this handle launches (mm_rtc.hip), or NULL */
     size_t n_chains = 0;
     uint64_t seed = 0, chain_offset = 0;
     uint32_t m = 0; /* self.m: transitions taken so far */
@@ -152,11 +158,15 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 k = &tab[i];
         generic_ok = mm_generic_kind_ok(t->kind) && t->dim >= 1;
         bool builtin_user = false;
-        if (t->kind < MM_USER_KIND_BASE && !k && generic_ok && t->dim <= 32) {
+        const int create_mode = std::is_same<TT, double>::value ? 2 : (std::is_same<ST, double>::value ? 0 : 1);
+        if (t->kind < MM_USER_KIND_BASE && !k && generic_ok && t->dim <= 32 && g_rtc_create_mode != 2) {
             /* a built-in target at a dimension without a compiled instance: its functor compiled into the one-chain-per-lane
              * kernels on first use (hipRTC, mm_rtc_builtin_nuts); NULL keeps the run-time-D kernel */
             DevGuard gb(device);
             user = mm_rtc_builtin_nuts(t->kind, t->dim);
+            /* ... and only if this type mode's kernels came out without register spills (mm_rtc.hip) */
+            if (user && !mm_rtc_nuts_usable(user, create_mode))
+                user = nullptr;
             builtin_user = user != nullptr;
         }
         if (t->kind >= MM_USER_KIND_BASE || builtin_user) {
@@ -168,6 +178,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 return MMCMC_ERR_UNSUPPORTED; /* a target + proposal model / an integer-state model has no NUTS kernels */
             if (mm_rtc_dim(user) != t->dim)
                 return MMCMC_ERR_SHAPE;
+            if (!builtin_user) {
+                DevGuard gu(device);
+                if (!mm_rtc_nuts_usable(user, create_mode))
+                    return MMCMC_ERR_UNSUPPORTED; /* this dimension and precision need more registers than a lane has */
+            }
             /* mm_nuts_stack_layout<TT, ST, D>::bytes and the output tile of mm_tile<TT, D>, for a run-time D */
             const size_t D = (size_t)t->dim, a16 = 15;
             user_stack_bytes = (((size_t)MM_NUTS_JMAX * 3 * D * 64 * sizeof(TT) + a16) / 16 * 16) +
@@ -181,6 +196,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
         } else if (!k && !generic_ok) {
             return MMCMC_ERR_UNSUPPORTED;
         }
+        rtc_unit = user;
         if (user && !builtin_user) {
             for (int i = 0; i < 8; ++i) /* P.p[0..8) = the description's params (mm_rtc.hip) */
                 P.p[i] = (TT)t->params[i];
@@ -268,7 +284,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int set_variant(int v) override
     {
-        if ((v == 0 && (k || user)) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 5 && k && k->run_pair) ||
+        if ((v == 0 && k) || (v >= 1 && v <= 3 && lg) || (v == 4 && k && k->run_async) || (v == 5 && k && k->run_pair) ||
             (v == 6 && generic_ok) || (v == 7 && user)) {
             variant = v;
             return MMCMC_OK;
@@ -542,7 +558,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
         const int type_mode = std::is_same<TT, double>::value ? 2 : (std::is_same<ST, double>::value ? 0 : 1);
         const unsigned int grid64 = (unsigned int)((n_chains + 63) / 64);
         hipError_t e;
-        const bool rtc_target = user && (variant == 7 || (variant == 0 && !k)); /* kernels of a run-time compiled unit */
+        const bool rtc_target = user && variant == 7; /* kernels of a run-time compiled unit */
         if (rtc_target) {
             mm_nuts_init_args<TT, ST> ia;
             ia.P = P;
@@ -601,17 +617,13 @@ template <class TT, class ST> struct Nuts : NutsBase {
         MM_HIP(hipEventRecord(ev0, st));
         if (rtc_target) {
             /* a run-time compiled target: asynchronous lanes with the leaves in pairs (mm_nuts_pair_body; dynamic LDS = the
-             * ring of uniforms, stack in the scratch area) while the vectors fit registers, else -- and as
-             * variant 0 -- the lanes in step (mm_nuts_run_body); bit-identical */
-            e = hipErrorNotFound;
-            /* ... while a chain's vectors stay in registers: f32 to 128 bytes (dimension 32), f64 to 96 (dimension 12);
-             * measured at D = 24: f32 15 ms against 29 in step, f64 79 against 39; at D = 16 f64 62 against 46 */
-            const size_t pair_bytes = kind == MMCMC_GAUSSIAN_ND ? (sizeof(TT) == 4 ? 64u : 80u) /* the dense gradient's registers */
-                                                                : (sizeof(TT) == 4 ? 128u : 96u);
-            if (variant == 7 && dim <= MM_RTC_NUTS_PAIR_MAX_DIM && (size_t)dim * sizeof(TT) <= pair_bytes)
-                e = mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
-            if (e == hipErrorNotFound)
-                e = mm_rtc_launch_nuts(user, type_mode, 0, &a, sizeof(a), grid64, user_lds, st);
+             * ring of uniforms, stack in the scratch area).  The unit's lanes-in-step kernel (mm_nuts_run_body) is NOT
+             * launched: compiled by the comgr already in the process (PyTorch's ROCm 7.0.2 here) it gave wrong, run-to-run
+             * different samples at RosenbrockND(19) / (23) in f64 and a memory fault at StandardNormal(25) in f32, while
+             * the same template compiled into the library by hipcc is correct at those dimensions
+             * (tools/experiments/repro_nuts_dims.py); the pair kernel passed every such comparison, and every unit is
+             * checked against the run-time-dimension kernel before its first use (rtc_unit_verified) */
+            e = mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
         } else if (use_generic) {
             ga.out = d_out;
             ga.n_pre = a.n_pre;
@@ -685,6 +697,49 @@ struct mmcmc_nuts {
     NutsBase *p;
 };
 
+/* A run-time compiled unit is checked once per (unit, type mode) and process before a handle relies on it: 96 chains, 5 + 5
+ * transitions from a fixed start, (a) twice -- the two must be the same bits --, (b) for a built-in target also against the
+ * run-time-dimension kernel (variant 6), which must agree bit for bit too.  Why: the unit is compiled by the hipRTC / comgr already loaded in the process (PyTorch's ROCm 7.0.2
+ * here, not the hipcc that built the library), and tools/experiments/repro_nuts_dims.py found kernels of such units that do
+ * not reproduce themselves (the lanes-in-step kernel at RosenbrockND(19) and (23) in f64, StandardNormal(25) in f32: no
+ * longer launched) while the same templates compiled into the library do.  A built-in target then runs the run-time-dimension kernel, a user target is refused. */
+extern "C" int mmcmc_nuts_create(mmcmc_nuts **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
+                                 double target_accept_p, int mode, int device);
+extern "C" int mmcmc_nuts_destroy(mmcmc_nuts *h);
+static bool rtc_unit_verified(const void *unit, const mmcmc_target_desc *target, int mode, int device)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, bool> verdict;
+    std::lock_guard<std::mutex> l(mu);
+    auto it = verdict.find({unit, mode});
+    if (it != verdict.end())
+        return it->second;
+    const size_t n = 96, dim = (size_t)target->dim, nc = 5, nd = 5, esz = mode == 2 ? 8 : 4;
+    std::vector<double> x0(n * dim);
+    for (size_t c = 0; c < n; ++c)
+        for (size_t i = 0; i < dim; ++i)
+            x0[c * dim + i] = 0.05 * (double)((int)((c * 7 + i * 13) % 17) - 8);
+    auto one = [&](int variant, std::vector<unsigned char> &bytes) -> bool {
+        mmcmc_nuts *t = nullptr;
+        if (mmcmc_nuts_create(&t, target, x0.data(), n, 0.8, mode, device) != MMCMC_OK)
+            return false;
+        bytes.assign(n * nc * dim * esz, 0);
+        t->p->seed = 0x5eedull;
+        bool ok = variant < 0 || t->p->set_variant(variant) == MMCMC_OK;
+        ok = ok && t->p->run(nc, nd, bytes.data(), 0, 1, nullptr) == MMCMC_OK;
+        (void)mmcmc_nuts_destroy(t);
+        return ok;
+    };
+    g_rtc_create_mode = 1;
+    std::vector<unsigned char> a, a2, g;
+    bool ok = one(-1, a) && one(-1, a2) && a == a2;
+    if (ok && target->kind < MM_USER_KIND_BASE)
+        ok = one(6, g) && a == g;
+    g_rtc_create_mode = 0;
+    verdict[{unit, mode}] = ok;
+    return ok;
+}
+
 extern "C" {
 
 int mmcmc_nuts_create(mmcmc_nuts **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
@@ -737,6 +792,16 @@ int mmcmc_nuts_create(mmcmc_nuts **out, const mmcmc_target_desc *target, const d
     if (!h) {
         delete p;
         return (int)hipErrorOutOfMemory;
+    }
+    if (p->rtc_unit && g_rtc_create_mode == 0 && !rtc_unit_verified(p->rtc_unit, target, mode, device)) {
+        /* the unit's kernels do not reproduce themselves (or the run-time-dimension kernel): not used */
+        (void)mmcmc_nuts_destroy(h);
+        if (target->kind >= MM_USER_KIND_BASE)
+            return MMCMC_ERR_UNSUPPORTED;
+        g_rtc_create_mode = 2;
+        const int st2 = mmcmc_nuts_create(out, target, init, n_chains, target_accept_p, mode, device);
+        g_rtc_create_mode = 0;
+        return st2;
     }
     *out = h;
     return MMCMC_OK;

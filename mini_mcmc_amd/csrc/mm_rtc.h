@@ -30,6 +30,9 @@ hipError_t mm_rtc_launch_run(const mm_user_target *t, int sampler, int dtype, vo
  * lanes and leaves in pairs (mm_nuts_pair_body; dynamic LDS = the ring of uniforms; hipErrorNotFound if the unit lacks it: it is
  * compiled up to MM_RTC_NUTS_PAIR_MAX_DIM; the caller decides by the size of a chain's vectors); one wave per workgroup */
 #define MM_RTC_NUTS_PAIR_MAX_DIM 32
+/* init_chain and the asynchronous-lane pair kernel of `mode` exist on the current device (the only NUTS run kernel of a
+ * run-time compiled unit that is launched: mm_nuts_api.hip) */
+int mm_rtc_nuts_usable(const mm_user_target *t, int mode);
 hipError_t mm_rtc_launch_nuts(const mm_user_target *t, int mode, int init, void *args, size_t args_bytes, unsigned int grid, size_t lds,
                               hipStream_t stream);
 /* unnorm_logp / unnorm_logp_and_grad of n rows; `args` = {mm_tparams<T> P, const T *x, T *logp, T *grad, u64 n} packed */

@@ -168,11 +168,10 @@ def test_user_target_under_nuts(O, mode):
         st = a.adapt_state()
         assert np.array_equal(st["epsilon"], ad[:, 0]) and np.array_equal(st["h_bar"], ad[:, 2])
         assert np.array_equal(a._run(4, 0, progress, "numpy"), b._run(4, 0, progress, "numpy"))  # the chain continues
-        # variant 7 is the asynchronous-lane kernel with the leaves in pairs up to dimension 16 (round 3); 0 selects the
-        # lanes-in-step kernel of the same compiled unit: the same numbers
-        c = NUTS(user, init, 0.8, mode=mode).set_seed(9).set_kernel_variant(0)
-        assert c.kernel_variant == 0
-        assert np.array_equal(c._run(9, 7, progress, "numpy"), out_a) and np.array_equal(c.leapfrog_counts(), nlf)
+        # variant 7 is the asynchronous-lane kernel with the leaves in pairs (round 3); the unit's lanes-in-step kernel is not
+        # offered (the comgr in the process miscompiled it at some dimensions: mm_nuts_api.hip)
+        with pytest.raises(Exception):
+            NUTS(user, init, 0.8, mode=mode).set_kernel_variant(0)
     if mode == 0:
         s, bb = 1.5, 0.2  # (b = 0.5 bends too hard for target_accept 0.8: tails under-explored by 8 %, as with any HMC)
         tgt = UserTarget("banana_nuts", 2, BANANA, params=[s, bb])

@@ -4,7 +4,7 @@
   - Gibbs mixture: likewise;
   - tracker: whole blocks (one wave per parameter, tiles of 16 rows) against step-by-step feeding (the plain kernel);
   - NUTS: asynchronous-lane pair kernel against the lanes in step, compiled and run-time compiled dimensions.
-usage: python tools/fuzz_variants.py [seconds per family, default 40]"""
+usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n, default dgtn]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,11 +15,12 @@ from mini_mcmc_amd.distributions import IsotropicGaussian, RosenbrockND, Standar
 from mini_mcmc_amd.nuts import NUTS
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+fam = sys.argv[2] if len(sys.argv) > 2 else "dgtn"
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 print("seed", rng.bit_generator.state["state"]["state"] & 0xffff)
 
 t0, n = time.time(), 0
-while time.time() - t0 < budget:
+while "d" in fam and time.time() - t0 < budget:
     model = [D.PoissonReflect(float(rng.uniform(0.5, 9))), D.BinomialClamp(int(rng.integers(1, 40)), float(rng.uniform(0.05, 0.95))),
              D.PoissonNonneg(float(rng.uniform(0.5, 9)))][int(rng.integers(3))]
     C = int(rng.integers(4096, 9000))
@@ -39,7 +40,7 @@ print(f"integer-state MH: {n} random cases, split kernel == one-wave kernel")
 from mini_mcmc_amd.core import init_det
 from mini_mcmc_amd.gibbs import GibbsSampler, MixtureConditional
 t0, n = time.time(), 0
-while time.time() - t0 < budget / 2:
+while "g" in fam and time.time() - t0 < budget / 2:
     C = int(rng.integers(4096, 9000))
     cond = MixtureConditional(float(rng.uniform(-3, 0)), float(rng.uniform(0.5, 2)), float(rng.uniform(0, 4)), float(rng.uniform(0.5, 2)), float(rng.uniform(0.05, 0.95)))
     seed = int(rng.integers(1 << 30))
@@ -52,7 +53,7 @@ while time.time() - t0 < budget / 2:
 print(f"Gibbs mixture: {n} random cases, split kernel == one-wave kernel")
 
 t0, n = time.time(), 0
-while time.time() - t0 < budget:
+while "t" in fam and time.time() - t0 < budget:
     chains, steps, params = int(rng.integers(2, 700)), int(rng.integers(2, 90)), int(rng.integers(1, 9))
     x = rng.standard_normal((chains, steps, params)).astype(np.float32)
     keep = rng.random((chains, steps)) < rng.uniform(0, 0.9)
@@ -76,15 +77,19 @@ while time.time() - t0 < budget:
 print(f"tracker: {n} random cases, whole blocks == step by step")
 
 t0, n = time.time(), 0
-while time.time() - t0 < budget:
-    d = int(rng.integers(1, 25))
+while "n" in fam and time.time() - t0 < budget:
+    d = int(rng.integers(1, 33))
     tgt = [StandardNormal(d), IsotropicGaussian(float(rng.uniform(0.5, 2)), d), RosenbrockND(max(d, 2))][int(rng.integers(3))]
     mode = int(rng.integers(3))
     C = int(rng.integers(1, 400))
     init = init_with_seed(C, tgt.dim, int(rng.integers(1000))) * 0.5
     seed = int(rng.integers(1 << 30))
     a = NUTS(tgt, init, 0.8, mode=mode).set_seed(seed)
-    b = NUTS(tgt, init, 0.8, mode=mode).set_seed(seed).set_kernel_variant(0)
+    b = NUTS(tgt, init, 0.8, mode=mode).set_seed(seed)
+    try:
+        b.set_kernel_variant(0)
+    except Exception:
+        b.set_kernel_variant(6)  # a run-time compiled unit: its reference is the run-time-dimension kernel
     prog = bool(rng.integers(2))
     nc, nd = int(rng.integers(1, 12)), int(rng.integers(0, 12))
     assert np.array_equal(a._run(nc, nd, prog, "numpy"), b._run(nc, nd, prog, "numpy")), (type(tgt).__name__, tgt.dim, mode, C, nc, nd, seed, a.kernel_variant)
@@ -92,4 +97,4 @@ while time.time() - t0 < budget:
     sa, sb = a.adapt_state(), b.adapt_state()
     assert all(np.array_equal(sa[k], sb[k]) for k in sa), (type(tgt).__name__, tgt.dim, mode)
     n += 1
-print(f"NUTS: {n} random cases, default kernel == lanes in step")
+print(f"NUTS: {n} random cases, default kernel == lanes in step / run-time-dimension kernel")

@@ -9,7 +9,7 @@ for tgt, d in ((StandardNormal(12), 12), (RosenbrockND(11), 11), (StandardNormal
         t0 = time.perf_counter()
         s = NUTS(tgt, init_with_seed(16384, d, 42) * 0.5, 0.8, mode=mode).set_seed(1)
         row = {"target": type(tgt).__name__, "dim": d, "mode": mode, "create_s": round(time.perf_counter() - t0, 2), "default": s.kernel_variant}
-        for v in (s.kernel_variant, 0, 6):  # 7: pair kernel up to D = 16; 0: lanes in step; 6: run-time-D kernel
+        for v in (s.kernel_variant, 6):  # 7: the run-time compiled pair kernel; 6: run-time-D kernel
             s2 = NUTS(tgt, init_with_seed(16384, d, 42) * 0.5, 0.8, mode=mode).set_seed(1).set_kernel_variant(v)
             s2._run(50, 50, True, "torch"); torch.cuda.synchronize()
             row[f"variant_{v}_ms"] = round(s2.timing()["kernel_ms"], 2)
