@@ -326,3 +326,26 @@ def test_gpu_nuts_any_dimension_vs_recursive_oracle_and_posterior(M, O):
     s = NUTS(M.dist.IsotropicGaussian(2.0, 20), M.core.init_with_seed(4096, 20, 1) * 0.5, 0.8, mode=0).set_seed(2)
     x = s._run(60, 60, True, "numpy").reshape(-1, 20).astype(np.float64)
     assert np.abs(x.mean(axis=0)).max() < 0.03 and np.abs(x.var(axis=0) / 4.0 - 1.0).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_gpu_nuts_run_time_compiled_units_at_the_dimensions_the_fuzz_found(M, O):
+    """tools/fuzz_variants.py (round 3) found run-time compiled NUTS kernels that did not reproduce themselves: the unit's
+    lanes-in-step kernel at RosenbrockND(19) / (23) in f64 (wrong samples) and StandardNormal(25) in f32 (memory fault),
+    miscompiled by the comgr in the process.  That kernel is no longer launched and every unit is verified before use
+    (mm_nuts_api.hip: rtc_unit_verified); here: the default mapping at those dimensions equals the run-time-D kernel and
+    itself, bit for bit."""
+    from mini_mcmc_amd.nuts import NUTS
+
+    for tgt, mode in ((M.dist.RosenbrockND(19), 2), (M.dist.RosenbrockND(23), 2), (M.dist.StandardNormal(25), 0), (M.dist.StandardNormal(25), 2)):
+        init = M.core.init_with_seed(77, tgt.dim, 31) * 0.5
+        outs = []
+        for v in (None, None, 6):
+            s = NUTS(tgt, init, 0.8, mode=mode).set_seed(5)
+            if v is not None:
+                s.set_kernel_variant(v)
+            else:
+                assert s.kernel_variant in (7, 6)  # 6 if the unit's check refused it
+            outs.append((s._run(4, 7, False, "numpy"), s.leapfrog_counts()))
+        for o, l in outs[1:]:
+            assert np.array_equal(o, outs[0][0]) and np.array_equal(l, outs[0][1]), (type(tgt).__name__, tgt.dim, mode)
