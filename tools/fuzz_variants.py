@@ -3,8 +3,11 @@
     inside and outside the table, continued runs);
   - Gibbs mixture: likewise;
   - tracker: whole blocks (one wave per parameter, tiles of 16 rows) against step-by-step feeding (the plain kernel);
-  - NUTS: asynchronous-lane pair kernel against the lanes in step, compiled and run-time compiled dimensions.
-usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n, default dgtn]"""
+  - NUTS: asynchronous-lane pair kernel against the lanes in step, compiled and run-time compiled dimensions;
+  - MH / HMC at the compiled dimensions up to 8: the four-waves-per-SIMD kernel (5) against the one-wave kernels (0, 2), any
+    chain count, run length, iterations per launch, f32 and f64;
+  - diagnostics: the power-spectrum kernel against the direct sums (R-hat / ESS to 1e-4 / 2e-3).
+usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n h s, default dgtnhs]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,7 +18,7 @@ from mini_mcmc_amd.distributions import IsotropicGaussian, RosenbrockND, Standar
 from mini_mcmc_amd.nuts import NUTS
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
-fam = sys.argv[2] if len(sys.argv) > 2 else "dgtn"
+fam = sys.argv[2] if len(sys.argv) > 2 else "dgtnhs"
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 print("seed", rng.bit_generator.state["state"]["state"] & 0xffff)
 
@@ -98,3 +101,61 @@ while "n" in fam and time.time() - t0 < budget:
     assert all(np.array_equal(sa[k], sb[k]) for k in sa), (type(tgt).__name__, tgt.dim, mode)
     n += 1
 print(f"NUTS: {n} random cases, default kernel == lanes in step / run-time-dimension kernel")
+
+from mini_mcmc_amd.distributions import Gaussian2D, Rosenbrock2D
+from mini_mcmc_amd.hmc import HMC
+from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+t0, n = time.time(), 0
+while "h" in fam and time.time() - t0 < budget:
+    d = int(rng.integers(1, 9))
+    dt = np.float32 if rng.random() < 0.6 else np.float64
+    kind = int(rng.integers(4))
+    tgt = [StandardNormal(d), IsotropicGaussian(float(rng.uniform(0.5, 2)), d), RosenbrockND(max(d, 2)), Gaussian2D([0.3, -0.2], [[1.0, 0.4], [0.4, 2.0]])][kind]
+    C = int(rng.integers(1, 1500))
+    init = (init_with_seed(C, tgt.dim, int(rng.integers(1000))) * 0.5).astype(dt)
+    seed = int(rng.integers(1 << 30))
+    hmc = bool(rng.integers(2))
+    def make():
+        if hmc:
+            return HMC(tgt, init, float(rng_eps), int(rng_L)).set_seed(seed)
+        return MetropolisHastings(tgt, IsotropicGaussian(float(rng_eps) * 4, tgt.dim), init).seed(seed)
+    rng_eps, rng_L = rng.uniform(0.01, 0.2), rng.integers(1, 13)
+    a, outs = make(), []
+    nc, nd, ipl = int(rng.integers(0, 140)), int(rng.integers(0, 60)), int(rng.choice([0, 0, 7, 50]))
+    for v in (None, 0, 2):
+        s_ = make()
+        try:
+            if v is not None:
+                s_.set_kernel_variant(v)
+        except Exception:
+            continue
+        if ipl:
+            s_.set_iters_per_launch(ipl)
+        o1 = s_.run(nc, nd)
+        o2 = s_.run(int(nc // 3), 3)  # continued
+        outs.append((o1, o2, s_.state()))
+    for o in outs[1:]:
+        assert all(np.array_equal(x, y) for x, y in zip(o, outs[0])), (type(tgt).__name__, tgt.dim, dt.__name__, C, nc, nd, ipl, seed, hmc)
+    n += 1
+print(f"MH / HMC: {n} random cases, default kernel == one-wave kernels")
+
+t0, n = time.time(), 0
+while "s" in fam and time.time() - t0 < budget:
+    c, m2, p = int(rng.integers(2, 400)), int(rng.integers(202, 2049)), int(rng.integers(1, 7))
+    x = np.zeros((c, m2, p), dtype=np.float32)
+    e = rng.standard_normal((c, m2, p)).astype(np.float32)
+    phi = float(rng.uniform(0, 0.95))
+    for t in range(1, m2):
+        x[:, t] = phi * x[:, t - 1] + e[:, t]
+    x += rng.uniform(-50, 50, size=(1, 1, p)).astype(np.float32)
+    tt = torch.from_numpy(x).cuda()
+    res = {}
+    try:
+        for k in ("fft", "direct"):
+            S.set_kernel(k)
+            res[k] = S.split_rhat_mean_ess(tt)
+    finally:
+        S.set_kernel("auto")
+    assert np.allclose(res["fft"][0], res["direct"][0], rtol=1e-4) and np.allclose(res["fft"][1], res["direct"][1], rtol=2e-3), (c, m2, p, phi)
+    n += 1
+print(f"diagnostics: {n} random cases, power spectrum == direct sums (1e-4 / 2e-3)")
