@@ -7,7 +7,7 @@
   - MH / HMC at the compiled dimensions up to 8: the four-waves-per-SIMD kernel (5) against the one-wave kernels (0, 2), any
     chain count, run length, iterations per launch, f32 and f64;
   - diagnostics: the power-spectrum kernel against the direct sums (R-hat / ESS to 1e-4 / 2e-3).
-usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n h s, default dgtnhs]"""
+usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n h s, default dgtnhsm]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,7 +18,7 @@ from mini_mcmc_amd.distributions import IsotropicGaussian, RosenbrockND, Standar
 from mini_mcmc_amd.nuts import NUTS
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
-fam = sys.argv[2] if len(sys.argv) > 2 else "dgtnhs"
+fam = sys.argv[2] if len(sys.argv) > 2 else "dgtnhsm"
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 print("seed", rng.bit_generator.state["state"]["state"] & 0xffff)
 
@@ -159,3 +159,20 @@ while "s" in fam and time.time() - t0 < budget:
     assert np.allclose(res["fft"][0], res["direct"][0], rtol=1e-4) and np.allclose(res["fft"][1], res["direct"][1], rtol=2e-3), (c, m2, p, phi)
     n += 1
 print(f"diagnostics: {n} random cases, power spectrum == direct sums (1e-4 / 2e-3)")
+
+t0, n = time.time(), 0
+while "m" in fam and time.time() - t0 < budget:
+    d = int(rng.integers(1, 9))
+    tgt = [StandardNormal(d), IsotropicGaussian(float(rng.uniform(0.5, 2)), d), RosenbrockND(max(d, 2))][int(rng.integers(3))]
+    mode, C = int(rng.integers(3)), int(rng.integers(64, 6000))
+    init = init_with_seed(C, tgt.dim, int(rng.integers(1000))) * 0.5
+    seed, depth = int(rng.integers(1 << 30)), int(rng.integers(3, 11))
+    prog, nc, nd = bool(rng.integers(2)), int(rng.integers(1, 10)), int(rng.integers(0, 10))
+    outs = []
+    for v in (5, 4, 0):
+        s_ = NUTS(tgt, init, 0.8, mode=mode).set_seed(seed).set_max_depth(depth).set_kernel_variant(v)
+        outs.append((s_._run(nc, nd, prog, "numpy"), s_.leapfrog_counts(), s_.depth_histogram()))
+    for o in outs[1:]:
+        assert all(np.array_equal(x, y) for x, y in zip(o, outs[0])), (type(tgt).__name__, tgt.dim, mode, C, depth, nc, nd, seed)
+    n += 1
+print(f"NUTS mappings 5 / 4 / 0 at the compiled dimensions, many chains, depth caps: {n} random cases, all equal")
