@@ -618,10 +618,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
         if (rtc_target) {
             /* a run-time compiled target: asynchronous lanes with the leaves in pairs (mm_nuts_pair_body; dynamic LDS = the
              * ring of uniforms, stack in the scratch area).  The unit's lanes-in-step kernel (mm_nuts_run_body) is NOT
-             * launched: compiled by the comgr already in the process (PyTorch's ROCm 7.0.2 here) it gave wrong, run-to-run
-             * different samples at RosenbrockND(19) / (23) in f64 and a memory fault at StandardNormal(25) in f32, while
-             * the same template compiled into the library by hipcc is correct at those dimensions
-             * (tools/experiments/repro_nuts_dims.py); the pair kernel passed every such comparison, and every unit is
+             * launched: it gave wrong, run-to-run different samples at RosenbrockND(19) / (23) in f64 and a memory fault at
+             * StandardNormal(25) in f32, while the same template compiled into the library by hipcc is correct at those
+             * dimensions (tools/experiments/repro_nuts_dims.py; not the compiler's version: PyTorch's in-process hipRTC 7.0.2
+             * and the build's own 7.2 in a separate link namespace fail alike; cause not found).  The pair kernel passed
+             * every such comparison, and every unit is
              * checked against the run-time-dimension kernel before its first use (rtc_unit_verified) */
             e = mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
         } else if (use_generic) {
@@ -699,10 +700,11 @@ struct mmcmc_nuts {
 
 /* A run-time compiled unit is checked once per (unit, type mode) and process before a handle relies on it: 96 chains, 5 + 5
  * transitions from a fixed start, (a) twice -- the two must be the same bits --, (b) for a built-in target also against the
- * run-time-dimension kernel (variant 6), which must agree bit for bit too.  Why: the unit is compiled by the hipRTC / comgr already loaded in the process (PyTorch's ROCm 7.0.2
- * here, not the hipcc that built the library), and tools/experiments/repro_nuts_dims.py found kernels of such units that do
- * not reproduce themselves (the lanes-in-step kernel at RosenbrockND(19) and (23) in f64, StandardNormal(25) in f32: no
- * longer launched) while the same templates compiled into the library do.  A built-in target then runs the run-time-dimension kernel, a user target is refused. */
+ * run-time-dimension kernel (variant 6), which must agree bit for bit too.  Why: tools/experiments/repro_nuts_dims.py found
+ * kernels of such units that do not reproduce themselves (the lanes-in-step kernel at RosenbrockND(19) and (23) in f64,
+ * StandardNormal(25) in f32: no longer launched) while the same templates compiled into the library do; the cause is not
+ * found, so what IS launched is checked.  A unit that fails leaves a built-in target on the run-time-dimension kernel; a
+ * user target is refused. */
 extern "C" int mmcmc_nuts_create(mmcmc_nuts **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
                                  double target_accept_p, int mode, int device);
 extern "C" int mmcmc_nuts_destroy(mmcmc_nuts *h);

@@ -332,7 +332,7 @@ def test_gpu_nuts_any_dimension_vs_recursive_oracle_and_posterior(M, O):
 def test_gpu_nuts_run_time_compiled_units_at_the_dimensions_the_fuzz_found(M, O):
     """tools/fuzz_variants.py (round 3) found run-time compiled NUTS kernels that did not reproduce themselves: the unit's
     lanes-in-step kernel at RosenbrockND(19) / (23) in f64 (wrong samples) and StandardNormal(25) in f32 (memory fault),
-    miscompiled by the comgr in the process.  That kernel is no longer launched and every unit is verified before use
+    cause not found (the same template compiled into the library is correct).  That kernel is no longer launched and every unit is verified before use
     (mm_nuts_api.hip: rtc_unit_verified); here: the default mapping at those dimensions equals the run-time-D kernel and
     itself, bit for bit."""
     from mini_mcmc_amd.nuts import NUTS

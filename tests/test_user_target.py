@@ -169,7 +169,7 @@ def test_user_target_under_nuts(O, mode):
         assert np.array_equal(st["epsilon"], ad[:, 0]) and np.array_equal(st["h_bar"], ad[:, 2])
         assert np.array_equal(a._run(4, 0, progress, "numpy"), b._run(4, 0, progress, "numpy"))  # the chain continues
         # variant 7 is the asynchronous-lane kernel with the leaves in pairs (round 3); the unit's lanes-in-step kernel is not
-        # offered (the comgr in the process miscompiled it at some dimensions: mm_nuts_api.hip)
+        # offered (it failed at some dimensions: mm_nuts_api.hip)
         with pytest.raises(Exception):
             NUTS(user, init, 0.8, mode=mode).set_kernel_variant(0)
     if mode == 0:
