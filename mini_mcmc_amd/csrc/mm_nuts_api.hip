@@ -620,9 +620,10 @@ template <class TT, class ST> struct Nuts : NutsBase {
              * ring of uniforms, stack in the scratch area).  The unit's lanes-in-step kernel (mm_nuts_run_body) is NOT
              * launched: it gave wrong, run-to-run different samples at RosenbrockND(19) / (23) in f64 and a memory fault at
              * StandardNormal(25) in f32, while the same template compiled into the library by hipcc is correct at those
-             * dimensions (tools/experiments/repro_nuts_dims.py; not the compiler's version: PyTorch's in-process hipRTC 7.0.2
-             * and the build's own 7.2 in a separate link namespace fail alike; cause not found).  The pair kernel passed
-             * every such comparison, and every unit is
+             * dimensions (tools/experiments/repro_nuts_dims.py).  Bisected: not the hipRTC version (PyTorch's in-process
+             * 7.0.2 and the build's own 7.2 in a separate link namespace fail alike), not the target id, not the module
+             * launch (the unit's source compiled offline by hipcc --genco and injected is correct): hipRTC's compilation
+             * of that kernel, cause not found.  The pair kernel passed every such comparison, and every unit is
              * checked against the run-time-dimension kernel before its first use (rtc_unit_verified) */
             e = mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
         } else if (use_generic) {
