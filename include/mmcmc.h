@@ -123,6 +123,12 @@ int mmcmc_mh_set_chain_offset(mmcmc_mh *h, uint64_t chain_offset);
  * accept_counts: host, [n_chains], accepted proposals per chain over the whole call (may be NULL). */
 int mmcmc_mh_run(mmcmc_mh *h, size_t n_collect, size_t n_discard, void *out, int out_is_device,
                  uint64_t *accept_counts, void *stream);
+/* the same into rows [row0, row0 + n_rows) of a DEVICE buffer out [n_chains, n_total_rows, dim]: one sample filled by
+ * several launches (run_progress' segments); n_rows = 0 with n_discard > 0 only advances the chains */
+int mmcmc_mh_run_rows(mmcmc_mh *h, size_t n_rows, size_t n_discard, void *out_device, size_t n_total_rows, size_t row0,
+                      void *stream);
+/* what the handle was created with (any pointer may be NULL) */
+int mmcmc_mh_shape(mmcmc_mh *h, size_t *n_chains, int *dim, int *dtype, int *device);
 /* MarkovChain::current_state for every chain   core.rs:43-44 ; host [n_chains, dim] */
 int mmcmc_mh_state(mmcmc_mh *h, void *out);
 int mmcmc_mh_sync(mmcmc_mh *h);
@@ -143,6 +149,9 @@ int mmcmc_hmc_set_chain_offset(mmcmc_hmc *h, uint64_t chain_offset);
 /* HMC::run(n_collect, n_discard) -> Tensor [n_chains, n_collect, dim]   hmc.rs:137-158 */
 int mmcmc_hmc_run(mmcmc_hmc *h, size_t n_collect, size_t n_discard, void *out, int out_is_device,
                   uint64_t *accept_counts, void *stream);
+int mmcmc_hmc_run_rows(mmcmc_hmc *h, size_t n_rows, size_t n_discard, void *out_device, size_t n_total_rows, size_t row0,
+                       void *stream);
+int mmcmc_hmc_shape(mmcmc_hmc *h, size_t *n_chains, int *dim, int *dtype, int *device);
 /* HMC::step   hmc.rs:304-377 : one transition of every chain */
 int mmcmc_hmc_step(mmcmc_hmc *h, void *stream);
 /* HMC::positions   hmc.rs:49 ; host [n_chains, dim] */
@@ -202,10 +211,13 @@ int mmcmc_nuts_kernel_variant(mmcmc_nuts *h);
 int mmcmc_nuts_set_compaction(mmcmc_nuts *h, int first_level, int n_groups);
 /* progress = 0: NUTS::run -> NUTSChain::run (nuts.rs:163-170, 457-471): n_collect + n_discard - 1 transitions, and
  *               with n_discard == 0 row 0 is the initial position (the reference's off-by-one, test_chain_1);
- * progress = 1: the stepping of run_progress (nuts.rs:491-522): all n_collect + n_discard transitions.
+ * progress = 1: the stepping of run_progress (nuts.rs:491-522): all n_collect + n_discard transitions;
+ * progress = 2: the same with EVERY state recorded, burn-in included (what run_progress' per-chain trackers are fed,
+ *               nuts.rs:491-506): out then has n_collect + n_discard rows per chain.
  * out: [n_chains, n_collect, dim] of the tensor type, device or host memory (may be NULL). */
 int mmcmc_nuts_run(mmcmc_nuts *h, size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress,
                    void *stream);
+int mmcmc_nuts_shape(mmcmc_nuts *h, size_t *n_chains, int *dim, int *mode, int *device);
 /* NUTSChain::position for every chain (nuts.rs:369); host [n_chains, dim] of the tensor type */
 int mmcmc_nuts_state(mmcmc_nuts *h, void *out);
 /* per-chain adaptation state: host [n_chains, 4] doubles = epsilon, epsilon_bar, h_bar, mu (nuts.rs:374-386) */
@@ -389,6 +401,39 @@ int mmcmc_tracker_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *p
 int mmcmc_tracker_init_last(mmcmc_tracker *h, const void *states, int states_is_device, int dtype, void *stream);
 int mmcmc_tracker_chain_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, float *avg_p_accept, void *stream);
 int mmcmc_tracker_n(mmcmc_tracker *h, uint64_t *n);
+int mmcmc_tracker_shape(mmcmc_tracker *h, size_t *n_chains, size_t *dim, int *device);
+/* withinvar_from_cs (stats.rs:155-178) over the per-chain ChainStats (mean, sm2 = (mean_sq - mean^2) n / (n - 1), n):
+ * within [dim], var [dim] (host) -- the pair collect_rhat and ess_from_chainstats share.  Needs at least two steps. */
+int mmcmc_tracker_within_var(mmcmc_tracker *h, float *within, float *var, void *stream);
+/* stats::ess_from_chainstats(sample, chain_stats) (stats.rs:668-671): the UN-split ESS of sample [n_chains, n, dim]
+ * (device or host memory, dtype) with within / var from the per-chain trackers that were fed the run
+ * (mmcmc_tracker_init_last + mmcmc_tracker_steps, or the tracker mmcmc_*_run_progress hands back); ess: host [dim].
+ * The autocovariance follows the reference's switch on n (stats.rs:549), Geyer's truncation as stats.rs:523-545. */
+int mmcmc_ess_from_chainstats(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,
+                              mmcmc_tracker *tracker, float *ess, int device, void *stream);
+
+/* ---- run_progress ------------------------------------------------------------------------------------------------
+ * ChainRunner::run_progress (core.rs:208-360, the MH flavour), HMC::run_progress (hmc.rs:222-294), NUTS::run_progress
+ * (nuts.rs:172-345 over NUTSChain::run_progress :473-526): burn-in + sampling with the reference's running diagnostics,
+ * returning the sample and RunStats.  The tracker feeding orders live here once (csrc/mm_progress.hip):
+ *   HMC  burn-in unobserved; one MultiChainTracker fed the positions sampling starts from, then every collected state;
+ *   MH   per-chain ChainTrackers built on the state before the first step, fed EVERY state, burn-in included;
+ *   NUTS as MH (all n_discard + n_collect states; the run is one launch, the trackers are fed after it).
+ * cb (may be NULL) is called after every `every` transitions (0: ten times per run) with what the reference's bar shows:
+ * p(accept) and max(rhat) -- the MultiChainTracker's for HMC (stats.rs:270-286), the average per-chain EMA and
+ * collect_rhat's NaN-skipping maximum for MH and NUTS (core.rs:268-293).
+ * out: [n_chains, n_collect, dim] of the sampler's dtype (NUTS: f32 for modes 0 / 1, f64 for mode 2), device or host, may
+ * be NULL; stats (may be NULL; needs n_collect >= 2): RunStats::from(sample); tracker_out (may be NULL): receives the
+ * tracker that was fed (the caller destroys it with mmcmc_tracker_destroy), e.g. for mmcmc_ess_from_chainstats.
+ * stream NULL: a stream of the call's own; the call returns when everything has finished. */
+typedef void (*mmcmc_progress_fn)(void *user, uint64_t transitions_done, uint64_t transitions_total, float p_accept,
+                                  float max_rhat);
+int mmcmc_mh_run_progress(mmcmc_mh *h, size_t n_collect, size_t n_discard, size_t every, mmcmc_progress_fn cb, void *user,
+                          void *out, int out_is_device, mmcmc_run_stats *stats, mmcmc_tracker **tracker_out, void *stream);
+int mmcmc_hmc_run_progress(mmcmc_hmc *h, size_t n_collect, size_t n_discard, size_t every, mmcmc_progress_fn cb, void *user,
+                           void *out, int out_is_device, mmcmc_run_stats *stats, mmcmc_tracker **tracker_out, void *stream);
+int mmcmc_nuts_run_progress(mmcmc_nuts *h, size_t n_collect, size_t n_discard, size_t every, mmcmc_progress_fn cb, void *user,
+                            void *out, int out_is_device, mmcmc_run_stats *stats, mmcmc_tracker **tracker_out, void *stream);
 int mmcmc_tracker_destroy(mmcmc_tracker *h);
 
 /* ---- Metropolis-Hastings on integer states ---------------------------------------------------------------------

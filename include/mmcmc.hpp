@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <memory>
 #include <vector>
 
 #include "mmcmc.h"
@@ -141,6 +142,82 @@ inline std::pair<std::vector<float>, std::vector<float>> split_rhat_mean_ess(con
     return {rhat, ess};
 }
 
+/* MultiChainTracker (stats.rs:189-306): step() takes host states [n_chains, k, dim] */
+class MultiChainTracker {
+    mmcmc_tracker *h_ = nullptr;
+    size_t n_chains_, dim_;
+
+  public:
+    MultiChainTracker(size_t n_chains, size_t n_params, int device = 0) : n_chains_(n_chains), dim_(n_params)
+    {
+        check(mmcmc_tracker_create(&h_, n_chains, n_params, device), "mmcmc_tracker_create");
+    }
+    /* own a tracker the library handed back (mmcmc_*_run_progress' tracker_out) */
+    explicit MultiChainTracker(mmcmc_tracker *adopt) : h_(adopt), n_chains_(0), dim_(0)
+    {
+        check(mmcmc_tracker_shape(h_, &n_chains_, &dim_, nullptr), "mmcmc_tracker_shape");
+    }
+    MultiChainTracker(const MultiChainTracker &) = delete;
+    MultiChainTracker &operator=(const MultiChainTracker &) = delete;
+    ~MultiChainTracker() { mmcmc_tracker_destroy(h_); }
+    template <class T> void step(const std::vector<T> &states)
+    {
+        const size_t k = states.size() / (n_chains_ * dim_);
+        check(mmcmc_tracker_steps(h_, states.data(), 0, dtype_of<T>(), k, 0, k, nullptr), "mmcmc_tracker_steps");
+    }
+    std::vector<float> rhat()
+    {
+        std::vector<float> r(dim_);
+        check(mmcmc_tracker_stats(h_, r.data(), nullptr, nullptr, nullptr), "mmcmc_tracker_stats");
+        return r;
+    }
+    float max_rhat()
+    {
+        float m = 0.f;
+        check(mmcmc_tracker_stats(h_, nullptr, &m, nullptr, nullptr), "mmcmc_tracker_stats");
+        return m;
+    }
+    float p_accept()
+    {
+        float p = 0.f;
+        check(mmcmc_tracker_stats(h_, nullptr, nullptr, &p, nullptr), "mmcmc_tracker_stats");
+        return p;
+    }
+    /* the per-chain flavour (ChainTracker + collect_rhat, stats.rs:26-178): rhat [dim]; max_rhat / avg_p_accept may be NULL */
+    std::vector<float> chain_rhat(float *max_rhat = nullptr, float *avg_p_accept = nullptr)
+    {
+        std::vector<float> r(dim_);
+        check(mmcmc_tracker_chain_stats(h_, r.data(), max_rhat, avg_p_accept, nullptr), "mmcmc_tracker_chain_stats");
+        return r;
+    }
+    uint64_t n() const
+    {
+        uint64_t v = 0;
+        check(mmcmc_tracker_n(h_, &v), "mmcmc_tracker_n");
+        return v;
+    }
+    mmcmc_tracker *handle() const { return h_; }
+};
+
+/* stats::ess_from_chainstats (stats.rs:668-671): un-split ESS of sample [chains, n, dim] with the per-chain trackers' within / var */
+inline std::vector<float> ess_from_chainstats(const std::vector<float> &sample, size_t chains, size_t n, size_t dim,
+                                              const MultiChainTracker &tracker, int device = 0)
+{
+    std::vector<float> ess(dim);
+    check(mmcmc_ess_from_chainstats(sample.data(), 0, MMCMC_F32, chains, n, dim, tracker.handle(), ess.data(), device, nullptr),
+          "mmcmc_ess_from_chainstats");
+    return ess;
+}
+
+/* what run_progress returns: (sample [n_chains, n_collect, dim], RunStats) as the reference, plus the tracker that was fed */
+template <class T> struct ProgressResult {
+    std::vector<T> sample;
+    RunStats stats;
+    std::unique_ptr<MultiChainTracker> tracker;
+};
+
+
+
 /* ---- MetropolisHastings<T> ---- */
 template <class T> class MetropolisHastings {
     mmcmc_mh *h_ = nullptr;
@@ -178,6 +255,18 @@ template <class T> class MetropolisHastings {
     }
     size_t n_chains() const { return n_chains_; }
     size_t dim() const { return dim_; }
+    /* ChainRunner::run_progress (core.rs:208-360): cb(user, done, total, p_accept, max_rhat) after every `every` transitions */
+    ProgressResult<T> run_progress(size_t n_collect, size_t n_discard, size_t every = 0, mmcmc_progress_fn cb = nullptr,
+                                   void *user = nullptr)
+    {
+        ProgressResult<T> r;
+        r.sample.resize(n_chains_ * n_collect * dim_);
+        mmcmc_tracker *t = nullptr;
+        check(mmcmc_mh_run_progress(h_, n_collect, n_discard, every, cb, user, r.sample.data(), 0, &r.stats.s, &t, nullptr),
+              "mmcmc_mh_run_progress");
+        r.tracker.reset(new MultiChainTracker(t));
+        return r;
+    }
 };
 
 /* ---- HMC<T> ---- */
@@ -208,6 +297,18 @@ template <class T> class HMC {
         check(mmcmc_hmc_run(h_, n_collect, n_discard, out.data(), 0, nullptr, nullptr), "mmcmc_hmc_run");
         check(mmcmc_hmc_sync(h_), "mmcmc_hmc_sync");
         return out;
+    }
+    /* HMC::run_progress (hmc.rs:222-294) */
+    ProgressResult<T> run_progress(size_t n_collect, size_t n_discard, size_t every = 0, mmcmc_progress_fn cb = nullptr,
+                                   void *user = nullptr)
+    {
+        ProgressResult<T> r;
+        r.sample.resize(n_chains_ * n_collect * dim_);
+        mmcmc_tracker *t = nullptr;
+        check(mmcmc_hmc_run_progress(h_, n_collect, n_discard, every, cb, user, r.sample.data(), 0, &r.stats.s, &t, nullptr),
+              "mmcmc_hmc_run_progress");
+        r.tracker.reset(new MultiChainTracker(t));
+        return r;
     }
     void step()
     {
@@ -307,6 +408,18 @@ template <class T> class NUTS {
         check(mmcmc_nuts_sync(h_), "mmcmc_nuts_sync");
         return out;
     }
+    /* NUTS::run_progress (nuts.rs:172-345): all N transitions; the per-chain trackers saw the initial position and every state */
+    ProgressResult<float> run_progress(size_t n_collect, size_t n_discard, size_t every = 0, mmcmc_progress_fn cb = nullptr,
+                                   void *user = nullptr)
+    {
+        ProgressResult<float> r;
+        r.sample.resize(n_chains_ * n_collect * dim_);
+        mmcmc_tracker *t = nullptr;
+        check(mmcmc_nuts_run_progress(h_, n_collect, n_discard, every, cb, user, r.sample.data(), 0, &r.stats.s, &t, nullptr),
+              "mmcmc_nuts_run_progress");
+        r.tracker.reset(new MultiChainTracker(t));
+        return r;
+    }
 };
 
 /* NUTS over several GPUs from one call (mmcmc_nuts_group_*): tensors f32, scalars T, like NUTS<T> */
@@ -385,6 +498,18 @@ class NUTS64 {
         check(mmcmc_nuts_sync(h_), "mmcmc_nuts_sync");
         return out;
     }
+    /* NUTS::run_progress (nuts.rs:172-345): all N transitions; the per-chain trackers saw the initial position and every state */
+    ProgressResult<double> run_progress(size_t n_collect, size_t n_discard, size_t every = 0, mmcmc_progress_fn cb = nullptr,
+                                   void *user = nullptr)
+    {
+        ProgressResult<double> r;
+        r.sample.resize(n_chains_ * n_collect * dim_);
+        mmcmc_tracker *t = nullptr;
+        check(mmcmc_nuts_run_progress(h_, n_collect, n_discard, every, cb, user, r.sample.data(), 0, &r.stats.s, &t, nullptr),
+              "mmcmc_nuts_run_progress");
+        r.tracker.reset(new MultiChainTracker(t));
+        return r;
+    }
 };
 
 /* MetropolisHastings<i32, f64, ...> over the reference's discrete test models (include/mmcmc.h: MMCMC_POISSON_REFLECT,
@@ -449,44 +574,6 @@ class GibbsMixtureSampler {
         std::vector<double> out(n_chains_ * n_collect * 2);
         check(mmcmc_gibbs_mixture_run(h_, n_collect, n_discard, out.data(), 0, nullptr), "mmcmc_gibbs_mixture_run");
         return out;
-    }
-};
-
-/* MultiChainTracker (stats.rs:189-306): step() takes host states [n_chains, k, dim] */
-class MultiChainTracker {
-    mmcmc_tracker *h_ = nullptr;
-    size_t n_chains_, dim_;
-
-  public:
-    MultiChainTracker(size_t n_chains, size_t n_params, int device = 0) : n_chains_(n_chains), dim_(n_params)
-    {
-        check(mmcmc_tracker_create(&h_, n_chains, n_params, device), "mmcmc_tracker_create");
-    }
-    MultiChainTracker(const MultiChainTracker &) = delete;
-    MultiChainTracker &operator=(const MultiChainTracker &) = delete;
-    ~MultiChainTracker() { mmcmc_tracker_destroy(h_); }
-    template <class T> void step(const std::vector<T> &states)
-    {
-        const size_t k = states.size() / (n_chains_ * dim_);
-        check(mmcmc_tracker_steps(h_, states.data(), 0, dtype_of<T>(), k, 0, k, nullptr), "mmcmc_tracker_steps");
-    }
-    std::vector<float> rhat()
-    {
-        std::vector<float> r(dim_);
-        check(mmcmc_tracker_stats(h_, r.data(), nullptr, nullptr, nullptr), "mmcmc_tracker_stats");
-        return r;
-    }
-    float max_rhat()
-    {
-        float m = 0.f;
-        check(mmcmc_tracker_stats(h_, nullptr, &m, nullptr, nullptr), "mmcmc_tracker_stats");
-        return m;
-    }
-    float p_accept()
-    {
-        float p = 0.f;
-        check(mmcmc_tracker_stats(h_, nullptr, nullptr, &p, nullptr), "mmcmc_tracker_stats");
-        return p;
     }
 };
 

@@ -36,6 +36,10 @@ class RunStats(C.Structure):
     _fields_ = [("ess", BasicStats), ("rhat", BasicStats)]
 
 
+# void (*mmcmc_progress_fn)(void *user, uint64_t done, uint64_t total, float p_accept, float max_rhat)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float)
+
+
 class Timing(C.Structure):
     _fields_ = [
         ("kernel_ms", C.c_float),
@@ -120,6 +124,21 @@ SIGNATURES = {
     "mmcmc_tracker_init_last": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "mmcmc_tracker_chain_stats": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "mmcmc_tracker_n": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "mmcmc_tracker_shape": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "mmcmc_tracker_within_var": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "mmcmc_ess_from_chainstats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_float),
+                                            C.c_int, _vp]),
+    "mmcmc_mh_run_rows": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, _vp]),
+    "mmcmc_hmc_run_rows": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, _vp]),
+    "mmcmc_mh_shape": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mmcmc_hmc_shape": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mmcmc_nuts_shape": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mmcmc_mh_run_progress": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, C.POINTER(RunStats),
+                                        C.POINTER(_vp), _vp]),
+    "mmcmc_hmc_run_progress": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, C.POINTER(RunStats),
+                                         C.POINTER(_vp), _vp]),
+    "mmcmc_nuts_run_progress": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, C.POINTER(RunStats),
+                                          C.POINTER(_vp), _vp]),
     "mmcmc_tracker_destroy": (C.c_int, [_vp]),
     "mmcmc_mh_discrete_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_size_t, C.c_int]),
     "mmcmc_mh_discrete_set_kernel_variant": (C.c_int, [_vp, C.c_int]),

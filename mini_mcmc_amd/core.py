@@ -83,44 +83,15 @@ class _Sampler:
 
     def run_progress(self, n_collect: int, n_discard: int = 0, every: int = 0, callback=None, to: str = "numpy"):
         """`run_progress(n_collect, n_discard)` of the reference (hmc.rs:222-294 / core.rs:208-360): burn-in, then
-        sampling with a MultiChainTracker fed the state before the loop and every collected state; returns
-        (sample [n_chains, n_collect, dim], RunStats).  Instead of a progress bar redrawn after each step, the run is
-        cut into launches of `every` transitions (default: 10 segments) and after each `callback(done, p_accept,
-        max_rhat)` is called -- the two numbers the reference's bar shows.  The tracker ends up in `self.tracker`."""
-        import torch
-
+        sampling with the reference's running diagnostics; returns (sample [n_chains, n_collect, dim], RunStats).
+        The tracker feeding order (HMC: one MultiChainTracker after the burn-in; MH: per-chain ChainTrackers through
+        it) is the library's (mmcmc_{mh,hmc}_run_progress, csrc/mm_progress.hip).  Instead of a progress bar redrawn
+        after each step, `callback(done, p_accept, max_rhat)` is called after every `every` transitions (default: ten
+        times per run) -- the two numbers the reference's bar shows.  The tracker ends up in `self.tracker`."""
         from . import stats as S
 
-        dev = torch.device("cuda", self.device)
-        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
-        tracker = S.MultiChainTracker(self.n_chains, self.dim, self.device)
-        # HMC burns in, then feeds one MultiChainTracker the state the sampling starts from and every collected state
-        # (hmc.rs:229-247); the generic runner (MH: core.rs:90-140) keeps one ChainTracker per chain, constructed
-        # with the chain's state before the first step and stepped with EVERY state, burn-in included
-        per_chain = self._prefix != "hmc"
-        if per_chain:
-            tracker.init_last(torch.as_tensor(self.state(), device=dev))
-            if n_discard:
-                tracker.step(self.run(n_discard, 0, to="torch", accept_counts=False))
-        else:
-            if n_discard:
-                self.run(0, n_discard, to="torch", accept_counts=False, collect=False)
-            tracker.step(torch.as_tensor(self.state(), device=dev))
-        out = torch.empty((self.n_chains, n_collect, self.dim), dtype=tdt, device=dev)
-        every = int(every) if every else max(1, (n_collect + 9) // 10)
-        done = 0
-        while done < n_collect:
-            k = min(every, n_collect - done)
-            seg = self.run(k, 0, to="torch", accept_counts=False)
-            out[:, done:done + k, :] = seg
-            tracker.step(out, t0=done, k=k)
-            done += k
-            if callback is not None and tracker.n >= 2:
-                _, mx, p = tracker.chain_stats() if per_chain else tracker._stats()
-                callback(done, float(p), float(mx))
-        self.tracker = tracker
-        stats = S.run_stats(out)
-        return (out if to == "torch" else out.cpu().numpy()), stats
+        return _run_progress_c(self, self._fn("run_progress"), n_collect, n_discard, every, callback, to,
+                               self.dtype, count_from=n_discard if self._prefix == "hmc" else 0)
 
     def enable_timing(self, on: bool = True):
         """HIP-event bracketing of run() for timing() (default on)."""
@@ -161,3 +132,27 @@ def draw_noise(seed: int, chain_offset: int, iteration: int, n_chains: int, dim:
                                   L.F32 if dtype == np.float32 else L.F64, z.ctypes.data, u.ctypes.data, device)
     L.check(st, "mmcmc_draw_noise")
     return z, u
+
+
+def _run_progress_c(obj, fn, n_collect, n_discard, every, callback, to, dtype, count_from=0):
+    """Shared by the three samplers: mmcmc_*_run_progress with a ctypes callback; `callback(done, p_accept, max_rhat)`
+    counts collected transitions for HMC (whose burn-in is unobserved) and all transitions otherwise."""
+    from . import stats as S
+
+    cb = L.PROGRESS_FN(lambda user, done, total, p, r: callback(int(done) - count_from, float(p), float(r))) if callback else None
+    rs = L.RunStats()
+    tr = C.c_void_p()
+    cbp = C.cast(cb, C.c_void_p) if cb else None
+    if to == "torch":
+        import torch
+
+        dev = torch.device("cuda", obj.device)
+        out = torch.empty((obj.n_chains, n_collect, obj.dim), dtype=torch.float32 if dtype == np.float32 else torch.float64, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        st = fn(obj._h, n_collect, n_discard, int(every), cbp, None, C.c_void_p(out.data_ptr()), 1, C.byref(rs), C.byref(tr), stream)
+    else:
+        out = np.empty((obj.n_chains, n_collect, obj.dim), dtype=dtype)
+        st = fn(obj._h, n_collect, n_discard, int(every), cbp, None, C.c_void_p(out.ctypes.data), 0, C.byref(rs), C.byref(tr), None)
+    L.check(st, "run_progress")
+    obj.tracker = S.MultiChainTracker._adopt(tr)
+    return out, S._run_stats_from_c(rs)

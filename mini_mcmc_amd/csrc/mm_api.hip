@@ -500,14 +500,20 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
     return MMCMC_OK;
 }
 
+/* n_total_rows / row0: the collected rows go to rows [row0, row0 + n_collect) of out [n_chains, n_total_rows, dim] (device
+ * memory only when n_total_rows != n_collect): how run_progress fills one sample by several launches (mm_progress.hip) */
 int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int out_is_device,
-                uint64_t *accept_counts, void *stream_v)
+                uint64_t *accept_counts, void *stream_v, size_t n_total_rows = 0, size_t row0 = 0)
 {
     if (!s)
         return MMCMC_ERR_INVALID_ARG;
     if (n_collect + n_discard == 0)
         return MMCMC_OK;
-    if ((uint64_t)n_collect * (uint64_t)s->dim >= (1ull << 30) || s->iter + n_collect + n_discard >= (1ull << 32))
+    if (n_total_rows == 0)
+        n_total_rows = n_collect;
+    if (row0 + n_collect > n_total_rows || ((n_total_rows != n_collect || row0 != 0) && out && !out_is_device))
+        return MMCMC_ERR_INVALID_ARG;
+    if ((uint64_t)n_total_rows * (uint64_t)s->dim >= (1ull << 30) || s->iter + n_collect + n_discard >= (1ull << 32))
         return MMCMC_ERR_SHAPE;
     DeviceGuard g(s->device);
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : s->stream;
@@ -538,7 +544,7 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
         MM_HIP(hipMemsetAsync(s->d_accept, 0, s->n_chains * sizeof(unsigned long long), stream));
 
     /* split the run into launches of at most iters_per_launch transitions (0 = one launch) */
-    uint64_t remaining_discard = n_discard, remaining_collect = n_collect, t0 = 0;
+    uint64_t remaining_discard = n_discard, remaining_collect = n_collect, t0 = row0;
     const uint64_t cap = s->iters_per_launch ? s->iters_per_launch : (n_discard + n_collect);
     uint32_t launches = 0;
     if (s->timing_enabled)
@@ -548,9 +554,9 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
         uint32_t nc = (uint32_t)std::min<uint64_t>(remaining_collect, cap - nd);
         int st;
         if (s->dtype == MMCMC_F32)
-            st = launch_range<float>(s, s->kf, s->Pf, (float *)d_out, n_collect, nd, nc, (uint32_t)t0, stream);
+            st = launch_range<float>(s, s->kf, s->Pf, (float *)d_out, n_total_rows, nd, nc, (uint32_t)t0, stream);
         else
-            st = launch_range<double>(s, s->kd, s->Pd, (double *)d_out, n_collect, nd, nc, (uint32_t)t0, stream);
+            st = launch_range<double>(s, s->kd, s->Pd, (double *)d_out, n_total_rows, nd, nc, (uint32_t)t0, stream);
         if (st != MMCMC_OK)
             return st;
         remaining_discard -= nd;
@@ -932,6 +938,27 @@ int mmcmc_mh_run(mmcmc_mh *h, size_t n_collect, size_t n_discard, void *out, int
     return h ? sampler_run(h->s, n_collect, n_discard, out, out_is_device, accept_counts, stream)
              : MMCMC_ERR_INVALID_ARG;
 }
+int mmcmc_mh_run_rows(mmcmc_mh *h, size_t n_rows, size_t n_discard, void *out_device, size_t n_total_rows, size_t row0,
+                      void *stream)
+{
+    return h ? sampler_run(h->s, n_rows, n_discard, out_device, 1, nullptr, stream, n_total_rows, row0) : MMCMC_ERR_INVALID_ARG;
+}
+static int sampler_shape(const Sampler *s, size_t *n_chains, int *dim, int *dtype, int *device)
+{
+    if (n_chains)
+        *n_chains = s->n_chains;
+    if (dim)
+        *dim = s->dim;
+    if (dtype)
+        *dtype = s->dtype;
+    if (device)
+        *device = s->device;
+    return MMCMC_OK;
+}
+int mmcmc_mh_shape(mmcmc_mh *h, size_t *n_chains, int *dim, int *dtype, int *device)
+{
+    return h ? sampler_shape(h->s, n_chains, dim, dtype, device) : MMCMC_ERR_INVALID_ARG;
+}
 int mmcmc_mh_state(mmcmc_mh *h, void *out) { return h ? sampler_state(h->s, out) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_mh_sync(mmcmc_mh *h) { return h ? sampler_sync(h->s) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_mh_timing(mmcmc_mh *h, mmcmc_timing *t) { return h ? sampler_timing(h->s, t) : MMCMC_ERR_INVALID_ARG; }
@@ -989,6 +1016,15 @@ int mmcmc_hmc_run(mmcmc_hmc *h, size_t n_collect, size_t n_discard, void *out, i
 {
     return h ? sampler_run(h->s, n_collect, n_discard, out, out_is_device, accept_counts, stream)
              : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_run_rows(mmcmc_hmc *h, size_t n_rows, size_t n_discard, void *out_device, size_t n_total_rows, size_t row0,
+                       void *stream)
+{
+    return h ? sampler_run(h->s, n_rows, n_discard, out_device, 1, nullptr, stream, n_total_rows, row0) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_shape(mmcmc_hmc *h, size_t *n_chains, int *dim, int *dtype, int *device)
+{
+    return h ? sampler_shape(h->s, n_chains, dim, dtype, device) : MMCMC_ERR_INVALID_ARG;
 }
 int mmcmc_hmc_step(mmcmc_hmc *h, void *stream)
 {

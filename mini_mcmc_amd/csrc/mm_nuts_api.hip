@@ -496,11 +496,16 @@ template <class TT, class ST> struct Nuts : NutsBase {
 
     int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream_v) override
     {
-        if ((uint64_t)n_collect * (uint64_t)dim >= (1ull << 30) || (uint64_t)m + n_collect + n_discard >= (1ull << 32))
+        if (progress < 0 || progress > 2)
+            return MMCMC_ERR_INVALID_ARG;
+        /* progress == 2: run_progress' stepping with EVERY state recorded, burn-in included (what the per-chain trackers of
+         * nuts.rs:486-506 are fed): out has n_collect + n_discard rows per chain */
+        const size_t n_rows = progress == 2 ? n_collect + n_discard : n_collect;
+        if ((uint64_t)n_rows * (uint64_t)dim >= (1ull << 30) || (uint64_t)m + n_collect + n_discard >= (1ull << 32))
             return MMCMC_ERR_SHAPE;
         DevGuard g(device);
         hipStream_t st = stream_v ? (hipStream_t)stream_v : stream;
-        const size_t out_bytes = n_chains * n_collect * (size_t)dim * sizeof(TT);
+        const size_t out_bytes = n_chains * n_rows * (size_t)dim * sizeof(TT);
         TT *d_out = nullptr;
         /* host output: a device staging buffer, released on every path out of this function */
         struct Staging {
@@ -512,7 +517,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
             }
         } staging;
         bool staged = false;
-        if (out && n_collect > 0) {
+        if (out && n_rows > 0) {
             if (out_is_device) {
                 d_out = (TT *)out;
             } else {
@@ -548,7 +553,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
             ga.c_pad = g_pad;
             ga.seed = seed;
             ga.chain_offset = chain_offset;
-            ga.n_total = n_collect;
+            ga.n_total = n_rows;
             ga.m0 = m;
             ga.n_pre = ga.n_rec = ga.write_initial = ga.out_t0 = 0;
             ga.n_discard = (unsigned int)n_discard;
@@ -584,7 +589,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
         a.n_chains = n_chains;
         a.seed = seed;
         a.chain_offset = chain_offset;
-        a.n_total = n_collect;
+        a.n_total = n_rows;
         a.m0 = m;
         a.out_t0 = 0;
         a.n_discard = (unsigned int)n_discard;
@@ -596,7 +601,11 @@ template <class TT, class ST> struct Nuts : NutsBase {
             a.async_batch = (unsigned int)atoi(e);
         a.scratch = d_scratch;
         const size_t total = n_collect + n_discard;
-        if (progress) {
+        if (progress == 2) {
+            a.write_initial = 0;
+            a.n_pre = 0;
+            a.n_rec = (unsigned int)total;
+        } else if (progress) {
             /* run_progress (nuts.rs:491-522): all N transitions, the last n_collect recorded */
             a.write_initial = 0;
             a.n_pre = (unsigned int)n_discard;
@@ -849,6 +858,20 @@ int mmcmc_nuts_run(mmcmc_nuts *h, size_t n_collect, size_t n_discard, void *out,
                    void *stream)
 {
     return h ? h->p->run(n_collect, n_discard, out, out_is_device, progress, stream) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_shape(mmcmc_nuts *h, size_t *n_chains, int *dim, int *mode, int *device)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    if (n_chains)
+        *n_chains = h->p->n_chains;
+    if (dim)
+        *dim = h->p->dim;
+    if (mode)
+        *mode = h->p->mode;
+    if (device)
+        *device = h->p->device;
+    return MMCMC_OK;
 }
 int mmcmc_nuts_state(mmcmc_nuts *h, void *out) { return (h && out) ? h->p->state(out) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_nuts_adapt_state(mmcmc_nuts *h, double *out)

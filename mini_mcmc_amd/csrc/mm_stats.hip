@@ -1696,6 +1696,8 @@ int mmcmc_stats_partials(const void *sample, int dtype, size_t n_chains, size_t 
 /* stats.rs:449-465 (withinvar), :425-427 (rhat), :509-545 (ess) on the gathered sufficient statistics, f32.
  * means, ssq: [c2, dim] in splitcat order (first halves of all chains, then second halves); acov_sum [m, dim]. */
 /* from the cross-chain sums to R-hat and ESS of parameter d (stats.rs:459-465, 425-427, 509-545), f32 */
+static float stats_ess_one(float w, float v, const float *acov_sum, size_t c2, size_t m, size_t dim, size_t d,
+                           std::vector<float> &rho);
 static void stats_finish_one(float dsum, float wsum, const float *acov_sum, size_t c2, size_t m, size_t dim, size_t d,
                              std::vector<float> &rho, float *rhat, float *ess)
 {
@@ -1704,6 +1706,14 @@ static void stats_finish_one(float dsum, float wsum, const float *acov_sum, size
     const float w = wsum / cf;
     const float v = ((nf - 1.0f) / nf) * w + b / nf;
     rhat[d] = std::sqrt(w / v); /* sqrt(W / var+): the reference's definition (quirk Q7) */
+    ess[d] = stats_ess_one(w, v, acov_sum, c2, m, dim, d, rho);
+}
+
+/* ess (stats.rs:496-546) of parameter d from within / var and the lag sums over `c2` chains of length m */
+static float stats_ess_one(float w, float v, const float *acov_sum, size_t c2, size_t m, size_t dim, size_t d,
+                           std::vector<float> &rho)
+{
+    const float nf = (float)m, cf = (float)c2;
     for (size_t t = 0; t < m; ++t) {
         const float avg_rho = (acov_sum[t * dim + d] / nf) / cf; /* mean over chains of autocov_c(t) */
         const float diff = -avg_rho + w;
@@ -1721,7 +1731,7 @@ static void stats_finish_one(float dsum, float wsum, const float *acov_sum, size
         out += p_t;
     }
     const float tau = -1.0f + 2.0f * out;
-    ess[d] = (1.0f / tau) * cf * nf;
+    return (1.0f / tau) * cf * nf;
 }
 
 int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_sum, size_t c2, size_t m, size_t dim,
@@ -1849,6 +1859,98 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
     for (size_t d = 0; d < dim; ++d)
         stats_finish_one((float)dsum[d], (float)wsum[d], acov_sum, c2, m, dim, d, rho, rhat, ess);
     return MMCMC_OK;
+}
+
+/* ess_from_chainstats (stats.rs:668-671): the UN-split ESS of sample [n_chains, n, dim] with within / var taken from the
+ * per-chain trackers' ChainStats (withinvar_from_cs, stats.rs:155-178).  The lag sums over the n_chains whole chains come
+ * from the same kernels as the split diagnostics: [n_chains, n, dim] read as [n_chains / 2, 2 n, dim] has chain 2k as the
+ * first and chain 2k + 1 as the second "half" of row k, each centred on its own mean; an odd last chain is run doubled
+ * and counted half. */
+extern "C" int mmcmc_tracker_within_var(struct mmcmc_tracker *h, float *within, float *var, void *stream);
+extern "C" int mmcmc_tracker_shape(struct mmcmc_tracker *h, size_t *n_chains, size_t *dim, int *device);
+int mmcmc_ess_from_chainstats(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,
+                              struct mmcmc_tracker *tracker, float *ess, int device, void *stream_v)
+{
+    if (!sample || !tracker || !ess || n_chains == 0 || dim == 0 || n < 1 || (dtype != MMCMC_F32 && dtype != MMCMC_F64))
+        return MMCMC_ERR_INVALID_ARG;
+    size_t tc = 0, td = 0;
+    int tdev = 0;
+    int st = mmcmc_tracker_shape(tracker, &tc, &td, &tdev);
+    if (st != MMCMC_OK)
+        return st;
+    if (tc != n_chains || td != dim)
+        return MMCMC_ERR_SHAPE;
+    st = check_device(device);
+    if (st != MMCMC_OK)
+        return st;
+    std::vector<float> within(dim), var(dim);
+    st = mmcmc_tracker_within_var(tracker, within.data(), var.data(), tdev == device ? stream_v : nullptr);
+    if (st != MMCMC_OK)
+        return st;
+    DevGuard g(device);
+    hipStream_t stream = (hipStream_t)stream_v;
+    const size_t esz = dtype == MMCMC_F32 ? 4 : 8, row = n * dim * esz;
+    const size_t pairs = n_chains / 2;
+    void *d_sample = nullptr, *d_tail = nullptr;
+    float *d_ws = nullptr;
+    int rc = MMCMC_OK;
+    hipError_t e = hipSuccess;
+    std::vector<float> acov(n * dim, 0.f), tmp(n * dim);
+    do {
+        const char *src = (const char *)sample;
+        if (!sample_is_device) {
+            if ((e = hipMalloc(&d_sample, n_chains * row)) != hipSuccess)
+                break;
+            if ((e = hipMemcpyAsync(d_sample, sample, n_chains * row, hipMemcpyHostToDevice, stream)) != hipSuccess)
+                break;
+            src = (const char *)d_sample;
+        }
+        /* means | ssq of the pseudo half-chains (unused) | lag sums */
+        const size_t n_ms = 2 * std::max<size_t>(pairs, 1) * dim;
+        if ((e = hipMalloc((void **)&d_ws, (2 * n_ms + n * dim) * sizeof(float))) != hipSuccess)
+            break;
+        float *d_means = d_ws, *d_ssq = d_ws + n_ms, *d_acov = d_ws + 2 * n_ms;
+        if (pairs) {
+            rc = mmcmc_stats_partials(src, dtype, pairs, 2 * n, dim, d_means, d_ssq, d_acov, device, stream_v);
+            if (rc != MMCMC_OK)
+                break;
+            if ((e = hipMemcpyAsync(acov.data(), d_acov, n * dim * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                break;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+                break;
+        }
+        if (n_chains & 1) {
+            if ((e = hipMalloc(&d_tail, 2 * row)) != hipSuccess)
+                break;
+            const char *last = src + (n_chains - 1) * row;
+            if ((e = hipMemcpyAsync(d_tail, last, row, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+                break;
+            if ((e = hipMemcpyAsync((char *)d_tail + row, last, row, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+                break;
+            rc = mmcmc_stats_partials(d_tail, dtype, 1, 2 * n, dim, d_means, d_ssq, d_acov, device, stream_v);
+            if (rc != MMCMC_OK)
+                break;
+            if ((e = hipMemcpyAsync(tmp.data(), d_acov, n * dim * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                break;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+                break;
+            for (size_t i = 0; i < n * dim; ++i)
+                acov[i] += 0.5f * tmp[i];
+        }
+        std::vector<float> rho(n);
+        for (size_t d = 0; d < dim; ++d)
+            ess[d] = stats_ess_one(within[d], var[d], acov.data(), n_chains, n, dim, d, rho);
+    } while (0);
+    (void)hipStreamSynchronize(stream);
+    if (d_sample)
+        (void)hipFree(d_sample);
+    if (d_tail)
+        (void)hipFree(d_tail);
+    if (d_ws)
+        (void)hipFree(d_ws);
+    if (e != hipSuccess)
+        return (int)e;
+    return rc;
 }
 
 /* stats.rs:310-336 basic_stats: sorted descending; min = last, median = [len/2], max = first, std with ddof 1 */

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(1024) void tracker_rhat_kernel(const float *__restr
 }
 
 /* collect_rhat (stats.rs:150-178) over the ChainStats of every chain, and the average per-chain acceptance EMA
- * (core.rs:268-281); out[d] = rhat, out[D] = mean p_accept.  One block per parameter (+ one for p_accept). */
+ * (core.rs:268-281); out[d] = rhat, out[D] = mean p_accept, out[D + 1 + d] = within, out[2 D + 1 + d] = var.  One block per parameter (+ one for p_accept). */
 __global__ __launch_bounds__(1024) void tracker_chain_stats_kernel(const float *__restrict__ mean,
                                                                    const float *__restrict__ mean_sq,
                                                                    const float *__restrict__ p_chain,
@@ -536,6 +536,8 @@ __global__ __launch_bounds__(1024) void tracker_chain_stats_kernel(const float *
     if (tid == 0) {
         const float var = between + within * ((n - 1.0f) / n);
         out[d] = sqrtf(var / within);
+        out[D + 1 + d] = within; /* withinvar_from_cs's pair (stats.rs:155-178), for ess_from_chainstats */
+        out[2 * D + 1 + d] = var;
     }
 }
 
@@ -585,7 +587,7 @@ int mmcmc_tracker_create(mmcmc_tracker **out, size_t n_chains, size_t dim, int d
     alloc0(&h->d_mean_sq, cd);
     alloc0(&h->d_last, cd);
     alloc0(&h->d_p, sizeof(float));
-    alloc0(&h->d_rhat, (dim + 1) * sizeof(float));
+    alloc0(&h->d_rhat, (3 * dim + 1) * sizeof(float));
     alloc0(&h->d_p_chain, n_chains * sizeof(float));
     if (e == hipSuccess) {
         std::vector<float> neg(n_chains, -1.0f); /* ChainTracker::new: p_accept = -1 (stats.rs:76) */
@@ -746,6 +748,41 @@ int mmcmc_tracker_chain_stats(mmcmc_tracker *h, float *rhat, float *max_rhat, fl
         *max_rhat = mx;
     if (avg_p_accept)
         *avg_p_accept = r[h->dim];
+    return MMCMC_OK;
+}
+
+/* withinvar_from_cs (stats.rs:155-178) over the per-chain ChainStats: what collect_rhat and ess_from_chainstats share */
+int mmcmc_tracker_within_var(mmcmc_tracker *h, float *within, float *var, void *stream)
+{
+    if (!h || !within || !var)
+        return MMCMC_ERR_INVALID_ARG;
+    if (h->n < 2)
+        return MMCMC_ERR_STATE;
+    DevGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tracker_chain_stats_kernel, dim3((unsigned int)h->dim + 1), dim3(1024), 0, st, h->d_mean,
+                       h->d_mean_sq, h->d_p_chain, (unsigned long long)h->n_chains, (unsigned int)h->dim, h->n, h->d_rhat);
+    MM_HIP(hipGetLastError());
+    std::vector<float> r(2 * h->dim);
+    MM_HIP(hipMemcpyAsync(r.data(), h->d_rhat + h->dim + 1, 2 * h->dim * sizeof(float), hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    for (size_t d = 0; d < h->dim; ++d) {
+        within[d] = r[d];
+        var[d] = r[h->dim + d];
+    }
+    return MMCMC_OK;
+}
+
+int mmcmc_tracker_shape(mmcmc_tracker *h, size_t *n_chains, size_t *dim, int *device)
+{
+    if (!h)
+        return MMCMC_ERR_INVALID_ARG;
+    if (n_chains)
+        *n_chains = h->n_chains;
+    if (dim)
+        *dim = h->dim;
+    if (device)
+        *device = h->device;
     return MMCMC_OK;
 }
 

@@ -90,12 +90,12 @@ class NUTS:
         """NUTS::run (nuts.rs:163-170): sample [n_chains, n_collect, dim]."""
         return self._run(n_collect, n_discard, False, to)
 
-    def run_progress(self, n_collect: int, n_discard: int, to: str = "numpy"):
-        """NUTS::run_progress (nuts.rs:194-338): (sample, RunStats)."""
-        from . import stats as S
+    def run_progress(self, n_collect: int, n_discard: int, to: str = "numpy", every: int = 0, callback=None):
+        """NUTS::run_progress (nuts.rs:172-345): (sample, RunStats); per-chain ChainTrackers fed the initial position and
+        all n_discard + n_collect states (nuts.rs:486-506) end up in `self.tracker` (mmcmc_nuts_run_progress)."""
+        from .core import _run_progress_c
 
-        sample = self._run(n_collect, n_discard, True, to)
-        return sample, S.run_stats(sample)
+        return _run_progress_c(self, L.lib().mmcmc_nuts_run_progress, n_collect, n_discard, every, callback, to, self.dtype)
 
     def positions(self) -> np.ndarray:
         out = np.empty((self.n_chains, self.dim), dtype=self.dtype)

@@ -224,6 +224,24 @@ class MultiChainTracker:
         self._h = C.c_void_p()
         L.check(L.lib().mmcmc_tracker_create(C.byref(self._h), self.n_chains, self.n_params, device), "mmcmc_tracker_create")
 
+    @classmethod
+    def _adopt(cls, handle: C.c_void_p) -> "MultiChainTracker":
+        """Own a tracker the library handed back (mmcmc_*_run_progress' tracker_out)."""
+        self = cls.__new__(cls)
+        self._h = handle
+        c, d, dev = C.c_size_t(), C.c_size_t(), C.c_int()
+        L.check(L.lib().mmcmc_tracker_shape(handle, C.byref(c), C.byref(d), C.byref(dev)), "mmcmc_tracker_shape")
+        self.n_chains, self.n_params, self.device = int(c.value), int(d.value), int(dev.value)
+        return self
+
+    def within_var(self):
+        """withinvar_from_cs (stats.rs:155-178) over the per-chain ChainStats: (within [n_params], var [n_params])"""
+        w = np.zeros(self.n_params, dtype=np.float32)
+        v = np.zeros(self.n_params, dtype=np.float32)
+        L.check(L.lib().mmcmc_tracker_within_var(self._h, w.ctypes.data_as(_fp), v.ctypes.data_as(_fp), None),
+                "mmcmc_tracker_within_var")
+        return w, v
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
@@ -285,3 +303,24 @@ class MultiChainTracker:
         n = C.c_uint64()
         L.check(L.lib().mmcmc_tracker_n(self._h, C.byref(n)), "mmcmc_tracker_n")
         return int(n.value)
+
+
+def ess_from_chainstats(sample, tracker: MultiChainTracker) -> np.ndarray:
+    """stats::ess_from_chainstats (stats.rs:668-671): the un-split ESS of sample [chains, n, params] with within / var
+    from the per-chain trackers (`tracker` fed with init_last + step, or the one run_progress hands back)."""
+    ptr, is_dev, code, shape, dev, stream, keep = _sample_args(sample)
+    if len(shape) != 3:
+        raise ValueError("sample must be [chains, n, params]")
+    c, n, p = shape
+    ess = np.empty(p, dtype=np.float32)
+    st = L.lib().mmcmc_ess_from_chainstats(ptr, is_dev, code, c, n, p, tracker._h, ess.ctypes.data_as(_fp),
+                                           dev if is_dev else tracker.device, stream)
+    L.check(st, "mmcmc_ess_from_chainstats")
+    return ess
+
+
+def _run_stats_from_c(rs) -> RunStats:
+    def b(name, x):
+        return BasicStats(name, x.min, x.median, x.max, x.mean, x.std)
+
+    return RunStats(b("ESS", rs.ess), b("Split R-hat", rs.rhat))

@@ -100,6 +100,16 @@ void o_multichain_tracker(const float *states, size_t steps, size_t chains, size
 void o_chain_trackers_rhat(const float *init, const float *states, size_t chains, size_t steps, size_t params,
                            float *rhat, float *p_accept);
 
+/* ess_from_chainstats stats.rs:668-671 (un-split ESS with the trackers' within / var, :155-178): per-chain trackers built on
+ * init[chains, params] and fed tracked[chains, steps, params]; sample[chains, n, params] */
+void o_ess_from_chainstats(const float *sample, size_t chains, size_t n, size_t params, const float *init,
+                           const float *tracked, size_t steps, float *ess);
+
+/* ---- cpu_bench.c: the timing harness of bench.py's cpu_baseline leg (one spawn per measurement, private samplers) ---- */
+double o_cpu_bench(int kind, const ot_target *target, const double *init, int chains_per_thread, int n_threads,
+                   double scale, int n_leapfrog, int is_f32, size_t n_collect, size_t n_discard, int reps,
+                   uint64_t seed, int nuts_mode, int nuts_max_depth, double *thread_seconds, double *work_out);
+
 #ifdef __cplusplus
 }
 #endif

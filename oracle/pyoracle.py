@@ -143,6 +143,9 @@ def lib() -> C.CDLL:
         "o_basic_stats": (None, [_fp, C.c_size_t, _fp]),
         "o_multichain_tracker": (None, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
         "o_chain_trackers_rhat": (None, [_fp, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
+        "o_ess_from_chainstats": (None, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp, C.c_size_t, _fp]),
+        "o_cpu_bench": (C.c_double, [C.c_int, tp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_size_t,
+                                     C.c_size_t, C.c_int, C.c_uint64, C.c_int, C.c_int, _dp, _dp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -161,7 +164,52 @@ def _f(a):
 
 
 def default_threads() -> int:
-    return os.cpu_count() or 1
+    return usable_cpus()
+
+
+def usable_cpus() -> int:
+    """Hardware threads this process may actually run on: the scheduler affinity mask, capped by the cgroup's CPU quota
+    (cpu.max, cgroup v2; cfs_quota_us / cfs_period_us, v1) -- os.cpu_count() reports the machine's, not ours."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+CPU_BENCH_HMC, CPU_BENCH_MH, CPU_BENCH_NUTS = 0, 1, 2
+
+
+def cpu_bench(kind, target: "Target", init, chains_per_thread, n_threads, scale, n_leapfrog=0, dtype=np.float32,
+              n_collect=400, n_discard=50, reps=1, seed=42, nuts_mode=2, nuts_max_depth=10):
+    """oracle/cpu_bench.c: ONE spawn, every thread a private sampler over its own block of `chains_per_thread` chains,
+    `reps` x run(n_collect, n_discard) each behind a common gate.  Returns (wall seconds, per-thread seconds, NUTS
+    leapfrog steps)."""
+    init = np.ascontiguousarray(init, dtype=np.float64)
+    assert init.shape == (chains_per_thread * n_threads, target.dim), init.shape
+    per = np.zeros(n_threads)
+    work = C.c_double(0.0)
+    wall = lib().o_cpu_bench(int(kind), target.ref, _d(init), int(chains_per_thread), int(n_threads), float(scale),
+                             int(n_leapfrog), int(dtype == np.float32), int(n_collect), int(n_discard), int(reps),
+                             int(seed), int(nuts_mode), int(nuts_max_depth), _d(per), C.byref(work))
+    if wall < 0:
+        raise ValueError("o_cpu_bench failed")
+    return wall, per, work.value
 
 
 # ---------------------------------------------------------------- RNG
@@ -570,6 +618,19 @@ def chain_trackers_rhat(init, states):
 
 _EH_PATH = os.path.join(_HERE, "_build", "libengine_host.so")
 _eh = None
+
+
+def ess_from_chainstats(sample, init, tracked):
+    """stats.rs:668-671: un-split ESS of sample [chains, n, params] with within / var from per-chain ChainTrackers
+    constructed on init [chains, params] and fed tracked [chains, steps, params]."""
+    s = np.ascontiguousarray(sample, dtype=np.float32)
+    i0 = np.ascontiguousarray(init, dtype=np.float32)
+    tr = np.ascontiguousarray(tracked, dtype=np.float32)
+    c, n, p = s.shape
+    assert i0.shape == (c, p) and tr.shape[0] == c and tr.shape[2] == p
+    ess = np.zeros(p, dtype=np.float32)
+    lib().o_ess_from_chainstats(_f(s), c, n, p, _f(i0), _f(tr), tr.shape[1], _f(ess))
+    return ess
 
 
 def engine_host_lib() -> C.CDLL:

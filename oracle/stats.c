@@ -401,9 +401,64 @@ void o_multichain_tracker(const float *states, size_t steps, size_t chains, size
     free(last);
 }
 
+static void chain_trackers_core(const float *init, const float *states, size_t chains, size_t steps, size_t params,
+                                float *rhat, float *p_accept_out, float *within_out, float *var_out);
+
 /* stats.rs:26-141 (ChainTracker) + :150-178 (collect_rhat) */
 void o_chain_trackers_rhat(const float *init, const float *states, size_t chains, size_t steps, size_t params,
                            float *rhat, float *p_accept_out)
+{
+    chain_trackers_core(init, states, chains, steps, params, rhat, p_accept_out, NULL, NULL);
+}
+
+/* ess_from_chainstats stats.rs:668-671: ess(sample, within, var) (:496-546, NOT split) with (within, var) =
+ * withinvar_from_cs (:155-178) of per-chain ChainTrackers that were constructed on init[chains, params] and fed
+ * tracked[chains, steps, params]; sample [chains, n, params] (the collected part of the run) */
+void o_ess_from_chainstats(const float *sample, size_t chains, size_t n, size_t params, const float *init,
+                           const float *tracked, size_t steps, float *ess)
+{
+    float *within = (float *)malloc(sizeof(float) * params);
+    float *var = (float *)malloc(sizeof(float) * params);
+    float *rhat = (float *)malloc(sizeof(float) * params);
+    chain_trackers_core(init, tracked, chains, steps, params, rhat, NULL, within, var);
+    float *avg_rho = (float *)calloc(n * params + 1, sizeof(float));
+    float *rho_c = (float *)malloc(sizeof(float) * (n * params + 1));
+    for (size_t ch = 0; ch < chains; ++ch) {
+        autocov(sample + ch * n * params, n, params, rho_c);
+        for (size_t i = 0; i < n * params; ++i)
+            avg_rho[i] = avg_rho[i] + rho_c[i];
+    }
+    for (size_t i = 0; i < n * params; ++i)
+        avg_rho[i] = avg_rho[i] / (float)chains;
+    for (size_t k = 0; k < params; ++k) {
+        float *rho = rho_c;
+        for (size_t t = 0; t < n; ++t) {
+            float diff = -avg_rho[t * params + k] + within[k];
+            rho[t] = -(diff / var[k]) + 1.0f;
+        }
+        float min = (n >= 2) ? rho[0] + rho[1] : 0.0f;
+        float out = 0.0f;
+        for (size_t t = 0; t + 1 < n; t += 2) {
+            float p_t = rho[t] + rho[t + 1];
+            if (p_t <= 0.0f)
+                break;
+            if (p_t > min)
+                p_t = min;
+            min = p_t;
+            out += p_t;
+        }
+        float tau = -1.0f + 2.0f * out;
+        ess[k] = (1.0f / tau) * (float)chains * (float)n;
+    }
+    free(within);
+    free(var);
+    free(rhat);
+    free(avg_rho);
+    free(rho_c);
+}
+
+static void chain_trackers_core(const float *init, const float *states, size_t chains, size_t steps, size_t params,
+                                float *rhat, float *p_accept_out, float *within_out, float *var_out)
 {
     const float ALPHA = 0.01f;
     float *means = (float *)calloc(chains * params, sizeof(float));
@@ -459,6 +514,10 @@ void o_chain_trackers_rhat(const float *init, const float *states, size_t chains
         float between = ss / (float)(chains * params - 1);
         float var = between + within * ((nmean - 1.0f) / nmean);
         rhat[k] = sqrtf(var / within);
+        if (within_out)
+            within_out[k] = within;
+        if (var_out)
+            var_out[k] = var;
     }
     free(means);
     free(sm2s);

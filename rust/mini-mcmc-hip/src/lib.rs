@@ -324,32 +324,46 @@ pub fn run_stats<T: GpuFloat>(sample: &Array3<T>) -> Result<RunStats, MmcmcError
 }
 
 impl<T: GpuFloat> GpuMetropolisHastings<T> {
-    /// `ChainRunner::run_progress(n_collect, n_discard)` (core.rs:208-360): the sample and its `RunStats`.  The
-    /// reference's progress bars (one OS thread per chain feeding indicatif) have no analogue at 65 536 chains; the
-    /// running diagnostics they display are `GpuTracker`.
-    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<T>, RunStats), Box<dyn std::error::Error>> {
-        let sample = self.run(n_collect, n_discard)?;
-        let stats = run_stats(&sample)?;
-        Ok((sample, stats))
+    /// `ChainRunner::run_progress(n_collect, n_discard)` (core.rs:208-360): the sample and its `RunStats`; the per-chain
+    /// `ChainTracker`s (built on the initial states, fed every state, burn-in included) come back as a `GpuTracker`.
+    /// The feeding order is the library's (`mmcmc_mh_run_progress`).  The reference's progress bars (one OS thread per
+    /// chain feeding indicatif) have no analogue at 65 536 chains.
+    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<T>, RunStats, GpuTracker), Box<dyn std::error::Error>> {
+        let mut out = Array3::<T>::default((self.n_chains, n_collect, self.dim));
+        let (mut stats, mut tr) = (RunStats::default(), null_mut());
+        check(unsafe { sys::mmcmc_mh_run_progress(self.h, n_collect, n_discard, 0, None, null_mut(), out.as_mut_ptr() as *mut c_void, 0, &mut stats, &mut tr, null_mut()) })?;
+        Ok((out, stats, GpuTracker { h: tr, dim: self.dim, n_chains: self.n_chains }))
     }
 }
 impl<T: GpuFloat> GpuHmc<T> {
-    /// `HMC::run_progress(n_collect, n_discard)` (hmc.rs:222-294): `(sample, RunStats)`
-    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<T>, RunStats), Box<dyn std::error::Error>> {
-        let sample = self.run(n_collect, n_discard)?;
-        let stats = run_stats(&sample)?;
-        Ok((sample, stats))
+    /// `HMC::run_progress(n_collect, n_discard)` (hmc.rs:222-294): `(sample, RunStats)` and the `MultiChainTracker` that
+    /// was fed the positions after the burn-in and every collected state (`mmcmc_hmc_run_progress`)
+    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<T>, RunStats, GpuTracker), Box<dyn std::error::Error>> {
+        let mut out = Array3::<T>::default((self.n_chains, n_collect, self.dim));
+        let (mut stats, mut tr) = (RunStats::default(), null_mut());
+        check(unsafe { sys::mmcmc_hmc_run_progress(self.h, n_collect, n_discard, 0, None, null_mut(), out.as_mut_ptr() as *mut c_void, 0, &mut stats, &mut tr, null_mut()) })?;
+        Ok((out, stats, GpuTracker { h: tr, dim: self.dim, n_chains: self.n_chains }))
     }
 }
 impl GpuNuts {
-    /// `NUTS::run_progress(n_collect, n_discard)` (nuts.rs:194-338): all N transitions (`run` performs N - 1), `(sample, RunStats)`
-    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<f32>, RunStats), Box<dyn std::error::Error>> {
+    /// `NUTS::run_progress(n_collect, n_discard)` (nuts.rs:172-345): all N transitions (`run` performs N - 1),
+    /// `(sample, RunStats)` and the per-chain trackers fed the initial position and every state (`mmcmc_nuts_run_progress`)
+    pub fn run_progress(&mut self, n_collect: usize, n_discard: usize) -> Result<(Array3<f32>, RunStats, GpuTracker), Box<dyn std::error::Error>> {
         let mut out = Array3::<f32>::default((self.n_chains, n_collect, self.dim));
-        check(unsafe { sys::mmcmc_nuts_run(self.h, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, 0, 1, null_mut()) })?;
-        check(unsafe { sys::mmcmc_nuts_sync(self.h) })?;
-        let stats = run_stats(&out)?;
-        Ok((out, stats))
+        let (mut stats, mut tr) = (RunStats::default(), null_mut());
+        check(unsafe { sys::mmcmc_nuts_run_progress(self.h, n_collect, n_discard, 0, None, null_mut(), out.as_mut_ptr() as *mut c_void, 0, &mut stats, &mut tr, null_mut()) })?;
+        Ok((out, stats, GpuTracker { h: tr, dim: self.dim, n_chains: self.n_chains }))
     }
+}
+
+/// `stats::ess_from_chainstats(sample, chain_stats)` (stats.rs:668-671): the un-split ESS with within / var from the
+/// per-chain trackers `tracker` (as returned by a `run_progress`)
+pub fn ess_from_chainstats(sample: ArrayView3<f32>, tracker: &GpuTracker) -> Result<Array1<f32>, MmcmcError> {
+    let (c, n, p) = sample.dim();
+    let owned = sample.as_standard_layout();
+    let mut ess = Array1::<f32>::zeros(p);
+    check(unsafe { sys::mmcmc_ess_from_chainstats(owned.as_ptr() as *const c_void, 0, sys::MMCMC_F32, c, n, p, tracker.h, ess.as_mut_ptr(), 0, null_mut()) })?;
+    Ok(ess)
 }
 
 /// `MultiChainTracker` (stats.rs:189-306) on the GPU: running R-hat and the acceptance EMA of all chains.

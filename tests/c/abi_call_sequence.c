@@ -113,6 +113,30 @@ int main(void)
     CHECK(mmcmc_nuts_sync(nuts));
     if (row[0] != 0.0f || row[1] != 1.0f)
         return 8;
+    /* NUTS::run_progress (nuts.rs:172-345) through the C ABI: sample + RunStats + the per-chain trackers, then
+     * stats::ess_from_chainstats (stats.rs:668-671) with them */
+    {
+        enum { CN = 64, NN = 40 };
+        double ninit[CN * 2];
+        CHECK(mmcmc_init_with_seed(CN, 2, 3, ninit));
+        mmcmc_nuts *np = NULL;
+        CHECK(mmcmc_nuts_create(&np, &dg, ninit, CN, 0.8, 0, 0));
+        CHECK(mmcmc_nuts_seed(np, 1));
+        float *ns = (float *)malloc(sizeof(float) * CN * NN * 2);
+        mmcmc_run_stats rs;
+        mmcmc_tracker *tr = NULL;
+        CHECK(mmcmc_nuts_run_progress(np, NN, 25, 0, NULL, NULL, ns, 0, &rs, &tr, NULL));
+        uint64_t tn = 0;
+        CHECK(mmcmc_tracker_n(tr, &tn));
+        float ess_cs[2], within[2], var[2];
+        CHECK(mmcmc_tracker_within_var(tr, within, var, NULL));
+        CHECK(mmcmc_ess_from_chainstats(ns, 0, MMCMC_F32, CN, NN, 2, tr, ess_cs, 0, NULL));
+        if (tn != NN + 25 || !(rs.ess.min > 1.f) || !(ess_cs[0] > 1.f && ess_cs[1] > 1.f) || !(within[0] > 0.f && var[0] > 0.f))
+            return 10;
+        CHECK(mmcmc_tracker_destroy(tr));
+        CHECK(mmcmc_nuts_destroy(np));
+        free(ns);
+    }
     CHECK(mmcmc_nuts_destroy(nuts));
     free(init3);
     free(init3f);

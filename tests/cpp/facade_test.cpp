@@ -99,6 +99,28 @@ int main(int argc, char **argv)
         MultiChainTracker tr(4, 3);
         tr.step(s3);
         REQUIRE(tr.max_rhat() > 0.9f && tr.p_accept() > 0.3f && tr.rhat().size() == 3);
+        // run_progress behind the C ABI (hmc.rs:222-294, core.rs:208-360): the feeding order is the library's
+        {
+            auto init2 = init_with_seed<float>(64, 2, 5);
+            HMC<float> hp(DiffableGaussian2D({0.0, 1.0}, {{{4.0, 2.0}, {2.0, 3.0}}}), init2, 64, 0.1f, 10);
+            hp.set_seed(3);
+            struct Seen { int calls = 0; uint64_t last = 0; } seen;
+            auto cb = [](void *u, uint64_t done, uint64_t total, float p, float r) {
+                auto *sn = (Seen *)u;
+                sn->calls += 1;
+                sn->last = done;
+                (void)total; (void)p; (void)r;
+            };
+            auto r = hp.run_progress(50, 20, 10, cb, &seen);
+            REQUIRE(r.sample.size() == 64u * 50u * 2u && seen.calls == 5 && seen.last == 70);
+            REQUIRE(r.tracker->n() == 51 && r.tracker->max_rhat() >= 0.9f && r.stats.s.ess.min > 1.0f);
+            MetropolisHastings<float> mp(Gaussian2D({0.0, 0.0}, {{{1.0, 0.0}, {0.0, 1.0}}}), IsotropicGaussian(1.0), init2, 64);
+            auto rm = mp.seed(4).run_progress(40, 10);
+            float mx = 0.f, pa = 0.f;
+            REQUIRE(rm.tracker->n() == 50 && rm.tracker->chain_rhat(&mx, &pa).size() == 2 && pa > 0.2f && pa < 0.9f);
+            auto ess = ess_from_chainstats(rm.sample, 64, 40, 2, *rm.tracker);
+            REQUIRE(ess.size() == 2 && ess[0] > 1.0f);
+        }
         // one call for every chain on a device group (here: two shards on device 0) == a single handle
         {
             auto init3 = init_with_seed<float>(130, 3, 42);

@@ -127,3 +127,78 @@ def test_run_progress_with_tracker_on_gpu(O):
     mh = MetropolisHastings(Gaussian2D([0, 0], [[1, 0], [0, 1]]), IsotropicGaussian(1.0), init_with_seed(8192, 2, 42, np.float32)).seed(42)
     _, st = mh.run_progress(100, 100)
     assert 0.4 < float(mh.tracker.p_accept) < 0.75 and st.rhat.max < 1.05
+
+
+@pytest.mark.gpu
+def test_run_progress_c_abi_feeding_orders_vs_oracle(O):
+    """mmcmc_{mh,hmc,nuts}_run_progress (csrc/mm_progress.hip): the tracker each of them hands back equals the oracle's
+    tracker fed in the reference's order -- HMC: positions after the burn-in, then the collected states (hmc.rs:229-262);
+    MH and NUTS: per-chain ChainTrackers on the initial state, then EVERY state, burn-in included (core.rs:103-112,
+    nuts.rs:486-506) -- and RunStats is RunStats::from(sample)."""
+    import ctypes as C
+
+    from mini_mcmc_amd import _lib as L
+    from mini_mcmc_amd import stats as S
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import DiffableGaussian2D, Gaussian2D, IsotropicGaussian, RosenbrockND
+    from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+    from mini_mcmc_amd.nuts import NUTS
+
+    # MH: a twin with the same seed gives the states of the burn-in the runner does not return
+    n_chains, nc, nd = 300, 37, 23
+    init = init_with_seed(n_chains, 2, 7, np.float32)
+    tgt = Gaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]])
+    mh = MetropolisHastings(tgt, IsotropicGaussian(1.0), init).seed(11)
+    seen = []
+    sample, stats = mh.run_progress(nc, nd, every=10, callback=lambda d, p, r: seen.append((d, p, r)))
+    twin = MetropolisHastings(tgt, IsotropicGaussian(1.0), init).seed(11)
+    every_state = twin.run(nc + nd, 0)
+    assert np.array_equal(sample, every_state[:, nd:, :])          # segmented launches = one run
+    assert [d for d, _, _ in seen] == [10, 20, 23, 33, 43, 53, 60]   # burn-in chunks, then the collected ones
+    rhat_o, p_o = O.chain_trackers_rhat(init, every_state)
+    rhat, mx, p = mh.tracker.chain_stats()
+    assert mh.tracker.n == nc + nd
+    np.testing.assert_allclose(rhat, rhat_o, rtol=2e-5)
+    assert abs(float(p) - float(p_o.astype(np.float64).mean())) < 1e-6
+    assert abs(seen[-1][1] - float(p)) < 1e-6 and abs(seen[-1][2] - float(mx)) <= 2e-5 * float(mx)
+    ref = S.run_stats(sample)
+    assert stats.ess.mean == ref.ess.mean and stats.rhat.max == ref.rhat.max
+    # ess_from_chainstats (stats.rs:668-671) with the tracker the runner hands back
+    ess = S.ess_from_chainstats(sample, mh.tracker)
+    ess_o = O.ess_from_chainstats(sample, init, every_state)
+    np.testing.assert_allclose(ess, ess_o, rtol=2e-3)
+    w, v = mh.tracker.within_var()
+    assert np.all(w > 0) and np.all(v > 0)
+    # odd chain count and a long sample (the power-spectrum branch above 100 draws, stats.rs:549)
+    mh2 = MetropolisHastings(tgt, IsotropicGaussian(1.0), init[:33]).seed(3)
+    s2, _ = mh2.run_progress(256, 0)
+    np.testing.assert_allclose(S.ess_from_chainstats(s2, mh2.tracker), O.ess_from_chainstats(s2, init[:33], s2), rtol=2e-3)
+
+    # NUTS: every state through the C ABI (progress = 2) on a twin
+    for mode, tgt_n, dim in ((0, DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), 2), (2, RosenbrockND(3), 3)):
+        init_n = init_with_seed(200, dim, 5) * 0.5
+        s = NUTS(tgt_n, init_n, 0.8, mode=mode).set_seed(9)
+        smp, st = s.run_progress(20, 15)
+        t = NUTS(tgt_n, init_n, 0.8, mode=mode).set_seed(9)
+        allr = np.empty((200, 35, dim), dtype=t.dtype)
+        L.check(L.lib().mmcmc_nuts_run(t._h, 20, 15, allr.ctypes.data, 0, 2, None), "mmcmc_nuts_run")
+        L.check(L.lib().mmcmc_nuts_sync(t._h), "sync")
+        assert np.array_equal(smp, allr[:, 15:, :])
+        plain = NUTS(tgt_n, init_n, 0.8, mode=mode).set_seed(9)._run(20, 15, True, "numpy")
+        assert np.array_equal(smp, plain)                            # recording the burn-in changes no state
+        rhat_o, p_o = O.chain_trackers_rhat(init_n.astype(np.float32), allr.astype(np.float32))
+        rhat, mx, p = s.tracker.chain_stats()
+        assert s.tracker.n == 35
+        np.testing.assert_allclose(rhat, rhat_o, rtol=3e-5)
+        assert abs(float(p) - float(p_o.astype(np.float64).mean())) < 1e-6
+        ref = S.run_stats(smp)
+        assert st.ess.min == ref.ess.min and st.rhat.mean == ref.rhat.mean
+
+
+def test_progress_abi_symbols():
+    import mini_mcmc_amd
+
+    lib = mini_mcmc_amd.lib()
+    for sym in ("mh_run_progress", "hmc_run_progress", "nuts_run_progress", "ess_from_chainstats", "tracker_within_var",
+                "tracker_shape", "mh_run_rows", "hmc_run_rows", "mh_shape", "hmc_shape", "nuts_shape"):
+        assert hasattr(lib, "mmcmc_" + sym)
