@@ -240,9 +240,37 @@ def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
         st_ms = (time.perf_counter() - t0) * 1e3
         out["config3_long"] = {"run": "run(1000, 200)", "kernel_ms": k, "stats_ms": st_ms, "ess_min": float(ess.min()),
                                "split_rhat_max_conventional": float((1.0 / rhat).max()),
-                               "ess_per_s": float(ess.min()) / ((k + st_ms) * 1e-3),
+                               ("ess_per_s" if float((1.0 / rhat).max()) <= 1.05 else "ess_per_s_unconverged"): float(ess.min()) / ((k + st_ms) * 1e-3),
                                "samples_per_s": C_PER_GPU * 1000 / (k * 1e-3)}
         del h, t
+        # an ESS/s that means something: (a) the reference's own converging HMC configuration (hmc.rs:576-787: 2-D Gaussian
+        # mean [0, 1], cov [[4, 2], [2, 3]], eps 0.1, L 10, 500 burn-in + 1000 draws; its test asserts split R-hat in
+        # [0.95, 1.05]) at 65 536 chains; (b) config 3's target with trajectories long enough to cross the banana
+        # (eps 0.02, L 150; profiles/r4b_converged_probe.jsonl: eps 0.032 / L 10 stays at R-hat 1.6-1.7 after 100 000
+        # transitions per chain within any 4000-draw window).  ess_per_s only where the conventional split R-hat <= 1.05.
+        from mini_mcmc_amd.distributions import DiffableGaussian2D
+
+        def converged_case(target, dim, eps, n_leap, n_burn, n_keep, what):
+            hh = HMC(target, init_with_seed(C_PER_GPU, dim, SEED, np.float32), eps, n_leap, device=dev.index or 0).set_seed(SEED)
+            tt = hh.run(n_keep, n_burn, to="torch", accept_counts=False)
+            torch.cuda.synchronize()
+            kk = float(hh.timing()["kernel_ms"])
+            S.split_rhat_mean_ess(tt)
+            t0 = time.perf_counter()
+            rh, es = S.split_rhat_mean_ess(tt)
+            sm = (time.perf_counter() - t0) * 1e3
+            rmax = float((1.0 / rh).max())
+            res = {"workload": what, "run": f"run({n_keep}, {n_burn})", "kernel_ms": kk, "stats_ms": sm, "ess_min": float(es.min()),
+                   "split_rhat_max_conventional": rmax, "converged": rmax <= 1.05,
+                   "samples_per_s": C_PER_GPU * n_keep / (kk * 1e-3),
+                   "leapfrog_steps_per_s": C_PER_GPU * (n_keep + n_burn) * n_leap / (kk * 1e-3)}
+            res["ess_per_s" if rmax <= 1.05 else "ess_per_s_unconverged"] = float(es.min()) / ((kk + sm) * 1e-3)
+            return res
+
+        out["config3_converged"] = converged_case(DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), 2, 0.1, 10, 500, 1000,
+                                                  "hmc.rs:576-787's configuration (DiffableGaussian2D, eps 0.1, L 10) at 65536 chains, f32")
+        out["config3_rosenbrock_long_trajectories"] = converged_case(RosenbrockND(DIM), DIM, 0.02, 150, 6000, 2000,
+                                                                     "RosenbrockND D=3 (config 3's target), eps 0.02, L 150, 65536 chains, f32")
         g = GaussianND.ill_conditioned(32, 1e4, 7)
         nuts = NUTS(g, init_with_seed(C_PER_GPU, 32, SEED) * 0.1, 0.8, mode=2, device=dev.index or 0).set_seed(SEED).set_max_depth(10)
         nuts._run(100, 200, True, "torch")

@@ -271,6 +271,18 @@ int mmcmc_hmc_kernel_variant(mmcmc_hmc *h); /* the variant in use (>= 0) or a ne
 #define MMCMC_USER_KIND_BASE 1000
 int mmcmc_target_register_source(const char *name, int dim, const char *hip_source, int *kind_out, char *log, size_t log_len);
 
+/* Which compiler builds run-time compiled units (process-wide; default AUTO).  AUTO: `hipcc --genco` in a child process
+ * wherever hipcc is found (PATH, then /opt/rocm/bin), hipRTC (libhiprtc.so, bound at run time) otherwise.  hipRTC was
+ * caught miscompiling one kernel of these units that hipcc compiles correctly, hence the order.
+ * HIPCC / HIPRTC pin one of them (registration then returns MMCMC_ERR_UNSUPPORTED where it is missing). */
+#define MMCMC_RTC_COMPILER_AUTO 0
+#define MMCMC_RTC_COMPILER_HIPCC 1
+#define MMCMC_RTC_COMPILER_HIPRTC 2
+int mmcmc_rtc_set_compiler(int which);
+/* which compiler built the unit behind a kind handed out by a mmcmc_*_register_source call: MMCMC_RTC_COMPILER_HIPCC or
+ * MMCMC_RTC_COMPILER_HIPRTC (MMCMC_ERR_INVALID_ARG: no such kind) */
+int mmcmc_rtc_unit_compiler(int kind);
+
 /* ---- user-defined proposals (csrc/mm_rtc.hip) --------------------------------------------------------------------
  * `Proposal` is an open trait too (distributions.rs:92-101), and the reference keeps BOTH q-terms in the acceptance
  * ratio because a proposal may be asymmetric (metropolis_hastings.rs:303-315; its own integration tests define custom
@@ -365,7 +377,9 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
  *           vector ALU), the power spectrum above (one wave-level FFT per chain and parameter, one inverse for all);
  *   FFT / TILE1 / TILE / MFMA / DIRECT   that kernel wherever its shape limits allow, AUTO's choice elsewhere
  *           (FFT: 2 <= n/2 <= 1024; TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).
- * For measurements and for the agreement test; results never depend on it beyond rounding. */
+ * For measurements and for the agreement test; results never depend on it beyond rounding.  Process-wide and meant to
+ * be set once: a call that races with it picks one kernel or the other (its work buffer fits both).  Under one selection
+ * R-hat / ESS are bit-reproducible across devices too: no kernel's summation grouping depends on the device. */
 #define MMCMC_STATS_KERNEL_AUTO 0
 #define MMCMC_STATS_KERNEL_FFT 1
 #define MMCMC_STATS_KERNEL_TILE1 2

@@ -12,8 +12,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <type_traits>
+#include <tuple>
 #include <vector>
 
 #include "mm_generic.h"
@@ -110,6 +113,8 @@ int validate_target(const mmcmc_target_desc *t)
         const mm_user_target *u = mm_rtc_find(t->kind);
         if (!u)
             return MMCMC_ERR_UNSUPPORTED;
+        if (mm_rtc_is_internal(u))
+            return MMCMC_ERR_UNSUPPORTED; /* a unit the library built for itself is not a kind a caller may name */
         if (mm_rtc_dim(u) != t->dim)
             return MMCMC_ERR_SHAPE;
         /* a target + proposal model (mmcmc_proposal_register_source) is reached through mmcmc_mh_create's proposal
@@ -192,6 +197,73 @@ struct Sampler {
 
     size_t esize() const { return dtype == MMCMC_F32 ? 4 : 8; }
 };
+
+int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, double scale, int n_leapfrog,
+                   const void *init, size_t n_chains, int dtype, int device);
+int sampler_destroy(Sampler *s);
+int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int out_is_device, uint64_t *accept_counts,
+                void *stream_v, size_t n_total_rows = 0, size_t row0 = 0);
+
+thread_local bool g_in_unit_check = false;
+
+/* A built-in target's run-time compiled MH / HMC unit (mm_rtc_builtin, variant 7) is checked once per (unit, sampler,
+ * dtype) and process before a handle relies on it, like the NUTS units (mm_nuts_api.hip): 96 chains, 5 + 5 transitions from
+ * a fixed start, run twice -- the same bits -- and against the run-time-dimension kernel (variant 6), bit for bit.  The
+ * compiler that builds these units was caught miscompiling a sibling kernel, and a miscompiled unit would
+ * otherwise return wrong samples silently.  Only real verdicts are cached: a failed allocation or launch inside the check
+ * leaves this handle on variant 6 and is tried again by the next one. */
+bool builtin_unit_verified(const mm_user_target *unit, int sampler, const mmcmc_target_desc *target, int dtype, int device)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<const void *, int, int>, bool> verdict;
+    const auto key = std::make_tuple((const void *)unit, sampler, dtype);
+    {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = verdict.find(key);
+        if (it != verdict.end())
+            return it->second;
+    }
+    const size_t n = 96, dim = (size_t)target->dim, nc = 5, nd = 5, esz = dtype == MMCMC_F32 ? 4 : 8;
+    std::vector<unsigned char> x0(n * dim * esz);
+    for (size_t c = 0; c < n; ++c)
+        for (size_t i = 0; i < dim; ++i) {
+            const double v = 0.05 * (double)((int)((c * 7 + i * 13) % 17) - 8);
+            if (dtype == MMCMC_F32)
+                ((float *)x0.data())[c * dim + i] = (float)v;
+            else
+                ((double *)x0.data())[c * dim + i] = v;
+        }
+    bool errored = false;
+    auto one = [&](int variant, std::vector<unsigned char> &bytes) -> bool {
+        Sampler *t = nullptr;
+        /* modest fixed scales: the check is about the kernels, not about the caller's tuning */
+        if (sampler_create(&t, sampler, target, sampler == MM_SAMPLER_HMC ? 0.01 : 0.25, sampler == MM_SAMPLER_HMC ? 3 : 0,
+                           x0.data(), n, dtype, device) != MMCMC_OK) {
+            errored = true;
+            return false;
+        }
+        bytes.assign(n * nc * dim * esz, 0);
+        t->seed = 0x5eedull;
+        bool ok = t->user == unit; /* the nested handle must be on this very unit */
+        if (ok)
+            t->variant = variant;
+        if (ok && sampler_run(t, nc, nd, bytes.data(), 0, nullptr, nullptr, 0, 0) != MMCMC_OK) {
+            errored = true;
+            ok = false;
+        }
+        (void)sampler_destroy(t);
+        return ok;
+    };
+    g_in_unit_check = true;
+    std::vector<unsigned char> a, a2, g;
+    const bool ok = one(7, a) && one(7, a2) && one(6, g) && a == a2 && a == g;
+    g_in_unit_check = false;
+    if (!errored) {
+        std::lock_guard<std::mutex> l(mu);
+        verdict[key] = ok;
+    }
+    return ok;
+}
 
 int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, double scale, int n_leapfrog,
                    const void *init, size_t n_chains, int dtype, int device)
@@ -323,6 +395,10 @@ int sampler_create(Sampler **out, int sampler, const mmcmc_target_desc *target, 
         return fail((int)e);
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess)
         return fail((int)e);
+    if (s->user && s->generic && !g_in_unit_check && !builtin_unit_verified(s->user, sampler, target, dtype, device)) {
+        s->user = nullptr; /* the run-time-dimension kernel only (set_kernel_variant(7) is refused then) */
+        s->variant = 6;
+    }
     *out = s;
     return MMCMC_OK;
 }
@@ -503,7 +579,7 @@ int launch_range(Sampler *s, const mm_kernel_entry<T> *k, const mm_tparams<T> &P
 /* n_total_rows / row0: the collected rows go to rows [row0, row0 + n_collect) of out [n_chains, n_total_rows, dim] (device
  * memory only when n_total_rows != n_collect): how run_progress fills one sample by several launches (mm_progress.hip) */
 int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int out_is_device,
-                uint64_t *accept_counts, void *stream_v, size_t n_total_rows = 0, size_t row0 = 0)
+                uint64_t *accept_counts, void *stream_v, size_t n_total_rows, size_t row0)
 {
     if (!s)
         return MMCMC_ERR_INVALID_ARG;

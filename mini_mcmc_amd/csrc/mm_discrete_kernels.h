@@ -18,8 +18,8 @@
 #ifndef MM_DISCRETE_KERNELS_H
 #define MM_DISCRETE_KERNELS_H
 
+#include "mm_kernels.h" /* first: it brings hip_runtime.h (MM_HD needs __forceinline__) when the unit is built by hipcc */
 #include "mm_discrete.h"
-#include "mm_kernels.h"
 
 struct mm_discrete_user_args {
     double params[8];

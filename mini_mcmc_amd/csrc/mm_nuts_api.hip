@@ -67,6 +67,8 @@ struct NutsBase {
     int compaction_groups = 0; /* variant 2: chain groups with their own launch sequence (0 = choose) */
     int device = 0, mode = 0, kind = 0, dim = 0;
     const void *rtc_unit = nullptr; /* the run-time compiled unit whose kernels this handle launches (mm_rtc.hip), or NULL */
+    int rtc_run_kernel = 2; /* which of the unit's run kernels: 2 asynchronous lanes, leaves in pairs (what handles launch);
+                               0 the lanes in step (launched only by rtc_unit_verified, as the second opinion on a user target) */
     size_t n_chains = 0;
     uint64_t seed = 0, chain_offset = 0;
     uint32_t m = 0; /* self.m: transitions taken so far */
@@ -164,7 +166,7 @@ template <class TT, class ST> struct Nuts : NutsBase {
              * kernels on first use (hipRTC, mm_rtc_builtin_nuts); NULL keeps the run-time-D kernel */
             DevGuard gb(device);
             user = mm_rtc_builtin_nuts(t->kind, t->dim);
-            /* ... and only if this type mode's kernels came out without register spills (mm_rtc.hip) */
+            /* ... and only if the unit has this type mode's init and pair kernels (mm_rtc_nuts_usable) */
             if (user && !mm_rtc_nuts_usable(user, create_mode))
                 user = nullptr;
             builtin_user = user != nullptr;
@@ -174,8 +176,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 user = mm_rtc_find(t->kind);
             if (!user)
                 return MMCMC_ERR_INVALID_ARG;
-            if (mm_rtc_is_model(user) || mm_rtc_is_discrete(user))
-                return MMCMC_ERR_UNSUPPORTED; /* a target + proposal model / an integer-state model has no NUTS kernels */
+            if (mm_rtc_is_model(user) || mm_rtc_is_discrete(user) || (!builtin_user && mm_rtc_is_internal(user)))
+                return MMCMC_ERR_UNSUPPORTED; /* a target + proposal model / an integer-state model has no NUTS kernels; a unit
+                                                 the library built for itself is not a kind a caller may name */
             if (mm_rtc_dim(user) != t->dim)
                 return MMCMC_ERR_SHAPE;
             if (!builtin_user) {
@@ -634,7 +637,9 @@ template <class TT, class ST> struct Nuts : NutsBase {
              * launch (the unit's source compiled offline by hipcc --genco and injected is correct): hipRTC's compilation
              * of that kernel, cause not found.  The pair kernel passed every such comparison, and every unit is
              * checked against the run-time-dimension kernel before its first use (rtc_unit_verified) */
-            e = mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
+            e = rtc_run_kernel == 2
+                    ? mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st)
+                    : mm_rtc_launch_nuts(user, type_mode, 0, &a, sizeof(a), grid64, user_lds, st); /* dynamic LDS = its output tile */
         } else if (use_generic) {
             ga.out = d_out;
             ga.n_pre = a.n_pre;
@@ -709,12 +714,16 @@ struct mmcmc_nuts {
 };
 
 /* A run-time compiled unit is checked once per (unit, type mode) and process before a handle relies on it: 96 chains, 5 + 5
- * transitions from a fixed start, (a) twice -- the two must be the same bits --, (b) for a built-in target also against the
- * run-time-dimension kernel (variant 6), which must agree bit for bit too.  Why: tools/experiments/repro_nuts_dims.py found
- * kernels of such units that do not reproduce themselves (the lanes-in-step kernel at RosenbrockND(19) and (23) in f64,
- * StandardNormal(25) in f32: no longer launched) while the same templates compiled into the library do; the cause is not
- * found, so what IS launched is checked.  A unit that fails leaves a built-in target on the run-time-dimension kernel; a
- * user target is refused. */
+ * transitions from a fixed start, (a) twice -- the two must be the same bits --, (b) against a SECOND, differently built
+ * kernel of the same transitions, which must agree bit for bit: for a built-in target the run-time-dimension kernel
+ * (variant 6, compiled into the library by hipcc); for a USER target -- whose functor exists only inside its unit -- the
+ * unit's own lanes-in-step kernel (mm_nuts_run_body: another control structure around the same functor, the pair the
+ * library's compiled instances are tested to agree on, variants 0 and 5).  Why: tools/experiments/repro_nuts_dims.py found
+ * hipRTC-built kernels that do not reproduce themselves or are plainly wrong (the lanes-in-step kernel at RosenbrockND(19)
+ * and (23) in f64, StandardNormal(25) in f32) while hipcc builds of the same source are right; units are now built by hipcc
+ * where it exists (mm_rtc.hip) and what IS launched is still checked.  A unit that fails leaves a built-in target on the
+ * run-time-dimension kernel; a user target is refused.  Only real verdicts are cached: an allocation or launch error
+ * inside the check fails this create and is tried again by the next one. */
 extern "C" int mmcmc_nuts_create(mmcmc_nuts **out, const mmcmc_target_desc *target, const double *init, size_t n_chains,
                                  double target_accept_p, int mode, int device);
 extern "C" int mmcmc_nuts_destroy(mmcmc_nuts *h);
@@ -722,33 +731,46 @@ static bool rtc_unit_verified(const void *unit, const mmcmc_target_desc *target,
 {
     static std::mutex mu;
     static std::map<std::pair<const void *, int>, bool> verdict;
-    std::lock_guard<std::mutex> l(mu);
-    auto it = verdict.find({unit, mode});
-    if (it != verdict.end())
-        return it->second;
+    {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = verdict.find({unit, mode});
+        if (it != verdict.end())
+            return it->second;
+    }
     const size_t n = 96, dim = (size_t)target->dim, nc = 5, nd = 5, esz = mode == 2 ? 8 : 4;
     std::vector<double> x0(n * dim);
     for (size_t c = 0; c < n; ++c)
         for (size_t i = 0; i < dim; ++i)
             x0[c * dim + i] = 0.05 * (double)((int)((c * 7 + i * 13) % 17) - 8);
-    auto one = [&](int variant, std::vector<unsigned char> &bytes) -> bool {
+    bool errored = false;
+    /* variant < 0: the handle's default (the unit's pair kernel); rtc_kernel: which run kernel of the unit */
+    auto one = [&](int variant, int rtc_kernel, std::vector<unsigned char> &bytes) -> bool {
         mmcmc_nuts *t = nullptr;
-        if (mmcmc_nuts_create(&t, target, x0.data(), n, 0.8, mode, device) != MMCMC_OK)
+        if (mmcmc_nuts_create(&t, target, x0.data(), n, 0.8, mode, device) != MMCMC_OK) {
+            errored = true;
             return false;
+        }
         bytes.assign(n * nc * dim * esz, 0);
         t->p->seed = 0x5eedull;
-        bool ok = variant < 0 || t->p->set_variant(variant) == MMCMC_OK;
-        ok = ok && t->p->run(nc, nd, bytes.data(), 0, 1, nullptr) == MMCMC_OK;
+        t->p->rtc_run_kernel = rtc_kernel;
+        bool ok = (variant < 0 ? t->p->rtc_unit == unit : t->p->set_variant(variant) == MMCMC_OK);
+        if (ok && t->p->run(nc, nd, bytes.data(), 0, 1, nullptr) != MMCMC_OK) {
+            errored = true;
+            ok = false;
+        }
         (void)mmcmc_nuts_destroy(t);
         return ok;
     };
     g_rtc_create_mode = 1;
     std::vector<unsigned char> a, a2, g;
-    bool ok = one(-1, a) && one(-1, a2) && a == a2;
-    if (ok && target->kind < MM_USER_KIND_BASE)
-        ok = one(6, g) && a == g;
+    bool ok = one(-1, 2, a) && one(-1, 2, a2) && a == a2;
+    if (ok)
+        ok = (target->kind < MM_USER_KIND_BASE ? one(6, 2, g) : one(-1, 0, g)) && a == g;
     g_rtc_create_mode = 0;
-    verdict[{unit, mode}] = ok;
+    if (!errored) {
+        std::lock_guard<std::mutex> l(mu);
+        verdict[{unit, mode}] = ok;
+    }
     return ok;
 }
 

@@ -15,6 +15,10 @@ int mm_rtc_base_kind(const mm_user_target *t);
 int mm_rtc_is_model(const mm_user_target *t);
 /* an integer-state model (mmcmc_discrete_register_source); `args` = mm_discrete_user_args, one wave per workgroup */
 int mm_rtc_is_discrete(const mm_user_target *t);
+/* a unit the library built for itself (mm_rtc_builtin / mm_rtc_builtin_nuts): not a kind a caller may pass in a description */
+int mm_rtc_is_internal(const mm_user_target *t);
+/* MMCMC_RTC_COMPILER_HIPCC / _HIPRTC: which compiler built the unit */
+int mm_rtc_compiler(const mm_user_target *t);
 /* a built-in target's register-resident MH / HMC kernels for a dimension <= 32 without a compiled instance, built on first
  * use (NULL: no hipRTC, or the unit failed to build) */
 const mm_user_target *mm_rtc_builtin(int kind, int dim);

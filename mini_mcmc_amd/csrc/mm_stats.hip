@@ -1233,23 +1233,14 @@ struct StatsFftPlan {
     unsigned int n_pt = 0, n_wg = 0, N = 0;
 };
 
-static int stats_cu_count(int device)
-{
-    static std::atomic<int> cus[64];
-    int v = cus[device & 63].load(std::memory_order_relaxed);
-    if (v <= 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0)
-            v = 256;
-        cus[device & 63].store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
-
-static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int device)
+/* sel < 0: read the process-wide selector; the workspace is sized with sel = MMCMC_STATS_KERNEL_FFT (and for the direct
+ * kernels as well), so that a mmcmc_stats_set_kernel() from another thread between the sizing and the launch of one call
+ * can change which kernel runs but never make the buffer too small */
+static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int device, int sel_in = -1)
 {
     StatsFftPlan p;
     const size_t m = n / 2;
-    const int sel = g_stats_kernel.load(std::memory_order_relaxed);
+    const int sel = sel_in >= 0 ? sel_in : g_stats_kernel.load(std::memory_order_relaxed);
     if (sel != MMCMC_STATS_KERNEL_AUTO && sel != MMCMC_STATS_KERNEL_FFT)
         return p;
     if (m > 1024 || m < 2 || (sel == MMCMC_STATS_KERNEL_AUTO && m <= 100))
@@ -1269,8 +1260,11 @@ static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int de
     if (const char *e = mm_tuning_env("MMCMC_FFT_TWL"))
         p.twl = atoi(e) != 0;
     /* resident workgroups of four waves: waves per SIMD x CUs, shared between the parameter tiles */
+    /* the workgroup count fixes which chains a wave sums in f32, so it must not depend on the device (CU count, partition
+     * mode): 256 compute units' worth, an MI355X's, on every device -- R-hat / ESS are then the same bits everywhere */
+    (void)device;
     const unsigned int wpe = (unsigned int)p.wpe;
-    const unsigned int resident = (unsigned int)stats_cu_count(device) * wpe;
+    const unsigned int resident = 256u * wpe;
     p.n_wg = std::max(1u, resident / p.n_pt);
     if (const char *e = mm_tuning_env("MMCMC_FFT_NWG_MULT")) /* workgroups per resident slot (percent) */
         p.n_wg = std::max(1u, (unsigned int)((unsigned long long)p.n_wg * (unsigned int)atoi(e) / 100u));
@@ -1380,7 +1374,7 @@ static size_t stats_ws_floats(size_t n_chains, size_t n, size_t dim, unsigned in
 {
     const size_t m = n / 2;
     size_t need = (size_t)stats_n_slabs(n_chains) * dim * m;
-    const StatsFftPlan p = stats_fft_plan(n_chains, n, dim, device);
+    const StatsFftPlan p = stats_fft_plan(n_chains, n, dim, device, MMCMC_STATS_KERNEL_FFT); /* whichever kernel runs */
     if (p.use)
         need = std::max(need, ((size_t)p.n_wg + n_parts) * dim * p.N);
     return need;

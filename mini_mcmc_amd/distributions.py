@@ -152,7 +152,7 @@ class UserTarget(Target):
 
     `source` is HIP C++ defining `template <class T> struct mmcmc_user_target` with `static constexpr int dim`,
     `logp(P, x)` and `logp_grad(P, x, g)` (include/mmcmc.h: mmcmc_target_register_source); it is compiled at run time
-    (hipRTC) into the engine's MH / HMC kernels for f32 and f64 and its NUTS kernel for the three type modes.  `params` (up to 8 numbers) arrive as `P.p[i]`,
+    (`hipcc --genco` in a child process where hipcc is installed, else hipRTC) into the engine's MH / HMC kernels for f32 and f64 and its NUTS kernel for the three type modes.  `params` (up to 8 numbers) arrive as `P.p[i]`,
     `matrix` ([dim, dim]) as `P.mat`.  `UserTarget.compile_log` holds the compiler's diagnostics."""
 
     def __init__(self, name: str, dim: int, source: str, params=(), matrix=None):
@@ -165,6 +165,17 @@ class UserTarget(Target):
             raise L.MmcmcError(st, "mmcmc_target_register_source" + (": " + self.compile_log[-2000:] if self.compile_log else ""))
         self.kind = kind.value
         self.name = name
+        #: "hipcc" (`hipcc --genco` in a child process: the default wherever hipcc is installed) or "hiprtc"
+        self.compiler = {1: "hipcc", 2: "hiprtc"}.get(L.lib().mmcmc_rtc_unit_compiler(self.kind), "?")
+
+
+RTC_COMPILERS = {"auto": 0, "hipcc": 1, "hiprtc": 2}
+
+
+def set_rtc_compiler(which: str = "auto") -> None:
+    """mmcmc_rtc_set_compiler: which compiler builds run-time compiled units from now on (process-wide).  "auto": hipcc in a
+    child process where it is installed, else hipRTC; "hipcc" / "hiprtc" pin one (for tests and A/B runs)."""
+    L.check(L.lib().mmcmc_rtc_set_compiler(RTC_COMPILERS[which]), "mmcmc_rtc_set_compiler")
 
 
 class UserProposal:

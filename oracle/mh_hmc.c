@@ -11,10 +11,11 @@
  * in the reference's operation order (no fused multiply-add; build with -ffp-contract=off), quirks kept:
  * Q1 cloned proposal generator, Q2 D+1 normals per proposal, Q3 logp(current) recomputed and strict '>',
  * Q4 the odd proposal normaliser, Q6 separate half-kicks and the extra final logp.
+ * Elementary functions are libm's in every mode (also on the engine's noise stream): nothing of the product's
+ * mm_math.h is consulted here.
  */
 #include "oracle.h"
 
-#include "../mini_mcmc_amd/csrc/mm_math.h"
 
 #include <math.h>
 #include <pthread.h>
@@ -157,18 +158,18 @@ void o_mh_use_engine_stream(o_mh *s, uint64_t seed, uint64_t chain_offset)
     }
 }
 
-/* the custom proposal's log q(to | from) (prop_kind 1); engine stream: the engine's log, like everything else there */
+/* the custom proposal's log q(to | from) (prop_kind 1); libm's log / exp in every mode */
 #define MH_LOGNORMAL_LOGQ(REAL, SUF, LN)                                                                     \
     static REAL lognormal_logq_##SUF(const o_mh *s, const REAL *from, const REAL *to)                        \
     {                                                                                                        \
         REAL std = (REAL)s->std, two = (REAL)2, var = std * std, acc = 0;                                    \
         for (int i = 0; i < s->dim; ++i) {                                                                   \
-            REAL lt = s->engine ? mm_##LN(to[i]) : LN(to[i]);                                                \
-            REAL lf = s->engine ? mm_##LN(from[i]) : LN(from[i]);                                            \
+            REAL lt = LN(to[i]);                                                                             \
+            REAL lf = LN(from[i]);                                                                           \
             REAL dd = lt - lf;                                                                               \
             acc += -lt - (dd * dd) / (two * var);                                                            \
         }                                                                                                    \
-        REAL ls = s->engine ? mm_##LN(std) : LN(std);                                                        \
+        REAL ls = LN(std);                                                                                   \
         return acc - (REAL)s->dim * (ls + (REAL)0.91893853320467274178);                                     \
     }
 MH_LOGNORMAL_LOGQ(float, f32, logf)
@@ -188,7 +189,7 @@ MH_LOGNORMAL_LOGQ(double, f64, log)
             /* MHMarkovChain::step metropolis_hastings.rs:303-315 with the custom proposal above */          \
             for (int i = 0; i < d; ++i) {                                                                    \
                 REAL z = (REAL)c->prop_rng.normal_f64(&c->prop_rng);                                         \
-                REAL e = s->engine ? mm_##EXP(std * z) : EXP(std * z);                                       \
+                REAL e = EXP(std * z);                                                                       \
                 prop[i] = cur[i] * e;                                                                        \
             }                                                                                                \
             REAL current_lp = LOGP(&s->target, cur);                                                         \
@@ -197,7 +198,7 @@ MH_LOGNORMAL_LOGQ(double, f64, log)
             REAL lqb = lognormal_logq_##SUF(s, prop, cur);                                                   \
             REAL log_accept_ratio = (proposed_lp + lqb) - (current_lp + lqf);                                \
             REAL u = (REAL)c->rng.accept_uniform(&c->rng);                                                   \
-            REAL ln_u = s->engine ? mm_##LN(u) : LN(u);                                                      \
+            REAL ln_u = LN(u); /* libm in every mode */                                                      \
             if (log_accept_ratio > ln_u) {                                                                   \
                 for (int i = 0; i < d; ++i)                                                                  \
                     c->state[i] = (double)prop[i];                                                           \
@@ -232,7 +233,7 @@ MH_LOGNORMAL_LOGQ(double, f64, log)
         lqb += norm;                                                                                         \
         REAL log_accept_ratio = (proposed_lp + lqb) - (current_lp + lqf);                                    \
         REAL u = (REAL)c->rng.accept_uniform(&c->rng);                                                       \
-        REAL ln_u = s->engine ? mm_##LN(u) : LN(u);                                                          \
+        REAL ln_u = LN(u); /* libm in every mode */                                                          \
         if (log_accept_ratio > ln_u) {                                                                       \
             for (int i = 0; i < d; ++i)                                                                      \
                 c->state[i] = (double)prop[i];                                                               \
@@ -410,7 +411,7 @@ void o_hmc_use_engine_stream(o_hmc *s, uint64_t seed, uint64_t chain_offset)
         REAL h_proposed = -logp_proposed + kp;                                                               \
         REAL accept_logp = h_current - h_proposed;                                                           \
         REAL u = (REAL)s->unif[ci];                                                                          \
-        REAL ln_u = s->engine ? mm_##LN(u) : LN(u);                                                          \
+        REAL ln_u = LN(u); /* libm in every mode */                                                          \
         if (accept_logp >= ln_u) { /* '>=' here, '>' in MH (Q3) */                                           \
             for (int i = 0; i < d; ++i)                                                                      \
                 s->positions[(size_t)ci * d + i] = (double)pos[i];                                           \

@@ -4,9 +4,13 @@
  * Backend (b), the engine stream, is an INDEPENDENT plain-C statement of the Philox4x32-10 generator
  * (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; pinned in
  * tests/test_oracle_rng.py by the Random123 known-answer vectors) and of the draw schedule written
- * down in DESIGN.md / mini_mcmc_amd/csrc/mm_rng.h.  It shares only the elementary functions
- * (mm_logf, mm_sincos2pi, ...) and the f32 normal's coefficient table (mm_icdf_table.h, data) with the product,
- * because those DEFINE the engine's log / sin / cos / inverse normal CDF.
+ * down in DESIGN.md / mini_mcmc_amd/csrc/mm_rng.h.  The NOISE of the engine stream shares the elementary functions
+ * (mm_log, mm_sincos2pi) and the f32 normal's coefficient table (mm_icdf_table.h, data) with the product, because those
+ * DEFINE the engine's noise: tests that compare trajectories on identical noise need the very same numbers.  Beside them
+ * stand statements that share nothing -- o_ndtri / o_engine_icdf24_independent (f64 inverse normal CDF by Halley's
+ * iteration on libm's erfc) and o_engine_normal_f64_libm (libm log / sin / cos) -- and tests/test_engine_stream.py
+ * compares the product's numbers with those over the whole 24-bit lattice / a million draws.  The samplers' own
+ * arithmetic (accept logarithms, targets) is libm's everywhere (mh_hmc.c, nuts.c, targets.c).
  */
 #include "orng.h"
 
@@ -109,6 +113,42 @@ float o_engine_icdf24(uint32_t w)
     return ((w >> 8) & 1u) ? -mag : mag;
 }
 
+/* The same normal stated WITHOUT the product's table: -Phi^-1(n 2^-25) in f64 -- Halley's iteration on libm's erfc from the
+ * Abramowitz-Stegun 26.2.22 starting point -- rounded to f32.  The product's table-driven value is an approximation of
+ * this number; tests/test_engine_stream.py compares the two over the whole 2^24 lattice (data against data). */
+double o_ndtri(double p)
+{
+    if (!(p > 0.0 && p < 1.0))
+        return p == 0.0 ? -INFINITY : (p == 1.0 ? INFINITY : NAN);
+    const int upper = p > 0.5;
+    const double q = upper ? 1.0 - p : p; /* lower-tail probability, (0, 1/2] */
+    const double t = sqrt(-2.0 * log(q));
+    double x = -(t - (2.30753 + 0.27061 * t) / (1.0 + t * (0.99229 + 0.04481 * t))); /* |error| < 3e-3 */
+    for (int it = 0; it < 8; ++it) {
+        const double cdf = 0.5 * erfc(-x * 0.70710678118654752440);      /* Phi(x), accurate in the lower tail */
+        const double pdf = 0.39894228040143267794 * exp(-0.5 * x * x);
+        const double f = cdf - q;
+        const double step = f / (pdf * (1.0 + 0.5 * x * f / pdf));        /* Halley: f'' / f' = -x */
+        x -= step;
+        if (fabs(step) <= 1e-16 * fmax(1.0, fabs(x)))
+            break;
+    }
+    return upper ? -x : x;
+}
+
+float o_engine_icdf24_independent(uint32_t w)
+{
+    const uint32_t n = (w >> 8) | 1u;
+    const float mag = (float)(-o_ndtri((double)n * 0x1.0p-25));
+    return ((w >> 8) & 1u) ? -mag : mag;
+}
+
+void o_engine_icdf24_independent_words(const uint32_t *w, size_t n, float *out)
+{
+    for (size_t i = 0; i < n; ++i)
+        out[i] = o_engine_icdf24_independent(w[i]);
+}
+
 void o_engine_icdf24_words(const uint32_t *w, size_t n, float *out)
 {
     for (size_t i = 0; i < n; ++i)
@@ -131,6 +171,18 @@ double o_engine_normal_f64(uint64_t seed, uint64_t chain, uint32_t iteration, ui
     double s, c;
     mm_sincos2pi(u2, &s, &c);
     return (i % 2) ? r * s : r * c;
+}
+
+/* the same Box-Muller pair from libm's log / sincos instead of the engine's (mm_math.h): what the engine's elementary
+ * functions are compared with, as data, in tests/test_engine_stream.py */
+double o_engine_normal_f64_libm(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i)
+{
+    uint32_t w[4];
+    o_engine_block(seed, chain, iteration, i / 2, w);
+    double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+    double r = sqrt(-2.0 * log(u1));
+    double a = 6.28318530717958647692 * u2;
+    return (i % 2) ? r * sin(a) : r * cos(a);
 }
 
 /* MH / HMC accept uniform of (chain, iteration) */

@@ -45,7 +45,12 @@ void o_engine_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t 
 float o_engine_normal_f32(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
 float o_engine_icdf24(uint32_t w); /* the f32 normal of one Philox word */
 void o_engine_icdf24_words(const uint32_t *w, size_t n, float *out);
+/* the same normal without the product's table: f64 inverse normal CDF (Halley on libm's erfc) rounded to f32 */
+double o_ndtri(double p);
+float o_engine_icdf24_independent(uint32_t w);
+void o_engine_icdf24_independent_words(const uint32_t *w, size_t n, float *out);
 double o_engine_normal_f64(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
+double o_engine_normal_f64_libm(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
 float o_engine_accept_f32(uint64_t seed, uint64_t chain, uint32_t iteration);
 double o_engine_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t k);
 

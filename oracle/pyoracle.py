@@ -87,7 +87,10 @@ def lib() -> C.CDLL:
         "o_engine_block": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _u32p]),
         "o_engine_normal_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "o_engine_icdf24_words": (None, [_u32p, C.c_size_t, _fp]),
+        "o_engine_icdf24_independent_words": (None, [_u32p, C.c_size_t, _fp]),
+        "o_ndtri": (C.c_double, [C.c_double]),
         "o_engine_normal_f64": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+        "o_engine_normal_f64_libm": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "o_engine_accept_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32]),
         "o_engine_aux_u53": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "ot_logp_f32": (C.c_float, [tp, _fp]),
@@ -263,6 +266,15 @@ def engine_icdf24(words):
     w = np.ascontiguousarray(words, dtype=np.uint32)
     out = np.empty(w.shape, dtype=np.float32)
     lib().o_engine_icdf24_words(w.ctypes.data_as(_u32p), w.size, out.ctypes.data_as(_fp))
+    return out
+
+
+def engine_icdf24_independent(words):
+    """The f32 normal of Philox words WITHOUT the product's coefficient table: f64 inverse normal CDF (Halley on libm's
+    erfc, oracle/orng.c) rounded to f32."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.empty(w.shape, dtype=np.float32)
+    lib().o_engine_icdf24_independent_words(w.ctypes.data_as(_u32p), w.size, _f(out))
     return out
 
 

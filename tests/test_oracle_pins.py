@@ -276,9 +276,9 @@ def test_mh_q1_shared_proposal_noise(O):
     np.testing.assert_allclose(d0[both], d1[both], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("n_runs", [30])
+@pytest.mark.parametrize("n_runs", [100])
 def test_hmc_ess_band(O, kats, n_runs):
-    # hmc.rs:576-787 (ignored benchmark in the reference; 100 runs there, 30 here with the same band)
+    # hmc.rs:576-787 (ignored benchmark in the reference): 100 runs and the same bands, as there
     k = kats["hmc_ess_bands"]
     t = O.diffable_gaussian2d(k["mean"], k["cov"], t_is_f32=True)
     e1, e2, rh = [], [], []

@@ -181,3 +181,115 @@ def test_user_target_under_nuts(O, mode):
         assert abs(x[:, 1].mean() - bb * s**2) < 0.03 and abs(x[:, 1].var() / (1 + 2 * bb**2 * s**4) - 1) < 0.03
     with pytest.raises(Exception):  # the registered dimension is part of the kind
         NUTS(user, init_with_seed(8, 2, 1), 0.8, mode=mode)
+
+
+def _rosenbrock_source(dim: int) -> str:
+    return ROSENBROCK3.replace("static constexpr int dim = 3;", f"static constexpr int dim = {dim};")
+
+
+STD_NORMAL_SRC = r"""
+template <class T> struct mmcmc_user_target {
+    static constexpr int dim = DIM;
+    MM_HD static T logp(const mm_tparams<T> &, const T *x) {
+        T acc = 0;
+        for (int i = 0; i < dim; ++i) acc = mm_fma(x[i], x[i], acc);
+        return T(-0.5) * acc;
+    }
+    MM_HD static T logp_grad(const mm_tparams<T> &P, const T *x, T *g) {
+        for (int i = 0; i < dim; ++i) g[i] = -x[i];
+        return logp(P, x);
+    }
+};
+"""
+
+
+@pytest.mark.gpu
+def test_units_are_built_by_hipcc_in_a_child_process_and_hiprtc_agrees_where_it_is_right(O):
+    """Run-time compiled units: `hipcc --genco` as a child process is the default wherever hipcc is installed (mm_rtc.hip;
+    hipRTC miscompiled a sibling kernel of these units); pinned to hipRTC the MH / HMC kernels of the same
+    source give the same bits, and both equal the built-in kernels of the same density."""
+    import shutil
+
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import IsotropicGaussian, RosenbrockND, UserTarget, set_rtc_compiler
+    from mini_mcmc_amd.hmc import HMC
+    from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+
+    if not (shutil.which("hipcc") or __import__("os").path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this machine: hipRTC is the only compiler")
+    try:
+        a = UserTarget("ros3_auto", 3, ROSENBROCK3)
+        assert a.compiler == "hipcc"
+        set_rtc_compiler("hiprtc")
+        b = UserTarget("ros3_rtc", 3, ROSENBROCK3)
+        assert b.compiler == "hiprtc"
+        set_rtc_compiler("hipcc")
+        c = UserTarget("ros3_cc", 3, ROSENBROCK3)
+        assert c.compiler == "hipcc"
+        # a source that does not compile: the child's diagnostics come back, nothing is registered
+        with pytest.raises(Exception) as ei:
+            UserTarget("broken", 3, ROSENBROCK3.replace("return -acc;", "return -acc"))
+        assert "error" in str(ei.value)
+    finally:
+        set_rtc_compiler("auto")
+    init = init_with_seed(300, 3, 4, np.float32)
+    outs = []
+    for tgt in (RosenbrockND(3), a, b, c):
+        h = HMC(tgt, init, 0.032, 10).set_seed(2)
+        m = MetropolisHastings(tgt, IsotropicGaussian(0.2), init).seed(2)
+        outs.append((h.run(20, 5), m.run(20, 5)))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
+@pytest.mark.gpu
+def test_user_source_nuts_at_the_dimensions_where_hiprtc_failed(O):
+    """The dimensions at which the hipRTC build of the lanes-in-step NUTS kernel was wrong (RosenbrockND 19 / 23 in f64,
+    StandardNormal 25): a USER restatement of those densities, compiled from source (hipcc child), is verified by
+    mm_nuts_api.hip's rtc_unit_verified against the unit's second kernel and here equals the library's own run-time-D kernel of
+    the built-in target, bit for bit (samples and leapfrog counts)."""
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import RosenbrockND, StandardNormal, UserTarget
+    from mini_mcmc_amd.nuts import NUTS
+
+    cases = [(19, 2, "ros"), (23, 2, "ros"), (25, 0, "std"), (25, 2, "std")]
+    made = {}
+    for dim, mode, what in cases:
+        if (dim, what) not in made:
+            src = _rosenbrock_source(dim) if what == "ros" else STD_NORMAL_SRC.replace("DIM", str(dim))
+            made[(dim, what)] = UserTarget(f"{what}{dim}_user", dim, src)
+        user = made[(dim, what)]
+        builtin = RosenbrockND(dim) if what == "ros" else StandardNormal(dim)
+        init = init_with_seed(77, dim, 31) * 0.5
+        su = NUTS(user, init, 0.8, mode=mode).set_seed(5)
+        assert su.kernel_variant == 7
+        sb = NUTS(builtin, init, 0.8, mode=mode).set_seed(5)
+        sb.set_kernel_variant(6)
+        ou, ob = su._run(4, 7, False, "numpy"), sb._run(4, 7, False, "numpy")
+        assert np.array_equal(ou, ob) and np.array_equal(su.leapfrog_counts(), sb.leapfrog_counts()), (what, dim, mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [9, 13, 19, 23, 25, 31])
+def test_builtin_mid_dimension_units_are_checked_and_equal_the_run_time_dimension_kernel(O, dim):
+    """Built-in targets at dimensions 9..31 default to register-resident MH / HMC kernels compiled on first use (variant 7).
+    Every such unit is compared once, bit for bit, with the run-time-D kernel before a handle relies on it
+    (mm_api.hip: builtin_unit_verified; on a mismatch the handle stays on variant 6) -- here the same comparison from
+    outside, for both samplers and both element types (tools/experiments/repro_hmc_dims.py is the full sweep)."""
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import IsotropicGaussian, RosenbrockND, StandardNormal
+    from mini_mcmc_amd.hmc import HMC
+    from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+
+    for tgt in (RosenbrockND(dim), StandardNormal(dim)):
+        for dt in (np.float32, np.float64):
+            init = (init_with_seed(200, dim, 31) * 0.5).astype(dt)
+            for sampler in ("hmc", "mh"):
+                outs = []
+                for v in (None, 6):
+                    s = HMC(tgt, init, 0.05, 7).set_seed(5) if sampler == "hmc" else \
+                        MetropolisHastings(tgt, IsotropicGaussian(0.3, dim), init).seed(5)
+                    if v is not None:
+                        s.set_kernel_variant(v)
+                    outs.append(s.run(9, 5))
+                assert np.array_equal(outs[0], outs[1]), (type(tgt).__name__, dim, dt.__name__, sampler)

@@ -16,9 +16,10 @@ from mini_mcmc_amd.distributions import DiffableGaussian2D, RosenbrockND
 from mini_mcmc_amd.hmc import HMC
 
 C = 65536
-cases = [("rosenbrock3", RosenbrockND(3), 3, 0.032, 10, [(0, 1000), (20000, 1000), (20000, 4000), (100000, 4000), (100000, 16000)]),
-         ("rosenbrock3_eps0.05_L20", RosenbrockND(3), 3, 0.05, 20, [(20000, 4000)]),
-         ("gaussian2d_hmc_rs_764", DiffableGaussian2D([0.0, 1.0], [[4.0, 2.0], [2.0, 3.0]]), 2, 0.1, 10, [(50, 400), (500, 1000)])]
+cases = [("rosenbrock3", RosenbrockND(3), 3, 0.02, 150, [(6000, 2000)]),
+         ("rosenbrock3", RosenbrockND(3), 3, 0.02, 300, [(4000, 2000)]),
+         ("rosenbrock3", RosenbrockND(3), 3, 0.015, 250, [(4000, 2000)]),
+         ("rosenbrock3", RosenbrockND(3), 3, 0.025, 120, [(6000, 2000)])]
 for name, tgt, d, eps, L, runs in cases:
     h = HMC(tgt, init_with_seed(C, d, 42, np.float32), eps, L).set_seed(42)
     done = 0
