@@ -70,11 +70,20 @@
 
 /* Section timers for tools/lg_profile.hip (s_memtime deltas of lane 0 per wave); compiled out of the product. */
 #ifdef MM_LG_PROFILE
+/* MM_LG_PROFILE_MASK: which sections are stamped (bit = section).  Every stamp costs ~100 cycles (s_memtime + the wait for
+ * it), and the full set -- a dozen per leaf -- makes the profiled kernel 2.7 times slower than the product; a coarse mask
+ * (0x3f: transition / doubling prologue and epilogue, end of a leaf, end of a walk) distorts little: the time of an unstamped
+ * section flows into the next stamped one. */
+#ifndef MM_LG_PROFILE_MASK
+#define MM_LG_PROFILE_MASK 0xffffu
+#endif
 #define MM_LG_TICK(L, sec)                                                                                        \
     do {                                                                                                          \
-        const unsigned long long _now = __builtin_amdgcn_s_memtime();                                             \
-        (L).prof_acc[sec] += _now - (L).prof_t;                                                                   \
-        (L).prof_t = _now;                                                                                        \
+        if ((MM_LG_PROFILE_MASK >> (sec)) & 1u) {                                                                 \
+            const unsigned long long _now = __builtin_amdgcn_s_memtime();                                         \
+            (L).prof_acc[sec] += _now - (L).prof_t;                                                               \
+            (L).prof_t = _now;                                                                                    \
+        }                                                                                                         \
     } while (0)
 #define MM_LG_COUNT(L, sec) ((L).prof_acc[sec] += 1)
 #else

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--chains", type=int, default=16384)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--lib", default="liblgprof.so", help="liblgprof.so (every section stamped), liblgprof_coarse.so (-DMM_LG_PROFILE_MASK=0x3fu), ...")
     args = ap.parse_args()
     import torch
 
@@ -24,7 +25,7 @@ def main():
     from mini_mcmc_amd.distributions import GaussianND
     from mini_mcmc_amd.nuts import NUTS
 
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblgprof.so"))
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), args.lib))
     lib.lgprof_scratch_doubles_per_wave.restype = C.c_ulonglong
     lib.lgprof_rec_doubles_per_chain.restype = C.c_ulonglong
     g = GaussianND.ill_conditioned(32, 1e4, 7)
@@ -53,6 +54,7 @@ def main():
     p = t_prof.cpu().numpy().astype(np.float64)
     names = ["transition prologue", "doubling prologue", "leapfrog", "walk", "doubling epilogue", "transition epilogue"]
     tot = p[:, :6].sum(axis=1) + p[:, 8:12].sum(axis=1)
+    print(f"lib {args.lib}  raw ticks per leaf iteration by section: " + " ".join(f"[{i}] {p[:, i].sum() / max(p[:, 6].sum(), 1):.0f}" for i in (0, 1, 2, 3, 4, 5, 8, 9, 10, 11)))
     print(f"chains {n}  steps {args.steps}  wall {dt * 1e3:.1f} ms  s_memtime ticks per wave: mean {tot.mean():.3e} max {tot.max():.3e}")
     for i, nm in enumerate(names):
         print(f"  {nm:22s} {100 * p[:, i].sum() / tot.sum():6.2f} %")
