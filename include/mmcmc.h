@@ -383,7 +383,10 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
  *   AUTO    what the reference does (stats.rs:549): direct sums for half-chains up to 100 draws (register tiles on the
  *           vector ALU), the power spectrum above (one wave-level FFT per chain and parameter, one inverse for all);
  *   FFT / TILE1 / TILE / MFMA / DIRECT   that kernel wherever its shape limits allow, AUTO's choice elsewhere
- *           (FFT: 2 <= n/2 <= 1024; TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).
+ *           (FFT: 2 <= n/2 <= 16384 -- one wave-level transform up to 1024, N1 residues of 2048-point transforms beyond;
+ *           TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).  Half-chains longer than
+ *           16384 draws fall to the direct sums, which end where a half-chain no longer fits a workgroup's LDS
+ *           (MMCMC_ERR_UNSUPPORTED: about 6800 draws at three parameters) -- thin such a sample first.
  * For measurements and for the agreement test; results never depend on it beyond rounding.  Process-wide and meant to
  * be set once: a call that races with it picks one kernel or the other (its work buffer fits both).  Under one selection
  * R-hat / ESS are bit-reproducible across devices too: no kernel's summation grouping depends on the device. */

@@ -227,13 +227,19 @@ MM_HD uint32_t mm_xor3(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
-/* Philox4x32-10 (Salmon et al., SC'11). */
+/* Philox4x32-10 (Salmon et al., SC'11).  MM_PHILOX_ROUNDS exists for ONE purpose: timing probes (tools/split_probe.hip
+ * -DMM_PHILOX_ROUNDS=7: the fewest rounds the authors report as passing BigCrush) -- the engine's stream IS ten rounds
+ * (the oracle, the numpy statement in the tests and every bit-exact comparison say so); a build with another count fails
+ * those tests. */
+#ifndef MM_PHILOX_ROUNDS
+#define MM_PHILOX_ROUNDS 10
+#endif
 MM_HD mm_u32x4 mm_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MM_PHILOX_ROUNDS; ++r) {
         uint32_t hi0, lo0, hi1, lo1;
         mm_mulhilo32(0xD2511F53u, c0, &hi0, &lo0);
         mm_mulhilo32(0xCD9E8D57u, c2, &hi1, &lo1);
@@ -358,7 +364,7 @@ MM_HD mm_u32x4x2 mm_block_pair(uint64_t seed, uint64_t chain, uint32_t iteration
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int r = 0; r < 10; ++r)
+    for (int r = 0; r < MM_PHILOX_ROUNDS; ++r)
         mm_philox_pair_round(s);
     return mm_philox_pair_words(s);
 }

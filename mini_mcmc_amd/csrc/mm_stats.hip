@@ -1037,6 +1037,179 @@ void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, uns
         out[i] = acc[i];
 }
 
+/* ---- half-chains longer than 1024 draws (n_collect > 2048): the same power spectrum, the transform cut in two --------------
+ * N = N1 x 2048 >= 2 m.  With t = n2 + 2048 n1 and f = k1 + N1 k2 (Cooley-Tukey),
+ *     Z[k1 + N1 k2] = sum_{n2 < 2048} w_2048^(n2 k2) . [ w_N^(n2 k1) . sum_{n1 < N1 / 2} z[n2 + 2048 n1] w_N1^(n1 k1) ]
+ * (the upper half of n1 is the zero padding): for every residue k1 a short sum over n1 per point, a twiddle, and the
+ * wave-level 2048-point transform of mm_stats_fft.h (all of whose inputs are data now: mm_fft_pass1_full).  One wave per
+ * workgroup takes the chains wg, wg + n_wg, ... of ONE parameter; its power spectrum S[N] lives in LDS (bins in natural
+ * order) and leaves as one slab [N] at the end: the tail kernel and the inverse are shared with the short-chain path.
+ * The chain is read N1 + 1 times (once for the means), from L2 after the first: this path is for samples whose direct
+ * lag sums would cost m^2 (a [65536, 4000, 3] sample: 406 ms through the direct kernel, and no kernel at all beyond
+ * m = 6800 at D = 3, where its LDS layout ends).  N <= 32768: m <= 16384. */
+template <class T, int N1>
+__global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n,
+                                                               unsigned int D, unsigned int m, unsigned int n_wg,
+                                                               const mm_cx *__restrict__ tw, const mm_cx *__restrict__ wN,
+                                                               float *__restrict__ means, float *__restrict__ ssq,
+                                                               float *__restrict__ slabs)
+{
+    constexpr int R1 = 32, HALF = N1 / 2;
+    constexpr unsigned int N = 2048u * N1;
+    /* loads are issued in batches of AC x HALF x 2 before any is used: one at a time (a dependent load per point) the kernel
+     * waited out a memory latency per point -- 11.9 ms for [65536, 4000, 3] */
+    constexpr int AC = HALF >= 8 ? 4 : 8;
+    using pl = mm_fft_plan<R1>;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    const unsigned int lane = threadIdx.x;
+    float *const S = lds_raw;                                        /* [N] */
+    mm_cx *const lds = reinterpret_cast<mm_cx *>(lds_raw + N);       /* the transform's exchange block */
+    const unsigned int d = blockIdx.x % D, wg = blockIdx.x / D;
+    for (unsigned int i = lane; i < N; i += 64u)
+        S[i] = 0.f;
+    MM_WAVE_LDS_SYNC();
+    auto tw1_of = [&](int b) -> mm_cx { return tw[b * 64 + lane]; };
+    auto tw2_of = [&](int g) -> mm_cx { return tw[R1 * 64 + g * 8 + (lane & 7u)]; };
+    const size_t second = (size_t)(n - m) * D; /* the second half-chain: rows [n - m, n) */
+    const float inv_m = 1.0f / (float)m;
+    for (unsigned long long c = wg; c < C; c += n_wg) {
+        const T *const base = sample + (size_t)c * n * D + d;
+        float s0 = 0.f, s1 = 0.f;
+        for (unsigned int t0 = lane; t0 < m; t0 += 64u * 8u) {
+            float u0[8], u1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned int t = t0 + 64u * u, tc = t < m ? t : m - 1u;
+                u0[u] = (float)base[(size_t)tc * D];
+                u1[u] = (float)base[second + (size_t)tc * D];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = t0 + 64u * u < m;
+                s0 += in ? u0[u] : 0.f;
+                s1 += in ? u1[u] : 0.f;
+            }
+        }
+        const float mu0 = wave_sum_dpp_bcast(s0) * inv_m, mu1 = wave_sum_dpp_bcast(s1) * inv_m;
+        float q0 = 0.f, q1 = 0.f;
+        for (unsigned int k1 = 0; k1 < (unsigned int)N1; ++k1) {
+            mm_cx w1[HALF]; /* w_N1^(n1 k1) */
+#pragma unroll
+            for (int n1 = 0; n1 < HALF; ++n1)
+                w1[n1] = wN[(((unsigned int)n1 * k1) & (unsigned int)(N1 - 1)) * 2048u];
+            mm_cx y[R1];
+#pragma unroll
+            for (int a0 = 0; a0 < R1; a0 += AC) {
+                float r0[AC][HALF], r1[AC][HALF];
+                mm_cx wt[AC];
+#pragma unroll
+                for (int aa = 0; aa < AC; ++aa) {
+                    const unsigned int n2 = 64u * (a0 + aa) + lane;
+                    wt[aa] = wN[(n2 * k1) & (N - 1u)]; /* w_N^(n2 k1) */
+#pragma unroll
+                    for (int n1 = 0; n1 < HALF; ++n1) {
+                        const unsigned int t = n2 + 2048u * n1, tc = t < m ? t : m - 1u;
+                        r0[aa][n1] = (float)base[(size_t)tc * D];
+                        r1[aa][n1] = (float)base[second + (size_t)tc * D];
+                    }
+                }
+#pragma unroll
+                for (int aa = 0; aa < AC; ++aa) {
+                    const unsigned int n2 = 64u * (a0 + aa) + lane;
+                    mm_cx acc = mm_cx{0.f, 0.f};
+#pragma unroll
+                    for (int n1 = 0; n1 < HALF; ++n1) {
+                        const bool in = n2 + 2048u * n1 < m;
+                        const mm_cx v = mm_cx{in ? r0[aa][n1] - mu0 : 0.f, in ? r1[aa][n1] - mu1 : 0.f};
+                        if (k1 == 0u) { /* every point passes here exactly once per k1 */
+                            q0 = fmaf(v.re, v.re, q0);
+                            q1 = fmaf(v.im, v.im, q1);
+                        }
+                        acc = mm_cx_add(acc, mm_cx_mul(v, w1[n1].re, w1[n1].im));
+                    }
+                    y[a0 + aa] = mm_cx_mul(acc, wt[aa].re, wt[aa].im);
+                }
+            }
+            mm_fft_pass1_full<R1>(y, tw1_of, lds, (int)lane);
+            MM_WAVE_LDS_SYNC();
+            mm_cx v2[pl::J][8];
+            mm_fft_pass2_load<R1>(v2, lds, (int)lane);
+            MM_WAVE_LDS_SYNC();
+            mm_fft_pass2_store<R1>(v2, tw2_of, lds, (int)lane);
+            MM_WAVE_LDS_SYNC();
+            float Sr[pl::J][8];
+#pragma unroll
+            for (int j = 0; j < pl::J; ++j)
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                    Sr[j][h] = 0.f;
+            mm_fft_pass3<R1>(lds, (int)lane, Sr);
+            MM_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int j = 0; j < pl::J; ++j)
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const unsigned int f = k1 + (unsigned int)N1 * (unsigned int)mm_fft_bin<R1>((int)lane, j, h);
+                    S[f] += Sr[j][h]; /* every (lane, j, h) owns its bin: no two lanes meet */
+                }
+        }
+        q0 = wave_sum_dpp_bcast(q0);
+        q1 = wave_sum_dpp_bcast(q1);
+        if (lane == 0u) {
+            means[(size_t)c * D + d] = mu0;
+            means[((size_t)c + (size_t)C) * D + d] = mu1;
+            ssq[(size_t)c * D + d] = q0;
+            ssq[((size_t)c + (size_t)C) * D + d] = q1;
+        }
+    }
+    MM_WAVE_LDS_SYNC();
+    float *const out = slabs + ((size_t)wg * D + d) * N;
+    for (unsigned int i = lane; i < N; i += 64u)
+        out[i] = S[i];
+}
+
+/* P[f D + d] = the sum of the tail kernel's partial totals, in f64 (fixed order) */
+__global__ __launch_bounds__(256) void mm_fft_psum_kernel(const float *__restrict__ parts, unsigned int n_parts, size_t total,
+                                                          double *__restrict__ P)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total)
+        return;
+    double t0 = 0.0, t1 = 0.0;
+    unsigned int p = 0;
+    for (; p + 1 < n_parts; p += 2) {
+        t0 += (double)parts[(size_t)p * total + i];
+        t1 += (double)parts[(size_t)(p + 1) * total + i];
+    }
+    if (p < n_parts)
+        t0 += (double)parts[(size_t)p * total + i];
+    P[i] = t0 + t1;
+}
+
+/* the inverse for long transforms: as mm_fft_finish_kernel, with the spectrum and the cosine table read from memory
+ * (N doubles each: beyond N = 2048 the two no longer fit a workgroup's default LDS) */
+__global__ __launch_bounds__(256) void mm_fft_finish_long_kernel(const double *__restrict__ P, unsigned int D, unsigned int N,
+                                                                 unsigned int m, const double *__restrict__ cos_tab,
+                                                                 float *__restrict__ acov)
+{
+    __shared__ double red[256];
+    const unsigned int d = blockIdx.x % D, lag0 = (blockIdx.x / D) * 32u, tid = threadIdx.x;
+    const unsigned int l = tid & 31u, q = tid >> 5, lag = lag0 + l;
+    double a0 = 0.0, a1 = 0.0;
+    const unsigned int f_lo = q * (N / 8), f_hi = f_lo + N / 8;
+    for (unsigned int f = f_lo; f < f_hi; f += 2) {
+        a0 = fma(P[(size_t)f * D + d], cos_tab[(f * lag) & (N - 1u)], a0);
+        a1 = fma(P[(size_t)(f + 1u) * D + d], cos_tab[((f + 1u) * lag) & (N - 1u)], a1);
+    }
+    red[q * 32 + l] = a0 + a1;
+    __syncthreads();
+    if (q == 0 && lag < m) {
+        const double r = ((red[l] + red[32 + l]) + (red[64 + l] + red[96 + l])) +
+                         ((red[128 + l] + red[160 + l]) + (red[192 + l] + red[224 + l]));
+        acov[(size_t)lag * D + d] = (float)(r / (double)N);
+    }
+}
+
 /* The inverse of the accumulated spectrum, once per parameter for all chains: block (d, group of 32 lags) adds the
  * partial totals parts[p][f D + d] of the tail kernel in f64 and evaluates
  *     acov[lag D + d] = (1 / N) sum_f P[f] cos(2 pi f lag / N),   lag < m,
@@ -1272,6 +1445,62 @@ static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int de
     return p;
 }
 
+/* the long-chain path (mm_chain_fft_long_kernel): half-chains of 1025 .. 16384 draws */
+struct StatsLongPlan {
+    bool use = false;
+    unsigned int N1 = 0, N = 0, n_wg = 0;
+};
+static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, int sel_in = -1)
+{
+    StatsLongPlan p;
+    const size_t m = n / 2;
+    const int sel = sel_in >= 0 ? sel_in : g_stats_kernel.load(std::memory_order_relaxed);
+    if ((sel != MMCMC_STATS_KERNEL_AUTO && sel != MMCMC_STATS_KERNEL_FFT) || m <= 1024 || m > 16384)
+        return p;
+    p.use = true;
+    p.N1 = 2;
+    while ((size_t)p.N1 * 2048 < 2 * m)
+        p.N1 *= 2;
+    p.N = 2048u * p.N1;
+    /* device-independent (the workgroup count fixes the f32 summation grouping): 512 waves' worth, fewer for few chains */
+    p.n_wg = (unsigned int)std::min<size_t>(512, n_chains);
+    return p;
+}
+
+/* w_N^j = exp(-2 pi i j / N), j < N, as f32 pairs, then cos(2 pi j / N) as f64: one table per device and N1, never freed */
+static const mm_cx *stats_long_tables(int device, unsigned int N1)
+{
+    static std::atomic<const mm_cx *> tab[64][8];
+    int k = 0;
+    while ((2u << k) < N1)
+        ++k; /* N1 = 2 -> 0, 4 -> 1, 8 -> 2, 16 -> 3 */
+    const mm_cx *t = tab[device & 63][k & 7].load(std::memory_order_acquire);
+    if (t)
+        return t;
+    const unsigned int N = 2048u * N1;
+    std::vector<mm_cx> h(2 * (size_t)N);
+    static_assert(sizeof(mm_cx) == sizeof(double), "the cosine table shares the allocation");
+    const double two_pi = 6.283185307179586476925286766559;
+    for (unsigned int j = 0; j < N; ++j) {
+        const double th = two_pi * (double)j / (double)N, cv = std::cos(th);
+        h[j] = mm_cx{(float)cv, (float)-std::sin(th)};
+        memcpy(&h[(size_t)N + j], &cv, sizeof(double));
+    }
+    mm_cx *d = nullptr;
+    if (hipMalloc((void **)&d, h.size() * sizeof(mm_cx)) != hipSuccess)
+        return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(mm_cx), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    const mm_cx *expected = nullptr;
+    if (!tab[device & 63][k & 7].compare_exchange_strong(expected, d, std::memory_order_acq_rel)) {
+        (void)hipFree(d);
+        return expected;
+    }
+    return d;
+}
+
 /* twiddles of the wave-level FFT: w_N^(lane b) as [R1][64], then w_64^(e g) as [8][8]; one table per device and
  * length, computed in f64 on the host at first use, never freed */
 static const double *stats_fft_cos_table(const mm_cx *tw, int r1)
@@ -1377,6 +1606,9 @@ static size_t stats_ws_floats(size_t n_chains, size_t n, size_t dim, unsigned in
     const StatsFftPlan p = stats_fft_plan(n_chains, n, dim, device, MMCMC_STATS_KERNEL_FFT); /* whichever kernel runs */
     if (p.use)
         need = std::max(need, ((size_t)p.n_wg + n_parts) * dim * p.N);
+    const StatsLongPlan lp = stats_long_plan(n_chains, n, MMCMC_STATS_KERNEL_FFT);
+    if (lp.use) /* slabs | partial totals | their f64 sum */
+        need = std::max(need, ((size_t)lp.n_wg + n_parts + 2) * dim * lp.N);
     return need;
 }
 
@@ -1426,6 +1658,64 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         hipLaunchKernelGGL(mm_fft_finish_kernel, dim3((unsigned int)dim * (unsigned int)((m + 31) / 32)), dim3(256),
                            (2 * (size_t)fp.N + 256) * sizeof(double), stream, bins, n_parts, (unsigned int)dim, fp.N,
                            (unsigned int)m, stats_fft_cos_table(tw, fp.r1), final_out ? final_out : acov_sum);
+        MM_HIP(hipGetLastError());
+        if (!slabs_ws)
+            MM_HIP(hipFreeAsync(ws, stream));
+        if (parts_out)
+            *parts_out = final_out ? 0 : 1;
+        return MMCMC_OK;
+    }
+    const StatsLongPlan lp = stats_long_plan(n_chains, n);
+    if (lp.use) {
+        const mm_cx *tw = stats_fft_twiddles(device, 32), *wN = stats_long_tables(device, lp.N1);
+        if (!tw || !wN)
+            return (int)hipErrorOutOfMemory;
+        const size_t slab_floats = (size_t)lp.n_wg * dim * lp.N, part_floats = (size_t)n_parts * dim * lp.N,
+                     p_floats = 2 * (size_t)dim * lp.N;
+        float *ws = slabs_ws;
+        if (!ws)
+            MM_HIP(hipMallocAsync((void **)&ws, (slab_floats + part_floats + p_floats) * sizeof(float), stream));
+        float *bins = ws + slab_floats;
+        double *P = reinterpret_cast<double *>(ws + ((slab_floats + part_floats + 1) / 2) * 2);
+        const size_t lds = ((size_t)lp.N + 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
+        const unsigned int grid = lp.n_wg * (unsigned int)dim;
+        hipError_t le = hipSuccess;
+#define MM_LONG_LAUNCH(TT, NN)                                                                                      \
+    do {                                                                                                            \
+        if (lds > 64 * 1024)                                                                                        \
+            le = hipFuncSetAttribute((const void *)mm_chain_fft_long_kernel<TT, NN>,                                \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+        if (le == hipSuccess)                                                                                       \
+            hipLaunchKernelGGL((mm_chain_fft_long_kernel<TT, NN>), dim3(grid), dim3(64), lds, stream, (const TT *)sample, \
+                               (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, lp.n_wg, tw, \
+                               wN, means, ssq, ws);                                                                 \
+    } while (0)
+#define MM_LONG_PICK(TT)                                                                                            \
+    do {                                                                                                            \
+        switch (lp.N1) {                                                                                            \
+        case 2: MM_LONG_LAUNCH(TT, 2); break;                                                                       \
+        case 4: MM_LONG_LAUNCH(TT, 4); break;                                                                       \
+        case 8: MM_LONG_LAUNCH(TT, 8); break;                                                                       \
+        default: MM_LONG_LAUNCH(TT, 16); break;                                                                     \
+        }                                                                                                           \
+    } while (0)
+        if (dtype == MMCMC_F32)
+            MM_LONG_PICK(float);
+        else
+            MM_LONG_PICK(double);
+#undef MM_LONG_PICK
+#undef MM_LONG_LAUNCH
+        MM_HIP(le);
+        MM_HIP(hipGetLastError());
+        const unsigned int total_b = (unsigned int)(dim * lp.N);
+        const unsigned int nb_red = (total_b + 63) / 64 * n_parts, nb_wb = wb_part ? (unsigned int)dim * MM_WB_CHUNKS : 0u;
+        hipLaunchKernelGGL(mm_stats_tail_kernel, dim3(nb_red + nb_wb), dim3(256), 0, stream, ws, lp.n_wg, (unsigned int)dim, lp.N,
+                           bins, nb_red, n_parts, means, ssq, (unsigned long long)(2 * n_chains), (float)m, wb_part);
+        MM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mm_fft_psum_kernel, dim3((total_b + 255) / 256), dim3(256), 0, stream, bins, n_parts, (size_t)total_b, P);
+        hipLaunchKernelGGL(mm_fft_finish_long_kernel, dim3((unsigned int)dim * (unsigned int)((m + 31) / 32)), dim3(256), 0, stream, P,
+                           (unsigned int)dim, lp.N, (unsigned int)m, reinterpret_cast<const double *>(wN + lp.N),
+                           final_out ? final_out : acov_sum);
         MM_HIP(hipGetLastError());
         if (!slabs_ws)
             MM_HIP(hipFreeAsync(ws, stream));

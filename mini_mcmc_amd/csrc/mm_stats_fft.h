@@ -234,6 +234,26 @@ MM_FD void mm_fft_pass1(const mm_cx (&z)[R1 / 2], TW tw1, P lds, int lane)
     }
 }
 
+/* pass 1 without the zero half: all R1 points of a lane are data (the inner transforms of the long-chain kernel, whose
+ * padding sits in the OUTER index).  v[a] = point 64 a + lane; row b receives u_b[lane] as above. */
+template <int R1, class P, class TW>
+MM_FD void mm_fft_pass1_full(mm_cx (&v)[R1], TW tw1, P lds, int lane)
+{
+    using pl = mm_fft_plan<R1>;
+    constexpr int RB = mm_log2i(R1);
+    mm_dft_dif<R1>(v); /* position p holds X[mm_bitrev(p, RB)] */
+#pragma unroll
+    for (int p = 0; p < R1; ++p) {
+        const int b = mm_bitrev(p, RB);
+        mm_cx t = v[p];
+        if (b != 0) {
+            const mm_cx w = tw1(b);
+            t = mm_cx_mul(v[p], w.re, w.im);
+        }
+        lds[b * pl::PITCH + lane] = t;
+    }
+}
+
 /* pass 2: lane (beta, e) takes u_b[8 c + e] of its rows b = beta + 8 j, radix 8 over c, twiddle tw2[g] = w_64^(e g),
  * and leaves V_b[g][e] at unit 72 b + 9 g + e of the same row (the row's other readers are the lanes of this group, and
  * a wave's LDS instructions execute in order: every lane's loads are issued before any lane's stores -- two functions so

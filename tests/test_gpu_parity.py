@@ -915,3 +915,38 @@ def test_nuts_repacking_between_launches_changes_no_result(M, O):
     out = s._run(20, 30, True, "numpy")
     ref, pos, ad, nlf = O.engine_host_nuts_run(0, O.ROSENBROCK_ND, 3, [], init, 0.8, 20, 30, seed=3, progress=True)
     assert np.array_equal(out, ref) and np.array_equal(s.leapfrog_counts(), nlf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2)])
+def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
+    """Half-chains beyond 1024 draws (mm_chain_fft_long_kernel: the transform cut into N1 residues of 2048-point wave-level
+    transforms): R-hat / ESS against oracle/stats.c's FFT branch (stats.rs:576-620), odd n (the middle draw dropped), few
+    chains, the largest supported length; equal to the direct sums where those still exist; reproducible bit for bit;
+    the partial statistics the multi-GPU path exchanges agree with the one-call path."""
+    from mini_mcmc_amd import stats as S
+
+    rng = np.random.default_rng(c + n)
+    x = _ar1(rng, c, n, p)
+    x[:, :, 0] += np.arange(c)[:, None] * 0.25
+    r0, e0 = O.split_rhat_mean_ess(x)
+    r1, e1 = S.split_rhat_mean_ess(x)
+    np.testing.assert_allclose(r1, r0, rtol=1e-4)
+    np.testing.assert_allclose(e1, e0, rtol=5e-3)
+    r2, e2 = S.split_rhat_mean_ess(x)
+    assert np.array_equal(r1, r2) and np.array_equal(e1, e2)
+    if n <= 9000:
+        try:
+            S.set_kernel("direct")
+            r3, e3 = S.split_rhat_mean_ess(x)
+        finally:
+            S.set_kernel("auto")
+        np.testing.assert_allclose(r3, r1, rtol=1e-5)
+        np.testing.assert_allclose(e3, e1, rtol=2e-4)
+    import torch
+
+    t = torch.as_tensor(x, device="cuda")
+    means, ssq, acov = S.stats_partials(t)
+    r4, e4 = S.stats_finish(means.cpu().numpy(), ssq.cpu().numpy(), acov.cpu().numpy())
+    np.testing.assert_allclose(r4, r1, rtol=1e-6)
+    np.testing.assert_allclose(e4, e1, rtol=1e-5)
