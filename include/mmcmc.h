@@ -449,7 +449,9 @@ int mmcmc_ess_from_chainstats(const void *sample, int sample_is_device, int dtyp
  * out: [n_chains, n_collect, dim] of the sampler's dtype (NUTS: f32 for modes 0 / 1, f64 for mode 2), device or host, may
  * be NULL; stats (may be NULL; needs n_collect >= 2): RunStats::from(sample); tracker_out (may be NULL): receives the
  * tracker that was fed (the caller destroys it with mmcmc_tracker_destroy), e.g. for mmcmc_ess_from_chainstats.
- * stream NULL: a stream of the call's own; the call returns when everything has finished. */
+ * stream NULL: a stream of the call's own; the call returns when everything has finished.  Device memory beside the sample:
+ * MH a block of `every` burn-in states, NUTS all n_discard + n_collect states of every chain (its adaptation makes the
+ * run one launch): n_chains x (n_discard + n_collect) x dim elements -- hipErrorOutOfMemory if that does not fit. */
 typedef void (*mmcmc_progress_fn)(void *user, uint64_t transitions_done, uint64_t transitions_total, float p_accept,
                                   float max_rhat);
 int mmcmc_mh_run_progress(mmcmc_mh *h, size_t n_collect, size_t n_discard, size_t every, mmcmc_progress_fn cb, void *user,
