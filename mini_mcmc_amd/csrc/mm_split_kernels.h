@@ -40,6 +40,12 @@
  * noise dominates, the transition wave takes a share of it and the noise wave the flushing; two tiles per pair.
  * Candidates (ring half RB, elements per chain and tile) in order of preference, the first that fits 160 KB wins: HMC wants
  * large tiles (few, long store bursts), MH wants RB = 8 (short transitions: barriers dearer than stores). */
+/* tiles per pair: 2 = the last noise wave writes the tiles out (MH), 1 = the transition wave flushes its own (HMC).
+ * -DMM_SPLIT_HMC_PFLUSH=1 (tools/split_probe.hip) hands HMC's tiles to the noise wave too. */
+#ifndef MM_SPLIT_HMC_PFLUSH
+#define MM_SPLIT_HMC_PFLUSH 0
+#endif
+#define MM_SPLIT_NTILE(MH) (((MH) || MM_SPLIT_HMC_PFLUSH) ? 2 : 1)
 template <class T, int D, int RB, int WANT, int NTILE> struct mm_split_try {
     static constexpr int epl = 16 / (int)sizeof(T);
     static constexpr int nw = (D + 1 + epl - 1) / epl * epl; /* noise row of one chain: z[D], ln u, padded to 16 bytes */
@@ -58,21 +64,21 @@ template <class T, int D, bool MH, int I = 0> struct mm_split_pick {
     static constexpr int rb_hmc[12] = {8, 4, 8, 4, 2, 8, 4, 2, 2, 8, 4, 2}, want_hmc[12] = {48, 48, 32, 32, 48, 24, 24, 32, 24, 16, 16, 16};
     static constexpr int rb_mh[12] = {8, 8, 8, 4, 4, 4, 8, 2, 2, 2, 4, 2}, want_mh[12] = {48, 32, 24, 48, 32, 24, 16, 48, 32, 24, 16, 16};
     static constexpr int rb = MH ? rb_mh[I] : rb_hmc[I], want = MH ? want_mh[I] : want_hmc[I];
-    using Try = mm_split_try<T, D, rb, want, (MH ? 2 : 1)>;
+    using Try = mm_split_try<T, D, rb, want, MM_SPLIT_NTILE(MH)>;
     using type = typename mm_cond<Try::ok, Try, typename mm_split_pick<T, D, MH, I + 1>::type>::type;
 };
 template <class T, int D, bool MH> struct mm_split_pick<T, D, MH, 12> {
-    using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, (MH ? 2 : 1)>; /* RB = TILE_T = 2: always fits up to dim 8 */
+    using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, MM_SPLIT_NTILE(MH)>; /* RB = TILE_T = 2: always fits up to dim 8 */
 };
 /* RBF != 0: a ring half of exactly RBF transitions (several noise waves per pair want a batch their pairs divide), the
  * largest tile that fits beside it */
 template <class T, int D, bool MH, int RBF, int I = 0> struct mm_split_pick_rb {
     static constexpr int want[6] = {48, 40, 32, 24, 16, 8};
-    using Try = mm_split_try<T, D, RBF, want[I], (MH ? 2 : 1)>;
+    using Try = mm_split_try<T, D, RBF, want[I], MM_SPLIT_NTILE(MH)>;
     using type = typename mm_cond<Try::ok, Try, typename mm_split_pick_rb<T, D, MH, RBF, I + 1>::type>::type;
 };
 template <class T, int D, bool MH, int RBF> struct mm_split_pick_rb<T, D, MH, RBF, 6> {
-    using type = mm_split_try<T, D, RBF, RBF * (int)(sizeof(T) / 4) * D, (MH ? 2 : 1)>;
+    using type = mm_split_try<T, D, RBF, RBF * (int)(sizeof(T) / 4) * D, MM_SPLIT_NTILE(MH)>;
 };
 template <class T, int D, bool MH, int RBF = 0>
 struct mm_split_plan : mm_cond<RBF == 0, typename mm_split_pick<T, D, MH>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2)>::type>::type {

@@ -202,3 +202,47 @@ def test_progress_abi_symbols():
     for sym in ("mh_run_progress", "hmc_run_progress", "nuts_run_progress", "ess_from_chainstats", "tracker_within_var",
                 "tracker_shape", "mh_run_rows", "hmc_run_rows", "mh_shape", "hmc_shape", "nuts_shape"):
         assert hasattr(lib, "mmcmc_" + sym)
+
+
+@pytest.mark.gpu
+def test_run_progress_at_baseline_sizes(O):
+    """mmcmc_*_run_progress at BASELINE.json's chain counts: config 3 (65 536 x run_progress(400, 50)), config 2
+    (65 536 x (1000, 100)) and config 5 (NUTS, 32-D f64, 65 536 x (100 + 200): the every-state buffer is 5 GB).  Size-independent
+    properties: the sample equals the plain run's bit for bit, the trackers saw the right number of states, the callback's
+    last report equals the tracker's final statistics, RunStats is RunStats::from(sample)."""
+    import torch
+
+    from mini_mcmc_amd import stats as S
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import Gaussian2D, GaussianND, IsotropicGaussian, RosenbrockND
+    from mini_mcmc_amd.hmc import HMC
+    from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+    from mini_mcmc_amd.nuts import NUTS
+
+    C = 65536
+    seen = []
+    h = HMC(RosenbrockND(3), init_with_seed(C, 3, 42, np.float32), 0.032, 10).set_seed(42)
+    smp, st = h.run_progress(400, 50, to="torch", callback=lambda d, p, r: seen.append((d, p, r)))
+    ref = HMC(RosenbrockND(3), init_with_seed(C, 3, 42, np.float32), 0.032, 10).set_seed(42).run(400, 50, to="torch")
+    assert torch.equal(smp, ref) and h.tracker.n == 401 and len(seen) == 10 and seen[-1][0] == 400
+    assert abs(seen[-1][2] - float(h.tracker.max_rhat())) <= 1e-6 * seen[-1][2]
+    r0 = S.run_stats(smp)
+    assert st.ess.min == r0.ess.min and st.rhat.max == r0.rhat.max
+    del smp, ref
+
+    m = MetropolisHastings(Gaussian2D([0, 0], [[1, 0], [0, 1]]), IsotropicGaussian(1.0), init_with_seed(C, 2, 42, np.float32)).seed(42)
+    smp, st = m.run_progress(1000, 100, to="torch")
+    ref = MetropolisHastings(Gaussian2D([0, 0], [[1, 0], [0, 1]]), IsotropicGaussian(1.0), init_with_seed(C, 2, 42, np.float32)).seed(42).run(1000, 100, to="torch")
+    assert torch.equal(smp, ref) and m.tracker.n == 1100
+    _, mx, p = m.tracker.chain_stats()
+    assert 0.4 < float(p) < 0.7 and 1.0 <= float(mx) < 1.02 and st.rhat.min > 0.98
+    ess_cs = S.ess_from_chainstats(smp, m.tracker)
+    assert np.all(ess_cs > 1e6)
+    del smp, ref
+
+    g = GaussianND.ill_conditioned(32, 1e4, 7)
+    init = init_with_seed(C, 32, 42) * 0.1
+    n = NUTS(g, init, 0.8, mode=2).set_seed(42).set_max_depth(10)
+    smp, st = n.run_progress(100, 200, to="torch")
+    ref = NUTS(g, init, 0.8, mode=2).set_seed(42).set_max_depth(10)._run(100, 200, True, "torch")
+    assert torch.equal(smp, ref) and n.tracker.n == 300 and np.isfinite(st.ess.min)
