@@ -40,8 +40,9 @@
  * noise dominates, the transition wave takes a share of it and the noise wave the flushing; two tiles per pair.
  * Candidates (ring half RB, elements per chain and tile) in order of preference, the first that fits 160 KB wins: HMC wants
  * large tiles (few, long store bursts), MH wants RB = 8 (short transitions: barriers dearer than stores). */
-/* tiles per pair: 2 = the last noise wave writes the tiles out (MH), 1 = the transition wave flushes its own (HMC).
- * -DMM_SPLIT_HMC_PFLUSH=1 (tools/split_probe.hip) hands HMC's tiles to the noise wave too. */
+/* NT, tiles per pair: 2 = the last noise wave writes the tiles out while the transition wave stages into the other one
+ * (MH; HMC at D <= 3 with a ring half of 8: mm_split_hmc_pf), 1 = the transition wave flushes its own tile (HMC otherwise).
+ * -DMM_SPLIT_HMC_PFLUSH=1 (tools/split_probe.hip) makes 2 the default for HMC as well. */
 #ifndef MM_SPLIT_HMC_PFLUSH
 #define MM_SPLIT_HMC_PFLUSH 0
 #endif
@@ -60,31 +61,40 @@ template <class T, int D, int RB, int WANT, int NTILE> struct mm_split_try {
     static constexpr int ntile = NTILE;
     static constexpr bool ok = tile_t >= RB && lds_bytes <= 160 * 1024;
 };
-template <class T, int D, bool MH, int I = 0> struct mm_split_pick {
+template <class T, int D, bool MH, int NT, int I = 0> struct mm_split_pick {
     static constexpr int rb_hmc[12] = {8, 4, 8, 4, 2, 8, 4, 2, 2, 8, 4, 2}, want_hmc[12] = {48, 48, 32, 32, 48, 24, 24, 32, 24, 16, 16, 16};
     static constexpr int rb_mh[12] = {8, 8, 8, 4, 4, 4, 8, 2, 2, 2, 4, 2}, want_mh[12] = {48, 32, 24, 48, 32, 24, 16, 48, 32, 24, 16, 16};
     static constexpr int rb = MH ? rb_mh[I] : rb_hmc[I], want = MH ? want_mh[I] : want_hmc[I];
-    using Try = mm_split_try<T, D, rb, want, MM_SPLIT_NTILE(MH)>;
-    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick<T, D, MH, I + 1>::type>::type;
+    using Try = mm_split_try<T, D, rb, want, NT>;
+    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick<T, D, MH, NT, I + 1>::type>::type;
 };
-template <class T, int D, bool MH> struct mm_split_pick<T, D, MH, 12> {
-    using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, MM_SPLIT_NTILE(MH)>; /* RB = TILE_T = 2: always fits up to dim 8 */
+template <class T, int D, bool MH, int NT> struct mm_split_pick<T, D, MH, NT, 12> {
+    using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, NT>; /* RB = TILE_T = 2: always fits up to dim 8 */
 };
 /* RBF != 0: a ring half of exactly RBF transitions (several noise waves per pair want a batch their pairs divide), the
  * largest tile that fits beside it */
-template <class T, int D, bool MH, int RBF, int I = 0> struct mm_split_pick_rb {
+template <class T, int D, bool MH, int RBF, int NT, int I = 0> struct mm_split_pick_rb {
     static constexpr int want[6] = {48, 40, 32, 24, 16, 8};
-    using Try = mm_split_try<T, D, RBF, want[I], MM_SPLIT_NTILE(MH)>;
-    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick_rb<T, D, MH, RBF, I + 1>::type>::type;
+    using Try = mm_split_try<T, D, RBF, want[I], NT>;
+    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick_rb<T, D, MH, RBF, NT, I + 1>::type>::type;
 };
-template <class T, int D, bool MH, int RBF> struct mm_split_pick_rb<T, D, MH, RBF, 6> {
-    using type = mm_split_try<T, D, RBF, RBF * (int)(sizeof(T) / 4) * D, MM_SPLIT_NTILE(MH)>;
+template <class T, int D, bool MH, int RBF, int NT> struct mm_split_pick_rb<T, D, MH, RBF, NT, 6> {
+    using type = mm_split_try<T, D, RBF, RBF * (int)(sizeof(T) / 4) * D, NT>;
 };
-template <class T, int D, bool MH, int RBF = 0>
-struct mm_split_plan : mm_cond<RBF == 0, typename mm_split_pick<T, D, MH>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2)>::type>::type {
-    using Base = typename mm_cond<RBF == 0, typename mm_split_pick<T, D, MH>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2)>::type>::type;
+template <class T, int D, bool MH, int RBF = 0, int NT = MM_SPLIT_NTILE(MH)>
+struct mm_split_plan : mm_cond<RBF == 0, typename mm_split_pick<T, D, MH, NT>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2), NT>::type>::type {
+    using Base = typename mm_cond<RBF == 0, typename mm_split_pick<T, D, MH, NT>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2), NT>::type>::type;
     static constexpr int rb = (int)(Base::ring_bytes / 2 / Base::row_bytes);
     static_assert(Base::tile_t >= rb && Base::lds_bytes <= 160 * 1024, "LDS plan of the split kernel");
+};
+/* HMC with the tiles written out by the least-loaded noise wave: where two tiles and a ring half of 8 transitions fit the
+ * 160 KB (f32 up to D = 3).  Config 3 in tools/split_probe.hip (tools/experiments/split_hmc_pflush.sh, three rounds):
+ * 0.1877 / 0.1850 / 0.1821 ms with the transition wave flushing its own tile, 0.1839 / 0.1814 / 0.1768 so -- a wave's store
+ * instructions are issue-bound (~100 cycles each) and the transition wave is the kernel's critical path; with the plan's own
+ * ring half (4) or the middle noise wave flushing it is slower (0.188-0.193).  Same bits. */
+template <class T, int D> struct mm_split_hmc_pf {
+    using Try = typename mm_split_pick_rb<T, D, false, 8, 2>::type;
+    static constexpr bool ok = sizeof(T) == 4 && Try::ok && Try::tile_t >= 8 && Try::lds_bytes <= 160 * 1024;
 };
 
 /* share of the noise the transition wave draws itself (pairs per batch): MH two of the four pairs of a batch of 8 */
@@ -141,11 +151,11 @@ __device__ unsigned long long mm_split_prof[2][3]; /* [role][barrier wait / tota
  * other's LDS and issue latencies where the step is short (MH).  RBF: ring half (0 = the plan's choice). */
 /* the kernel proper is a device function so that a run-time compiled translation unit (user targets, csrc/mm_rtc.hip) can
  * wrap it in an extern "C" kernel of its own, like mm_run_kernel_body */
-template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0, int NT = MM_SPLIT_NTILE(SAMPLER == MM_SAMPLER_MH)>
 __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
 {
     constexpr int D = Tgt::dim;
-    using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH, RBF>;
+    using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH, RBF, NT>;
     using Tile = typename Plan::Tile;
     constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride, NW = Plan::nw, RB = Plan::rb, EPL = Plan::epl;
     constexpr int QN = 2 * QP; /* transitions per batch whose noise the transition wave draws itself */
@@ -471,20 +481,20 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     }
 }
 
-template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0, int NT = MM_SPLIT_NTILE(SAMPLER == MM_SAMPLER_MH)>
 __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_run_args<T> a)
 {
-    mm_run_split_body<T, Tgt, SAMPLER, LCT, QP, NN, RBF>(a);
+    mm_run_split_body<T, Tgt, SAMPLER, LCT, QP, NN, RBF, NT>(a);
 }
 
 #if !defined(__HIPCC_RTC__)
 #include <atomic>
-template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0>
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0, int NT = MM_SPLIT_NTILE(SAMPLER == MM_SAMPLER_MH)>
 hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
 {
-    using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH, RBF>;
+    using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH, RBF, NT>;
     static std::atomic<unsigned long long> attr_set{0}; /* > 64 KB of dynamic LDS has to be allowed once per kernel and device */
-    auto kern = mm_run_split_kernel<T, Tgt, SAMPLER, LCT, QP, NN, RBF>;
+    auto kern = mm_run_split_kernel<T, Tgt, SAMPLER, LCT, QP, NN, RBF, NT>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
