@@ -378,6 +378,39 @@ def test_hmc_gaussian_ess_band_on_gpu(M, O, kats):
     assert np.all(np.abs(np.cov(flat.T) - np.array(k["cov"])) < 0.1)
 
 
+def test_mh_gaussian_ess_band_on_gpu(M, O, kats):
+    # metropolis_hastings.rs:417-513 (the reference's ignored benchmark): 3 chains x 1000 (after 500), sigma_prop 1, mean
+    # ESS of the first coordinate in [65, 125]; many 3-chain groups at once, started as the reference starts them (N(0, 1))
+    k, band = kats["mh_statistical"], kats["mh_ess_bands"]["ess1_band"]
+    groups = 200
+    init = M.core.init_with_seed(3 * groups, 2, 17, np.float64)
+    tgt = M.dist.Gaussian2D(k["mean"], k["cov"])
+    s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(k["proposal_std"]), init).seed(5).run(1000, 500)
+    ess = np.array([O.split_rhat_mean_ess(s[3 * i:3 * i + 3].astype(np.float32))[1] for i in range(groups)])
+    assert band[0] <= ess[:, 0].mean() <= band[1], ess.mean(axis=0)
+
+
+def test_mh_single_chain_from_a_far_start_and_against_a_wrong_target_on_gpu(M, kats):
+    # tests/metrohast_2d_gaussian_test.rs:16-92: ONE chain from (10, 12), 10 000 + 2 500, mean and covariance within 0.5 of
+    # the target's -- and the same run against the identity covariance must NOT match (max |cov difference| > 1.0)
+    k = kats["mh_single_chain_statistical"]
+
+    def moments(cov):
+        tgt = M.dist.Gaussian2D(k["mean"], cov)
+        init = np.array([k["init"]], dtype=np.float64)
+        s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(k["proposal_std"]), init).seed(k["seed"])
+        out = s.run(k["n_collect"], k["n_discard"])
+        assert out.shape == (1, k["n_collect"], 2)
+        flat = out.reshape(-1, 2)
+        return flat.mean(axis=0), np.cov(flat.T)
+
+    mean, cov = moments(k["cov"])
+    assert np.all(np.abs(mean - k["mean"]) < k["mean_atol"]), mean
+    assert np.abs(cov - np.array(k["cov"])).max() < k["cov_atol"], cov
+    _, cov_false = moments(k["false_cov"])
+    assert np.abs(cov_false - np.array(k["cov"])).max() > k["false_target_cov_diff_gt"], cov_false
+
+
 # ---------------------------------------------------------------- diagnostics on the GPU (stats.rs:416-546)
 
 
