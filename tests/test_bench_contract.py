@@ -73,3 +73,28 @@ def test_bench_line_contract_and_roofline_is_the_hbm_fraction():
     assert cb["per_thread_over_single_thread"] >= 0.5 or "per_thread_note" in cb
     assert ("ess_per_s" in j) != ("ess_per_s_unconverged" in j)
     assert ("ess_per_s" in j) == (j["split_rhat_max_conventional"] <= 1.05)
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_two_ranks_rehearsed_on_one_device():
+    """The driver's N > 1 call -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, one rank per
+    GPU -- rehearsed with both ranks on device 0 over gloo (MMCMC_BENCH_DRYRUN_ONE_DEVICE=1: RCCL refuses one device twice);
+    the line says it is a dry run.  Keeps the rank bookkeeping (shards, barriers, max over ranks, rank 0 prints) alive."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MMCMC_BENCH_DRYRUN_ONE_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--preroll-seconds", "0", "--no-side"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and "DRY RUN" in j["data"]
+    assert j["config"]["parallelism"].startswith("chains sharded x2")
+    assert "cpu_baseline" not in j  # the contract times the CPU baseline on rank 0 at N = 1 only
