@@ -167,6 +167,81 @@ __global__ __launch_bounds__(64) void mm_half_chain_kernel(const T *__restrict__
         slab[i] = acc[i];
 }
 
+/* Half-chains of ANY length (round 4; the last resort of stats_partials_impl: D m beyond what the kernels above can stage in
+ * LDS and m beyond the power-spectrum kernels' 16 384 -- a few very long chains, e.g. one chain of 10^5 draws).  Nothing of a
+ * half-chain is resident: the moments kernel reads it twice from global memory (one wave per half-chain and parameter), the
+ * lag kernel gives a workgroup 256 consecutive lags of one parameter and walks its share of the half-chains in windows of
+ * 1024 draws staged in LDS (A = y[t], B = y[t + lag0 + ...], zero past the end, so the inner loop has no bounds test);
+ * window sums in f32, their total in f64.  O(C D m^2) like stats.rs:632-654's brute-force branch, but on 256 CUs. */
+template <class T>
+__global__ __launch_bounds__(64) void mm_half_chain_moments_any_kernel(const T *__restrict__ sample, unsigned long long C,
+                                                                       unsigned int n, unsigned int D, unsigned int m,
+                                                                       float *__restrict__ means, float *__restrict__ ssq)
+{
+    const unsigned int lane = threadIdx.x;
+    const unsigned long long hc = blockIdx.x / D;
+    const unsigned int d = blockIdx.x % D;
+    const unsigned long long chain = hc < C ? hc : hc - C;
+    const unsigned int row0 = hc < C ? 0u : n - m;
+    const T *src = sample + (chain * n + row0) * D + d;
+    float s = 0.f;
+    for (unsigned int t = lane; t < m; t += 64)
+        s += (float)src[(size_t)t * D];
+    const float mean = wave_sum(s) / (float)m;
+    float q = 0.f;
+    for (unsigned int t = lane; t < m; t += 64) {
+        const float v = (float)src[(size_t)t * D] - mean;
+        q = fmaf(v, v, q);
+    }
+    q = wave_sum(q);
+    if (lane == 0) {
+        means[hc * D + d] = mean;
+        ssq[hc * D + d] = q;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void mm_lag_sums_any_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n,
+                                                              unsigned int D, unsigned int m, const float *__restrict__ means,
+                                                              unsigned int n_slabs, float *__restrict__ slabs)
+{
+    constexpr unsigned int W = 1024, L = 256;
+    __shared__ float A[W], B[W + L];
+    const unsigned int tid = threadIdx.x, lag0 = blockIdx.x * L, d = blockIdx.y, slab = blockIdx.z;
+    const unsigned long long n_half = 2ull * C;
+    double total = 0.0;
+    for (unsigned long long hc = slab; hc < n_half; hc += n_slabs) {
+        const unsigned long long chain = hc < C ? hc : hc - C;
+        const unsigned int row0 = hc < C ? 0u : n - m;
+        const T *src = sample + (chain * n + row0) * D + d;
+        const float mean = means[hc * D + d];
+        for (unsigned int t0 = 0; t0 + lag0 < m; t0 += W) { /* windows whose products can be non-zero for this tile */
+            __syncthreads();
+            for (unsigned int i = tid; i < W; i += L) {
+                const unsigned int t = t0 + i;
+                A[i] = t < m ? (float)src[(size_t)t * D] - mean : 0.f;
+            }
+            for (unsigned int j = tid; j < W + L; j += L) {
+                const unsigned int t = t0 + lag0 + j;
+                B[j] = t < m ? (float)src[(size_t)t * D] - mean : 0.f;
+            }
+            __syncthreads();
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+            for (unsigned int i = 0; i < W; i += 4) {
+                a0 = fmaf(A[i], B[i + tid], a0);
+                a1 = fmaf(A[i + 1], B[i + 1 + tid], a1);
+                a2 = fmaf(A[i + 2], B[i + 2 + tid], a2);
+                a3 = fmaf(A[i + 3], B[i + 3 + tid], a3);
+            }
+            total += (double)((a0 + a1) + (a2 + a3));
+        }
+    }
+    const unsigned int lag = lag0 + tid;
+    if (lag < m)
+        slabs[((size_t)slab * D + d) * m + lag] = (float)total;
+}
+
 /* The same half-chain statistics with the lag sums on the matrix cores.  For one parameter of one half-chain the
  * biased autocovariance sums c_k = sum_t y[t] y[t+k] are a product of two Hankel/Toeplitz operands:
  *     A[i][t] = y[t + i]  (16 x K),   B[t][j] = y[t - 16 j - 256 tau]  (K x 16)   =>   (A B)[i][j] = c_(i + 16 j + 256 tau)
@@ -1827,8 +1902,28 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
     } else {
         const unsigned int m_pad = (unsigned int)(m + 64 + ((m + 64) % 2 == 0 ? 1 : 0)); /* odd row pitch */
         const size_t lds = ((size_t)dim * m_pad + (size_t)dim * m) * sizeof(float);
-        if (lds > 160 * 1024)
-            return MMCMC_ERR_UNSUPPORTED;
+        if (lds > 160 * 1024 || m > 16384) {
+            /* nothing stages such a half-chain (or only one wave per half-chain would: [2, 32770, 1] 46 ms against 1 ms here):
+             * moments and lag sums straight from global memory, any length */
+            n_slabs = std::min(n_slabs, 16u);
+            if (!slabs)
+                MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
+            const unsigned int g_mom = (unsigned int)(2 * n_chains * dim);
+            const dim3 g_lag((unsigned int)((m + 255) / 256), (unsigned int)dim, n_slabs);
+            if (dtype == MMCMC_F32) {
+                hipLaunchKernelGGL(mm_half_chain_moments_any_kernel<float>, dim3(g_mom), dim3(64), 0, stream, (const float *)sample,
+                                   (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, means, ssq);
+                hipLaunchKernelGGL(mm_lag_sums_any_kernel<float>, g_lag, dim3(256), 0, stream, (const float *)sample,
+                                   (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, means, n_slabs,
+                                   slabs);
+            } else {
+                hipLaunchKernelGGL(mm_half_chain_moments_any_kernel<double>, dim3(g_mom), dim3(64), 0, stream, (const double *)sample,
+                                   (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, means, ssq);
+                hipLaunchKernelGGL(mm_lag_sums_any_kernel<double>, g_lag, dim3(256), 0, stream, (const double *)sample,
+                                   (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, means, n_slabs,
+                                   slabs);
+            }
+        } else {
         if (!slabs)
             MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
         if (lds > 64 * 1024) {
@@ -1844,6 +1939,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
             hipLaunchKernelGGL(mm_half_chain_kernel<double>, dim3(n_slabs), dim3(64), lds, stream,
                                (const double *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim,
                                (unsigned int)m, m_pad, means, ssq, slabs);
+        }
     }
     MM_HIP(hipGetLastError());
     const unsigned int total = (unsigned int)(dim * m);

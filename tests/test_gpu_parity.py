@@ -951,11 +951,13 @@ def test_nuts_repacking_between_launches_changes_no_result(M, O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2)])
+@pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2), (5, 2050, 2),
+                                   (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2)])
 def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
     """Half-chains beyond 1024 draws (mm_chain_fft_long_kernel: the transform cut into N1 residues of 2048-point wave-level
-    transforms): R-hat / ESS against oracle/stats.c's FFT branch (stats.rs:576-620), odd n (the middle draw dropped), few
-    chains, the largest supported length; equal to the direct sums where those still exist; reproducible bit for bit;
+    transforms) and beyond 16 384 (mm_lag_sums_any_kernel: any length, straight from global memory): R-hat / ESS against
+    oracle/stats.c's FFT branch (stats.rs:576-620), odd n (the middle draw dropped), few chains, the first and the last length
+    of each path, one chain of 10^5 draws; equal to the direct sums where those still exist; reproducible bit for bit;
     the partial statistics the multi-GPU path exchanges agree with the one-call path."""
     from mini_mcmc_amd import stats as S
 
