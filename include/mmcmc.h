@@ -385,8 +385,8 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
  *   FFT / TILE1 / TILE / MFMA / DIRECT   that kernel wherever its shape limits allow, AUTO's choice elsewhere
  *           (FFT: 2 <= n/2 <= 16384 -- one wave-level transform up to 1024, N1 residues of 2048-point transforms beyond;
  *           TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).  Half-chains longer than
- *           16384 draws fall to the direct sums, which end where a half-chain no longer fits a workgroup's LDS
- *           (MMCMC_ERR_UNSUPPORTED: about 6800 draws at three parameters) -- thin such a sample first.
+ *           16384 draws -- and, under DIRECT, any the staging kernels cannot hold in a workgroup's LDS -- are reduced
+ *           straight from global memory (O(chains x dim x n^2), meant for a few very long chains): any n < 2^31.
  * For measurements and for the agreement test; results never depend on it beyond rounding.  Process-wide and meant to
  * be set once: a call that races with it picks one kernel or the other (its work buffer fits both).  Under one selection
  * R-hat / ESS are bit-reproducible across devices too: no kernel's summation grouping depends on the device. */
