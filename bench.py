@@ -292,9 +292,9 @@ def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
 def main_group(args) -> None:
     """--group: the same headline through the in-library device group -- one process, N devices (MMCMC_BENCH_GROUP_DEVICES =
     comma-separated device list overrides 0..N-1, e.g. "0,0" rehearses two shards on one GPU through the host exchange).
-    A step = mmcmc_hmc_group_run of all N x 65 536 chains (every shard's kernel on its own device and stream, the call
-    returns when all have finished); the diagnostics afterwards go through ncclAllGather / ncclAllReduce inside the
-    library, and the line says which path they took."""
+    A step = mmcmc_hmc_group_run of all N x 65 536 chains: every shard's kernel enqueued on its own device and stream, no
+    wait between steps (as at N = 1); mmcmc_hmc_group_sync closes the timed region.  The diagnostics afterwards go through
+    ncclAllGather / ncclAllReduce inside the library, and the line says which path they took."""
     import numpy as np
     import torch
 
@@ -310,23 +310,28 @@ def main_group(args) -> None:
     init = init_with_seed(C_PER_GPU * n, DIM, SEED, np.float32)
     g = HMCGroup(RosenbrockND(DIM), init, STEP_SIZE, N_LEAPFROG, devices=devices).set_seed(SEED)
 
+    exch_status, rccl_ranks = g.exchange()  # decided (and the RCCL communicators made) when the group was created
+
     def step():
-        g.run(N_COLLECT, N_DISCARD, to_host=False)
+        # nothing goes back to the host: every shard's launch is ENQUEUED on that shard's stream and the call returns
+        # (include/mmcmc.h) -- the same back-to-back queueing as the N = 1 line's mmcmc_hmc_run on torch's stream
+        g.run(N_COLLECT, N_DISCARD, to_host=False, accept_counts=False)
 
     t_pre, pre = time.perf_counter(), 0
     while time.perf_counter() - t_pre < args.preroll_seconds:
-        for _ in range(20):
+        for _ in range(100):
             step()
-        pre += 20
+        g.sync()
+        pre += 100
     for _ in range(args.warmup):
         step()
-    for d in set(devices):
-        torch.cuda.synchronize(d)
+    g.sync()
     t0 = time.perf_counter()
+    g.timer_start()
     for _ in range(args.steps):
         step()
-    for d in set(devices):
-        torch.cuda.synchronize(d)
+    kernel_ms_per_device = g.timer_stop() / args.steps  # HIP events on every shard's own stream around the timed region
+    g.sync()
     dt = time.perf_counter() - t0
     g.split_rhat_mean_ess()
     ts = time.perf_counter()
@@ -337,6 +342,8 @@ def main_group(args) -> None:
     ms = dt / args.steps * 1e3
     alg_bytes = C_PER_GPU * DIM * 4 * (N_COLLECT + 2)
     rhat_max = float((1.0 / rhat).max())
+    shards_on = {d: devices.count(d) for d in devices}
+    k_ms = max(float(kernel_ms_per_device[i]) / shards_on[devices[i]] for i in range(n))
     res = {
         "metric": "samples/sec (all chains), 3D Rosenbrock HMC", "value": samples / dt, "unit": "samples/s", "n_gpus": n,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
@@ -344,20 +351,25 @@ def main_group(args) -> None:
         "config": {"workload": "BASELINE.json configs[2] per device (configs[3] at 8): RosenbrockND D=3 HMC, 65536 chains/GPU, "
                                "eps=0.032, L=10, f32, run(400, 50) per step", "chains_per_gpu": C_PER_GPU, "dim": DIM,
                    "n_leapfrog": N_LEAPFROG, "n_collect": N_COLLECT, "n_discard": N_DISCARD, "devices": devices,
-                   "parallelism": f"in-library device group x{n}: one process, one host thread + stream per device, no data-path collective"},
+                   "parallelism": f"in-library device group x{n}: one process, one stream per device, launches enqueued back to back, no data-path collective"},
         "leapfrog_steps_per_s": float(args.steps) * C_PER_GPU * n * (N_COLLECT + N_DISCARD) * N_LEAPFROG / dt,
         "ess_min": float(ess.min()), "split_rhat_max_conventional": rhat_max,
         "stats_ms": stats_s * 1e3,
         "diagnostics_exchange": {1: "rccl (ncclAllGather + ncclAllReduce inside libmmcmc.so)", 0: "host (a device is listed twice)",
                                  -1: "host FALLBACK: no RCCL library could be loaded", -2: "host FALLBACK: ncclCommInitAll failed"}[g.exchange_status],
+        "diagnostics_exchange_decided_at_create": exch_status,
         "preroll": {"seconds": args.preroll_seconds, "steps": pre},
-        "rccl_ranks": n if g.exchange_status == 1 else 0,
-        # a group step includes the host's fan-out to N device threads and their join: per-device kernel time is not separated,
-        # so the HBM figure is from ms_per_step (an under-estimate of the kernel's)
-        "roofline": {"bound": "hbm", "achieved": alg_bytes * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * n, "unit": "GB/s",
-                     "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": n,
-                     "note": "from ms_per_step (host fan-out to the device threads included); vector-instruction issue binds the kernel (N = 1 line: fp32, issue)"},
+        "rccl_ranks": rccl_ranks,
+        "kernel_ms_per_device": [float(x) for x in kernel_ms_per_device],
+        # the kernel's launch duration per device: HIP events on each shard's own stream around the timed region / steps (with a
+        # device listed twice its two streams share the device, so each stream's figure covers both shards' launches)
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": n, "kernel_ms": k_ms,
+                     "kernel_ms_how": "slowest device: HIP events on the shard's stream around the timed region / steps / shards on that device",
+                     "whole_job": {"achieved": alg_bytes * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * len(set(devices)),
+                                   "how": "all shards' algorithmic bytes / ms_per_step (wall clock, host loop included)"},
+                     "note": "vector-instruction issue binds the kernel (N = 1 line: fp32, issue)"},
     }
     conv = rhat_max <= 1.05
     res["ess_per_s" if conv else "ess_per_s_unconverged"] = float(ess.min()) * args.steps / (dt + stats_s * args.steps)

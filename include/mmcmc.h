@@ -313,8 +313,8 @@ int mmcmc_proposal_register_source(const char *name, int target_kind, int dim, c
 /* ---- device groups: one call runs every chain on N GPUs (csrc/mm_group.hip) ------------------------------------
  * `run` of the reference executes ALL chains of the sampler (ChainRunner::run core.rs:176-186, HMC::run hmc.rs:137-158).
  * A group shards n_chains contiguously over `devices` (device i: global chains [first_i, first_i + n_i), stream keyed by
- * the global index, so the sample does not depend on the number of devices), runs the shards from one host thread per
- * device with no data-path collective, and reduces split-R-hat / ESS (stats.rs:416-546) over all chains: per-device
+ * the global index, so the sample does not depend on the number of devices), runs the shards with no data-path
+ * collective, and reduces split-R-hat / ESS (stats.rs:416-546) over all chains: per-device
  * sufficient statistics, RCCL ncclAllGather of the per-half-chain means / sums of squares + ncclAllReduce of the lag
  * sums over xGMI, host finish in the single-GPU summation order.  (RCCL is bound at run time; if it is missing, or a
  * device is listed twice -- several shards on one GPU --, the statistics travel through the host; *used_rccl says which:
@@ -322,7 +322,16 @@ int mmcmc_proposal_register_source(const char *name, int target_kind, int dim, c
  * loaded; -2 = the host because ncclCommInitAll failed -- check it in a scaling run.)
  *   init: host [n_chains, dim] of dtype.  run: the sample stays on the devices (mmcmc_hmc_group_shard gives each shard's
  *   device pointer [n_i, n_collect, dim]); out_host, if not NULL, also receives [n_chains, n_collect, dim];
- *   accept_counts: host [n_chains] or NULL.  A second run continues the chains. */
+ *   accept_counts: host [n_chains] or NULL.  A second run continues the chains.
+ *   ASYNCHRONOUS when nothing goes back to the host: an MH / HMC group_run with out_host == NULL and accept_counts == NULL
+ *   enqueues every shard's launch on that shard's stream and returns (as mmcmc_hmc_run does on a caller's stream), so runs
+ *   issued back to back keep all devices busy; mmcmc_*_group_sync waits for them.  _state, _split_rhat_mean_ess and a later
+ *   run are ordered behind the queued work by the streams; read a shard's device pointer only after _sync.  With a host
+ *   destination or accept counts (and for NUTS) the call returns when the results are there.
+ *   _stream_timer(g, 0, NULL) records a start event on every shard's stream, _stream_timer(g, 1, ms) the end events, waits
+ *   and writes each shard's elapsed device milliseconds into ms [n_devices].
+ *   _exchange: how the diagnostics' statistics will travel -- decided in _create, where the RCCL communicators are made
+ *   (ncclCommInitAll; *status as *used_rccl above, *n_rccl_ranks = ranks of the communicator or 0). */
 typedef struct mmcmc_hmc_group mmcmc_hmc_group;
 int mmcmc_hmc_group_create(mmcmc_hmc_group **out, const mmcmc_target_desc *target, const void *init, size_t n_chains,
                            double step_size, int n_leapfrog, int dtype, const int *devices, int n_devices);
@@ -332,6 +341,9 @@ int mmcmc_hmc_group_run(mmcmc_hmc_group *g, size_t n_collect, size_t n_discard, 
 int mmcmc_hmc_group_state(mmcmc_hmc_group *g, void *out); /* host [n_chains, dim] */
 int mmcmc_hmc_group_split_rhat_mean_ess(mmcmc_hmc_group *g, float *rhat, float *ess, int *used_rccl); /* of the last run */
 int mmcmc_hmc_group_shard(mmcmc_hmc_group *g, int i, int *device, size_t *first_chain, size_t *n_chains, void **sample_dev);
+int mmcmc_hmc_group_sync(mmcmc_hmc_group *g);
+int mmcmc_hmc_group_stream_timer(mmcmc_hmc_group *g, int stop, float *ms_per_device);
+int mmcmc_hmc_group_exchange(mmcmc_hmc_group *g, int *status, int *n_rccl_ranks);
 int mmcmc_hmc_group_destroy(mmcmc_hmc_group *g);
 typedef struct mmcmc_mh_group mmcmc_mh_group;
 int mmcmc_mh_group_create(mmcmc_mh_group **out, const mmcmc_target_desc *target, const mmcmc_proposal_desc *proposal,
@@ -341,6 +353,9 @@ int mmcmc_mh_group_set_chain_offset(mmcmc_mh_group *g, uint64_t first_global_cha
 int mmcmc_mh_group_run(mmcmc_mh_group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts);
 int mmcmc_mh_group_state(mmcmc_mh_group *g, void *out);
 int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *g, float *rhat, float *ess, int *used_rccl);
+int mmcmc_mh_group_sync(mmcmc_mh_group *g);
+int mmcmc_mh_group_stream_timer(mmcmc_mh_group *g, int stop, float *ms_per_device);
+int mmcmc_mh_group_exchange(mmcmc_mh_group *g, int *status, int *n_rccl_ranks);
 int mmcmc_mh_group_destroy(mmcmc_mh_group *g);
 /* NUTS::run / run_progress (nuts.rs:163-170, 194-338) of every chain on N devices: `init` host [n_chains, dim] doubles
  * and `mode` as in mmcmc_nuts_create; out_host [n_chains, n_collect, dim] of the mode's tensor type (f32 for modes 0 and
@@ -355,6 +370,9 @@ int mmcmc_nuts_group_run(mmcmc_nuts_group *g, size_t n_collect, size_t n_discard
 int mmcmc_nuts_group_state(mmcmc_nuts_group *g, void *out); /* host [n_chains, dim] of the tensor type */
 int mmcmc_nuts_group_leapfrog_counts(mmcmc_nuts_group *g, uint64_t *out); /* host [n_chains] */
 int mmcmc_nuts_group_split_rhat_mean_ess(mmcmc_nuts_group *g, float *rhat, float *ess, int *used_rccl);
+int mmcmc_nuts_group_sync(mmcmc_nuts_group *g);
+int mmcmc_nuts_group_stream_timer(mmcmc_nuts_group *g, int stop, float *ms_per_device);
+int mmcmc_nuts_group_exchange(mmcmc_nuts_group *g, int *status, int *n_rccl_ranks);
 int mmcmc_nuts_group_destroy(mmcmc_nuts_group *g);
 
 /* ---- diagnostics: stats.rs ------------------------------------------------------------------------------

@@ -369,6 +369,20 @@ template <class T> class HMCGroup {
         check(mmcmc_hmc_group_run(g_, n_collect, n_discard, out.data(), nullptr), "mmcmc_hmc_group_run");
         return out;
     }
+    /* the same run with the sample left on the devices: only ENQUEUED on the shards' streams (returns at once; several in a
+     * row keep every device busy); sync() waits, split_rhat_mean_ess() orders itself behind them */
+    void run_on_devices(size_t n_collect, size_t n_discard)
+    {
+        check(mmcmc_hmc_group_run(g_, n_collect, n_discard, nullptr, nullptr), "mmcmc_hmc_group_run");
+    }
+    void sync() { check(mmcmc_hmc_group_sync(g_), "mmcmc_hmc_group_sync"); }
+    /* how the diagnostics will travel (1 RCCL, 0 host by design, < 0 host as a fallback), known from construction on */
+    int exchange() const
+    {
+        int status = 0;
+        check(mmcmc_hmc_group_exchange(g_, &status, nullptr), "mmcmc_hmc_group_exchange");
+        return status;
+    }
     /* stats::split_rhat_mean_ess of the last run over the chains of all devices (RCCL inside the library) */
     std::pair<std::vector<float>, std::vector<float>> split_rhat_mean_ess()
     {

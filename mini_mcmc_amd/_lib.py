@@ -173,6 +173,9 @@ SIGNATURES = {
     "mmcmc_hmc_group_state": (C.c_int, [_vp, _vp]),
     "mmcmc_hmc_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mmcmc_hmc_group_shard": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
+    "mmcmc_hmc_group_sync": (C.c_int, [_vp]),
+    "mmcmc_hmc_group_stream_timer": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
+    "mmcmc_hmc_group_exchange": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmcmc_hmc_group_destroy": (C.c_int, [_vp]),
     "mmcmc_mh_group_create": (C.c_int, [C.POINTER(_vp), _TP, _PP, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "mmcmc_mh_group_seed": (C.c_int, [_vp, C.c_uint64]),
@@ -180,6 +183,9 @@ SIGNATURES = {
     "mmcmc_mh_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint64)]),
     "mmcmc_mh_group_state": (C.c_int, [_vp, _vp]),
     "mmcmc_mh_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mmcmc_mh_group_sync": (C.c_int, [_vp]),
+    "mmcmc_mh_group_stream_timer": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
+    "mmcmc_mh_group_exchange": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmcmc_mh_group_destroy": (C.c_int, [_vp]),
     "mmcmc_nuts_group_create": (C.c_int, [C.POINTER(_vp), _TP, C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "mmcmc_nuts_group_seed": (C.c_int, [_vp, C.c_uint64]),
@@ -189,6 +195,9 @@ SIGNATURES = {
     "mmcmc_nuts_group_state": (C.c_int, [_vp, _vp]),
     "mmcmc_nuts_group_leapfrog_counts": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "mmcmc_nuts_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mmcmc_nuts_group_sync": (C.c_int, [_vp]),
+    "mmcmc_nuts_group_stream_timer": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
+    "mmcmc_nuts_group_exchange": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmcmc_nuts_group_destroy": (C.c_int, [_vp]),
 }
 

@@ -5,8 +5,12 @@
  * with one sampler handle per device the caller of the C ABI would have to write the sharding and the exchange of the
  * diagnostics itself.  A group owns one handle per device -- device i holds the contiguous block of global chains
  * [first_i, first_i + n_i), keyed into the random stream by their GLOBAL index, so the samples do not depend on the
- * number of devices -- and runs them from one host thread per device (every call into the per-device ABI blocks only
- * its own thread).  Chains never talk to each other while sampling: no data-path collective.  The one exchange is
+ * number of devices.  A `run` that hands nothing back to the host (no host sample, no accept counts; MH / HMC) is
+ * ENQUEUED on every shard's stream by the calling thread and returns at once -- like the single-device call on a
+ * caller's stream, so back-to-back runs keep every device busy without a host round trip per run (mmcmc_*_group_sync
+ * waits; everything that reads results is ordered behind the queued work by the shard's stream).  Calls that block
+ * (host output, accept counts, NUTS with its adaptation hand-offs, the diagnostics) run from one host thread per
+ * device, each blocking only its own thread.  Chains never talk to each other while sampling: no data-path collective.  The one exchange is
  * the split-R-hat / ESS reduction (stats.rs:416-546): every device reduces its own sample to the per-half-chain
  * statistics (mmcmc_stats_partials), RCCL all-gathers means / sums of squares over xGMI (ncclAllGather) and
  * all-reduces the lag sums (ncclAllReduce), and the host finish (mmcmc_stats_finish) runs on the gathered statistics
@@ -136,6 +140,7 @@ struct Shard {
     float *d_stats = nullptr; /* means [2 cmax, dim] | ssq [2 cmax, dim] | acov [m, dim] | gathered [N][2][2 cmax dim] */
     size_t stats_cap = 0;
     ncclComm_t comm = nullptr;
+    hipEvent_t tev0 = nullptr, tev1 = nullptr; /* the stream timer (group_stream_timer) */
     std::unique_ptr<Worker> worker;
 };
 
@@ -190,6 +195,10 @@ int group_destroy(Group *g)
             (void)hipFree(s.d_sample);
         if (s.d_stats)
             (void)hipFree(s.d_stats);
+        if (s.tev0)
+            (void)hipEventDestroy(s.tev0);
+        if (s.tev1)
+            (void)hipEventDestroy(s.tev1);
         if (s.stream)
             (void)hipStreamDestroy(s.stream);
     }
@@ -249,6 +258,11 @@ int group_create(Group **out, int sampler, const mmcmc_target_desc *target, cons
                           : sampler ? mmcmc_hmc_set_chain_offset(s.hmc, s.first) : mmcmc_mh_set_chain_offset(s.mh, s.first);
         if (rc != MMCMC_OK)
             return rc;
+        /* nobody reads the per-handle launch timing of a shard: no event packets between back-to-back launches */
+        if (sampler == 1)
+            (void)mmcmc_hmc_enable_timing(s.hmc, 0);
+        else if (sampler == 0)
+            (void)mmcmc_mh_enable_timing(s.mh, 0);
         if (hipSetDevice(s.device) != hipSuccess)
             return MMCMC_ERR_NO_DEVICE;
         hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
@@ -257,6 +271,23 @@ int group_create(Group **out, int sampler, const mmcmc_target_desc *target, cons
     if (st != MMCMC_OK) {
         group_destroy(g);
         return st;
+    }
+    /* the communicators are made HERE, not inside the first diagnostics call: a timed reduction never pays
+     * ncclCommInitAll, and a failure is known (mmcmc_*_group_exchange) before any sampling has been paid for */
+    if (g->use_rccl) {
+        const size_t N = g->sh.size();
+        std::vector<ncclComm_t> comms(N);
+        std::vector<int> devs(N);
+        for (size_t i = 0; i < N; ++i)
+            devs[i] = g->sh[i].device;
+        if (rccl().CommInitAll(comms.data(), (int)N, devs.data()) != 0) {
+            g->use_rccl = false; /* e.g. no peer access: the statistics travel through the host, and the status says so */
+            g->exchange_status = -2;
+        } else {
+            for (size_t i = 0; i < N; ++i)
+                g->sh[i].comm = comms[i];
+            g->comm_ready = true;
+        }
     }
     *out = g;
     return MMCMC_OK;
@@ -289,32 +320,67 @@ int group_set_chain_offset(Group *g, uint64_t off)
     return MMCMC_OK;
 }
 
+static int shard_reserve_sample(Shard &s, size_t bytes)
+{
+    if (bytes <= s.sample_cap)
+        return MMCMC_OK;
+    /* work queued on the shard's stream may still write the old buffer */
+    hipError_t e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess)
+        return (int)e;
+    if (s.d_sample)
+        (void)hipFree(s.d_sample);
+    s.d_sample = nullptr;
+    s.sample_cap = 0;
+    if ((e = hipMalloc(&s.d_sample, bytes)) != hipSuccess)
+        return (int)e;
+    s.sample_cap = bytes;
+    return MMCMC_OK;
+}
+
 /* run(n_collect, n_discard) of every chain; the sample stays on the devices (one shard each) and, when out_host is
- * given, is also copied into the caller's [n_chains, n_collect, dim] array; accept_counts [n_chains] or NULL */
+ * given, is also copied into the caller's [n_chains, n_collect, dim] array; accept_counts [n_chains] or NULL.
+ * MH / HMC with neither: enqueued on every shard's stream from this thread, returns without waiting (group_sync). */
 int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts)
 {
     if (!g)
         return MMCMC_ERR_INVALID_ARG;
     const size_t esz = g->esize(), row = n_collect * (size_t)g->dim * esz;
+    if (g->sampler != 2 && !out_host && !accept_counts) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        int st = MMCMC_OK;
+        for (Shard &s : g->sh) {
+            if (hipSetDevice(s.device) != hipSuccess) {
+                st = MMCMC_ERR_NO_DEVICE;
+                break;
+            }
+            if ((st = shard_reserve_sample(s, s.n * row)) != MMCMC_OK)
+                break;
+            void *d_out = n_collect ? s.d_sample : nullptr;
+            st = g->sampler ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, nullptr, s.stream)
+                            : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, nullptr, s.stream);
+            if (st != MMCMC_OK)
+                break;
+        }
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+        if (st == MMCMC_OK)
+            g->last_collect = n_collect;
+        return st;
+    }
     const int st = for_each_shard(g, [&](Shard &s, int) -> int {
         if (hipSetDevice(s.device) != hipSuccess)
             return MMCMC_ERR_NO_DEVICE;
         const size_t bytes = s.n * row;
-        if (bytes > s.sample_cap) {
-            if (s.d_sample)
-                (void)hipFree(s.d_sample);
-            s.d_sample = nullptr;
-            s.sample_cap = 0;
-            hipError_t e = hipMalloc(&s.d_sample, bytes);
-            if (e != hipSuccess)
-                return (int)e;
-            s.sample_cap = bytes;
-        }
+        int rc = shard_reserve_sample(s, bytes);
+        if (rc != MMCMC_OK)
+            return rc;
         uint64_t *acc = accept_counts ? accept_counts + s.first : nullptr;
         void *d_out = n_collect ? s.d_sample : nullptr;
-        int rc = g->sampler == 2 ? mmcmc_nuts_run(s.nuts, n_collect, n_discard, d_out, 1, g->progress, s.stream)
-                 : g->sampler    ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, acc, s.stream)
-                                 : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, acc, s.stream);
+        rc = g->sampler == 2 ? mmcmc_nuts_run(s.nuts, n_collect, n_discard, d_out, 1, g->progress, s.stream)
+             : g->sampler    ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, acc, s.stream)
+                             : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, acc, s.stream);
         if (rc != MMCMC_OK)
             return rc;
         hipError_t e = hipSuccess;
@@ -327,6 +393,71 @@ int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint
     if (st == MMCMC_OK)
         g->last_collect = n_collect;
     return st;
+}
+
+/* wait for everything queued on the shards' streams */
+int group_sync(Group *g)
+{
+    if (!g)
+        return MMCMC_ERR_INVALID_ARG;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    int st = MMCMC_OK;
+    for (Shard &s : g->sh) {
+        hipError_t e = hipSetDevice(s.device);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s.stream);
+        if (e != hipSuccess && st == MMCMC_OK)
+            st = (int)e;
+    }
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+    return st;
+}
+
+/* Stream timer: stop = 0 records a start event on every shard's stream; stop = 1 records the end events, waits for them
+ * and writes the elapsed milliseconds of every shard into ms [n_devices] -- the time the DEVICE spent on what was queued
+ * in between (bench.py: kernel time per device of a scaling run, free of the host's launch loop). */
+int group_stream_timer(Group *g, int stop, float *ms)
+{
+    if (!g || (stop && !ms))
+        return MMCMC_ERR_INVALID_ARG;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    hipError_t e = hipSuccess;
+    for (Shard &s : g->sh) {
+        if ((e = hipSetDevice(s.device)) != hipSuccess)
+            break;
+        if (!s.tev0 && (e = hipEventCreate(&s.tev0)) != hipSuccess)
+            break;
+        if (!s.tev1 && (e = hipEventCreate(&s.tev1)) != hipSuccess)
+            break;
+        if ((e = hipEventRecord(stop ? s.tev1 : s.tev0, s.stream)) != hipSuccess)
+            break;
+    }
+    if (e == hipSuccess && stop) {
+        size_t i = 0;
+        for (Shard &s : g->sh) {
+            if ((e = hipSetDevice(s.device)) != hipSuccess || (e = hipEventSynchronize(s.tev1)) != hipSuccess ||
+                (e = hipEventElapsedTime(&ms[i], s.tev0, s.tev1)) != hipSuccess)
+                break;
+            ++i;
+        }
+    }
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+    return e == hipSuccess ? MMCMC_OK : (int)e;
+}
+
+/* how the diagnostics' statistics will travel (decided at creation): the values of *used_rccl */
+int group_exchange(Group *g, int *status, int *n_rccl_ranks)
+{
+    if (!g || !status)
+        return MMCMC_ERR_INVALID_ARG;
+    *status = g->exchange_status;
+    if (n_rccl_ranks)
+        *n_rccl_ranks = g->comm_ready ? (int)g->sh.size() : 0;
+    return MMCMC_OK;
 }
 
 int group_state(Group *g, void *out)
@@ -351,20 +482,6 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
     const size_t part = 2 * g->cmax * D;             /* per-device means (or ssq), padded to the largest shard */
     const size_t own = 2 * part + m * D;             /* means | ssq | acov */
     const size_t total = own + N * 2 * part + m * D; /* + gathered [N][means | ssq] + reduced acov */
-    if (g->use_rccl && !g->comm_ready) {
-        std::vector<ncclComm_t> comms(N);
-        std::vector<int> devs(N);
-        for (size_t i = 0; i < N; ++i)
-            devs[i] = g->sh[i].device;
-        if (rccl().CommInitAll(comms.data(), (int)N, devs.data()) != 0) {
-            g->use_rccl = false; /* e.g. no peer access: exchange through the host, and say so */
-            g->exchange_status = -2;
-        } else {
-            for (size_t i = 0; i < N; ++i)
-                g->sh[i].comm = comms[i];
-            g->comm_ready = true;
-        }
-    }
     if (used_rccl)
         *used_rccl = g->exchange_status;
     std::vector<float> h_own(g->use_rccl ? 0 : N * own);
@@ -507,6 +624,15 @@ int mmcmc_hmc_group_shard(mmcmc_hmc_group *h, int i, int *device, size_t *first_
         *sample_dev = s.d_sample;
     return MMCMC_OK;
 }
+int mmcmc_hmc_group_sync(mmcmc_hmc_group *h) { return h ? group_sync(h->g) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_hmc_group_stream_timer(mmcmc_hmc_group *h, int stop, float *ms_per_device)
+{
+    return h ? group_stream_timer(h->g, stop, ms_per_device) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_group_exchange(mmcmc_hmc_group *h, int *status, int *n_rccl_ranks)
+{
+    return h ? group_exchange(h->g, status, n_rccl_ranks) : MMCMC_ERR_INVALID_ARG;
+}
 int mmcmc_hmc_group_destroy(mmcmc_hmc_group *h)
 {
     if (!h)
@@ -543,6 +669,15 @@ int mmcmc_mh_group_state(mmcmc_mh_group *h, void *out) { return h ? group_state(
 int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *h, float *rhat, float *ess, int *used_rccl)
 {
     return h ? group_split_rhat_ess(h->g, rhat, ess, used_rccl) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_mh_group_sync(mmcmc_mh_group *h) { return h ? group_sync(h->g) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_mh_group_stream_timer(mmcmc_mh_group *h, int stop, float *ms_per_device)
+{
+    return h ? group_stream_timer(h->g, stop, ms_per_device) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_mh_group_exchange(mmcmc_mh_group *h, int *status, int *n_rccl_ranks)
+{
+    return h ? group_exchange(h->g, status, n_rccl_ranks) : MMCMC_ERR_INVALID_ARG;
 }
 int mmcmc_mh_group_destroy(mmcmc_mh_group *h)
 {
@@ -603,6 +738,15 @@ int mmcmc_nuts_group_leapfrog_counts(mmcmc_nuts_group *h, uint64_t *out)
 int mmcmc_nuts_group_split_rhat_mean_ess(mmcmc_nuts_group *h, float *rhat, float *ess, int *used_rccl)
 {
     return h ? group_split_rhat_ess(h->g, rhat, ess, used_rccl) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_group_sync(mmcmc_nuts_group *h) { return h ? group_sync(h->g) : MMCMC_ERR_INVALID_ARG; }
+int mmcmc_nuts_group_stream_timer(mmcmc_nuts_group *h, int stop, float *ms_per_device)
+{
+    return h ? group_stream_timer(h->g, stop, ms_per_device) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_nuts_group_exchange(mmcmc_nuts_group *h, int *status, int *n_rccl_ranks)
+{
+    return h ? group_exchange(h->g, status, n_rccl_ranks) : MMCMC_ERR_INVALID_ARG;
 }
 int mmcmc_nuts_group_destroy(mmcmc_nuts_group *h)
 {

@@ -1978,9 +1978,13 @@ static float *stats_workspace(int device, size_t n_floats)
 
 /* wait for the work queued so far by polling an event: a blocking hipStreamSynchronize sleeps on an interrupt and
  * wakes up tens of microseconds after a sub-millisecond reduction has finished */
-static hipError_t stats_wait(hipStream_t stream)
+static hipError_t stats_wait(int device, hipStream_t stream)
 {
-    static thread_local hipEvent_t ev = nullptr;
+    /* one event per host thread AND device (an event belongs to the device that was current when it was created: a
+     * single-threaded caller that reduces on device 0 and then on device 1 must not record a device-0 event on a
+     * device-1 stream); the caller holds a DevGuard on `device` */
+    static thread_local hipEvent_t evs[64] = {};
+    hipEvent_t &ev = evs[device & 63];
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
         return hipStreamSynchronize(stream);
     hipError_t e = hipEventRecord(ev, stream);
@@ -2201,7 +2205,7 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
                                     stream)) != hipSuccess)
                 break;
         }
-        if ((e = stats_wait(stream)) != hipSuccess)
+        if ((e = stats_wait(device, stream)) != hipSuccess)
             break;
         for (size_t i = 0; i < m * dim; ++i) { /* lag sums: the partial totals in their fixed order */
             float t = h[i];

@@ -25,15 +25,39 @@ class _Group:
         L.check(self._fn("set_chain_offset")(self._h, int(first_global_chain)), "group_set_chain_offset")
         return self
 
-    def run(self, n_collect: int, n_discard: int = 0, to_host: bool = True):
-        """sample [n_chains, n_collect, dim] on the host (to_host=False: it stays on the devices, see `shards`)."""
+    def run(self, n_collect: int, n_discard: int = 0, to_host: bool = True, accept_counts: bool = True):
+        """sample [n_chains, n_collect, dim] on the host (to_host=False: it stays on the devices, see `shards`).
+        to_host=False and accept_counts=False: the launches are only ENQUEUED on the shards' streams and the call
+        returns at once (include/mmcmc.h); `sync()` waits, the diagnostics and `state()` order themselves behind them."""
         out = np.empty((self.n_chains, n_collect, self.dim), dtype=self.dtype) if to_host else None
-        acc = np.zeros(self.n_chains, dtype=np.uint64)
+        acc = np.zeros(self.n_chains, dtype=np.uint64) if accept_counts else None
         st = self._fn("run")(self._h, n_collect, n_discard, out.ctypes.data if to_host else None,
-                             acc.ctypes.data_as(C.POINTER(C.c_uint64)))
+                             acc.ctypes.data_as(C.POINTER(C.c_uint64)) if accept_counts else None)
         L.check(st, f"mmcmc_{self._prefix}_group_run")
         self.accept_counts = acc
         return out
+
+    def sync(self):
+        """wait for every run queued on the shards' streams"""
+        L.check(self._fn("sync")(self._h), "group_sync")
+        return self
+
+    def timer_start(self):
+        """record a start event on every shard's stream"""
+        L.check(self._fn("stream_timer")(self._h, 0, None), "group_stream_timer")
+
+    def timer_stop(self) -> np.ndarray:
+        """record the end events, wait for them: elapsed device milliseconds per shard since `timer_start`"""
+        ms = np.zeros(len(self.devices), dtype=np.float32)
+        L.check(self._fn("stream_timer")(self._h, 1, ms.ctypes.data_as(C.POINTER(C.c_float))), "group_stream_timer")
+        return ms
+
+    def exchange(self):
+        """(status, rccl_ranks): how the diagnostics' statistics will travel, decided when the group was created
+        (1 RCCL; 0 the host by design: a device listed twice; -1 / -2 the host as a fallback)"""
+        st, n = C.c_int(0), C.c_int(0)
+        L.check(self._fn("exchange")(self._h, C.byref(st), C.byref(n)), "group_exchange")
+        return st.value, n.value
 
     def state(self) -> np.ndarray:
         out = np.empty((self.n_chains, self.dim), dtype=self.dtype)

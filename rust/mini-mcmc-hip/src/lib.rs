@@ -447,6 +447,20 @@ impl<T: GpuFloat> GpuHmcGroup<T> {
         let st = unsafe { sys::mmcmc_hmc_group_run(self.g, n_collect, n_discard, out.as_mut_ptr() as *mut c_void, self.accept_counts.as_mut_ptr()) };
         if st == sys::MMCMC_OK { Ok(out) } else { Err(shape_error(st)) }
     }
+    /// The same run with the sample left on the devices: only enqueued on the shards' streams (returns at once; several in
+    /// a row keep every device busy).  `sync` waits; `split_rhat_mean_ess` orders itself behind the queued runs.
+    pub fn run_on_devices(&mut self, n_collect: usize, n_discard: usize) -> Result<(), MmcmcError> {
+        check(unsafe { sys::mmcmc_hmc_group_run(self.g, n_collect, n_discard, null_mut(), null_mut()) })
+    }
+    pub fn sync(&mut self) -> Result<(), MmcmcError> {
+        check(unsafe { sys::mmcmc_hmc_group_sync(self.g) })
+    }
+    /// How the diagnostics will travel, known from construction on (the RCCL communicators are made there)
+    pub fn exchange(&self) -> Result<GroupExchange, MmcmcError> {
+        let mut how: c_int = 0;
+        check(unsafe { sys::mmcmc_hmc_group_exchange(self.g, &mut how, null_mut()) })?;
+        Ok(exchange_of(how))
+    }
     /// `(rhat, ess)` of the last run over the chains of all devices, and how the statistics travelled
     pub fn split_rhat_mean_ess(&mut self) -> Result<(Array1<f32>, Array1<f32>, GroupExchange), MmcmcError> {
         let (mut rhat, mut ess) = (Array1::<f32>::zeros(self.dim), Array1::<f32>::zeros(self.dim));

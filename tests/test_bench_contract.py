@@ -19,7 +19,9 @@ def _run(args, env_extra=None, timeout=600):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
                          timeout=timeout)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]  # RCCL prints a version banner on stdout
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
 
 
 def test_bench_decides_group_before_touching_a_gpu():
@@ -45,6 +47,23 @@ def test_bench_group_path_on_one_device(args):
     assert j["diagnostics_exchange"].startswith("host (a device is listed twice)") and j["rccl_ranks"] == 0
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_group_line_measures_the_kernel_like_the_plain_line():
+    """The in-library device group must not put a host round trip between steps: on one device `--gpus 1 --group` is within
+    3 % of the plain N = 1 line, and two shards on the one device within a few per cent of twice it.
+    Best of three each: the two calls are separate processes on a box whose clocks move by a per cent or two."""
+    common = ["--steps", "300", "--warmup", "10", "--no-side", "--no-cpu-baseline"]
+    plain = min(_run(common)["ms_per_step"] for _ in range(3))
+    g1 = [_run(common + ["--gpus", "1", "--group"]) for _ in range(3)]
+    group = min(j["ms_per_step"] for j in g1)
+    assert group <= plain * 1.03, (group, plain)
+    j = g1[0]
+    assert j["rccl_ranks"] == 1 and j["diagnostics_exchange"].startswith("rccl") and len(j["kernel_ms_per_device"]) == 1
+    assert j["roofline"]["kernel_ms"] <= j["ms_per_step"] * 1.02
+    two = min(_run(common + ["--gpus", "2", "--group"], {"MMCMC_BENCH_GROUP_DEVICES": "0,0"})["ms_per_step"] for _ in range(3))
+    assert two <= 2 * plain * 1.05, (two, plain)
 
 
 @pytest.mark.gpu

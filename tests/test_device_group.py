@@ -21,7 +21,7 @@ def test_group_symbols_exported_and_no_device_without_gpu():
     from mini_mcmc_amd import _lib as L
 
     lib = mini_mcmc_amd.lib()
-    for sym in ("create", "seed", "set_chain_offset", "run", "state", "split_rhat_mean_ess", "destroy"):
+    for sym in ("create", "seed", "set_chain_offset", "run", "state", "split_rhat_mean_ess", "sync", "stream_timer", "exchange", "destroy"):
         assert hasattr(lib, "mmcmc_hmc_group_" + sym) and hasattr(lib, "mmcmc_mh_group_" + sym) and hasattr(lib, "mmcmc_nuts_group_" + sym)
     if not torch.cuda.is_available():
         from mini_mcmc_amd.distributions import RosenbrockND
@@ -177,3 +177,43 @@ def test_config4_shape_on_one_device(O):
     assert not g.used_rccl and np.all(np.isfinite(rhat)) and np.all(ess > 1e5)
     st = g.state()
     assert st.shape == (C_, 3) and np.array_equal(st[k * per:(k + 1) * per], one.state())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_group_async_runs_equal_the_blocking_ones(devices):
+    """A run that hands nothing back to the host is only enqueued on the shards' streams (include/mmcmc.h): several of them
+    back to back, then the diagnostics, state and a blocking run, must give what the blocking calls give -- the streams
+    order everything -- and the exchange path is known from creation on (the RCCL communicators are made there)."""
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import RosenbrockND
+    from mini_mcmc_amd.group import HMCGroup
+    from mini_mcmc_amd.hmc import HMC
+
+    C_, nc, nd = 4099, 200, 20
+    init = init_with_seed(C_, 3, 42, np.float32)
+    a = HMCGroup(RosenbrockND(3), init, 0.032, 10, devices=devices).set_seed(42)
+    b = HMCGroup(RosenbrockND(3), init, 0.032, 10, devices=devices).set_seed(42)
+    status, ranks = a.exchange()
+    assert (status, ranks) == ((1, 1) if len(devices) == 1 else (0, 0))
+    a.timer_start()
+    for k in range(5):
+        assert a.run(nc, nd if k == 0 else 0, to_host=False, accept_counts=False) is None  # enqueued only
+    ms = a.timer_stop()
+    assert ms.shape == (len(devices),) and (ms > 0).all()
+    for k in range(5):
+        ref = b.run(nc, nd if k == 0 else 0)  # blocking, host copy
+    ra, ea = a.split_rhat_mean_ess()  # ordered behind the five queued runs by the shards' streams
+    rb, eb = b.split_rhat_mean_ess()
+    assert np.array_equal(ra, rb) and np.array_equal(ea, eb) and a.exchange_status == status
+    assert np.array_equal(a.state(), b.state()) and np.array_equal(a.state(), ref[:, -1, :])
+    # a growing sample buffer while launches are still queued on the old one, then a blocking run behind the queue
+    a.run(nc, 0, to_host=False, accept_counts=False)
+    a.run(2 * nc, 0, to_host=False, accept_counts=False)
+    b.run(nc, 0, to_host=False)
+    b.run(2 * nc, 0, to_host=False)
+    assert np.array_equal(a.run(7, 0), b.run(7, 0)) and np.array_equal(a.accept_counts, b.accept_counts)
+    a.sync()
+    one = HMC(RosenbrockND(3), init, 0.032, 10).set_seed(42)
+    one.run(5 * nc + 3 * nc + 7, nd)
+    assert np.array_equal(a.state(), one.state())
