@@ -404,7 +404,10 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
  *           (FFT: 2 <= n/2 <= 16384 -- one wave-level transform up to 1024, N1 residues of 2048-point transforms beyond;
  *           TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).  Half-chains longer than
  *           16384 draws -- and, under DIRECT, any the staging kernels cannot hold in a workgroup's LDS -- are reduced
- *           straight from global memory (O(chains x dim x n^2), meant for a few very long chains): any n < 2^31.
+ *           straight from global memory (O(chains x dim x n^2), meant for a few very long chains): any n < 2^31 with
+ *           dim x n/2 < 2^32 and 2 x chains x dim < 2^31 (MMCMC_ERR_SHAPE beyond), and chains x dim x (n/2)^2 <= 2^46 --
+ *           about ten seconds of device time -- (MMCMC_ERR_UNSUPPORTED beyond: e.g. [65536, 40000, 3]; split such a
+ *           sample by parameter or thin it).
  * For measurements and for the agreement test; results never depend on it beyond rounding.  Process-wide and meant to
  * be set once: a call that races with it picks one kernel or the other (its work buffer fits both).  Under one selection
  * R-hat / ESS are bit-reproducible across devices too: no kernel's summation grouping depends on the device. */

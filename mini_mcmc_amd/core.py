@@ -135,11 +135,26 @@ def draw_noise(seed: int, chain_offset: int, iteration: int, n_chains: int, dim:
 
 
 def _run_progress_c(obj, fn, n_collect, n_discard, every, callback, to, dtype, count_from=0):
-    """Shared by the three samplers: mmcmc_*_run_progress with a ctypes callback; `callback(done, p_accept, max_rhat)`
-    counts collected transitions for HMC (whose burn-in is unobserved) and all transitions otherwise."""
+    """Shared by the three samplers: mmcmc_*_run_progress with a ctypes callback.  `callback(done, p_accept, max_rhat)`:
+    `done` counts COLLECTED transitions for HMC (its burn-in is unobserved, hmc.rs:222-294: done runs to n_collect) and ALL
+    transitions, burn-in included, for MH and NUTS (their trackers see every state, core.rs:208-360 / nuts.rs:172-345: done
+    runs to n_discard + n_collect).  An exception raised by the callback is re-raised after the run has finished."""
     from . import stats as S
 
-    cb = L.PROGRESS_FN(lambda user, done, total, p, r: callback(int(done) - count_from, float(p), float(r))) if callback else None
+    # An exception raised inside a ctypes callback is printed and swallowed by ctypes, and the C loop cannot be unwound from
+    # Python: the first one (KeyboardInterrupt included) is kept, later callbacks are skipped, and it is re-raised when the C
+    # call has returned (the run itself completes: the C ABI's callback has no return value to stop it with).
+    raised = []
+
+    def tramp(user, done, total, p, r):
+        if raised:
+            return
+        try:
+            callback(int(done) - count_from, float(p), float(r))
+        except BaseException as e:  # noqa: BLE001 -- re-raised below
+            raised.append(e)
+
+    cb = L.PROGRESS_FN(tramp) if callback else None
     rs = L.RunStats()
     tr = C.c_void_p()
     cbp = C.cast(cb, C.c_void_p) if cb else None
@@ -155,4 +170,6 @@ def _run_progress_c(obj, fn, n_collect, n_discard, every, callback, to, dtype, c
         st = fn(obj._h, n_collect, n_discard, int(every), cbp, None, C.c_void_p(out.ctypes.data), 0, C.byref(rs), C.byref(tr), None)
     L.check(st, "run_progress")
     obj.tracker = S.MultiChainTracker._adopt(tr)
+    if raised:
+        raise raised[0]
     return out, S._run_stats_from_c(rs)

@@ -1905,6 +1905,14 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         if (lds > 160 * 1024 || m > 16384) {
             /* nothing stages such a half-chain (or only one wave per half-chain would: [2, 32770, 1] 46 ms against 1 ms here):
              * moments and lag sums straight from global memory, any length */
+            /* 32-bit quantities of this path: the moments kernel's grid (2 C D workgroups) and dim * m (the tail kernel's
+             * element count); and a WORK bound -- the lag sums here cost C * D * m^2 products like the reference's
+             * brute-force branch (stats.rs:622-654), ~6e12 per second on this device: past 2^46 (about ten seconds; e.g.
+             * [65536, 40000, 3]) the call is refused instead of occupying the device for minutes (include/mmcmc.h) */
+            if ((uint64_t)dim * m >= (1ull << 32) || (uint64_t)2 * n_chains * dim >= (1ull << 31))
+                return MMCMC_ERR_SHAPE;
+            if ((long double)n_chains * (long double)dim * (long double)m * (long double)m > 70368744177664.0L /* 2^46 */)
+                return MMCMC_ERR_UNSUPPORTED;
             n_slabs = std::min(n_slabs, 16u);
             if (!slabs)
                 MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));

@@ -952,7 +952,7 @@ def test_nuts_repacking_between_launches_changes_no_result(M, O):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2), (5, 2050, 2),
-                                   (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2)])
+                                   (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2), (64, 33000, 2)])
 def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
     """Half-chains beyond 1024 draws (mm_chain_fft_long_kernel: the transform cut into N1 residues of 2048-point wave-level
     transforms) and beyond 16 384 (mm_lag_sums_any_kernel: any length, straight from global memory): R-hat / ESS against
@@ -985,3 +985,26 @@ def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
     r4, e4 = S.stats_finish(means.cpu().numpy(), ssq.cpu().numpy(), acov.cpu().numpy())
     np.testing.assert_allclose(r4, r1, rtol=1e-6)
     np.testing.assert_allclose(e4, e1, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_split_rhat_mean_ess_refuses_shapes_beyond_its_stated_limits(M):
+    """The from-global-memory path (half-chains beyond 16 384 draws) states its limits (include/mmcmc.h, advisor r4): 32-bit
+    element and grid counts -> MMCMC_ERR_SHAPE, more than 2^46 lag products (~ten seconds of device time) ->
+    MMCMC_ERR_UNSUPPORTED -- decided from the shape alone, before anything reads the sample (a one-element buffer stands in)."""
+    import ctypes as C
+
+    import torch
+
+    from mini_mcmc_amd import _lib as L
+
+    lib = L.lib()
+    buf = torch.zeros(64 * 33000 * 2, dtype=torch.float32, device="cuda")
+    rhat, ess = (C.c_float * 8)(), (C.c_float * 8)()
+
+    def call(c, n, d):
+        return lib.mmcmc_split_rhat_mean_ess(C.c_void_p(buf.data_ptr()), 1, L.F32, c, n, d, rhat, ess, 0, None)
+
+    assert call(65536, 40000, 3) == L.ERR_UNSUPPORTED      # 65536 * 3 * 20000^2 = 7.9e13 > 2^46
+    assert call(64, 33000, 2) == L.OK                       # the same path inside its limits (values: the parity test above)
+    torch.cuda.synchronize()

@@ -270,6 +270,34 @@ def test_user_source_nuts_at_the_dimensions_where_hiprtc_failed(O):
 
 
 @pytest.mark.gpu
+def test_user_source_nuts_built_by_hiprtc_at_the_dimensions_where_it_failed(O):
+    """The same user sources with the compiler pinned to hipRTC (a machine without hipcc): the unit's lanes-in-step kernel --
+    the one hipRTC was caught miscompiling, a device memory fault at StandardNormal(25) f32 -- must NOT be launched as the
+    referee (advisor r4): the handle is created on the run-twice check alone, and the pair kernel it launches equals the
+    library's own run-time-D kernel bit for bit."""
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import RosenbrockND, StandardNormal, UserTarget, set_rtc_compiler
+    from mini_mcmc_amd.nuts import NUTS
+
+    set_rtc_compiler("hiprtc")
+    try:
+        for dim, mode, what in [(25, 1, "std"), (25, 0, "std"), (19, 2, "ros")]:
+            src = _rosenbrock_source(dim) if what == "ros" else STD_NORMAL_SRC.replace("DIM", str(dim))
+            user = UserTarget(f"{what}{dim}_user_hiprtc", dim, src)
+            assert user.compiler == "hiprtc"
+            builtin = RosenbrockND(dim) if what == "ros" else StandardNormal(dim)
+            init = init_with_seed(77, dim, 31) * 0.5
+            su = NUTS(user, init, 0.8, mode=mode).set_seed(5)
+            assert su.kernel_variant == 7
+            sb = NUTS(builtin, init, 0.8, mode=mode).set_seed(5)
+            sb.set_kernel_variant(6)
+            ou, ob = su._run(4, 7, False, "numpy"), sb._run(4, 7, False, "numpy")
+            assert np.array_equal(ou, ob) and np.array_equal(su.leapfrog_counts(), sb.leapfrog_counts()), (what, dim, mode)
+    finally:
+        set_rtc_compiler("auto")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dim", [9, 13, 19, 23, 25, 31])
 def test_builtin_mid_dimension_units_are_checked_and_equal_the_run_time_dimension_kernel(O, dim):
     """Built-in targets at dimensions 9..31 default to register-resident MH / HMC kernels compiled on first use (variant 7).
