@@ -271,6 +271,35 @@ def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
                                                   "hmc.rs:576-787's configuration (DiffableGaussian2D, eps 0.1, L 10) at 65536 chains, f32")
         out["config3_rosenbrock_long_trajectories"] = converged_case(RosenbrockND(DIM), DIM, 0.02, 150, 6000, 2000,
                                                                      "RosenbrockND D=3 (config 3's target), eps 0.02, L 150, 65536 chains, f32")
+        # (c) round 5: the metric's own target CONVERGED -- NUTS in the reference's type split (f32 tensors, f64 scalars:
+        # NUTS<f64, Autodiff<NdArray>>), per-chain dual-averaging step size, target_accept_p 0.98, 1000 + 1000, 65 536 chains
+        # (profiles/r5b_converged_probe.jsonl: fixed-step HMC leaves chains stuck in the stiff tail -- var(x2) 1.2-1.5x the exact
+        # value, R-hat 1.08-1.23 at any length tried --; NUTS at 0.8 under-explores it; at 0.95 / 0.98 R-hat is 1.028 / 1.019).
+        # The sample's moments are checked against the exact ones (quadrature over x0: x1 | x0 and x2 | x1 are Gaussian).
+        nr = NUTS(RosenbrockND(DIM), init_with_seed(C_PER_GPU, DIM, SEED), 0.98, mode=0, device=dev.index or 0).set_seed(SEED)
+        tn = nr._run(1000, 1000, True, "torch")
+        torch.cuda.synchronize()
+        kn = float(nr.timing()["kernel_ms"])
+        S.split_rhat_mean_ess(tn)
+        t0 = time.perf_counter()
+        rh, es = S.split_rhat_mean_ess(tn)
+        sm = (time.perf_counter() - t0) * 1e3
+        rmax = float((1.0 / rh).max())
+        xd = tn.double()
+        true_mean, true_var = [0.78522, 0.84746, 1.06837], [0.22937, 0.35018, 1.63898]
+        mean = [float(v) for v in xd.mean(dim=(0, 1)).cpu()]
+        var = [float(v) for v in xd.reshape(-1, DIM).var(dim=0).cpu()]
+        lfn = float(nr.leapfrog_counts().sum())
+        res_n = {"workload": "RosenbrockND D=3 (config 3's target), NUTS mode 0 (f32 tensors, f64 scalars), target_accept_p 0.98, "
+                             "65536 chains, 1000 warm-up + 1000 draws", "kernel_ms": kn, "stats_ms": sm, "ess_min": float(es.min()),
+                 "split_rhat_max_conventional": rmax, "converged": rmax <= 1.05, "samples_per_s": C_PER_GPU * 1000 / (kn * 1e-3),
+                 "leapfrog_steps_per_s": lfn / (kn * 1e-3),
+                 "posterior_mean": mean, "posterior_var": var, "exact_mean": true_mean, "exact_var": true_var,
+                 "max_rel_moment_error": max(max(abs(mean[i] - true_mean[i]) / true_mean[i] for i in range(DIM)),
+                                             max(abs(var[i] - true_var[i]) / true_var[i] for i in range(DIM)))}
+        res_n["ess_per_s" if rmax <= 1.05 else "ess_per_s_unconverged"] = float(es.min()) / ((kn + sm) * 1e-3)
+        out["config3_rosenbrock_converged"] = res_n
+        del nr, tn, xd
         g = GaussianND.ill_conditioned(32, 1e4, 7)
         nuts = NUTS(g, init_with_seed(C_PER_GPU, 32, SEED) * 0.1, 0.8, mode=2, device=dev.index or 0).set_seed(SEED).set_max_depth(10)
         nuts._run(100, 200, True, "torch")

@@ -21,6 +21,7 @@
 
 #include "mm_generic.h"
 #include "mm_hmc_lg.h"
+#include "mm_hostcopy.h"
 #include "mm_kernels.h"
 #include "mm_host_rng.h"
 #include "mm_params.h"
@@ -178,6 +179,8 @@ struct Sampler {
     bool generic_ok = false;   /* the target kind has a run-time-dimension form */
     bool wide_ok = false;      /* HMC with one chain per workgroup (mm_wide.hip): a huge dimension, variant 8 */
     void *d_gscratch = nullptr; /* its HBM store when the chain vectors do not fit LDS */
+    void *d_stage = nullptr;    /* device staging of a sample that goes to the host (sampler_run) */
+    size_t stage_cap = 0;
     size_t c_pad = 0;
     unsigned int block = 64;
     void *d_state = nullptr;
@@ -416,6 +419,8 @@ int sampler_destroy(Sampler *s)
     (void)hipFree(s->d_accept_total);
     if (s->d_gscratch)
         (void)hipFree(s->d_gscratch);
+    if (s->d_stage)
+        (void)hipFree(s->d_stage);
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
     (void)hipStreamDestroy(s->stream);
@@ -595,22 +600,24 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : s->stream;
     const size_t out_bytes = s->n_chains * n_collect * (size_t)s->dim * s->esize();
     void *d_out = nullptr;
-    /* host output: a device staging buffer, released on every path out of this function */
-    struct Staging {
-        void *p = nullptr;
-        ~Staging()
-        {
-            if (p)
-                (void)hipFree(p);
-        }
-    } staging;
+    /* host output: the kernels write a device staging buffer the handle keeps (grown on demand, freed with the handle: a
+     * hipMalloc + hipFree of the sample's size per call cost more than the kernel), mm_copy_to_host brings it over */
     bool staged = false;
     if (out && n_collect > 0) {
         if (out_is_device) {
             d_out = out;
         } else {
-            MM_HIP(hipMalloc(&staging.p, out_bytes));
-            d_out = staging.p;
+            if (out_bytes > s->stage_cap) {
+                if (s->d_stage) {
+                    MM_HIP(hipStreamSynchronize(stream));
+                    (void)hipFree(s->d_stage);
+                }
+                s->d_stage = nullptr;
+                s->stage_cap = 0;
+                MM_HIP(hipMalloc(&s->d_stage, out_bytes));
+                s->stage_cap = out_bytes;
+            }
+            d_out = s->d_stage;
             staged = true;
         }
     }
@@ -648,10 +655,8 @@ int sampler_run(Sampler *s, size_t n_collect, size_t n_discard, void *out, int o
     s->timing.state_bytes = (uint64_t)launches * 2ull * s->n_chains * s->dim * s->esize();
     s->timing.kernel_ms = -1.0f;
 
-    if (staged) {
-        MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
-        MM_HIP(hipStreamSynchronize(stream));
-    }
+    if (staged)
+        MM_HIP(mm_copy_to_host(out, d_out, out_bytes, s->device, stream));
     if (accept_counts) {
         static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
         MM_HIP(hipMemcpyAsync(accept_counts, s->d_accept, s->n_chains * sizeof(uint64_t), hipMemcpyDeviceToHost,

@@ -5,6 +5,7 @@
  * per wave in LDS (64 chains x 64 iterations) and written as 256-byte rows.
  */
 #include "../../include/mmcmc.h"
+#include "mm_hostcopy.h"
 
 #include <hip/hip_runtime.h>
 
@@ -530,8 +531,7 @@ int mmcmc_mh_discrete_run(mmcmc_mh_discrete *h, size_t n_collect, size_t n_disca
     }
     h->iter += (uint32_t)(n_collect + n_discard);
     if (staged) {
-        MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(mm_copy_to_host(out, d_out, out_bytes, h->device, st));
         MM_HIP(hipFree(d_out));
     }
     return MMCMC_OK;

@@ -5,6 +5,7 @@
  * [C, n_collect, 2] f64 are staged per wave in LDS (64 chains x 16 sweeps) and written as 256-byte rows.
  */
 #include "../../include/mmcmc.h"
+#include "mm_hostcopy.h"
 
 #include <hip/hip_runtime.h>
 
@@ -314,8 +315,7 @@ int mmcmc_gibbs_mixture_run(mmcmc_gibbs_mixture *h, size_t n_collect, size_t n_d
     }
     h->iter += (uint32_t)(n_collect + n_discard);
     if (staged) {
-        MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(mm_copy_to_host(out, d_out, out_bytes, h->device, st));
         MM_HIP(hipFree(d_out));
     }
     return MMCMC_OK;

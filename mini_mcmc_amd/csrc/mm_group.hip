@@ -19,6 +19,7 @@
  * exercise), the few KB of statistics are exchanged through the host instead.
  */
 #include "../../include/mmcmc.h"
+#include "mm_hostcopy.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -384,9 +385,9 @@ int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint
         if (rc != MMCMC_OK)
             return rc;
         hipError_t e = hipSuccess;
-        if (out_host && n_collect)
-            e = hipMemcpyAsync((char *)out_host + s.first * row, s.d_sample, bytes, hipMemcpyDeviceToHost, s.stream);
-        if (e == hipSuccess)
+        if (out_host && n_collect) /* through the device's own pinned bounce ring: every shard over its own link, side by side */
+            e = mm_copy_to_host((char *)out_host + s.first * row, s.d_sample, bytes, s.device, s.stream);
+        else
             e = hipStreamSynchronize(s.stream);
         return e == hipSuccess ? MMCMC_OK : (int)e;
     });

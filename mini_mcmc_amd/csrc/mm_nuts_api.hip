@@ -3,6 +3,7 @@
  * Mirrors NUTS::{new, set_seed, run, run_progress} (nuts.rs:123-170, 194-353) over NUTSChain (nuts.rs:410-691).
  */
 #include "../../include/mmcmc.h"
+#include "mm_hostcopy.h"
 
 #include <hip/hip_runtime.h>
 
@@ -869,10 +870,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
         timing.out_bytes = d_out ? out_bytes : 0;
         timing.state_bytes = 2ull * n_chains * dim * sizeof(TT);
         timing.kernel_ms = -1.f;
-        if (staged) {
-            MM_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-            MM_HIP(hipStreamSynchronize(st));
-        }
+        if (staged)
+            MM_HIP(mm_copy_to_host(out, d_out, out_bytes, device, st));
         return MMCMC_OK;
     }
 

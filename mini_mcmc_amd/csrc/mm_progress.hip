@@ -14,6 +14,7 @@
  * called after every `every` transitions (0 = ten times per run) with the two numbers the reference's bar shows.
  * Host-only code over the public C ABI (mmcmc_*_run_rows, mmcmc_tracker_*, mmcmc_run_stats_from): no kernels here. */
 #include "../../include/mmcmc.h"
+#include "mm_hostcopy.h"
 
 #include <hip/hip_runtime.h>
 
@@ -118,10 +119,8 @@ int finish(const void *d_out, void *out, int out_is_device, int dtype, size_t n_
 {
     if (stats && n_collect >= 2)
         MMP(mmcmc_run_stats_from(d_out, 1, dtype, n_chains, n_collect, dim, stats, device, stream));
-    if (out && !out_is_device && n_collect) {
-        MMP_HIP(hipMemcpyAsync(out, d_out, n_chains * n_collect * dim * (dtype == MMCMC_F32 ? 4 : 8), hipMemcpyDeviceToHost,
-                               (hipStream_t)stream));
-    }
+    if (out && !out_is_device && n_collect)
+        MMP_HIP(mm_copy_to_host(out, d_out, n_chains * n_collect * dim * (dtype == MMCMC_F32 ? 4 : 8), device, (hipStream_t)stream));
     MMP_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (tracker_out) {
         *tracker_out = tr.t;

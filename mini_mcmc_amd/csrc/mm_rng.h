@@ -175,6 +175,30 @@ template <class Tab> MM_HD float mm_lnu_f32(float u, const Tab &tab)
     MM_KEEP_SCALAR(r); /* as in mm_icdf_f32: two logarithms side by side are not worth pairing */
     return r;
 }
+/* `ratio > ln u` of the f32 accept rule (MH: metropolis_hastings.rs:311, strict), ln u = mm_lnu_f32(u) by definition, decided
+ * WITHOUT the table whenever possible (round 5; the f32 sibling of mm_ratio_exceeds_ln_u below): on the device the
+ * hardware's base-2 logarithm (v_log_f32, 1 ulp) times ln 2 is within MM_LNU_BAND (1 + |ln u|) of the table's value over
+ * the whole lattice u = (s + 1) 2^-24 (tests/test_gpu_parity.py::test_lnu_filter_bound_holds_over_the_whole_lattice: the
+ * largest deviation is a tenth of the band), so a ratio outside that band around it is decided there -- two instructions
+ * and no LDS gather -- and only a ratio inside it, a few lanes in a million, evaluates the table logarithm.  The DECISION
+ * is that of the plain comparison in every case (NaN compares false everywhere and rejects); only its cost changes: the
+ * 16-byte gather of the logarithm's row was 3.5 % of the MH step (profiles/r4u_mh_table_probe3.log).  Host builds take
+ * the plain comparison: same decisions, so the twins stay bit-identical. */
+#define MM_LNU_BAND 2e-6f
+template <class Tab> MM_HD bool mm_ratio_exceeds_lnu_f32(float ratio, float u, const Tab &tab)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float l = __builtin_amdgcn_logf(u) * 0.6931471805599453f;
+    const float band = fmaf(__builtin_fabsf(l), MM_LNU_BAND, MM_LNU_BAND);
+    const float d = ratio - l;
+    bool acc = d > band;
+    if (__builtin_expect(__builtin_fabsf(d) <= band, 0))
+        acc = ratio > mm_lnu_f32(u, tab);
+    return acc;
+#else
+    return ratio > mm_lnu_f32(u, tab);
+#endif
+}
 /* the accept uniform's logarithm per element type: f32 the table above, f64 mm_log */
 template <class Tab> MM_HD float mm_ln_accept(float u, const Tab &tab) { return mm_lnu_f32(u, tab); }
 template <class Tab> MM_HD double mm_ln_accept(double u, const Tab &) { return mm_log(u); }

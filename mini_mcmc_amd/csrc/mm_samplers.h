@@ -68,7 +68,8 @@ MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z
 /* noise of (chain, iter) AND (chain, iter + 1) in one go: za/lna for iter, zb/lnb for iter + 1, ln* = log of the
  * accept uniform.  f32: the two Philox evaluations are interleaved; values are bit-identical to mm_draw_noise +
  * mm_ln_accept.  f64: two scalar evaluations (there is no packed f64 arithmetic to gain from). */
-template <int D, class Tab = mm_icdf_global>
+/* LN = false: *lna / *lnb receive the accept uniforms THEMSELVES (for mm_ratio_exceeds_lnu_f32: the MH split kernel) */
+template <int D, class Tab = mm_icdf_global, bool LN = true>
 MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, float *za, float *lna, float *zb, float *lnb,
                               const Tab &tab = Tab())
 {
@@ -77,8 +78,8 @@ MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, floa
         mm_u32x4x2 blk = mm_block_pair(seed, chain, iter, (uint32_t)b);
         if (b == 0) {
             const mm_f2 u = mm_spare_u24x2(blk);
-            *lna = mm_lnu_f32(u[0], tab);
-            *lnb = mm_lnu_f32(u[1], tab);
+            *lna = LN ? mm_lnu_f32(u[0], tab) : u[0];
+            *lnb = LN ? mm_lnu_f32(u[1], tab) : u[1];
         }
         MM_UNROLL
         for (int i = 0; i < 4; ++i)
@@ -89,10 +90,11 @@ MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, floa
     }
 }
 
-template <int D, class Tab = mm_icdf_global>
+template <int D, class Tab = mm_icdf_global, bool LN = true>
 MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, double *za, double *lna, double *zb, double *lnb,
                               const Tab & = Tab())
 {
+    static_assert(LN, "the f64 accept test takes ln u");
     double u;
     mm_draw_noise<D>(seed, chain, iter, za, &u);
     *lna = mm_log(u);
@@ -120,8 +122,19 @@ template <class Tgt> struct mm_has_proposal<Tgt, typename mm_void_t<typename Tgt
  * Built-in proposal: the isotropic Gaussian random walk x' = x + sigma z, whose q-terms cancel and are dropped (Q4).
  * A target with a `proposal` of its own: MHMarkovChain::step with BOTH q-terms, in the reference's order
  * (metropolis_hastings.rs:303-315): log_accept_ratio = (lp' + log q(x | x')) - (lp + log q(x' | x)). */
-template <class T, class Tgt>
-MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, T ln_u, unsigned int *n_accepted = nullptr)
+/* the accept test as a functor of the log accept ratio: against a given ln u, or against the f32 uniform itself through
+ * the table-free filter (mm_rng.h: mm_ratio_exceeds_lnu_f32) -- the same decision */
+template <class T> struct mm_accept_ln {
+    T ln_u;
+    MM_HD bool operator()(T log_accept_ratio) const { return log_accept_ratio > ln_u; }
+};
+template <class Tab> struct mm_accept_u_f32 {
+    float u;
+    const Tab &tab;
+    MM_HD bool operator()(float log_accept_ratio) const { return mm_ratio_exceeds_lnu_f32(log_accept_ratio, u, tab); }
+};
+template <class T, class Tgt, class Accept>
+MM_HD int mm_mh_step_accept(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, const Accept &accept, unsigned int *n_accepted = nullptr)
 {
     constexpr int D = Tgt::dim;
     T prop[D];
@@ -140,7 +153,7 @@ MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, cons
         lpp = Tgt::logp(P, prop);
         log_accept_ratio = lpp - *lp;
     }
-    int acc = log_accept_ratio > ln_u;
+    int acc = accept(log_accept_ratio);
     if (acc) {
         MM_UNROLL
         for (int i = 0; i < D; ++i)
@@ -150,6 +163,11 @@ MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, cons
             ++*n_accepted; /* the kernels count here: one add under the accept mask instead of a select and an add */
     }
     return acc;
+}
+template <class T, class Tgt>
+MM_HD int mm_mh_step_noise(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, T ln_u, unsigned int *n_accepted = nullptr)
+{
+    return mm_mh_step_accept<T, Tgt>(P, prop_std, x, lp, z, mm_accept_ln<T>{ln_u}, n_accepted);
 }
 
 template <class T, class Tgt>

@@ -97,6 +97,9 @@ template <class T, int D> struct mm_split_hmc_pf {
     static constexpr bool ok = sizeof(T) == 4 && Try::ok && Try::tile_t >= 8 && Try::lds_bytes <= 160 * 1024;
 };
 
+#ifndef MM_SPLIT_MH_UFILT
+#define MM_SPLIT_MH_UFILT 1 /* 0: ln u from the table in the noise waves (the form before round 5; A/B in tools/split_probe.hip) */
+#endif
 /* share of the noise the transition wave draws itself (pairs per batch): MH two of the four pairs of a batch of 8 */
 #ifndef MM_SPLIT_MH_QP
 #define MM_SPLIT_MH_QP 2 /* config 2: 0.312 / 0.298 / 0.275 ms with 0 / 1 / 2 pairs */
@@ -111,7 +114,10 @@ template <class T, int D, int NN = 1> struct mm_split_mh_qp {
     static constexpr int rb = mm_split_plan<T, D, true>::rb;
     static constexpr int one = rb >= 8 ? MM_SPLIT_MH_QP : (rb >= 4 && MM_SPLIT_MH_QP ? 1 : 0);
     /* with three noise waves, in the library (tools/time_cfg23.py, config 2): 0 / 1 / 2 pairs 0.2514 / 0.2527 / 0.2503 ms */
-    static constexpr int value = one;
+    /* round 5, f32 with the table-free accept filter (MM_SPLIT_MH_UFILT): the noise lost the logarithm, the transition gained the
+     * band test, so the transition wave takes ONE pair of the batch instead of two -- 0 / 1 / 2 pairs: 0.2046 / 0.2040 / 0.2304 ms
+     * against 0.2072 for the table form at 2 (tools/experiments/split_mh_ufilt.sh, profiles/r5d_split_mh_ufilt*.log) */
+    static constexpr int value = (sizeof(T) == 4 && MM_SPLIT_MH_UFILT && one > 1) ? 1 : one;
 };
 
 /* Role timing for tools/split_probe.hip (-DMM_SPLIT_PROFILE): s_memtime ticks each role spends at the batch barrier
@@ -160,6 +166,11 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride, NW = Plan::nw, RB = Plan::rb, EPL = Plan::epl;
     constexpr int QN = 2 * QP; /* transitions per batch whose noise the transition wave draws itself */
     constexpr bool PFLUSH = Plan::ntile == 2; /* the noise wave writes the tiles out */
+    /* MH in f32: the ring carries the accept uniform u itself, not ln u, and the transition decides `ratio > ln u` through
+     * the table-free filter (mm_rng.h: mm_ratio_exceeds_lnu_f32) -- the noise loses the logarithm's 16-byte LDS gather and
+     * ~12 instructions per transition, the transition gains ~5; the same decisions bit for bit.  HMC keeps ln u in the ring:
+     * its transition wave is the kernel's critical path and the noise waves have slack. */
+    constexpr bool UFILT = SAMPLER == MM_SAMPLER_MH && sizeof(T) == 4 && MM_SPLIT_MH_UFILT;
     static_assert(QN <= RB, "QP");
     typedef T mm_vrow __attribute__((ext_vector_type(EPL)));
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
@@ -227,7 +238,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
                 T rows[2 * PAIRS][NW];
                 MM_UNROLL
                 for (int q = 0; q < PAIRS; ++q)
-                    mm_draw_noise_pair<D>(a.seed, chain, it + j + 2 * q, rows[2 * q], &rows[2 * q][D], rows[2 * q + 1], &rows[2 * q + 1][D], tab);
+                    mm_draw_noise_pair<D, Tab, !UFILT>(a.seed, chain, it + j + 2 * q, rows[2 * q], &rows[2 * q][D], rows[2 * q + 1], &rows[2 * q + 1][D], tab);
                 MM_UNROLL
                 for (int r = 0; r < 2 * PAIRS; ++r) {
                     MM_UNROLL
@@ -315,6 +326,8 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     auto transition = [&](T *z, T ln_u) __attribute__((always_inline)) {
         if (SAMPLER == MM_SAMPLER_HMC)
             (void)mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u, mm_no_hook(), &n_acc32);
+        else if constexpr (UFILT)
+            (void)mm_mh_step_accept<T, Tgt>(a.P, a.scale, x, &lp, z, mm_accept_u_f32<Tab>{ln_u, tab}, &n_acc32); /* `ln_u` holds u */
         else
             (void)mm_mh_step_noise<T, Tgt>(a.P, a.scale, x, &lp, z, ln_u, &n_acc32);
         /* accepts are counted inside the step, one add under the accept mask; lanes past n_chains count too (their counters
@@ -327,7 +340,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     auto draw_own = [&](unsigned int it_batch) __attribute__((always_inline)) {
         MM_UNROLL
         for (int q = 0; q < QN; q += 2)
-            mm_draw_noise_pair<D>(a.seed, chain, it_batch + q, zq[q], &lnq[q], zq[q + 1], &lnq[q + 1], tab);
+            mm_draw_noise_pair<D, Tab, !UFILT>(a.seed, chain, it_batch + q, zq[q], &lnq[q], zq[q + 1], &lnq[q + 1], tab);
     };
     /* Collected states are staged two transitions at a time where that makes wider LDS writes (MM_SPLIT_STAGE_PAIRS): the
      * state after the first transition of a pair waits in registers and both leave in 2 D sizeof(T) bytes cut into

@@ -1008,3 +1008,30 @@ def test_split_rhat_mean_ess_refuses_shapes_beyond_its_stated_limits(M):
     assert call(65536, 40000, 3) == L.ERR_UNSUPPORTED      # 65536 * 3 * 20000^2 = 7.9e13 > 2^46
     assert call(64, 33000, 2) == L.OK                       # the same path inside its limits (values: the parity test above)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_lnu_filter_bound_holds_over_the_whole_lattice(tmp_path):
+    """mm_ratio_exceeds_lnu_f32 (csrc/mm_rng.h, round 5): the MH split kernel decides `log_accept_ratio > ln u` from the
+    hardware's base-2 logarithm and evaluates the table logarithm -- the DEFINITION of ln u in the f32 stream -- only inside a
+    narrow band.  tests/hip/lnu_filter_lattice.hip, compiled here with hipcc against the engine's header, runs over ALL 2^24
+    accept uniforms: the table-free value stays within half the band of the table's (the filter's safety margin), and the
+    filtered decision equals the plain comparison for 16 probe ratios per uniform placed at, next to and around both values
+    (and 0, +-inf, NaN).  The full-size check that every accept decision of config 2 is unchanged is
+    test_config2_full_size_checksum."""
+    import json
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "lnu_lattice")
+    src = os.path.join(ROOT, "tests", "hip", "lnu_filter_lattice.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-I" + os.path.join(ROOT, "mini_mcmc_amd", "csrc"),
+                        src, "-o", exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["uniforms"] == 1 << 24 and j["mismatches"] == 0
+    assert j["max_dev_over_band"] < 0.5, j
+    assert j["probes_in_band"] >= 3 * (1 << 24)  # the probes really exercise the exact branch

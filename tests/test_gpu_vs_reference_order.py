@@ -353,6 +353,36 @@ def test_nuts_mode0_full_size_distribution_vs_recursive_oracle(M, O, which):
     assert np.all(np.abs(ca - cb) <= 0.03 * scale), (which, np.abs(ca - cb) / scale)
 
 
+def test_rosenbrock3_converged_posterior_equals_the_exact_moments(M):
+    """BASELINE's metric target, CONVERGED (round 5): RosenbrockND(3) at 65 536 chains under NUTS in the reference's type split
+    (mode 0), target_accept_p 0.98, 1000 warm-up + 1000 draws.  The density factorises -- x1 | x0 and x2 | x1 are Gaussian
+    (precisions 202 and 200), x0 has the marginal exp(-(1 - x0)^2 - (100 / 101) (1 - x0^2)^2) -- so its moments are exact by
+    one-dimensional quadrature, independent of any sampler: the pooled sample must show them within north_star's 1 %, and
+    the conventional split R-hat over the 131 072 half-chains must be under 1.05 (what lets bench.py call its ESS/s one)."""
+    from mini_mcmc_amd import stats as S
+    from mini_mcmc_amd.nuts import NUTS
+
+    x0 = np.linspace(-5.0, 6.0, 220001)
+    w = np.exp(-(1 - x0) ** 2 - (100.0 / 101.0) * (1 - x0 ** 2) ** 2)
+    w /= w.sum()
+    mu1, s1 = (100.0 * x0 ** 2 + 1.0) / 101.0, 1.0 / 202.0
+    m0 = (w * x0).sum()
+    m1 = (w * mu1).sum()
+    e1sq = (w * (mu1 ** 2 + s1)).sum()
+    e14 = (w * (mu1 ** 4 + 6 * mu1 ** 2 * s1 + 3 * s1 ** 2)).sum()
+    mean = np.array([m0, m1, e1sq])
+    var = np.array([(w * (x0 - m0) ** 2).sum(), e1sq - m1 ** 2, e14 + 1.0 / 200.0 - e1sq ** 2])
+    s = NUTS(M.dist.RosenbrockND(3), M.core.init_with_seed(65536, 3, 42), 0.98, mode=0).set_seed(42)
+    t = s._run(1000, 1000, True, "torch")
+    rhat, ess = S.split_rhat_mean_ess(t)
+    assert float((1.0 / rhat).max()) <= 1.05, rhat
+    assert float(ess.min()) > 1e6, ess
+    x = t.double().reshape(-1, 3)
+    got_mean, got_var = x.mean(dim=0).cpu().numpy(), x.var(dim=0).cpu().numpy()
+    np.testing.assert_allclose(got_mean, mean, rtol=0.01)
+    np.testing.assert_allclose(got_var, var, rtol=0.01)
+
+
 def test_nuts_depth_cap_matches_oracle_cap(M, O):
     from mini_mcmc_amd.nuts import NUTS
 
