@@ -152,6 +152,9 @@ struct mm_nuts_lg_args {
 #ifndef MM_LG_PAIR_UNROLL
 #define MM_LG_PAIR_UNROLL 0 /* two pairs per trip (leaf index mod 4 constant): 468 -> 465 ms for 30 % more code: off */
 #endif
+#ifndef MM_LG_LEAN
+#define MM_LG_LEAN 1 /* round 5: the leaf loop without lane guards (mm_lg_doubling: "lean pair loop"); 0 = the guarded loop only */
+#endif
 #ifndef MM_LG_WALK_UNROLL
 #define MM_LG_WALK_UNROLL 3 /* config 5: 0 510 ms, 1 496, 2 473, 3 469, 4 470 */
 #endif
@@ -806,6 +809,249 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     };
 
     MM_LG_TICK(L, 1);
+    /* ---- the lean pair loop (round 5) -------------------------------------------------------------------------------
+     * The guarded loop below protects every scalar of a chain that is done (or takes no part) with lane masks and lets
+     * every lane decide by itself whether it still walks; measured on the product's own doubling with all 16 chains live
+     * and valid (tools/nuts_lg_floor_probe.hip) that costs 3300 cycles per leaf iteration where the mandatory arithmetic
+     * takes 2340.  Here NOTHING is guarded.  The live chains of a wave share the leaf index, so the walk of a pair has ONE
+     * shape -- merges at the levels of the pair index's trailing ones, then a push -- and runs as wave-uniform
+     * straight-line code for all 64 lanes; a lane whose chain is dead (takes no part, or its doubling was cut short)
+     * computes on garbage: its columns of the matrix product, its own slots of the records and its scalars are private,
+     * and nothing of it is read again -- except the three sums a chain that dies DURING the doubling hands to the dual
+     * averaging (alpha, n_alpha, n), which are frozen in shadow registers at the moment it dies.  A chain dies when a
+     * subtree of its is not valid (s' = 0, nuts.rs:858-899): from there the recursion only returns, adding the counts and
+     * acceptance sums of the first children it passes -- `retire` does exactly that, at once, under the mask of the lanes
+     * concerned (rare: once per chain and transition at most).  The auxiliary uniforms are drawn in lock-step (a chain
+     * alive at doubling j has consumed 2^j + j of them), so the draw index is one scalar.  Every live lane executes the
+     * same operations on the same values as in the guarded loop: the bits do not move (tests: test_nuts_lane_group_*,
+     * test_nuts_config5_full_size_*). */
+    bool lean = false;
+    unsigned int ka = 0;
+    if constexpr (MM_LG_LEAN && OCC == 1) {
+        const unsigned long long am = __ballot(alive);
+        if (j >= 1 && am != 0ull) {
+            ka = (unsigned int)__builtin_amdgcn_readlane((int)L.aux_k, (int)__ffsll((long long)am) - 1);
+            lean = __ballot(alive && L.aux_k != ka) == 0ull;
+        }
+    }
+    if (lean) {
+        bool dead = !alive, died = false;
+        unsigned int live01 = alive ? 1u : 0u;
+        unsigned int F_n = 0, F_nalpha = 0;
+        double F_alpha = 0.0;
+        unsigned int have_s = 0xffffffffu; /* the first draw refills */
+        const int lane15x4 = (L.lane & 15) * 4;
+        auto draw = [&]() __attribute__((always_inline)) -> double {
+            const unsigned int b = ka >> 1, g = b >> 2;
+            if (g != have_s) {
+                L.aux_blk = mm_block(a.seed, L.chain, L.m, MM_AUX_BLOCK + 4u * g + (unsigned int)L.q);
+                have_s = g;
+            }
+            const bool odd = (ka & 1u) != 0u;
+            const int src = lane15x4 + 64 * (int)(b & 3u);
+            const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? L.aux_blk.w[2] : L.aux_blk.w[0]));
+            const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? L.aux_blk.w[3] : L.aux_blk.w[1]));
+            ka += 1u;
+            return mm_u53(hi, lo);
+        };
+        auto leaf_l = [&](unsigned int leaf) __attribute__((always_inline)) {
+            leaf_iters += 1u;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cp[s] = fma(nh, cg[s], cp[s]);
+                cx[s] = fma(epsv, cp[s], cx[s]);
+            }
+            mm_lg_ax<D, false>(L, cx, cg);
+            double xy = 0.0, pp = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cp[s] = fma(nh, cg[s], cp[s]);
+                xy = fma(cx[s], cg[s], xy);
+                pp = fma(cp[s], cp[s], pp);
+            }
+            mm_lg_group_sum2(xy, pp, &xy, &pp);
+            const double lp = -0.5 * xy;
+            const double jointp = lp - pp * 0.5;
+            lf += live01;
+            S_n = (L.logu < jointp) ? 1u : 0u;
+            S_s = (L.logu - 1000.0) < jointp;
+            S_nalpha = 1;
+            if (j > 1 && (leaf & 3u) == 0u) {
+                const int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
+                if (cc <= 1 + Cfg::LF) {
+                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        f[s * 64] = cx[s];
+                        f[(NS + s) * 64] = cp[s];
+                    }
+                } else {
+                    double *f = scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        f[s * 64] = cx[s];
+                        f[(NS + s) * 64] = cp[s];
+                    }
+                }
+            }
+            d_last = jointp - L.joint;
+        };
+        auto merge_l = [&](const double *mfx, const double *mfp, const double *prime, auto level0, double alpha, unsigned int n1,
+                           unsigned int na1) __attribute__((always_inline)) {
+            const double u = draw();
+            double ca = 0.0, cb = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double d = cx[s] - mfx[s];
+                ca = fma(d, mfp[s], ca);
+                cb = fma(d, cp[s], cb);
+            }
+            mm_lg_group_sum2(ca, cb, &ca, &cb);
+            const bool crit = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
+            unsigned int den = n1 + S_n;
+            if (den < 1)
+                den = 1;
+            const bool take2 = u < ((double)S_n / (double)den);
+            S_n += n1;
+            S_alpha = alpha + S_alpha;
+            S_nalpha += na1;
+            S_s = S_s && crit;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                double second;
+                if constexpr (decltype(level0)::value)
+                    second = cx[s];
+                else
+                    second = S_prime[s];
+                S_prime[s] = take2 ? second : prime[s];
+            }
+        };
+        /* the lanes of `who` return up the recursion with s' = 0 from level k_from: the sums of the first children they pass
+         * (what the guarded loop's merges add for a lane that keeps walking); then they are dead and their sums frozen */
+        auto retire = [&](unsigned int leaf, int k_from, bool who) __attribute__((always_inline)) {
+            for (int k = k_from; k < j; ++k) {
+                if ((leaf >> k) & 1u) {
+                    double alpha, cnt_d;
+                    if (k <= Cfg::LE) {
+                        const mm_lds_double *e = lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64;
+                        alpha = e[NS * 64];
+                        cnt_d = e[(NS + 1) * 64];
+                    } else {
+                        const double *e = scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64;
+                        alpha = e[NS * 64];
+                        cnt_d = e[(NS + 1) * 64];
+                    }
+                    if (who) {
+                        const unsigned long long cnt = (unsigned long long)__double_as_longlong(cnt_d);
+                        S_n += (unsigned int)cnt;
+                        S_alpha = alpha + S_alpha;
+                        S_nalpha += (unsigned int)(cnt >> 32);
+                    }
+                }
+            }
+            if (who) {
+                F_n = S_n;
+                F_alpha = S_alpha;
+                F_nalpha = S_nalpha;
+                died = true;
+                dead = true;
+                live01 = 0u;
+            }
+        };
+        constexpr int WU = MM_LG_WALK_UNROLL;
+        for (unsigned int leaf = 0; leaf < n_leaves; leaf += 2) {
+            if (__ballot(!dead) == 0ull)
+                break;
+            /* ---- the first leaf of the pair: its one-leaf subtree waits for the sibling in registers */
+            leaf_l(leaf);
+            const double d_first = d_last;
+            double pfx[NS], pfp[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                pfx[s] = cx[s];
+                pfp[s] = cp[s];
+            }
+            const unsigned int P_n = S_n, P_nalpha = S_nalpha;
+            {
+                const bool inv = !dead && !S_s; /* not valid: handed up as it is (nuts.rs:858-899) */
+                if (__ballot(inv) != 0ull) {
+                    const double a_first = mm_lg_accept_prob(d_first);
+                    if (inv)
+                        S_alpha = a_first;
+                    retire(leaf, 1, inv);
+                    if (__ballot(!dead) == 0ull)
+                        break;
+                }
+            }
+            /* ---- its sibling, both acceptance statistics in one pass (even rows the first leaf's d, odd rows the second's),
+             *      the merge at level 0 */
+            leaf_l(leaf | 1u);
+            double P_alpha;
+            {
+                const double e = mm_lg_accept_prob((L.q & 1) ? d_last : d_first);
+                typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+                const unsigned int elo = (unsigned int)__double2loint(e), ehi = (unsigned int)__double2hiint(e);
+                const u2 l2 = __builtin_amdgcn_permlane16_swap(elo, elo, false, false);
+                const u2 h2 = __builtin_amdgcn_permlane16_swap(ehi, ehi, false, false);
+                P_alpha = __hiloint2double((int)h2[0], (int)l2[0]);
+                S_alpha = __hiloint2double((int)h2[1], (int)l2[1]);
+            }
+            merge_l(pfx, pfp, pfx, mm_true_t(), P_alpha, P_n, P_nalpha);
+            /* ---- the pair is handed up: merges at the levels of the trailing ones of the pair index, then a push */
+            const unsigned int lf1 = leaf | 1u;
+            int k_stop = 0; /* the level of the push; j: the doubling is complete */
+            auto level = [&](int k) __attribute__((always_inline)) {
+                if (k >= j) {
+                    k_stop = j;
+                } else if ((lf1 >> k) & 1u) {
+                    rec rk;
+                    load_rec(k, first_slot(lf1, k), rk);
+                    const unsigned long long cnt = (unsigned long long)__double_as_longlong(rk.cnt);
+                    merge_l(rk.fx, rk.fp, rk.prime, mm_false_t(), rk.alpha, (unsigned int)cnt, (unsigned int)(cnt >> 32));
+                } else {
+                    const double cnt =
+                        __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
+                    if (k <= Cfg::LE) {
+                        mm_lds_double *e = lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+                            e[s * 64] = S_prime[s];
+                        e[NS * 64] = S_alpha;
+                        e[(NS + 1) * 64] = cnt;
+                    } else {
+                        double *e = scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+                            e[s * 64] = S_prime[s];
+                        e[NS * 64] = S_alpha;
+                        e[(NS + 1) * 64] = cnt;
+                    }
+                    k_stop = k;
+                }
+            };
+#pragma unroll
+            for (int k = 1; k <= WU; ++k)
+                if (k_stop == 0)
+                    level(k);
+            for (int k = WU + 1; k_stop == 0; ++k)
+                level(k);
+            if (k_stop >= j)
+                break; /* reached the doubling's own level: complete */
+            {
+                const bool inv = !dead && !S_s; /* the subtree turned: it does not wait, it returns */
+                if (__ballot(inv) != 0ull)
+                    retire(lf1, k_stop + 1, inv);
+            }
+        }
+        if (died) {
+            S_n = F_n;
+            S_alpha = F_alpha;
+            S_nalpha = F_nalpha;
+            S_s = false;
+        }
+        L.aux_k = ka;
+        L.aux_have = have_s;
+    } else
     if (j == 0) {
         if (__ballot(!done) != 0ull) {
             leaf_eval(0u, mm_false_t());

@@ -1,0 +1,323 @@
+// Floor probe for config 5's lane-group NUTS kernel (mm_nuts_lg.h; VERDICT r4 next #2's stop rule): the LEAF and the
+// MANDATORY MERGE ARITHMETIC only, built from the product's own device functions, with everything else taken away --
+// no scheduler, no work queues, no per-chain records in HBM, no `walking` / `done` control flow, no dual averaging, no
+// output, every one of the 16 chain slots of a wave always busy.  What is kept per PAIR of leaves is what the
+// reference's build_tree (nuts.rs:764-946) makes any implementation of this mapping do:
+//   2 x leaf      leapfrog (24 f64 FMAs per lane), A x on the matrix cores (16 v_mfma_f64_16x16x4), x.Ax and p.p with their
+//                 group sum, the slice tests;
+//   1 x           the pair's two acceptance statistics min(1, exp(d)) in one pass (even / odd rows);
+//   1 x merge     at level 0 against the first leaf waiting in registers: the stop criterion (8 subtractions, 16 FMAs, group
+//                 sum), the merge uniform (the stream's auxiliary Philox draw), n'' / (n' + n''), the 8 proposal selects;
+//   1 x merge     at a level >= 1 (a pair index has one trailing one on average) with the sibling's entry and first-leaf
+//                 record read from LDS -- the cheapest memory there is (the product keeps levels 1..3 there, deeper in HBM);
+//   1 x push      of the subtree into LDS (10 stores); every second pair files a first-leaf record (16 stores).
+// Output: cycles per leaf iteration of a wave at one wave per SIMD on all 1024 SIMDs, and what that is in milliseconds for
+// config 5's 2.87e8 leaf iterations (the product: 3970 cycles, 464 ms).
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I mini_mcmc_amd/csrc tools/nuts_lg_floor_probe.hip -o /tmp/lg_floor
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "mm_nuts_lg.h"
+
+template <int D, int VARIANT>
+__global__ __launch_bounds__(64) void floor_kernel(const double *__restrict__ mat, double *out, unsigned int n_pairs, double eps,
+                                                   unsigned long long seed, unsigned long long *cycles)
+{
+    using Cfg = mm_lg_cfg<D, 1>;
+    constexpr int NS = Cfg::NS, ES = Cfg::ES, FS = Cfg::FS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    mm_lds_double *lds = (mm_lds_double *)raw; /* one entry (ES slots) and one first-leaf record (FS slots), lane-interleaved */
+    mm_lg_lane<D> L;
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    L.chain = (unsigned long long)blockIdx.x * 16ull + (unsigned long long)(L.lane & 15);
+    L.cl = L.chain;
+    L.m = 1;
+    L.aux_k = 0;
+    L.aux_have = 0xffffffffu;
+    L.aux_blk.w[0] = L.aux_blk.w[1] = L.aux_blk.w[2] = L.aux_blk.w[3] = 0u;
+    mm_lg_load_A<D>(L, mat);
+    double cx[NS], cp[NS], cg[NS], S_prime[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        cx[s] = 1e-3 * (double)((L.lane * 7 + s * 13) % 17 - 8);
+        cp[s] = 1e-2 * (double)((L.lane * 5 + s * 11) % 13 - 6);
+        S_prime[s] = cx[s];
+    }
+    mm_lg_ax<D>(L, cx, cg);
+    for (int i = L.lane; i < (ES + FS) * 64; i += 64)
+        lds[i] = 0.0;
+    const double h = eps * 0.5, nh = -h;
+    const double joint0 = -1.0, logu = -3.0;
+    unsigned int S_n = 0, S_nalpha = 0, acc_n = 0;
+    double S_alpha = 0.0, d_last = 0.0, acc_alpha = 0.0;
+    bool S_s = true;
+
+    auto leaf = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cp[s] = fma(nh, cg[s], cp[s]);
+            cx[s] = fma(eps, cp[s], cx[s]);
+        }
+        mm_lg_ax<D>(L, cx, cg);
+        double xy = 0.0, pp = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cp[s] = fma(nh, cg[s], cp[s]);
+            xy = fma(cx[s], cg[s], xy);
+            pp = fma(cp[s], cp[s], pp);
+        }
+        mm_lg_group_sum2(xy, pp, &xy, &pp);
+        const double jointp = -0.5 * xy - pp * 0.5;
+        S_n = (logu < jointp) ? 1u : 0u;
+        S_s = (logu - 1000.0) < jointp;
+        S_nalpha = 1;
+        d_last = jointp - joint0;
+    };
+    auto merge = [&](const double *fx, const double *fp, const double *prime, bool level0, double alpha, unsigned int n1, unsigned int na1)
+        __attribute__((always_inline)) {
+        const double u = mm_lg_aux_peek<D>(L, seed);
+        L.aux_k += 1;
+        double ca = 0.0, cb = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double d = cx[s] - fx[s];
+            ca = fma(d, fp[s], ca);
+            cb = fma(d, cp[s], cb);
+        }
+        mm_lg_group_sum2(ca, cb, &ca, &cb);
+        const bool crit = ca >= 0.0 && cb >= 0.0;
+        unsigned int den = n1 + S_n;
+        if (den < 1)
+            den = 1;
+        const bool take2 = u < ((double)S_n / (double)den);
+        S_n += n1;
+        S_alpha = alpha + S_alpha;
+        S_nalpha += na1;
+        S_s = S_s && crit;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double second = level0 ? cx[s] : S_prime[s];
+            S_prime[s] = take2 ? second : prime[s];
+        }
+    };
+
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (unsigned int pair = 0; pair < n_pairs; ++pair) {
+        leaf();
+        const double d_first = d_last;
+        double fx[NS], fp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            fx[s] = cx[s];
+            fp[s] = cp[s];
+        }
+        const unsigned int P_n = S_n, P_nalpha = S_nalpha;
+        leaf();
+        double P_alpha;
+        {
+            const double e = mm_lg_accept_prob((L.q & 1) ? d_last : d_first);
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            const unsigned int elo = (unsigned int)__double2loint(e), ehi = (unsigned int)__double2hiint(e);
+            const u2 l = __builtin_amdgcn_permlane16_swap(elo, elo, false, false);
+            const u2 hh = __builtin_amdgcn_permlane16_swap(ehi, ehi, false, false);
+            P_alpha = __hiloint2double((int)hh[0], (int)l[0]);
+            S_alpha = __hiloint2double((int)hh[1], (int)l[1]);
+        }
+        merge(fx, fp, fx, true, P_alpha, P_n, P_nalpha);
+        if (VARIANT >= 1) {
+            /* one merge at a level >= 1 per pair (a pair index has one trailing one on average): the sibling's entry and its
+             * first-leaf record from LDS, all 26 loads issued together */
+            double rx[NS], rp[NS], rprime[NS];
+            const mm_lds_double *e = lds, *f = lds + ES * 64;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                rprime[s] = e[s * 64 + L.lane];
+            const double ralpha = e[NS * 64 + L.lane];
+            const unsigned long long rcnt = (unsigned long long)__double_as_longlong(e[(NS + 1) * 64 + L.lane]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                rx[s] = f[s * 64 + L.lane];
+                rp[s] = f[(NS + s) * 64 + L.lane];
+            }
+            merge(rx, rp, rprime, false, ralpha, (unsigned int)rcnt & 1u, (unsigned int)(rcnt >> 32) & 1u);
+        }
+        if (VARIANT >= 2) {
+            /* one push per pair; every second pair files the first-leaf record of a level >= 2 subtree */
+            mm_lds_double *e = lds, *f = lds + ES * 64;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                e[s * 64 + L.lane] = S_prime[s];
+            e[NS * 64 + L.lane] = S_alpha;
+            e[(NS + 1) * 64 + L.lane] = __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
+            if ((pair & 1u) == 0u) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    f[s * 64 + L.lane] = cx[s];
+                    f[(NS + s) * 64 + L.lane] = cp[s];
+                }
+            }
+        }
+        acc_n += S_n + (S_s ? 1u : 0u);
+        acc_alpha += S_alpha;
+        /* keep the trajectory bounded whatever eps does over 10^5 steps: fold the edge back towards the start (2 NS instructions per
+         * PAIR, next to ~600) */
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cx[s] *= 0.999;
+            cp[s] *= 0.999;
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double sum = acc_alpha + (double)acc_n;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        sum += cx[s] + cp[s] + S_prime[s];
+    out[(size_t)blockIdx.x * 64 + L.lane] = sum;
+    if (L.lane == 0)
+        cycles[blockIdx.x] = t1 - t0;
+}
+
+// The PRODUCT's doubling (mm_lg_doubling, as compiled into the library's kernels) in its best case: every wave keeps 16 live
+// chains, a step size so small that no subtree ever turns (every chain valid, nobody walks past its push, no chain done
+// early), records where the product keeps them (levels 1..3 in LDS, deeper in the wave's HBM scratch, edges in the chain
+// records), no scheduler: `reps` doublings of level j back to back.  The difference to the floor above is what the product's
+// general control flow (done / walking masks, dynamic level loop, record placement) costs even when nothing diverges; the
+// difference to the product's 3970 cycles per leaf iteration is what divergence, partial units and the scheduler cost.
+template <int D> __global__ __launch_bounds__(64) void product_doubling_kernel(const mm_nuts_lg_args a, int j, unsigned int reps, double eps, double *out)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw2[];
+    mm_lg_lane<D> L;
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    L.cl = (unsigned long long)blockIdx.x * 16 + (L.lane & 15);
+    L.active = true;
+    L.chain = L.cl;
+    L.n_lf = 0;
+    L.n_leaf_iters = 0;
+    L.m = 1;
+    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw2 + L.lane;
+    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
+    mm_lg_load_A<D>(L, a.mat);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        L.x[s] = 1e-3 * (double)((L.lane * 7 + s * 13) % 17 - 8);
+    mm_lg_begin<D>(L, a);
+    L.logu = L.joint - 50.0; /* every leaf inside the slice */
+    bool alive = true;
+    for (unsigned int r = 0; r < reps; ++r) {
+        alive = true;
+        mm_lg_doubling<D>(L, a, j, alive, eps, lds, scr);
+    }
+    double sum = L.alpha + (double)L.n + (double)L.n_lf;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        sum += L.x[s];
+    out[(size_t)blockIdx.x * 64 + L.lane] = sum + (alive ? 1.0 : 0.0);
+}
+
+static void run_product(const double *dA, double *dout, int j, unsigned int reps)
+{
+    constexpr int D = 32;
+    using Cfg = mm_lg_cfg<D>;
+    const int grid = 1024;
+    mm_nuts_lg_args a{};
+    a.mat = dA;
+    a.n_chains = (unsigned long long)grid * 16;
+    a.c_pad = a.n_chains;
+    a.seed = 42;
+    a.max_depth = 12;
+    a.target_accept_p = 0.8;
+    (void)hipMalloc((void **)&a.rec, Cfg::rec_doubles(a.c_pad) * sizeof(double));
+    (void)hipMalloc((void **)&a.scratch, Cfg::scratch_doubles_per_wave * grid * sizeof(double));
+    (void)hipMemset(a.rec, 0, Cfg::rec_doubles(a.c_pad) * sizeof(double));
+    (void)hipMemset(a.scratch, 0, Cfg::scratch_doubles_per_wave * grid * sizeof(double));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(product_doubling_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((product_doubling_kernel<D>), dim3(grid), dim3(64), Cfg::lds_bytes, 0, a, j, reps, 1e-7, dout);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best)
+            best = ms;
+    }
+    std::vector<double> ho(1024 * 64);
+    (void)hipMemcpy(ho.data(), dout, ho.size() * 8, hipMemcpyDeviceToHost);
+    double cs = 0;
+    for (double v : ho)
+        cs += v;
+    const double iters = (double)reps * (double)(1u << j);
+    const double ms_per_iter = best / iters;
+    printf("{\"variant\": \"the product's mm_lg_doubling, level %d x %u, all 16 chains live and valid, no scheduler\", \"ms\": %.3f, "
+           "\"leaf_iterations_per_wave\": %.0f, \"ns_per_leaf_iteration\": %.2f, \"cycles_per_leaf_iteration_at_2.4GHz\": %.0f, "
+           "\"config5_ms_at_2.87e8_leaf_iterations\": %.1f, \"checksum\": %.6e}\n",
+           j, reps, best, iters, ms_per_iter * 1e6, ms_per_iter * 1e-3 * 2.4e9, ms_per_iter * 2.87e8 / 1024.0, cs);
+    (void)hipFree(a.rec);
+    (void)hipFree(a.scratch);
+}
+
+template <int VARIANT> static void run(const char *what, const double *dA, double *dout, unsigned long long *dcyc, unsigned int n_pairs)
+{
+    constexpr int D = 32;
+    using Cfg = mm_lg_cfg<D, 1>;
+    const int grid = 1024;
+    const size_t lds = (size_t)(Cfg::ES + Cfg::FS) * 64 * sizeof(double);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((floor_kernel<D, VARIANT>), dim3(grid), dim3(64), lds, 0, dA, dout, n_pairs, 0.004, 42ull, dcyc);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best)
+            best = ms;
+    }
+    std::vector<double> ho(1024 * 64);
+    (void)hipMemcpy(ho.data(), dout, ho.size() * 8, hipMemcpyDeviceToHost);
+    double cs = 0;
+    for (double v : ho)
+        cs += v;
+    const double iters = 2.0 * n_pairs; /* leaf iterations per wave */
+    const double ms_per_iter_all_simds = best / iters;
+    const double cfg5_iters_per_simd = 2.87e8 / 1024.0;
+    printf("{\"variant\": \"%s\", \"ms\": %.3f, \"leaf_iterations_per_wave\": %.0f, \"ns_per_leaf_iteration\": %.2f, "
+           "\"cycles_per_leaf_iteration_at_2.4GHz\": %.0f, \"config5_ms_at_2.87e8_leaf_iterations\": %.1f, \"checksum\": %.6e}\n",
+           what, best, iters, ms_per_iter_all_simds * 1e6, ms_per_iter_all_simds * 1e-3 * 2.4e9, ms_per_iter_all_simds * cfg5_iters_per_simd, cs);
+}
+
+int main()
+{
+    constexpr int D = 32;
+    std::vector<double> hA(D * D, 0.0);
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j)
+            hA[i * D + j] = (i == j) ? 1.0 + 9999.0 * i / (D - 1) : 0.05 / (1 + abs(i - j));
+    double *dA, *dout;
+    unsigned long long *dcyc;
+    (void)hipMalloc(&dA, sizeof(double) * D * D);
+    (void)hipMemcpy(dA, hA.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
+    (void)hipMalloc(&dout, 1024 * 64 * 8);
+    (void)hipMalloc(&dcyc, 1024 * 8);
+    const unsigned int n_pairs = 20000; /* 40 000 leaf iterations per wave: ~60 ms */
+    run<0>("leaf + paired acceptance statistic + level-0 merge", dA, dout, dcyc, n_pairs);
+    run<1>("... + one merge per pair with records from LDS", dA, dout, dcyc, n_pairs);
+    run<2>("... + one push per pair and a first-leaf record every second pair, into LDS", dA, dout, dcyc, n_pairs);
+    run_product(dA, dout, 7, 300);
+    run_product(dA, dout, 5, 1200);
+    run_product(dA, dout, 9, 75);
+    return 0;
+}
