@@ -113,7 +113,7 @@ def _cpu_side_baselines(seconds_each: float) -> dict:
     ziggurat, every chain holding a clone of the proposal generator (quirk Q1), D + 1 normals per proposal (Q2), logp
     recomputed, q-terms kept -- metropolis_hastings.rs:150-153, 303-315; distributions.rs:364-372), 1024 chains per thread;
     config 5 = the recursive NUTS restatement (oracle/nuts.c, nuts.rs:550-946) on the same 32-D target and the same
-    200 warm-up + 100 draws as the GPU leg, 32 chains per thread."""
+    500 warm-up + 500 draws as the GPU leg, 32 chains per thread."""
     import numpy as np
 
     import oracle as O
@@ -131,22 +131,22 @@ def _cpu_side_baselines(seconds_each: float) -> dict:
 
     g = GaussianND.ill_conditioned(32, 1e4, 7)
     tgt = O.gaussian_nd(g.precision)
-    per_thread = 32
+    per_thread = 8  # 8 chains x 1000 transitions x ~185 leapfrog steps per thread: a few seconds
     init = O.init_with_seed(per_thread * cores, 32, SEED) * 0.1
     res5 = []
     for n in sorted({1, cores}):
-        wall, per, lf = O.cpu_bench(O.CPU_BENCH_NUTS, tgt, init[:per_thread * n], per_thread, n, 0.8, 0, np.float64, 100, 200, reps=1,
+        wall, per, lf = O.cpu_bench(O.CPU_BENCH_NUTS, tgt, init[:per_thread * n], per_thread, n, 0.8, 0, np.float64, 500, 500, reps=1,
                                     seed=SEED, nuts_mode=2, nuts_max_depth=10)
-        res5.append({"threads": n, "wall_s": wall, "value": lf / wall, "draws_per_s": per_thread * n * 100 / wall})
+        res5.append({"threads": n, "wall_s": wall, "value": lf / wall, "draws_per_s": per_thread * n * 500 / wall})
     top5 = res5[-1]
     out["config5_nuts"] = {"value": top5["value"], "unit": "leapfrog-steps/s", "cores": top5["threads"], "kind": "port",
                            "draws_per_s": top5["draws_per_s"], "single_thread_leapfrog_steps_per_s": res5[0]["value"], "threads_sweep": res5,
-                           "sample": f"{per_thread} chains on each of {top5['threads']} threads x (200 warm-up + 100 draws) in {top5['wall_s']:.1f} s, "
+                           "sample": f"{per_thread} chains on each of {top5['threads']} threads x (500 warm-up + 500 draws) in {top5['wall_s']:.1f} s, "
                                      "recursive NUTS restatement, f64, max depth 10"}
     return out
 
 
-ROUND_TAG = "r4"  # profiles/*_kernel_*.json are quoted only when written this round (their "round" starts with this)
+ROUND_TAG = "r5"  # profiles/*_kernel_*.json are quoted only when written this round (their "round" starts with this)
 
 
 def _profile_json(name: str, kernel_name: str, variant: int):
@@ -302,14 +302,33 @@ def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
         del nr, tn, xd
         g = GaussianND.ill_conditioned(32, 1e4, 7)
         nuts = NUTS(g, init_with_seed(C_PER_GPU, 32, SEED) * 0.1, 0.8, mode=2, device=dev.index or 0).set_seed(SEED).set_max_depth(10)
-        nuts._run(100, 200, True, "torch")
+        nuts._run(500, 500, True, "torch")
         torch.cuda.synchronize()
         tm = nuts.timing()
         k = float(tm["kernel_ms"])
         lf = float(nuts.leapfrog_counts().sum())
-        out["config5_nuts"] = {"kernel_ms": k, "n_launches": int(tm["n_launches"]), "leapfrog_steps_per_s": lf / (k * 1e-3),
-                               "draws_per_s": C_PER_GPU * 100 / (k * 1e-3), "kernel_variant": nuts.kernel_variant,
-                               "f64_mfma_frac": lf * 2 * 32 * 32 / (k * 1e-3) / 78.6e12}
+        # issue: (MFMA + vector-issue cycles) / wave cycles of the scheduler kernel from this round's SQ counters (tools/pmc_nuts.sh ->
+        # profiles/nuts5_kernel_counters.json), quoted only while that summary is of this round
+        nc5 = None
+        try:
+            j5 = json.load(open(os.path.join(ROOT, "profiles", "nuts5_kernel_counters.json")))
+            if str(j5.get("round", "")).startswith(ROUND_TAG):
+                nc5 = {kk: j5[kk] for kk in ("round", "source", "issue_frac", "mfma_busy_over_wave_cycles", "valu_active_over_wave_cycles",
+                                             "wait_any_over_wave_cycles", "valu_instructions_per_leaf_iteration") if kk in j5}
+        except (OSError, ValueError):
+            pass
+        out["config5_nuts"] = {"schedule": "500 warm-up + 500 draws (SURVEY 8d)", "kernel_ms": k, "n_launches": int(tm["n_launches"]),
+                               "leapfrog_steps_per_s": lf / (k * 1e-3),
+                               "draws_per_s": C_PER_GPU * 500 / (k * 1e-3), "kernel_variant": nuts.kernel_variant,
+                               "f64_mfma_frac": lf * 2 * 32 * 32 / (k * 1e-3) / 78.6e12, "issue": nc5}
+        del nuts
+        # the same at round 4's shorter schedule (200 + 100), the figure VERDICT r4 set its <= 400 ms bar on
+        nuts = NUTS(g, init_with_seed(C_PER_GPU, 32, SEED) * 0.1, 0.8, mode=2, device=dev.index or 0).set_seed(SEED).set_max_depth(10)
+        nuts._run(100, 200, True, "torch")
+        torch.cuda.synchronize()
+        k = float(nuts.timing()["kernel_ms"])
+        lf = float(nuts.leapfrog_counts().sum())
+        out["config5_nuts_200_100"] = {"kernel_ms": k, "leapfrog_steps_per_s": lf / (k * 1e-3), "f64_mfma_frac": lf * 2 * 32 * 32 / (k * 1e-3) / 78.6e12}
         del nuts
         if cpu_seconds > 0:
             out["cpu_baselines"] = _cpu_side_baselines(cpu_seconds)

@@ -558,6 +558,11 @@ int mmcmc_logp_grad_batch(const mmcmc_target_desc *target, int dtype, const void
  *      draw it.  z: host [n_chains, dim] of dtype, u: host [n_chains] of dtype; computed on the device. */
 int mmcmc_draw_noise(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n_chains, int dim, int dtype,
                      void *z, void *u, int device);
+/* The noise of the METROPOLIS-HASTINGS sampler: in f32 at dim <= 2 it draws from a stream of its own -- one Philox block per
+ * TWO transitions, the accept uniform's low byte from a second block (csrc/mm_rng.h, "paired stream": half the generator
+ * work of the step) --; everywhere else this is mmcmc_draw_noise. */
+int mmcmc_draw_noise_mh(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n_chains, int dim, int dtype, void *z,
+                        void *u, int device);
 
 #ifdef __cplusplus
 }

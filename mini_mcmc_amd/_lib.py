@@ -163,6 +163,7 @@ SIGNATURES = {
     "mmcmc_save_csv": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_char_p]),
     "mmcmc_logp_grad_batch": (C.c_int, [_TP, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int]),
     "mmcmc_draw_noise": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int]),
+    "mmcmc_draw_noise_mh": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int]),
     "mmcmc_target_register_source": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "mmcmc_discrete_register_source": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "mmcmc_proposal_register_source": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),

@@ -123,12 +123,14 @@ class _Sampler:
             pass
 
 
-def draw_noise(seed: int, chain_offset: int, iteration: int, n_chains: int, dim: int, dtype=np.float32, device=0):
+def draw_noise(seed: int, chain_offset: int, iteration: int, n_chains: int, dim: int, dtype=np.float32, device=0, sampler: str = ""):
     """The noise the sampling kernels draw for (chain, iteration): (z[n_chains, dim], u[n_chains]); computed on
-    the GPU by the same device functions the kernels use."""
+    the GPU by the same device functions the kernels use.  sampler="mh": the Metropolis-Hastings sampler's noise, which in
+    f32 at dim <= 2 is a stream of its own (two transitions per Philox block: mmcmc_draw_noise_mh)."""
     z = np.empty((n_chains, dim), dtype=dtype)
     u = np.empty(n_chains, dtype=dtype)
-    st = L.lib().mmcmc_draw_noise(seed, chain_offset, iteration, n_chains, dim,
+    fn = L.lib().mmcmc_draw_noise_mh if sampler == "mh" else L.lib().mmcmc_draw_noise
+    st = fn(seed, chain_offset, iteration, n_chains, dim,
                                   L.F32 if dtype == np.float32 else L.F64, z.ctypes.data, u.ctypes.data, device)
     L.check(st, "mmcmc_draw_noise")
     return z, u

@@ -773,12 +773,15 @@ int logp_grad_batch_t(const mmcmc_target_desc *target, const void *x, size_t n, 
 }
 
 template <class T>
-int draw_noise_t(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n, int dim, void *z, void *u)
+int draw_noise_t(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n, int dim, void *z, void *u, int mh = 0)
 {
     int nn = 0;
     const mm_noise_entry<T> *t = noise_table<T>(&nn);
     const mm_noise_entry<T> *k = nullptr;
-    for (int i = 0; i < nn; ++i)
+    /* mh: the MH sampler's paired stream (f32, dim <= 2: mm_rng.h) through the run-time-dimension kernel; the same noise as
+     * mmcmc_draw_noise's everywhere else */
+    const bool paired = mh && std::is_same<T, float>::value && dim <= 2;
+    for (int i = 0; i < nn && !paired; ++i)
         if (t[i].dim == dim)
             k = &t[i];
     if (!k && dim <= 0)
@@ -793,7 +796,7 @@ int draw_noise_t(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_
         if (k)
             e = k->noise(seed, chain_offset, iteration, (unsigned long long)n, dz, du, nullptr);
         else if constexpr (std::is_same<T, float>::value)
-            e = mm_launch_noise_generic_f32(seed, chain_offset, iteration, dim, (unsigned long long)n, dz, du, nullptr);
+            e = mm_launch_noise_generic_f32(seed, chain_offset, iteration, dim, (unsigned long long)n, dz, du, nullptr, paired ? 1 : 0);
         else
             e = mm_launch_noise_generic_f64(seed, chain_offset, iteration, dim, (unsigned long long)n, dz, du, nullptr);
         if (e != hipSuccess)
@@ -1151,6 +1154,19 @@ int mmcmc_draw_noise(uint64_t seed, uint64_t chain_offset, uint32_t iteration, s
     DeviceGuard g(device);
     return dtype == MMCMC_F32 ? draw_noise_t<float>(seed, chain_offset, iteration, n_chains, dim, z, u)
                               : draw_noise_t<double>(seed, chain_offset, iteration, n_chains, dim, z, u);
+}
+
+int mmcmc_draw_noise_mh(uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n_chains, int dim, int dtype,
+                        void *z, void *u, int device)
+{
+    if (!z || !u || n_chains == 0 || dim <= 0 || (dtype != MMCMC_F32 && dtype != MMCMC_F64))
+        return MMCMC_ERR_INVALID_ARG;
+    int st = check_device(device);
+    if (st != MMCMC_OK)
+        return st;
+    DeviceGuard g(device);
+    return dtype == MMCMC_F32 ? draw_noise_t<float>(seed, chain_offset, iteration, n_chains, dim, z, u, 1)
+                              : draw_noise_t<double>(seed, chain_offset, iteration, n_chains, dim, z, u, 1);
 }
 
 } /* extern "C" */

@@ -99,10 +99,23 @@ template <class T, class S> MM_HD T mm_gen_logp_grad(int kind, const mm_tparams<
 }
 
 /* the noise of (chain, iteration) in the order mm_draw_noise produces it: f(i, z_i) for i = 0 .. D-1; returns ln u */
-template <class F> MM_HD float mm_gen_noise(uint64_t seed, uint64_t chain, uint32_t iter, int D, float, F &&f)
+/* mhp: the MH sampler's paired f32 stream at D <= 2 (mm_rng.h); callers pass sampler == MH && D <= 2 */
+template <class F> MM_HD float mm_gen_noise(uint64_t seed, uint64_t chain, uint32_t iter, int D, float, F &&f, bool mhp = false, float *u_out = nullptr)
 {
     float ln_u = 0;
     const mm_icdf_global tab;
+    if (mhp) {
+        const mm_u32x4 blk = mm_mhp_block(seed, chain, iter);
+        const uint32_t h = iter & 1u;
+        const uint32_t wa = h ? blk.w[2] : blk.w[0], wb = h ? blk.w[3] : blk.w[1];
+        f(0, mm_icdf_f32(wa, tab));
+        if (D > 1)
+            f(1, mm_icdf_f32(wb, tab));
+        const float u = mm_mhp_u(mm_mhp_s16(wa, wb), mm_mhp_low_byte(seed, chain, iter));
+        if (u_out)
+            *u_out = u;
+        return mm_lnu_f32(u, tab);
+    }
     for (int b = 0; 4 * b < D; ++b) {
         const mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
         if (b == 0)
@@ -112,7 +125,7 @@ template <class F> MM_HD float mm_gen_noise(uint64_t seed, uint64_t chain, uint3
     }
     return ln_u;
 }
-template <class F> MM_HD double mm_gen_noise(uint64_t seed, uint64_t chain, uint32_t iter, int D, double, F &&f)
+template <class F> MM_HD double mm_gen_noise(uint64_t seed, uint64_t chain, uint32_t iter, int D, double, F &&f, bool = false, double * = nullptr)
 {
     for (int b = 0; 2 * b < D; ++b) {
         const mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
@@ -131,7 +144,8 @@ MM_HD int mm_gen_mh_step(int kind, const mm_tparams<T> &P, T prop_std, const S &
                          uint32_t iter)
 {
     const int D = s.dim;
-    const T ln_u = mm_gen_noise(seed, chain, iter, D, T(0), [&](int i, T z) { s.st(MM_GV_XN, i, mm_fma(prop_std, z, s.ld(MM_GV_X, i))); });
+    const T ln_u = mm_gen_noise(seed, chain, iter, D, T(0), [&](int i, T z) { s.st(MM_GV_XN, i, mm_fma(prop_std, z, s.ld(MM_GV_X, i))); },
+                                sizeof(T) == 4 && D <= 2);
     const T lpp = mm_gen_logp_grad<T, S>(kind, P, s, MM_GV_XN, -1);
     const T log_accept_ratio = lpp - *lp;
     const int acc = log_accept_ratio > ln_u;
@@ -281,12 +295,18 @@ __global__ void mm_logp_grad_generic_kernel(const mm_tparams<T> P, int kind, int
 
 template <class T>
 __global__ void mm_noise_generic_kernel(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration, int dim,
-                                        unsigned long long n, T *z, T *u)
+                                        unsigned long long n, T *z, T *u, int mh)
 {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
     /* u itself, not its logarithm, is what mmcmc_draw_noise returns: the same words as mm_draw_noise */
+    if (mh && sizeof(T) == 4 && dim <= 2) { /* the MH sampler's paired stream */
+        T uu = T(0);
+        mm_gen_noise(seed, chain_offset + i, iteration, dim, T(0), [&](int k, T zk) { z[i * dim + k] = zk; }, true, &uu);
+        u[i] = uu;
+        return;
+    }
     mm_gen_noise(seed, chain_offset + i, iteration, dim, T(0), [&](int k, T zk) { z[i * dim + k] = zk; });
     if constexpr (sizeof(T) == 4)
         u[i] = mm_spare_u24(mm_block(seed, chain_offset + i, iteration, 0u));
@@ -310,9 +330,9 @@ hipError_t mm_launch_logp_grad_generic_f64(const mm_tparams<double> &P, int kind
                                            double *grad, double *scratch, unsigned long long n, unsigned long long n_pad,
                                            hipStream_t stream);
 hipError_t mm_launch_noise_generic_f32(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration, int dim,
-                                       unsigned long long n, float *z, float *u, hipStream_t stream);
+                                       unsigned long long n, float *z, float *u, hipStream_t stream, int mh = 0);
 hipError_t mm_launch_noise_generic_f64(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration, int dim,
-                                       unsigned long long n, double *z, double *u, hipStream_t stream);
+                                       unsigned long long n, double *z, double *u, hipStream_t stream, int mh = 0);
 #endif /* __HIPCC__ */
 
 #endif /* MM_GENERIC_H */

@@ -44,19 +44,19 @@ hipError_t mm_launch_logp_grad_generic_f64(const mm_tparams<double> &P, int kind
 
 template <class T>
 static hipError_t launch_noise_generic(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration, int dim,
-                                       unsigned long long n, T *z, T *u, hipStream_t stream)
+                                       unsigned long long n, T *z, T *u, hipStream_t stream, int mh)
 {
     const unsigned int block = 256, grid = (unsigned int)((n + block - 1) / block);
-    hipLaunchKernelGGL((mm_noise_generic_kernel<T>), dim3(grid), dim3(block), 0, stream, seed, chain_offset, iteration, dim, n, z, u);
+    hipLaunchKernelGGL((mm_noise_generic_kernel<T>), dim3(grid), dim3(block), 0, stream, seed, chain_offset, iteration, dim, n, z, u, mh);
     return hipGetLastError();
 }
 hipError_t mm_launch_noise_generic_f32(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration, int dim,
-                                       unsigned long long n, float *z, float *u, hipStream_t stream)
+                                       unsigned long long n, float *z, float *u, hipStream_t stream, int mh)
 {
-    return launch_noise_generic<float>(seed, chain_offset, iteration, dim, n, z, u, stream);
+    return launch_noise_generic<float>(seed, chain_offset, iteration, dim, n, z, u, stream, mh);
 }
 hipError_t mm_launch_noise_generic_f64(unsigned long long seed, unsigned long long chain_offset, unsigned int iteration, int dim,
-                                       unsigned long long n, double *z, double *u, hipStream_t stream)
+                                       unsigned long long n, double *z, double *u, hipStream_t stream, int mh)
 {
-    return launch_noise_generic<double>(seed, chain_offset, iteration, dim, n, z, u, stream);
+    return launch_noise_generic<double>(seed, chain_offset, iteration, dim, n, z, u, stream, mh);
 }

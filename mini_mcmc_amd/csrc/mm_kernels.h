@@ -234,6 +234,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
     T *lds = reinterpret_cast<T *>(mm_lds_raw + Tile::lds_bytes_table);
     /* where the f32 normals' table is read from: the block's LDS copy (f64 draws do not use a table) */
     using Tab = typename mm_cond<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
+    constexpr bool MHP = mm_mh_paired<T, D, SAMPLER>::value; /* the MH sampler's paired f32 stream at D <= 2 (mm_rng.h) */
     Tab tab;
     if constexpr (sizeof(T) == 4) {
         mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, blockDim.x);
@@ -264,7 +265,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
     T zc[D], ln_uc = 0; /* PIPE: noise of the current transition, drawn one transition ahead */
     if (PIPE) {
         T u;
-        mm_draw_noise<D>(a.seed, chain, it, zc, &u, tab);
+        mm_draw_noise<D, Tab, MHP>(a.seed, chain, it, zc, &u, tab);
         ln_uc = mm_ln_accept(u, tab);
     }
 
@@ -272,7 +273,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
         int acc;
         if (PIPE) {
             T zn[D], un;
-            mm_draw_noise<D>(a.seed, chain, it + 1, zn, &un, tab);
+            mm_draw_noise<D, Tab, MHP>(a.seed, chain, it + 1, zn, &un, tab);
             const T ln_un = mm_ln_accept(un, tab);
             if (SAMPLER == MM_SAMPLER_HMC)
                 acc = mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, zc, ln_uc);
@@ -298,7 +299,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
          * a time, TILE_T / 2 pairs with unconditional staging, then the flush -- a taken branch costs a wave more
          * than the three LDS writes it would skip. */
         T za[D], zb[D], lna, lnb;
-        mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
+        mm_draw_noise_pair<D, Tab, true, MHP>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
         unsigned int n_acc32 = 0;
         /* every lambda here MUST be inlined: an out-of-line call that captures x / g / lp by reference pins them (and the
          * kernel arguments) in scratch memory for the whole kernel -- what the compiler did for the larger targets */
@@ -318,7 +319,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
         auto silent = [&](unsigned int n) __attribute__((always_inline)) {
             for (unsigned int i = 0; i < n; i += 2) {
                 T zna[D], znb[D], lnna, lnnb;
-                mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
+                mm_draw_noise_pair<D, Tab, true, MHP>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
                 transition(za, lna);
                 transition(zb, (i + 1 < n) ? lnb : never);
                 MM_UNROLL
@@ -332,7 +333,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
             }
             if (n & 1u) {
                 it -= 1u;
-                mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
+                mm_draw_noise_pair<D, Tab, true, MHP>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
             }
         };
         silent(a.n_discard + (a.out ? 0u : a.n_collect));
@@ -343,7 +344,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
                 T *dst = row;
                 for (unsigned int i = 0; i < nt; i += 2) {
                     T zna[D], znb[D], lnna, lnnb;
-                    mm_draw_noise_pair<D>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
+                    mm_draw_noise_pair<D, Tab, true, MHP>(a.seed, chain, it + 2u, zna, &lnna, znb, &lnnb, tab);
                     transition(za, lna);
                     MM_UNROLL
                     for (int k = 0; k < D; ++k)
@@ -367,7 +368,7 @@ __device__ __forceinline__ void mm_run_kernel_body(const mm_run_args<T> &a)
                 if (nt & 1u) {
                     it -= 1u;
                     if (rows_out + nt < a.n_collect)
-                        mm_draw_noise_pair<D>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
+                        mm_draw_noise_pair<D, Tab, true, MHP>(a.seed, chain, it, za, &lna, zb, &lnb, tab);
                 }
                 mm_flush_tile<T, D>(a, tile, lane, wave_c0, (unsigned long long)a.out_t0 + rows_out, nt);
                 rows_out += nt;

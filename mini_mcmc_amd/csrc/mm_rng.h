@@ -175,6 +175,37 @@ template <class Tab> MM_HD float mm_lnu_f32(float u, const Tab &tab)
     MM_KEEP_SCALAR(r); /* as in mm_icdf_f32: two logarithms side by side are not worth pairing */
     return r;
 }
+/* ---- the Metropolis-Hastings sampler's f32 stream at D <= 2: TWO transitions per Philox block (round 5) -------------
+ * A transition of the random walk at D <= 2 needs two normals (24 bits each) and a 24-bit accept uniform: 72 of a block's
+ * 128 bits -- and the ten rounds were half of the MH step's issue slots (profiles/r5e_split_mh_stream_probe.log: one block per
+ * two transitions, timing only: -14 %).  So, for sampler = MH, T = f32, D <= 2 (mm_mh_paired) and ONLY there:
+ *     k = iteration >> 1, h = iteration & 1
+ *     W = philox4x32-10(key = seed, counter = (chain, k, MM_MHP_BLOCK))            one block for iterations 2k and 2k + 1
+ *     z_i = icdf24(W[2h + i]), i < D                                                 (as everywhere: mm_icdf_f32)
+ *     s16 = low byte of W[2h] | low byte of W[2h + 1] << 8                           the HIGH 16 bits of the accept uniform
+ *     s8  = byte h of word 0 of philox(key = seed, counter = (chain, k, MM_MHP_BLOCK | 1))   its LOW 8 bits
+ *     u   = (s16 * 256 + s8 + 1) 2^-24                                               uniform on the same 2^24 lattice as before
+ * u is a pure function of (seed, chain, iteration) like every other draw, so results stay independent of launch partition,
+ * continuation and sharding.  Its low byte comes from a SECOND block on purpose: `ratio > ln u` is decided by the high 16
+ * bits alone unless ratio falls between ln(u_lo) and ln(u_hi) (u_lo / u_hi = the smallest / largest u with that s16) --
+ * about 3 wave-steps in 1000 -- so the sampling kernel evaluates the second block only then (mm_accept_mhp_f32 below); the
+ * host build, the other kernels and the oracle evaluate it always.  Same decisions either way.  HMC, NUTS, f64 and D > 2
+ * keep the stream described at the top of this file. */
+#define MM_MHP_BLOCK 0x20000000u
+template <class T, int D, int SAMPLER> struct mm_mh_paired {
+    static constexpr bool value = SAMPLER == 0 /* MM_SAMPLER_MH */ && sizeof(T) == 4 && D <= 2;
+};
+MM_HD uint32_t mm_mhp_s16(uint32_t wa, uint32_t wb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(wb, wa, 0x0c0c0400u); /* [wa.b0, wb.b0, 0, 0] */
+#else
+    return (wa & 255u) | ((wb & 255u) << 8);
+#endif
+}
+MM_HD float mm_mhp_u_hi(uint32_t s16) { return fmaf((float)s16, 0x1.0p-16f, 0x1.0p-16f); }        /* (s16 + 1) 2^-16: exact */
+MM_HD float mm_mhp_u(uint32_t s16, uint32_t s8) { return fmaf((float)(s16 * 256u + s8), 0x1.0p-24f, 0x1.0p-24f); } /* exact */
+
 /* `ratio > ln u` of the f32 accept rule (MH: metropolis_hastings.rs:311, strict), ln u = mm_lnu_f32(u) by definition, decided
  * WITHOUT the table whenever possible (round 5; the f32 sibling of mm_ratio_exceeds_ln_u below): on the device the
  * hardware's base-2 logarithm (v_log_f32, 1 ulp) times ln 2 is within MM_LNU_BAND (1 + |ln u|) of the table's value over
@@ -197,6 +228,25 @@ template <class Tab> MM_HD bool mm_ratio_exceeds_lnu_f32(float ratio, float u, c
     return acc;
 #else
     return ratio > mm_lnu_f32(u, tab);
+#endif
+}
+/* `ratio > ln u` for the MH sampler's paired stream (below: u = (s16 256 + s8 + 1) 2^-24 with s8 from a second block): decided
+ * from u_hi = (s16 + 1) 2^-16 alone whenever ratio lies outside [ln u_lo, ln u_hi] widened by the filter's band -- `low`
+ * (s8, the second Philox block) is called only inside, then the comparison is the plain one on the exact u.  Bounds:
+ * mm_lnu_f32 is within a tenth of the band of v_log_f32 * ln 2 (lattice test) and u_lo <= u <= u_hi. */
+template <class Tab, class Low> MM_HD bool mm_ratio_exceeds_lnu_mhp(float ratio, float u_hi, const Low &low, const Tab &tab)
+{
+    const uint32_t s16 = (uint32_t)(u_hi * 0x1.0p16f) - 1u; /* exact */
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float u_lo = u_hi - 255.0f * 0x1.0p-24f; /* (s16 256 + 1) 2^-24: exact */
+    const float l_hi = __builtin_amdgcn_logf(u_hi) * 0.6931471805599453f, l_lo = __builtin_amdgcn_logf(u_lo) * 0.6931471805599453f;
+    const float b_hi = fmaf(__builtin_fabsf(l_hi), MM_LNU_BAND, MM_LNU_BAND), b_lo = fmaf(__builtin_fabsf(l_lo), MM_LNU_BAND, MM_LNU_BAND);
+    bool acc = ratio - l_hi > b_hi;
+    if (__builtin_expect(!acc && !(ratio - l_lo <= -b_lo), 0)) /* NaN lands here and is rejected by the plain comparison */
+        acc = ratio > mm_lnu_f32(mm_mhp_u(s16, low()), tab);
+    return acc;
+#else
+    return ratio > mm_lnu_f32(mm_mhp_u(s16, low()), tab);
 #endif
 }
 /* the accept uniform's logarithm per element type: f32 the table above, f64 mm_log */
@@ -288,6 +338,13 @@ MM_HD mm_u32x4 mm_block(uint64_t seed, uint64_t chain, uint32_t iteration, uint3
 {
     return mm_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), iteration, block, (uint32_t)seed,
                             (uint32_t)(seed >> 32));
+}
+/* the MH sampler's paired stream (above): the block of iterations 2k, 2k + 1 and the low byte of an iteration's uniform */
+MM_HD mm_u32x4 mm_mhp_block(uint64_t seed, uint64_t chain, uint32_t iteration) { return mm_block(seed, chain, iteration >> 1, MM_MHP_BLOCK); }
+MM_HD uint32_t mm_mhp_low_byte(uint64_t seed, uint64_t chain, uint32_t iteration)
+{
+    const mm_u32x4 a = mm_block(seed, chain, iteration >> 1, MM_MHP_BLOCK | 1u);
+    return (a.w[0] >> (8u * (iteration & 1u))) & 255u;
 }
 
 /* s = low bytes of w0, w1, w2 side by side.  On the device two byte permutes (v_perm_b32: selector bytes 0-3 take bytes

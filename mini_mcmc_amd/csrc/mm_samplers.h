@@ -35,9 +35,22 @@ inline double mm_exp_hotT(double x) { return mm_exp(x); }
 
 /* noise of (chain, iteration): z[0..D) ~ N(0,1) and the accept uniform u in (0,1]  (schedule: mm_rng.h).
  * Tab: where the f32 normal's table is read from (mm_icdf_global by default, mm_icdf_lds in the sampling kernel). */
-template <int D, class Tab = mm_icdf_global>
+/* MHP: the MH sampler's paired stream (f32, D <= 2; mm_rng.h: two transitions per Philox block) -- u is the EXACT accept
+ * uniform here (both blocks evaluated) */
+template <int D, class Tab = mm_icdf_global, bool MHP = false>
 MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, float *z, float *u, const Tab &tab = Tab())
 {
+    if constexpr (MHP) {
+        static_assert(D <= 2, "paired MH stream: D <= 2");
+        const mm_u32x4 blk = mm_mhp_block(seed, chain, iter);
+        const uint32_t h = iter & 1u;
+        const uint32_t wa = h ? blk.w[2] : blk.w[0], wb = h ? blk.w[3] : blk.w[1];
+        z[0] = mm_icdf_f32(wa, tab);
+        if (D > 1)
+            z[1] = mm_icdf_f32(wb, tab);
+        *u = mm_mhp_u(mm_mhp_s16(wa, wb), mm_mhp_low_byte(seed, chain, iter));
+        return;
+    }
     MM_UNROLL
     for (int b = 0; b < (D + 3) / 4; ++b) {
         mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
@@ -50,9 +63,10 @@ MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, float *z,
     }
 }
 
-template <int D, class Tab = mm_icdf_global>
+template <int D, class Tab = mm_icdf_global, bool MHP = false>
 MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z, double *u, const Tab & = Tab())
 {
+    static_assert(!MHP, "the paired MH stream is f32 only");
     MM_UNROLL
     for (int b = 0; b < (D + 1) / 2; ++b) {
         mm_u32x4 blk = mm_block(seed, chain, iter, (uint32_t)b);
@@ -69,10 +83,39 @@ MM_HD void mm_draw_noise(uint64_t seed, uint64_t chain, uint32_t iter, double *z
  * accept uniform.  f32: the two Philox evaluations are interleaved; values are bit-identical to mm_draw_noise +
  * mm_ln_accept.  f64: two scalar evaluations (there is no packed f64 arithmetic to gain from). */
 /* LN = false: *lna / *lnb receive the accept uniforms THEMSELVES (for mm_ratio_exceeds_lnu_f32: the MH split kernel) */
-template <int D, class Tab = mm_icdf_global, bool LN = true>
+/* MHP (the MH sampler's paired stream): LN = true: ln of the exact uniforms (both blocks evaluated); LN = false: *lna / *lnb
+ * receive u_hi = (s16 + 1) 2^-16, the upper end of the uniform's interval, for mm_ratio_exceeds_lnu_mhp (no second block).
+ * An EVEN iter shares one block between the two transitions; an odd one (wave-uniform, after an odd burn-in) takes two. */
+template <int D, class Tab = mm_icdf_global, bool LN = true, bool MHP = false>
 MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, float *za, float *lna, float *zb, float *lnb,
                               const Tab &tab = Tab())
 {
+    if constexpr (MHP) {
+        static_assert(D <= 2, "paired MH stream: D <= 2");
+        uint32_t a0, a1, b0, b1;
+        if ((iter & 1u) == 0u) {
+            const mm_u32x4 blk = mm_mhp_block(seed, chain, iter);
+            a0 = blk.w[0], a1 = blk.w[1], b0 = blk.w[2], b1 = blk.w[3];
+        } else {
+            const mm_u32x4 ba = mm_mhp_block(seed, chain, iter), bb = mm_mhp_block(seed, chain, iter + 1u);
+            a0 = ba.w[2], a1 = ba.w[3], b0 = bb.w[0], b1 = bb.w[1];
+        }
+        za[0] = mm_icdf_f32(a0, tab);
+        zb[0] = mm_icdf_f32(b0, tab);
+        if (D > 1) {
+            za[1] = mm_icdf_f32(a1, tab);
+            zb[1] = mm_icdf_f32(b1, tab);
+        }
+        const uint32_t sa = mm_mhp_s16(a0, a1), sb = mm_mhp_s16(b0, b1);
+        if (LN) {
+            *lna = mm_lnu_f32(mm_mhp_u(sa, mm_mhp_low_byte(seed, chain, iter)), tab);
+            *lnb = mm_lnu_f32(mm_mhp_u(sb, mm_mhp_low_byte(seed, chain, iter + 1u)), tab);
+        } else {
+            *lna = mm_mhp_u_hi(sa);
+            *lnb = mm_mhp_u_hi(sb);
+        }
+        return;
+    }
     MM_UNROLL
     for (int b = 0; b < (D + 3) / 4; ++b) {
         mm_u32x4x2 blk = mm_block_pair(seed, chain, iter, (uint32_t)b);
@@ -90,11 +133,11 @@ MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, floa
     }
 }
 
-template <int D, class Tab = mm_icdf_global, bool LN = true>
+template <int D, class Tab = mm_icdf_global, bool LN = true, bool MHP = false>
 MM_HD void mm_draw_noise_pair(uint64_t seed, uint64_t chain, uint32_t iter, double *za, double *lna, double *zb, double *lnb,
                               const Tab & = Tab())
 {
-    static_assert(LN, "the f64 accept test takes ln u");
+    static_assert(LN && !MHP, "the f64 accept test takes ln u; the paired MH stream is f32 only");
     double u;
     mm_draw_noise<D>(seed, chain, iter, za, &u);
     *lna = mm_log(u);
@@ -132,6 +175,19 @@ template <class Tab> struct mm_accept_u_f32 {
     float u;
     const Tab &tab;
     MM_HD bool operator()(float log_accept_ratio) const { return mm_ratio_exceeds_lnu_f32(log_accept_ratio, u, tab); }
+};
+/* ... against the paired stream's u_hi, the uniform's low byte drawn only when the decision needs it (mm_rng.h) */
+template <class Tab> struct mm_accept_mhp_f32 {
+    float u_hi;
+    uint64_t seed, chain;
+    uint32_t iter;
+    const Tab &tab;
+    MM_HD bool operator()(float log_accept_ratio) const
+    {
+        const uint64_t sd = seed, ch = chain;
+        const uint32_t it = iter;
+        return mm_ratio_exceeds_lnu_mhp(log_accept_ratio, u_hi, [sd, ch, it]() { return mm_mhp_low_byte(sd, ch, it); }, tab);
+    }
 };
 template <class T, class Tgt, class Accept>
 MM_HD int mm_mh_step_accept(const mm_tparams<T> &P, T prop_std, T *x, T *lp, const T *z, const Accept &accept, unsigned int *n_accepted = nullptr)
@@ -175,7 +231,7 @@ MM_HD int mm_mh_step(const mm_tparams<T> &P, T prop_std, T *x, T *lp, uint64_t s
 {
     constexpr int D = Tgt::dim;
     T z[D], u;
-    mm_draw_noise<D>(seed, chain, iter, z, &u);
+    mm_draw_noise<D, mm_icdf_global, mm_mh_paired<T, D, 0>::value>(seed, chain, iter, z, &u);
     return mm_mh_step_noise<T, Tgt>(P, prop_std, x, lp, z, mm_ln_accept(u, mm_icdf_global()));
 }
 

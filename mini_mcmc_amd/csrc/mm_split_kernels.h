@@ -117,7 +117,9 @@ template <class T, int D, int NN = 1> struct mm_split_mh_qp {
     /* round 5, f32 with the table-free accept filter (MM_SPLIT_MH_UFILT): the noise lost the logarithm, the transition gained the
      * band test, so the transition wave takes ONE pair of the batch instead of two -- 0 / 1 / 2 pairs: 0.2046 / 0.2040 / 0.2304 ms
      * against 0.2072 for the table form at 2 (tools/experiments/split_mh_ufilt.sh, profiles/r5d_split_mh_ufilt*.log) */
-    static constexpr int value = (sizeof(T) == 4 && MM_SPLIT_MH_UFILT && one > 1) ? 1 : one;
+    /* the sampler's paired stream (f32, D <= 2: one Philox block per two transitions, mm_rng.h): the noise is now the light
+     * role and keeps all of it -- 0 / 1 / 2 pairs: 0.1730 / 0.1927 / 0.2230 ms (profiles/r5i_split_mh_paired_layouts.log) */
+    static constexpr int value = (sizeof(T) == 4 && D <= 2 && MM_SPLIT_MH_UFILT) ? 0 : ((sizeof(T) == 4 && MM_SPLIT_MH_UFILT && one > 1) ? 1 : one);
 };
 
 /* Role timing for tools/split_probe.hip (-DMM_SPLIT_PROFILE): s_memtime ticks each role spends at the batch barrier
@@ -171,6 +173,11 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
      * ~12 instructions per transition, the transition gains ~5; the same decisions bit for bit.  HMC keeps ln u in the ring:
      * its transition wave is the kernel's critical path and the noise waves have slack. */
     constexpr bool UFILT = SAMPLER == MM_SAMPLER_MH && sizeof(T) == 4 && MM_SPLIT_MH_UFILT;
+    /* MH, f32, D <= 2: the sampler's paired stream (mm_rng.h) -- ONE Philox block per pair of transitions; the ring carries
+     * u_hi (the upper end of the accept uniform's interval), the transition evaluates the uniform's low byte (a second block)
+     * only when the decision needs it (mm_accept_mhp_f32) */
+    constexpr bool MHP = mm_mh_paired<T, D, SAMPLER>::value;
+    static_assert(!MHP || UFILT || !MM_SPLIT_MH_UFILT, "paired MH stream");
     static_assert(QN <= RB, "QP");
     typedef T mm_vrow __attribute__((ext_vector_type(EPL)));
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
@@ -238,7 +245,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
                 T rows[2 * PAIRS][NW];
                 MM_UNROLL
                 for (int q = 0; q < PAIRS; ++q)
-                    mm_draw_noise_pair<D, Tab, !UFILT>(a.seed, chain, it + j + 2 * q, rows[2 * q], &rows[2 * q][D], rows[2 * q + 1], &rows[2 * q + 1][D], tab);
+                    mm_draw_noise_pair<D, Tab, !UFILT, MHP>(a.seed, chain, it + j + 2 * q, rows[2 * q], &rows[2 * q][D], rows[2 * q + 1], &rows[2 * q + 1][D], tab);
                 MM_UNROLL
                 for (int r = 0; r < 2 * PAIRS; ++r) {
                     MM_UNROLL
@@ -323,9 +330,11 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
             z[k] = row[k];
         *ln_u = row[D];
     };
-    auto transition = [&](T *z, T ln_u) __attribute__((always_inline)) {
+    auto transition = [&](T *z, T ln_u, unsigned int iter_t) __attribute__((always_inline)) {
         if (SAMPLER == MM_SAMPLER_HMC)
             (void)mm_hmc_step_noise<T, Tgt, LCT>(a.P, a.scale, a.n_leapfrog, x, &lp, g, z, ln_u, mm_no_hook(), &n_acc32);
+        else if constexpr (UFILT && MHP)
+            (void)mm_mh_step_accept<T, Tgt>(a.P, a.scale, x, &lp, z, mm_accept_mhp_f32<Tab>{ln_u, a.seed, chain, iter_t, tab}, &n_acc32); /* `ln_u` holds u_hi */
         else if constexpr (UFILT)
             (void)mm_mh_step_accept<T, Tgt>(a.P, a.scale, x, &lp, z, mm_accept_u_f32<Tab>{ln_u, tab}, &n_acc32); /* `ln_u` holds u */
         else
@@ -340,7 +349,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     auto draw_own = [&](unsigned int it_batch) __attribute__((always_inline)) {
         MM_UNROLL
         for (int q = 0; q < QN; q += 2)
-            mm_draw_noise_pair<D, Tab, !UFILT>(a.seed, chain, it_batch + q, zq[q], &lnq[q], zq[q + 1], &lnq[q + 1], tab);
+            mm_draw_noise_pair<D, Tab, !UFILT, MHP>(a.seed, chain, it_batch + q, zq[q], &lnq[q], zq[q + 1], &lnq[q + 1], tab);
     };
     /* Collected states are staged two transitions at a time where that makes wider LDS writes (MM_SPLIT_STAGE_PAIRS): the
      * state after the first transition of a pair waits in registers and both leave in 2 D sizeof(T) bytes cut into
@@ -389,12 +398,12 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
             MM_UNROLL
             for (int q = 0; q < QN; q += 2) {
                 if ((unsigned int)q < nb) {
-                    transition(zq[q], lnq[q]);
+                    transition(zq[q], lnq[q], it + q);
                     if ((unsigned int)q + 1u < nb) {
                         MM_UNROLL
                         for (int k = 0; k < D; ++k)
                             held[k] = x[k];
-                        transition(zq[q + 1], lnq[q + 1]);
+                        transition(zq[q + 1], lnq[q + 1], it + q + 1);
                         if (stage)
                             put_pair(stage + q * D, held);
                     } else if (stage) {
@@ -406,17 +415,17 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
             for (; j + 1u < nb; j += 2u) {
                 T zn[D], lnn; /* rows past nb hold stale data: requested, never used */
                 load_row(src + (size_t)(j + 1u) * 64 * NW, zn, &lnn);
-                transition(zc, lnc);
+                transition(zc, lnc, it + j);
                 MM_UNROLL
                 for (int k = 0; k < D; ++k)
                     held[k] = x[k];
                 load_row(src + (size_t)min(j + 2u, (unsigned int)RB - 1u) * 64 * NW, zc, &lnc);
-                transition(zn, lnn);
+                transition(zn, lnn, it + j + 1u);
                 if (stage)
                     put_pair(stage + j * D, held);
             }
             if (j < nb) {
-                transition(zc, lnc);
+                transition(zc, lnc, it + j);
                 if (stage)
                     put_one(stage + j * D);
             }
@@ -424,7 +433,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
             MM_UNROLL
             for (int q = 0; q < QN; ++q) {
                 if ((unsigned int)q < nb) {
-                    transition(zq[q], lnq[q]);
+                    transition(zq[q], lnq[q], it + q);
                     if (stage)
                         put_one(stage + q * D);
                 }
@@ -432,7 +441,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
             for (unsigned int j = QN; j < nb; ++j) {
                 T zn[D], lnn; /* rows past nb hold stale data: requested, never used */
                 load_row(src + (size_t)min(j + 1u, (unsigned int)RB - 1u) * 64 * NW, zn, &lnn);
-                transition(zc, lnc);
+                transition(zc, lnc, it + j);
                 if (stage)
                     put_one(stage + j * D);
                 MM_UNROLL

@@ -155,6 +155,9 @@ void o_mh_use_engine_stream(o_mh *s, uint64_t seed, uint64_t chain_offset)
     for (int i = 0; i < s->n_chains; ++i) {
         o_rng_init_engine_stream(&s->chains[i].prop_rng, seed, chain_offset + (uint64_t)i);
         o_rng_init_engine_stream(&s->chains[i].rng, seed, chain_offset + (uint64_t)i);
+        /* the engine's MH sampler draws from its paired stream in f32 at dim <= 2 (csrc/mm_rng.h) */
+        o_rng_engine_mh_paired(&s->chains[i].prop_rng, s->dim);
+        o_rng_engine_mh_paired(&s->chains[i].rng, s->dim);
     }
 }
 

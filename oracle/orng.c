@@ -194,6 +194,24 @@ float o_engine_accept_f32(uint64_t seed, uint64_t chain, uint32_t iteration)
     return (float)(s + 1u) * 0x1.0p-24f;
 }
 
+/* the MH sampler's paired f32 stream (csrc/mm_rng.h, round 5) */
+float o_engine_mhp_normal_f32(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i)
+{
+    uint32_t w[4];
+    o_engine_block(seed, chain, iteration >> 1, 0x20000000u, w);
+    return o_engine_icdf24(w[2u * (iteration & 1u) + i]);
+}
+float o_engine_mhp_accept_f32(uint64_t seed, uint64_t chain, uint32_t iteration)
+{
+    uint32_t w[4], a[4];
+    o_engine_block(seed, chain, iteration >> 1, 0x20000000u, w);
+    o_engine_block(seed, chain, iteration >> 1, 0x20000001u, a);
+    const uint32_t h = iteration & 1u;
+    const uint32_t s16 = (w[2u * h] & 255u) | ((w[2u * h + 1u] & 255u) << 8);
+    const uint32_t s8 = (a[0] >> (8u * h)) & 255u;
+    return (float)(s16 * 256u + s8 + 1u) * 0x1.0p-24f;
+}
+
 double o_engine_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t k)
 {
     uint32_t w[4];
@@ -204,6 +222,8 @@ double o_engine_aux_u53(uint64_t seed, uint64_t chain, uint32_t iteration, uint3
 static double eng_normal(o_rng *r)
 {
     uint32_t i = r->n_normal++;
+    if (r->mh_paired)
+        return (double)o_engine_mhp_normal_f32(r->seed, r->chain, (uint32_t)r->iteration, i);
     return r->is_f32 ? (double)o_engine_normal_f32(r->seed, r->chain, (uint32_t)r->iteration, i)
                      : o_engine_normal_f64(r->seed, r->chain, (uint32_t)r->iteration, i);
 }
@@ -217,6 +237,8 @@ static double eng_uniform_f64(o_rng *r) { return eng_aux(r); }
 static float eng_uniform_f32(o_rng *r) { return (float)eng_aux(r); }
 static double eng_accept_uniform(o_rng *r)
 {
+    if (r->mh_paired)
+        return (double)o_engine_mhp_accept_f32(r->seed, r->chain, (uint32_t)r->iteration);
     return r->is_f32 ? (double)o_engine_accept_f32(r->seed, r->chain, (uint32_t)r->iteration)
                      : o_engine_aux_u53(r->seed, r->chain, (uint32_t)r->iteration, 0);
 }
@@ -241,3 +263,5 @@ void o_rng_init_engine_stream(o_rng *r, uint64_t seed, uint64_t chain)
     r->seed = seed;
     r->chain = chain;
 }
+
+void o_rng_engine_mh_paired(o_rng *r, int dim) { r->mh_paired = r->is_f32 && dim <= 2; }

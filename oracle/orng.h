@@ -32,12 +32,20 @@ struct o_rng {
     rc_rng rc;                                        /* state of backend (a) */
     uint64_t seed, chain, iteration;                  /* state of backend (b) */
     uint32_t draw, n_normal;                          /* running indices within the iteration, (b) */
+    int mh_paired;                                    /* (b): the MH sampler's f32 stream at dim <= 2 (o_rng_engine_mh_paired) */
 };
 
 /* (a): SmallRng::seed_from_u64(seed).  Keeps r->is_f32. */
 void o_rng_init_rand_compat(o_rng *r, uint64_t seed);
 /* (b): engine stream of global chain id `chain` under `seed`.  Keeps r->is_f32. */
 void o_rng_init_engine_stream(o_rng *r, uint64_t seed, uint64_t chain);
+/* (b) for the Metropolis-Hastings sampler in f32 at dim <= 2: the engine's paired stream (csrc/mm_rng.h: one Philox block
+ * per TWO transitions -- iteration t takes words 2 (t & 1), 2 (t & 1) + 1 of block (chain, t >> 1, 0x20000000) for its normals
+ * and the high 16 bits of its accept uniform, the low 8 bits from word 0 of block (chain, t >> 1, 0x20000001)).  Call after
+ * o_rng_init_engine_stream; no effect for f64. */
+void o_rng_engine_mh_paired(o_rng *r, int dim);
+float o_engine_mhp_normal_f32(uint64_t seed, uint64_t chain, uint32_t iteration, uint32_t i);
+float o_engine_mhp_accept_f32(uint64_t seed, uint64_t chain, uint32_t iteration);
 
 /* raw pieces of (b), exported for the known-answer tests and for noise injection */
 void o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

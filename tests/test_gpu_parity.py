@@ -1035,3 +1035,8 @@ def test_lnu_filter_bound_holds_over_the_whole_lattice(tmp_path):
     assert j["uniforms"] == 1 << 24 and j["mismatches"] == 0
     assert j["max_dev_over_band"] < 0.5, j
     assert j["probes_in_band"] >= 3 * (1 << 24)  # the probes really exercise the exact branch
+    # the paired MH stream's filter (mm_ratio_exceeds_lnu_mhp): the accept uniform's low byte supplied on demand only -- same
+    # decisions over all 2^16 x 2^8 uniforms and 20 probe ratios each; the byte is demanded for the probes placed inside the
+    # interval [ln u_lo, ln u_hi] (at least seven of the twenty) and not for those two bands outside it
+    assert j["paired_mismatches"] == 0
+    assert 7 * (1 << 24) <= j["paired_low_byte_demanded"] <= 16 * (1 << 24), j

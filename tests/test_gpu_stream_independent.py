@@ -73,6 +73,68 @@ def test_device_f32_noise_is_the_inverse_cdf_of_philox_words(dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim", [1, 2])
+def test_device_mh_paired_f32_noise_is_two_transitions_per_philox_block(dim):
+    """The Metropolis-Hastings sampler's f32 stream at dim <= 2 (csrc/mm_rng.h, round 5), restated here from its text: iteration
+    t takes words 2 (t & 1), 2 (t & 1) + 1 of block (chain, t >> 1, 0x20000000): normals from their top 24 bits, the accept
+    uniform's high 16 bits from their low bytes, its low 8 bits from byte (t & 1) of word 0 of block (chain, t >> 1,
+    0x20000001).  Both iterations of a pair, an odd and an even start; at dim 3 the MH noise is the common stream."""
+    from scipy.special import ndtri
+
+    from mini_mcmc_amd.core import draw_noise
+
+    seed, off, n = 0x1234567ABCDEF01, (5 << 32) + 17, 20000
+    chains = np.uint64(off) + np.arange(n, dtype=np.uint64)
+    for it in (76, 77, 1):
+        z, u = draw_noise(seed, off, it, n, dim, np.float32, sampler="mh")
+        w = block(seed, chains, it >> 1, 0x20000000)
+        a = block(seed, chains, it >> 1, 0x20000001)
+        h = it & 1
+        wa, wb = w[:, 2 * h], w[:, 2 * h + 1]
+        s16 = (wa & 255) | ((wb & 255) << 8)
+        s8 = (a[:, 0] >> (8 * h)) & 255
+        assert np.array_equal(u, ((s16.astype(np.float64) * 256 + s8 + 1.0) * 2.0**-24).astype(np.float32))  # exact
+        for i, wi in enumerate((wa, wb)[:dim]):
+            nn = ((wi >> 8) | 1).astype(np.float64)
+            mag = -ndtri(nn * 2.0**-25)
+            got = z[:, i].astype(np.float64)
+            assert np.max(np.abs(np.abs(got) - mag) / np.maximum(1.0, mag)) < 1.6e-7
+            sgn_bit = ((wi >> 8) & 1).astype(bool)
+            assert np.all(np.signbit(got) == sgn_bit) or np.all(np.signbit(got) == ~sgn_bit)
+    z3, u3 = draw_noise(seed, off, 77, n, 3, np.float32, sampler="mh")
+    z0, u0 = draw_noise(seed, off, 77, n, 3, np.float32)
+    assert np.array_equal(z3, z0) and np.array_equal(u3, u0)
+
+
+@pytest.mark.gpu
+def test_device_mh_f32_run_follows_from_the_paired_draws():
+    """Five MH transitions of 20 000 chains on the standard 2-D Gaussian in f32 through the SAMPLING kernel (whose accept test
+    sees only the high 16 bits of the uniform unless it needs more): proposals and accept decisions recomputed from the
+    independent restatement of the paired stream agree on every chain not within rounding of a threshold."""
+    from mini_mcmc_amd.core import draw_noise, init_with_seed
+    from mini_mcmc_amd.distributions import Gaussian2D, IsotropicGaussian
+    from mini_mcmc_amd.metropolis_hastings import MetropolisHastings
+
+    n, seed, steps = 20000, 99, 5
+    init = init_with_seed(n, 2, 7, np.float32)
+    mh = MetropolisHastings(Gaussian2D([0.0, 0.0], [[1.0, 0.0], [0.0, 1.0]]), IsotropicGaussian(0.7), init).seed(seed)
+    out = mh.run(steps, 0)
+    x = init.astype(np.float64)
+    clear_all = np.ones(n, dtype=bool)
+    for t in range(steps):
+        z, u = draw_noise(seed, 0, t, n, 2, np.float32, sampler="mh")
+        prop = x + 0.7 * z.astype(np.float64)
+        ratio = -0.5 * (prop**2).sum(1) + 0.5 * (x**2).sum(1)
+        lnu = np.log(u.astype(np.float64))
+        clear_all &= np.abs(ratio - lnu) > 1e-5
+        acc = ratio > lnu
+        x = np.where(acc[:, None], prop, x)
+        ok = clear_all
+        assert np.allclose(out[ok, t, :], x[ok], rtol=0, atol=2e-5 * (t + 1))
+    assert clear_all.mean() > 0.995
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dim", [1, 2, 3, 8, 32])
 def test_device_f64_noise_is_box_muller_of_philox_words(dim):
     from mini_mcmc_amd.core import draw_noise
