@@ -842,6 +842,10 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         unsigned int have_s = 0xffffffffu; /* the first draw refills */
         const int lane15x4 = (L.lane & 15) * 4;
         auto draw = [&]() __attribute__((always_inline)) -> double {
+#ifdef MM_LG_EXP_CHEAP_DRAW
+            ka += 1u;
+            return 0.25 + 1e-9 * (double)ka;
+#endif
             const unsigned int b = ka >> 1, g = b >> 2;
             if (g != have_s) {
                 L.aux_blk = mm_block(a.seed, L.chain, L.m, MM_AUX_BLOCK + 4u * g + (unsigned int)L.q);
@@ -876,7 +880,11 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             S_n = (L.logu < jointp) ? 1u : 0u;
             S_s = (L.logu - 1000.0) < jointp;
             S_nalpha = 1;
+#ifdef MM_LG_EXP_NO_FILING /* timing experiments of tools/experiments/nuts_lg_lean_strip.sh: wrong trees */
+            if (false) {
+#else
             if (j > 1 && (leaf & 3u) == 0u) {
+#endif
                 const int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
                 if (cc <= 1 + Cfg::LF) {
                     mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
@@ -972,17 +980,10 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 pfp[s] = cp[s];
             }
             const unsigned int P_n = S_n, P_nalpha = S_nalpha;
-            {
-                const bool inv = !dead && !S_s; /* not valid: handed up as it is (nuts.rs:858-899) */
-                if (__ballot(inv) != 0ull) {
-                    const double a_first = mm_lg_accept_prob(d_first);
-                    if (inv)
-                        S_alpha = a_first;
-                    retire(leaf, 1, inv);
-                    if (__ballot(!dead) == 0ull)
-                        break;
-                }
-            }
+            /* a first leaf that is not valid is handed up as it is and its sibling never built (nuts.rs:858-899): here the lane
+             * runs on regardless and is set right at the end of the pair (ONE check per pair: a branch on a freshly computed
+             * lane mask drains the wave's pipeline) */
+            const bool first_ok = S_s;
             /* ---- its sibling, both acceptance statistics in one pass (even rows the first leaf's d, odd rows the second's),
              *      the merge at level 0 */
             leaf_l(leaf | 1u);
@@ -1029,19 +1030,46 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                     k_stop = k;
                 }
             };
+#ifdef MM_LG_EXP_FIXED_WALK
+            {
+                rec rk;
+                load_rec(1, 2, rk);
+                const unsigned long long cnt = (unsigned long long)__double_as_longlong(rk.cnt);
+                merge_l(rk.fx, rk.fp, rk.prime, mm_false_t(), rk.alpha, (unsigned int)cnt & 1u, (unsigned int)(cnt >> 32) & 1u);
+                mm_lds_double *e = lds + (size_t)(Cfg::lds_E) * 64;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    e[s * 64] = S_prime[s];
+                e[NS * 64] = S_alpha;
+                e[(NS + 1) * 64] = __longlong_as_double((long long)((unsigned long long)S_n | ((unsigned long long)S_nalpha << 32)));
+                k_stop = (lf1 + 1u >= n_leaves) ? j : 1;
+            }
+#else
 #pragma unroll
             for (int k = 1; k <= WU; ++k)
                 if (k_stop == 0)
                     level(k);
             for (int k = WU + 1; k_stop == 0; ++k)
                 level(k);
+#endif
+#ifndef MM_LG_EXP_NO_RETIRE
+            {
+                const bool inv1 = !dead && !first_ok;       /* the first leaf was not valid: what the sibling added is undone */
+                const bool inv2 = !dead && first_ok && !S_s; /* the pair's subtree turned: it does not wait, it returns */
+                if (__ballot(inv1 || inv2) != 0ull) {
+                    if (inv1) {
+                        S_n = P_n;
+                        S_nalpha = P_nalpha;
+                        S_alpha = P_alpha; /* min(1, exp(d)) of the first leaf */
+                        lf -= 1u;          /* the sibling's leapfrog step was not the chain's */
+                    }
+                    retire(leaf, 1, inv1);
+                    retire(lf1, k_stop + 1, inv2);
+                }
+            }
+#endif
             if (k_stop >= j)
                 break; /* reached the doubling's own level: complete */
-            {
-                const bool inv = !dead && !S_s; /* the subtree turned: it does not wait, it returns */
-                if (__ballot(inv) != 0ull)
-                    retire(lf1, k_stop + 1, inv);
-            }
         }
         if (died) {
             S_n = F_n;
