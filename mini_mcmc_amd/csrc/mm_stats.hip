@@ -2195,24 +2195,18 @@ int mmcmc_split_rhat_mean_ess(const void *sample, int sample_is_device, int dtyp
             e = hipErrorOutOfMemory;
             break;
         }
-        float *d_means = d_buf, *d_ssq = d_buf + c2 * dim, *d_acov = d_buf + 2 * c2 * dim;
-        double *d_wb = reinterpret_cast<double *>(d_acov + n_acov);
+        float *d_means = d_buf, *d_ssq = d_buf + c2 * dim;
+        /* The few KB the host needs -- the lag sums (one total, or kParts partial totals) and the cross-chain sums -- are
+         * WRITTEN BY THE KERNELS straight into the pinned host buffer (device-visible like all hipHostMalloc memory; visible to
+         * the host once the event behind the last kernel has completed): the two or three copy commands that used to follow the
+         * kernels cost more than the reduction's tail (round 5: 0.150 -> see DESIGN.md 5.2) */
+        float *d_acov = h;
+        double *d_wb = reinterpret_cast<double *>(h + n_acov);
         unsigned int n_written = kParts;
         rc = stats_partials_impl(sample_is_device ? sample : d_sample, dtype, n_chains, n, dim, d_means, d_ssq, d_acov,
                                  d_wb, d_buf + nb, kParts, device, stream_v, &n_written);
         if (rc != MMCMC_OK)
             break;
-        if (n_written == kParts) {
-            if ((e = hipMemcpyAsync(h, d_acov, (n_acov + 2 * n_wb) * sizeof(float), hipMemcpyDeviceToHost, stream)) !=
-                hipSuccess)
-                break;
-        } else { /* the power-spectrum path leaves the total in part 0: two small copies instead of sixteen parts */
-            if ((e = hipMemcpyAsync(h, d_acov, m * dim * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-                break;
-            if ((e = hipMemcpyAsync(h + n_acov, d_acov + n_acov, 2 * n_wb * sizeof(float), hipMemcpyDeviceToHost,
-                                    stream)) != hipSuccess)
-                break;
-        }
         if ((e = stats_wait(device, stream)) != hipSuccess)
             break;
         for (size_t i = 0; i < m * dim; ++i) { /* lag sums: the partial totals in their fixed order */
