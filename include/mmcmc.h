@@ -209,13 +209,6 @@ int mmcmc_nuts_set_max_depth(mmcmc_nuts *h, int max_depth);
 int mmcmc_nuts_set_kernel_variant(mmcmc_nuts *h, int variant);
 int mmcmc_nuts_kernel_variant(mmcmc_nuts *h);
 int mmcmc_nuts_set_compaction(mmcmc_nuts *h, int first_level, int n_groups);
-/* The asynchronous-lane kernels (variants 5 and 7) from 4096 chains and 16 transitions on: with launches > 1 a run() is cut
- * into that many launches (after 1/8, 1/4, 1/2 ... of the transitions) and before each but the first the chains are dealt
- * to the waves anew by the leapfrog steps they took in the previous one -- chains of similar work together, the heaviest
- * in sparsely filled waves.  Default 1 (one launch, natural waves): on the reference's targets a chain's work does not
- * persist from window to window and the extra launch tails cost more than the packing gains; for
- * workloads whose chains differ persistently.  No result depends on it (1 .. 8). */
-int mmcmc_nuts_set_repacking(mmcmc_nuts *h, int launches);
 /* progress = 0: NUTS::run -> NUTSChain::run (nuts.rs:163-170, 457-471): n_collect + n_discard - 1 transitions, and
  *               with n_discard == 0 row 0 is the initial position (the reference's off-by-one, test_chain_1);
  * progress = 1: the stepping of run_progress (nuts.rs:491-522): all n_collect + n_discard transitions;

@@ -124,7 +124,6 @@ SIGNATURES = {
     "mmcmc_tracker_init_last": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "mmcmc_tracker_chain_stats": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "mmcmc_tracker_n": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
-    "mmcmc_nuts_set_repacking": (C.c_int, [_vp, C.c_int]),
     "mmcmc_rtc_set_compiler": (C.c_int, [C.c_int]),
     "mmcmc_rtc_unit_compiler": (C.c_int, [C.c_int]),
     "mmcmc_tracker_shape": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

@@ -52,65 +52,6 @@ struct DevGuard {
 /* 0: normal; 1: inside the self-test of a run-time compiled unit; 2: create without run-time compiled built-in units */
 thread_local int g_rtc_create_mode = 0;
 
-/* ---- re-packing the chains of the asynchronous-lane kernel between the launches of one run -------------------------------
- * A wave runs until its longest chain ends, the launch until the longest chain of all does, and that chain's leaves run the
- * slower the more wave-mates it has (tools/nuts_tick_latency.py: RosenbrockND(3), the longest chain alone 2350 cycles per
- * leaf, among 63 others 3850).  A chain's work per transition is persistent -- it follows from its adapted step size --,
- * so after a launch the chains are dealt to the next launch's waves by the work (leapfrog steps) they did in it: heaviest
- * first, chains of similar work together, and the nearer a chain is to the heaviest the fewer lanes its wave gets
- * (k lanes where (1 + (k - 1) / R) w <= w_max, R = cycles per leaf alone / extra cycles per wave-mate).  Placement never
- * changes a result (mm_nuts_args::perm). */
-constexpr unsigned int kRepackBuckets = 128;
-
-__global__ void repack_work_kernel(const unsigned long long *nlf, unsigned long long *prev, unsigned int *w, unsigned long long n,
-                                   unsigned int *wmax)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned int d = 0u;
-    if (i < n) {
-        const unsigned long long now = nlf[i], dd = now - prev[i];
-        prev[i] = now;
-        d = dd > 0xfffffffeull ? 0xfffffffeu : (unsigned int)dd;
-        w[i] = d;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned int o = (unsigned int)__shfl_xor((int)d, off, 64);
-        d = o > d ? o : d;
-    }
-    if ((threadIdx.x & 63) == 0 && d)
-        atomicMax(wmax, d);
-}
-__device__ __forceinline__ unsigned int repack_bucket(unsigned int w, unsigned int wmax)
-{
-    const unsigned long long b = (unsigned long long)w * kRepackBuckets / ((unsigned long long)wmax + 1ull);
-    return kRepackBuckets - 1u - (unsigned int)(b < kRepackBuckets ? b : kRepackBuckets - 1u); /* 0 = the heaviest */
-}
-__global__ void repack_hist_kernel(const unsigned int *w, unsigned long long n, const unsigned int *wmax, unsigned int *hist)
-{
-    __shared__ unsigned int h[kRepackBuckets];
-    for (unsigned int i = threadIdx.x; i < kRepackBuckets; i += blockDim.x)
-        h[i] = 0u;
-    __syncthreads();
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        atomicAdd(&h[repack_bucket(w[i], *wmax)], 1u);
-    __syncthreads();
-    for (unsigned int b = threadIdx.x; b < kRepackBuckets; b += blockDim.x)
-        if (h[b])
-            atomicAdd(&hist[b], h[b]);
-}
-/* plan: [0, NB) first slot of the bucket, [NB, 2 NB) lanes per wave of the bucket, [2 NB, 3 NB) cursors (zeroed) */
-__global__ void repack_scatter_kernel(const unsigned int *w, unsigned long long n, const unsigned int *wmax, unsigned int *plan,
-                                      unsigned int *perm)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const unsigned int b = repack_bucket(w[i], *wmax);
-    const unsigned int pos = atomicAdd(&plan[2 * kRepackBuckets + b], 1u), k = plan[kRepackBuckets + b];
-    perm[plan[b] + (pos / k) * 64u + pos % k] = (unsigned int)i;
-}
-
 struct NutsBase {
     virtual ~NutsBase() {}
     virtual int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream) = 0;
@@ -127,10 +68,6 @@ struct NutsBase {
     int compaction_groups = 0; /* variant 2: chain groups with their own launch sequence (0 = choose) */
     int device = 0, mode = 0, kind = 0, dim = 0;
     const void *rtc_unit = nullptr; /* the run-time compiled unit whose kernels this handle launches (mm_rtc.hip), or NULL */
-    int repack_launches = 1; /* asynchronous-lane pair kernel: launches per run() with the chains re-packed by their recent
-                                work in between (1 = one launch, chains in their natural waves: the default, see
-                                run_pair_repacked for why); mmcmc_nuts_set_repacking */
-    double repack_ratio = 96.0; /* R of the packing rule (see repack_work_kernel) */
     int rtc_run_kernel = 2; /* which of the unit's run kernels: 2 asynchronous lanes, leaves in pairs (what handles launch);
                                0 the lanes in step (launched only by rtc_unit_verified, as the second opinion on a user target) */
     size_t n_chains = 0;
@@ -168,9 +105,6 @@ template <class TT, class ST> struct Nuts : NutsBase {
     unsigned long long *d_nlf = nullptr;
     unsigned int *d_hist = nullptr;
     unsigned char *d_scratch = nullptr;
-    unsigned long long *d_nlf_prev = nullptr; /* re-packing: leapfrog totals at the end of the previous launch */
-    unsigned int *d_work = nullptr, *d_perm = nullptr, *d_plan = nullptr; /* work [C], perm [slots], plan [3 NB + NB hist + 1 max] */
-    size_t perm_cap = 0, scratch_waves = 0;
     bool stack_in_lds = true;
     const mm_nuts_lg_entry *lg = nullptr;
     double *d_lg_scratch = nullptr, *d_lg_rec = nullptr;
@@ -196,10 +130,6 @@ template <class TT, class ST> struct Nuts : NutsBase {
         (void)hipFree(d_nlf);
         (void)hipFree(d_hist);
         (void)hipFree(d_scratch);
-        (void)hipFree(d_nlf_prev);
-        (void)hipFree(d_work);
-        (void)hipFree(d_perm);
-        (void)hipFree(d_plan);
         (void)hipFree(d_gstore);
         (void)hipFree(d_lg_scratch);
         (void)hipFree(d_lg_rec);
@@ -319,10 +249,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
             }
         } else if (user) {
             variant = 7;
-            /* room for the waves of a re-packed launch too (run_pair_repacked: a quarter more, plus one per bucket) */
             const size_t waves0 = (n_chains + 63) / 64;
-            scratch_waves = n_chains >= 4096 ? waves0 + waves0 / 4 + kRepackBuckets : waves0;
-            MM_HIP(hipMalloc((void **)&d_scratch, scratch_waves * user_stack_bytes));
+            MM_HIP(hipMalloc((void **)&d_scratch, waves0 * user_stack_bytes));
             stack_in_lds = false;
         } else {
             variant = 6;
@@ -575,121 +503,10 @@ template <class TT, class ST> struct Nuts : NutsBase {
     {
         if (rtc_target) {
             mm_nuts_args<TT, ST> b = a;
-            const unsigned int grid = (unsigned int)(((b.perm ? b.n_slots : b.n_chains) + 63) / 64);
+            const unsigned int grid = (unsigned int)((b.n_chains + 63) / 64);
             return mm_rtc_launch_nuts(user, type_mode, 2, &b, sizeof(b), grid, (size_t)MM_NUTS_RING * 64 * sizeof(double), st);
         }
         return k->run_pair(a, st);
-    }
-
-    /* the run in `repack_launches` launches -- cut after 1/8, 1/4, 1/2 of the transitions (early, while the step sizes still
-     * adapt and the work per chain settles) -- with the chains dealt to the waves anew before each but the first.
-     * MEASURED SLOWER, hence off by default (profiles/r4g_nuts_repack_timing.jsonl, 65 536 chains, 100 + 100):
-     * RosenbrockND(3) 21.0 ms in one launch, 27.3 / 31.4 / 32.9 ms in 2 / 3 / 4; the 2-D Gaussian 1.8 -> 2.8 ... 3.9 ms.  The
-     * premise does not hold: a chain's work in one window says almost nothing about the next
-     * (profiles/r4g_nuts_persistence.jsonl: correlation 0.08-0.11 between windows of the warm-up, 0.6 between the second half
-     * of the warm-up and the sampling phase for RosenbrockND(3), 0.00 throughout for StandardNormal(8), whose tree depths
-     * are a fresh draw every transition), so the packing is no better than the natural one while every cut adds a
-     * launch tail -- each launch ends with ITS longest chain.  Kept selectable: placement changes no result
-     * (tests/test_gpu_parity.py), and a workload with persistently uneven chains would gain. */
-    hipError_t run_pair_repacked(const mm_nuts_args<TT, ST> &a0, bool rtc_target, int type_mode, hipStream_t st)
-    {
-        const unsigned int total = a0.n_pre + a0.n_rec;
-        std::vector<unsigned int> ends;
-        for (int i = repack_launches - 1; i >= 1; --i) {
-            const unsigned int t = total >> i;
-            if (t >= 4 && (ends.empty() || t >= ends.back() + 4))
-                ends.push_back(t);
-        }
-        ends.push_back(total);
-        const size_t n_waves0 = (n_chains + 63) / 64, cap_waves = n_waves0 + n_waves0 / 4 + kRepackBuckets;
-        hipError_t e;
-        if (!d_nlf_prev) {
-            if ((e = hipMalloc((void **)&d_nlf_prev, n_chains * sizeof(unsigned long long))) != hipSuccess)
-                return e;
-            if ((e = hipMalloc((void **)&d_work, n_chains * sizeof(unsigned int))) != hipSuccess)
-                return e;
-            if ((e = hipMalloc((void **)&d_perm, cap_waves * 64 * sizeof(unsigned int))) != hipSuccess)
-                return e;
-            perm_cap = cap_waves * 64;
-            if ((e = hipMalloc((void **)&d_plan, (4 * kRepackBuckets + 1) * sizeof(unsigned int))) != hipSuccess)
-                return e;
-        }
-        if ((e = hipMemcpyAsync(d_nlf_prev, d_nlf, n_chains * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st)) != hipSuccess)
-            return e;
-        unsigned int t0 = 0;
-        bool packed = false;
-        size_t n_slots = 0;
-        for (size_t si = 0; si < ends.size(); ++si) {
-            const unsigned int t1 = ends[si];
-            mm_nuts_args<TT, ST> a = a0;
-            a.m0 = a0.m0 + t0;
-            const unsigned int pre0 = t0 < a0.n_pre ? t0 : a0.n_pre, pre1 = t1 < a0.n_pre ? t1 : a0.n_pre;
-            a.n_pre = pre1 - pre0;
-            a.n_rec = (t1 - t0) - a.n_pre;
-            a.write_initial = t0 == 0 ? a0.write_initial : 0u;
-            /* rows written before this launch: the initial one and the recorded transitions before t0 */
-            a.out_t0 = a0.out_t0 + (t0 == 0 ? 0u : (a0.write_initial ? 1u : 0u) + (t0 - pre0));
-            a.perm = packed ? d_perm : nullptr;
-            a.n_slots = packed ? n_slots : 0;
-            if ((e = launch_pair(a, rtc_target, type_mode, st)) != hipSuccess)
-                return e;
-            ++n_launches_run;
-            t0 = t1;
-            if (si + 1 == ends.size())
-                break;
-            /* ---- deal the chains to the next launch's waves by the work of this one ---- */
-            unsigned int *const d_hist_r = d_plan + 3 * kRepackBuckets, *const d_wmax = d_plan + 4 * kRepackBuckets;
-            if ((e = hipMemsetAsync(d_plan, 0, (4 * kRepackBuckets + 1) * sizeof(unsigned int), st)) != hipSuccess)
-                return e;
-            const unsigned int blocks = (unsigned int)((n_chains + 255) / 256);
-            hipLaunchKernelGGL(repack_work_kernel, dim3(blocks), dim3(256), 0, st, d_nlf, d_nlf_prev, d_work,
-                               (unsigned long long)n_chains, d_wmax);
-            hipLaunchKernelGGL(repack_hist_kernel, dim3(blocks), dim3(256), 0, st, d_work, (unsigned long long)n_chains, d_wmax, d_hist_r);
-            if ((e = hipGetLastError()) != hipSuccess)
-                return e;
-            unsigned int h[kRepackBuckets + 1];
-            if ((e = hipMemcpyAsync(h, d_hist_r, sizeof h, hipMemcpyDeviceToHost, st)) != hipSuccess)
-                return e;
-            if ((e = hipStreamSynchronize(st)) != hipSuccess)
-                return e;
-            if (h[kRepackBuckets] == 0u) { /* nobody moved: keep the placement */
-                continue;
-            }
-            unsigned int plan[2 * kRepackBuckets];
-            double R = repack_ratio;
-            size_t waves = 0;
-            for (int tries = 0; tries < 24; ++tries, R *= 2.0) {
-                waves = 0;
-                for (unsigned int b = 0; b < kRepackBuckets; ++b) {
-                    /* chains of bucket b did at least w_max (NB - 1 - b) / NB: lanes k with (1 + (k - 1) / R) w_lo <= w_max */
-                    const double lo = (double)(kRepackBuckets - 1u - b) / (double)kRepackBuckets;
-                    double kd = lo > 0.0 ? 1.0 + R * (1.0 / lo - 1.0) : 64.0;
-                    unsigned int kk = kd >= 64.0 ? 64u : (unsigned int)kd;
-                    kk = kk < 1u ? 1u : kk;
-                    plan[b] = (unsigned int)(waves * 64);
-                    plan[kRepackBuckets + b] = kk;
-                    waves += (h[b] + kk - 1u) / kk;
-                }
-                if (waves <= cap_waves)
-                    break;
-            }
-            if (waves > cap_waves) /* cannot happen: at a huge R every bucket takes 64 lanes per wave */
-                return hipErrorInvalidValue;
-            n_slots = waves * 64;
-            if ((e = hipMemsetAsync(d_perm, 0xff, n_slots * sizeof(unsigned int), st)) != hipSuccess)
-                return e;
-            if ((e = hipMemcpyAsync(d_plan, plan, sizeof plan, hipMemcpyHostToDevice, st)) != hipSuccess)
-                return e;
-            hipLaunchKernelGGL(repack_scatter_kernel, dim3(blocks), dim3(256), 0, st, d_work, (unsigned long long)n_chains, d_wmax,
-                               d_plan, d_perm);
-            if ((e = hipGetLastError()) != hipSuccess)
-                return e;
-            /* `plan` is a stack array handed to an asynchronous copy: it must not go out of scope before the copy has run */
-            if ((e = hipStreamSynchronize(st)) != hipSuccess)
-                return e;
-            packed = true;
-        }
-        return hipSuccess;
     }
 
     int run(size_t n_collect, size_t n_discard, void *out, int out_is_device, int progress, void *stream_v) override
@@ -798,8 +615,6 @@ template <class TT, class ST> struct Nuts : NutsBase {
         if (const char *e = mm_tuning_env("MMCMC_NUTS_ASYNC_BATCH")) /* tuning aid; no result depends on it */
             a.async_batch = (unsigned int)atoi(e);
         a.scratch = d_scratch;
-        a.perm = nullptr;
-        a.n_slots = 0;
         const size_t total = n_collect + n_discard;
         if (progress == 2) {
             a.write_initial = 0;
@@ -824,17 +639,8 @@ template <class TT, class ST> struct Nuts : NutsBase {
             a.n_rec = (unsigned int)n_collect;
         }
         MM_HIP(hipEventRecord(ev0, st));
-        /* the asynchronous-lane pair kernel in several launches with the chains re-packed by their recent work in between
-         * (see repack_work_kernel): only with the pending-subtree stack in LDS (the HBM scratch is sized per natural wave) */
-        const bool pair_kernel = (rtc_target && rtc_run_kernel == 2) || (!rtc_target && !use_generic && !use_lg && variant == 5 && k && k->run_pair);
-        const size_t pair_lds = (size_t)MM_NUTS_RING * 64 * sizeof(double) +
-                                (size_t)max_depth * 64 * (3 * (size_t)dim * sizeof(TT) + sizeof(ST) + 3 * sizeof(uint32_t));
         const unsigned int a_pre = a.n_pre, a_rec = a.n_rec;
-        const size_t waves0 = (n_chains + 63) / 64;
-        const bool room = rtc_target ? scratch_waves >= waves0 + waves0 / 4 + kRepackBuckets : pair_lds <= MM_NUTS_ASYNC_LDS_LIMIT;
-        if (pair_kernel && repack_launches > 1 && n_chains >= 4096 && (size_t)a_pre + a_rec >= 16 && room) {
-            e = run_pair_repacked(a, rtc_target, type_mode, st);
-        } else if (rtc_target) {
+        if (rtc_target) {
             /* a run-time compiled target: asynchronous lanes with the leaves in pairs (mm_nuts_pair_body; dynamic LDS = the
              * ring of uniforms, stack in the scratch area).  The unit's lanes-in-step kernel (mm_nuts_run_body) is NOT
              * launched: it gave wrong, run-to-run different samples at RosenbrockND(19) / (23) in f64 and a memory fault at
@@ -1079,13 +885,6 @@ int mmcmc_nuts_set_kernel_variant(mmcmc_nuts *h, int variant)
     return h ? h->p->set_variant(variant) : MMCMC_ERR_INVALID_ARG;
 }
 int mmcmc_nuts_kernel_variant(mmcmc_nuts *h) { return h ? h->p->variant : MMCMC_ERR_INVALID_ARG; }
-int mmcmc_nuts_set_repacking(mmcmc_nuts *h, int launches)
-{
-    if (!h || launches < 1 || launches > 8)
-        return MMCMC_ERR_INVALID_ARG;
-    h->p->repack_launches = launches;
-    return MMCMC_OK;
-}
 int mmcmc_nuts_set_compaction(mmcmc_nuts *h, int first_level, int n_groups)
 {
     if (!h || first_level < 0 || first_level > MM_NUTS_JMAX || n_groups < 0 || n_groups > 16)

@@ -35,13 +35,6 @@ template <class TT, class ST> struct mm_nuts_args {
     int stack_in_lds;
     unsigned int async_batch;  /* mm_nuts_async_kernel: lanes between transitions wait for this many (0 = default) */
     unsigned char *scratch;    /* global stack storage when !stack_in_lds: per wave mm_nuts_stack_bytes<>() */
-    /* mm_nuts_pair_kernel only: which chain a lane runs.  NULL: slot = chain (64 consecutive chains per wave).  Else slot s
-     * (wave s / 64, lane s % 64) of n_slots runs local chain perm[s], 0xffffffff = the lane idles: the host re-packs the
-     * chains between the launches of one run so that chains of similar recent work share a wave and the heaviest sit in
-     * sparsely filled ones (mm_nuts_api.hip).  A chain's results do not depend on where it runs: its stream is keyed by its
-     * global index, its rows, state, adaptation state and counters are addressed by it. */
-    const unsigned int *perm;
-    unsigned long long n_slots;
 };
 
 template <class TT, class ST, int D> struct mm_nuts_stack_layout {
@@ -379,13 +372,8 @@ __device__ __forceinline__ void mm_nuts_pair_body(const mm_nuts_args<TT, ST> &a)
     if (lane <= MM_NUTS_JMAX)
         hist_lds[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
-    unsigned long long c = (unsigned long long)blockIdx.x * 64 + lane;
-    bool active = c < a.n_chains;
-    if (a.perm) { /* re-packed: the slot's chain, or none */
-        const unsigned int p = c < a.n_slots ? a.perm[c] : 0xffffffffu;
-        active = p != 0xffffffffu && (unsigned long long)p < a.n_chains;
-        c = active ? (unsigned long long)p : 0ull;
-    }
+    const unsigned long long c = (unsigned long long)blockIdx.x * 64 + lane;
+    const bool active = c < a.n_chains;
     const unsigned long long chain = a.chain_offset + c;
     double *const ring = reinterpret_cast<double *>(mm_lds_raw) + lane; /* slot s of this lane: ring[64 s] */
     constexpr size_t ring_bytes = (size_t)MM_NUTS_RING * 64 * sizeof(double);
@@ -558,7 +546,7 @@ template <class TT, class ST, class Tgt>
 hipError_t mm_launch_nuts_run_pair(const mm_nuts_args<TT, ST> &a, hipStream_t stream)
 {
     using Lay = mm_nuts_stack_layout<TT, ST, Tgt::dim>;
-    const unsigned int grid = (unsigned int)(((a.perm ? a.n_slots : a.n_chains) + 63) / 64);
+    const unsigned int grid = (unsigned int)((a.n_chains + 63) / 64);
     const size_t ring = (size_t)MM_NUTS_RING * 64 * sizeof(double);
     const size_t need = ring + Lay::bytes_for(a.max_depth);
     if (need <= MM_NUTS_ASYNC_LDS_LIMIT)

@@ -65,12 +65,6 @@ class NUTS:
         L.check(L.lib().mmcmc_nuts_set_compaction(self._h, int(first_level), int(n_groups)), "mmcmc_nuts_set_compaction")
         return self
 
-    def set_repacking(self, launches: int = 4) -> "NUTS":
-        """Asynchronous-lane kernels: launches per run() with the chains re-packed by their recent work in between (1 = one
-        launch, natural waves).  No result depends on it."""
-        L.check(L.lib().mmcmc_nuts_set_repacking(self._h, int(launches)), "mmcmc_nuts_set_repacking")
-        return self
-
     @property
     def kernel_variant(self) -> int:
         return int(L.lib().mmcmc_nuts_kernel_variant(self._h))

@@ -916,41 +916,6 @@ def test_nuts_posterior_and_run_progress_stats(M, O):
 
 
 @pytest.mark.gpu
-def test_nuts_repacking_between_launches_changes_no_result(M, O):
-    """mmcmc_nuts_set_repacking (off by default: measured slower): a run() of the asynchronous-lane kernel cut
-    into several launches, the chains dealt to the waves anew in between by their recent work (heaviest first, the heaviest
-    in sparse waves).  Samples, positions,
-    adaptation state, leapfrog counts and the depth histogram equal the single launch's bit for bit -- with the initial row
-    of run() (nuts.rs:457-471), a ragged chain count, a chain offset, f32 and f64 tensors, a continued run, a run-time
-    compiled dimension -- and the host build."""
-    from mini_mcmc_amd.nuts import NUTS
-
-    cases = [(M.dist.RosenbrockND(3), 3, 0, 5000, False), (M.dist.RosenbrockND(3), 3, 2, 4100, True),
-             (M.dist.StandardNormal(8), 8, 0, 4500, True), (M.dist.RosenbrockND(11), 11, 0, 4200, True)]
-    for tgt, d, mode, n, progress in cases:
-        init = M.core.init_with_seed(n, d, 17) * 0.5
-        res = []
-        for launches in (1, 4, 7):
-            s = NUTS(tgt, init, 0.8, mode=mode).set_seed(3).set_chain_offset(1 << 20).set_repacking(launches)
-            a = s._run(20, 30, progress, "numpy")
-            b = s._run(9, 8, progress, "numpy")  # continues: init_chain again, m goes on
-            # 16 / 17 transitions: cuts at 4 and 8 -- where the pending-subtree stack sits in LDS (f32 tensors up to D = 3 here)
-            # or in the HBM scratch of a run-time compiled unit; elsewhere the run stays one launch
-            packs = (mode == 0 and d <= 3) or d == 11  # (a run-time compiled unit keeps its stack in HBM, sized for re-packing)
-            assert s.timing()["n_launches"] == (3 if (launches > 1 and packs) else 1), (d, mode, launches)
-            res.append((a, b, s.positions(), s.adapt_state()["epsilon"], s.leapfrog_counts(), s.depth_histogram()))
-        for r in res[1:]:
-            for x, y in zip(r, res[0]):
-                assert np.array_equal(x, y), (type(tgt).__name__, d, mode)
-    # the single launch is what the host build reproduces (tests above); one direct check here
-    init = M.core.init_with_seed(4100, 3, 17) * 0.5
-    s = NUTS(M.dist.RosenbrockND(3), init, 0.8, mode=0).set_seed(3).set_repacking(4)
-    out = s._run(20, 30, True, "numpy")
-    ref, pos, ad, nlf = O.engine_host_nuts_run(0, O.ROSENBROCK_ND, 3, [], init, 0.8, 20, 30, seed=3, progress=True)
-    assert np.array_equal(out, ref) and np.array_equal(s.leapfrog_counts(), nlf)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2), (5, 2050, 2),
                                    (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2), (64, 33000, 2)])
 def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):

@@ -1,4 +1,5 @@
-"""The asynchronous-lane NUTS kernel with and without re-packing the chains between the launches of a run
+"""[round 5: the feature this script timed -- mmcmc_nuts_set_repacking, measured slower in round 4 -- has been removed from the library; kept as the record of how profiles/r4g_nuts_repack_timing.jsonl was made]
+The asynchronous-lane NUTS kernel with and without re-packing the chains between the launches of a run
 (mmcmc_nuts_set_repacking): kernel time of run_progress(100, 100) at 65 536 chains, same bits either way.
 python3 tools/nuts_repack_timing.py [launch counts ...]"""
 import json, os, sys
