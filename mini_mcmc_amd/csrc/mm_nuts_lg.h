@@ -859,6 +859,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             return mm_u53(hi, lo);
         };
         auto leaf_l = [&](unsigned int leaf) __attribute__((always_inline)) {
+            MM_LG_COUNT(L, 6);
             leaf_iters += 1u;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -1071,6 +1072,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if (k_stop >= j)
                 break; /* reached the doubling's own level: complete */
         }
+        MM_LG_TICK(L, 2); /* tools/lg_profile.py: the whole lean loop lands in section 2 */
         if (died) {
             S_n = F_n;
             S_alpha = F_alpha;
