@@ -181,6 +181,10 @@ int group_destroy(Group *g)
 {
     if (!g)
         return MMCMC_ERR_INVALID_ARG;
+    /* runs may still be queued on the shards' streams (the asynchronous group_run): nothing they use may be freed under them */
+    for (Shard &s : g->sh)
+        if (s.stream && hipSetDevice(s.device) == hipSuccess)
+            (void)hipStreamSynchronize(s.stream);
     for (Shard &s : g->sh) {
         s.worker.reset();
         (void)hipSetDevice(s.device);

@@ -118,18 +118,23 @@ hipError_t mm_copy_to_host(void *dst, const void *d_src, size_t bytes, int devic
             consumed[i % kRing].fetch_add(1, std::memory_order_release);
         }
     };
+    /* T copy threads beside this one, which drives the DMA ring.  A host that cannot start threads (resource limits) gets
+     * the plain copy: nothing may throw across the C ABI */
     std::vector<std::thread> threads;
-    threads.reserve((size_t)T);
-    for (int t = 1; t < T; ++t)
-        threads.emplace_back(worker, t);
-    /* this thread drives the DMA ring (and is worker 0 only when it is the only thread) */
+    try {
+        threads.reserve((size_t)T);
+        for (int t = 0; t < T; ++t)
+            threads.emplace_back(worker, t);
+    } catch (...) {
+        failed.store(true, std::memory_order_relaxed);
+        for (std::thread &th : threads)
+            th.join();
+        if ((e = hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream)) != hipSuccess)
+            return e;
+        return hipStreamSynchronize(stream);
+    }
     size_t issued = 0, pub = 0;
     e = hipSuccess;
-    std::thread self_worker;
-    if (T == 1)
-        self_worker = std::thread(worker, 0);
-    else
-        threads.emplace_back(worker, 0);
     while (pub < n_chunks) {
         bool progressed = false;
         if (issued < n_chunks) {
@@ -165,8 +170,6 @@ hipError_t mm_copy_to_host(void *dst, const void *d_src, size_t bytes, int devic
     }
     for (std::thread &th : threads)
         th.join();
-    if (self_worker.joinable())
-        self_worker.join();
     if (e != hipSuccess)
         (void)hipStreamSynchronize(stream); /* nothing of ours may still be in flight when the buffers are reused */
     return e;
