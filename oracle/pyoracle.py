@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
         "o_engine_normal_f64": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "o_engine_normal_f64_libm": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "o_engine_accept_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32]),
+        "o_engine_mhp_normal_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+        "o_engine_mhp_accept_f32": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32]),
         "o_engine_aux_u53": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "ot_logp_f32": (C.c_float, [tp, _fp]),
         "ot_logp_f64": (C.c_double, [tp, _dp]),
@@ -285,6 +287,13 @@ def engine_normals_f64(seed, chain, iteration, n):
 
 def engine_accept_f32(seed, chain, iteration):
     return np.float32(lib().o_engine_accept_f32(seed, chain, iteration))
+
+
+def engine_mhp_noise_f32(seed, chain, iteration, dim):
+    """The MH sampler's paired f32 stream at dim <= 2 (csrc/mm_rng.h, oracle/orng.c: o_engine_mhp_*): (z[dim], u)."""
+    L = lib()
+    return (np.array([L.o_engine_mhp_normal_f32(seed, chain, iteration, i) for i in range(dim)], dtype=np.float32),
+            np.float32(L.o_engine_mhp_accept_f32(seed, chain, iteration)))
 
 
 def engine_aux_u53(seed, chain, iteration, k):

@@ -42,6 +42,37 @@ def test_engine_normals_and_uniforms_distribution(O):
     assert a.min() > 0 and a.max() <= 1 and abs(a.mean() - 0.5) < 0.01
 
 
+def test_mh_paired_stream_restatement_is_two_transitions_per_block(O):
+    """The MH sampler's f32 stream at dim <= 2 (csrc/mm_rng.h, round 5) as oracle/orng.c restates it, against its TEXT written out
+    here on the oracle's Philox: iteration t takes words 2h, 2h + 1 (h = t & 1) of block (chain, t >> 1, 0x20000000) -- the normals
+    from their top 24 bits (the same inverse-CDF map as everywhere), the accept uniform's high 16 bits from their low bytes --
+    and the uniform's low 8 bits from byte h of word 0 of block (chain, t >> 1, 0x20000001); u = (s16 256 + s8 + 1) 2^-24.
+    (The GPU is compared with an independent numpy statement of the same text in tests/test_gpu_stream_independent.py; the host
+    twin of the engine's MH step with this restatement, reference order, in tests/test_step_parity.py.)"""
+    seed = 0x1122334455667788
+    key = [seed & 0xFFFFFFFF, seed >> 32]
+    for chain in (0, 5, (7 << 32) | 123456):
+        for t in (0, 1, 76, 77, 1001):
+            w = O.philox4x32_10([chain & 0xFFFFFFFF, chain >> 32, t >> 1, 0x20000000], key)
+            a = O.philox4x32_10([chain & 0xFFFFFFFF, chain >> 32, t >> 1, 0x20000001], key)
+            h = t & 1
+            wa, wb = w[2 * h], w[2 * h + 1]
+            z, u = O.engine_mhp_noise_f32(seed, chain, t, 2)
+            want = np.zeros(2, dtype=np.float32)
+            O.lib().o_engine_icdf24_words((C.c_uint32 * 2)(wa, wb), 2, want.ctypes.data_as(C.POINTER(C.c_float)))
+            assert np.array_equal(z, want)
+            s16 = (wa & 255) | ((wb & 255) << 8)
+            s8 = (a[0] >> (8 * h)) & 255
+            assert u == np.float32((s16 * 256 + s8 + 1) * 2.0**-24)
+            z1, u1 = O.engine_mhp_noise_f32(seed, chain, t, 1)
+            assert z1[0] == z[0] and u1 == u
+    # two iterations of a pair share the block, neighbouring pairs do not: the four normals of (2k, 2k + 1) are distinct words
+    zs = np.array([O.engine_mhp_noise_f32(42, c, t, 2)[0] for c in range(4000) for t in (10, 11)], dtype=np.float64).reshape(-1)
+    us = np.array([O.engine_mhp_noise_f32(42, c, t, 2)[1] for c in range(4000) for t in (10, 11)], dtype=np.float64)
+    assert abs(zs.mean()) < 0.03 and abs(zs.var() - 1) < 0.05 and abs(us.mean() - 0.5) < 0.02
+    assert abs(np.corrcoef(us[0::2], us[1::2])[0, 1]) < 0.05  # the two uniforms of a pair: disjoint bits
+
+
 def test_f32_normal_is_the_inverse_cdf_on_the_whole_24_bit_lattice(O):
     """mm_rng.h "icdf24": z = sign * -Phi^-1(n 2^-25), n = (w >> 8) | 1.  EVERY one of the 2^23 magnitudes: the
     product's evaluation (host build of mm_icdf_f32) equals the oracle's independent restatement bit for bit and is
@@ -209,8 +240,32 @@ template <int D> int check(uint64_t seed) {
   }
   return bad;
 }
+// the MH sampler's paired stream (f32, D <= 2): the pair call from an EVEN iteration (one shared block) and from an ODD one
+// (two blocks) against the per-iteration call; with LN = false the pair hands out u_hi = the upper end of the uniform's
+// interval, from which the filtered accept test must decide as the plain comparison does on the exact u
+template <int D> int check_mhp(uint64_t seed) {
+  int bad = 0;
+  const mm_icdf_global tab;
+  for (uint64_t chain = 0; chain < 2000; ++chain) for (uint32_t it = 0; it < 9; ++it) {
+    float za[D], zb[D], la, lb, ha, hb, z1[D], z2[D], u1, u2;
+    mm_draw_noise_pair<D, mm_icdf_global, true, true>(seed, chain * 7919u, it, za, &la, zb, &lb);
+    mm_draw_noise<D, mm_icdf_global, true>(seed, chain * 7919u, it, z1, &u1);
+    mm_draw_noise<D, mm_icdf_global, true>(seed, chain * 7919u, it + 1, z2, &u2);
+    for (int i = 0; i < D; ++i) bad += (za[i] != z1[i]) + (zb[i] != z2[i]);
+    bad += (la != mm_lnu_f32(u1, tab)) + (lb != mm_lnu_f32(u2, tab));
+    mm_draw_noise_pair<D, mm_icdf_global, false, true>(seed, chain * 7919u, it, za, &ha, zb, &hb);
+    bad += !(u1 <= ha && ha - u1 < 0x1.0p-16f) + !(u2 <= hb && hb - u2 < 0x1.0p-16f);
+    const float probes[] = {la, la + 1e-6f, la - 1e-6f, 0.0f, -1.0f, -20.0f};
+    for (float r : probes) {
+      const uint64_t sd = seed, ch = chain * 7919u; const uint32_t t = it;
+      bad += mm_ratio_exceeds_lnu_mhp(r, ha, [sd, ch, t]() { return mm_mhp_low_byte(sd, ch, t); }, tab) != (r > la);
+    }
+  }
+  return bad;
+}
 int main() {
   int bad = check<1>(1) + check<2>(42) + check<3>(42) + check<4>(5) + check<5>(6) + check<8>(7) + check<16>(8) + check<32>(9);
+  bad += check_mhp<1>(3) + check_mhp<2>(42);
   double za[3], zb[3], la, lb, z1[3], z2[3], u1, u2;
   mm_draw_noise_pair<3>(42, 5, 10, za, &la, zb, &lb);
   mm_draw_noise<3>(42, 5, 10, z1, &u1); mm_draw_noise<3>(42, 5, 11, z2, &u2);
