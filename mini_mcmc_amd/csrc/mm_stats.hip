@@ -1147,9 +1147,34 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
     auto tw2_of = [&](int g) -> mm_cx { return tw[R1 * 64 + g * 8 + (lane & 7u)]; };
     const size_t second = (size_t)(n - m) * D; /* the second half-chain: rows [n - m, n) */
     const float inv_m = 1.0f / (float)m;
+    /* N1 = 2 (half-chains up to 2048 draws): a lane's R1 points of both half-chains stay in its registers, so the chain is
+     * read ONCE -- the means and both residue passes take their points from there -- instead of three times (round 5:
+     * [65536, 4000, 3] 4.0 -> 3.3 ms).  At N1 = 4 the 128 cached values per lane made the kernel SLOWER ([65536, 8000, 3]
+     * 13.4 -> 19.4 ms): kept to N1 = 2 */
+    constexpr bool CACHE = HALF == 1;
     for (unsigned long long c = wg; c < C; c += n_wg) {
         const T *const base = sample + (size_t)c * n * D + d;
         float s0 = 0.f, s1 = 0.f;
+        float c0[CACHE ? R1 : 1][CACHE ? HALF : 1], c1[CACHE ? R1 : 1][CACHE ? HALF : 1];
+        if constexpr (CACHE) {
+#pragma unroll
+            for (int a = 0; a < R1; ++a)
+#pragma unroll
+                for (int n1 = 0; n1 < HALF; ++n1) {
+                    const unsigned int t = 64u * a + lane + 2048u * n1, tc = t < m ? t : m - 1u;
+                    c0[a][n1] = (float)base[(size_t)tc * D];
+                    c1[a][n1] = (float)base[second + (size_t)tc * D];
+                }
+            /* the same summation order as the strided pass below: t = lane + 64 i ascending per lane, i.e. n1-major */
+#pragma unroll
+            for (int n1 = 0; n1 < HALF; ++n1)
+#pragma unroll
+                for (int a = 0; a < R1; ++a) {
+                    const bool in = 64u * a + lane + 2048u * n1 < m;
+                    s0 += in ? c0[a][n1] : 0.f;
+                    s1 += in ? c1[a][n1] : 0.f;
+                }
+        } else
         for (unsigned int t0 = lane; t0 < m; t0 += 64u * 8u) {
             float u0[8], u1[8];
 #pragma unroll
@@ -1183,9 +1208,14 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
                     wt[aa] = wN[(n2 * k1) & (N - 1u)]; /* w_N^(n2 k1) */
 #pragma unroll
                     for (int n1 = 0; n1 < HALF; ++n1) {
-                        const unsigned int t = n2 + 2048u * n1, tc = t < m ? t : m - 1u;
-                        r0[aa][n1] = (float)base[(size_t)tc * D];
-                        r1[aa][n1] = (float)base[second + (size_t)tc * D];
+                        if constexpr (CACHE) {
+                            r0[aa][n1] = c0[a0 + aa][n1];
+                            r1[aa][n1] = c1[a0 + aa][n1];
+                        } else {
+                            const unsigned int t = n2 + 2048u * n1, tc = t < m ? t : m - 1u;
+                            r0[aa][n1] = (float)base[(size_t)tc * D];
+                            r1[aa][n1] = (float)base[second + (size_t)tc * D];
+                        }
                     }
                 }
 #pragma unroll
