@@ -17,8 +17,10 @@
  *                writes the full tiles to HBM (the stores' issue latency costs the transition wave nothing).
  *   The ring has two halves of RB transitions, there are two tiles per pair; one s_barrier per RB transitions hands a
  *   filled ring half and a full tile over and the drained / flushed ones back.  Where the noise outweighs the
- *   transition (MH: ~115 of ~140 instructions) the transition wave draws QP of the RB / 2 noise pairs of a batch
- *   itself, so that both waves carry about the same load.
+ *   transition (MH before round 5: ~115 of ~140 instructions) the transition wave draws QP of the RB / 2 noise pairs of a
+ *   batch itself, so that both waves carry about the same load (mm_split_mh_qp; round 5: with the table-free accept test
+ *   and the MH sampler's paired stream -- one Philox block per two transitions, mm_rng.h -- the noise is the light role
+ *   and keeps all of it, QP = 0).
  *   NN > 1 (f32 instances: 3): NN noise waves per pair in a 256 (1 + NN)-thread workgroup, the noise pairs of a batch dealt
  *   to them in turn -- neither role is near its own issue bound, both wait on LDS table reads and dependent issue, and
  *   with the chain count fixing the number of transition waves the noise is the part that can be spread over more
