@@ -68,6 +68,45 @@ Rccl &rccl()
     return r;
 }
 
+/* withinvar's cross-chain sums (stats.rs:449-465) over the GATHERED per-half-chain statistics, on the device (round 5: the
+ * host used to copy all N x 2 x part floats back and walk them -- 1 ms at one device, and growing with the device count):
+ * block (x = 4 d + quarter, y = rank i) sums a quarter of rank i's 2 n_i half-chains of parameter d in f64 -- sum of the means,
+ * of their squares, of the biased variances ssq / m -- into out[((i D + d) 4 + quarter) 3 ..]; the host adds the N x 4 partial
+ * sums of a parameter in index order and forms sum((mean - overall)^2) = Sq - Sd^2 / c2.  gathered: [N][means (part) | ssq (part)],
+ * a rank's valid entries first (2 n_i D), zero padding behind. */
+struct GroupCounts {
+    unsigned int n2[64]; /* 2 n_i */
+};
+__global__ __launch_bounds__(256) void mm_group_cross_sums_kernel(const float *__restrict__ gathered, size_t part, unsigned int D,
+                                                                  float nf, GroupCounts cnt, double *__restrict__ out)
+{
+    __shared__ double red[3][256];
+    const unsigned int d = blockIdx.x >> 2, quarter = blockIdx.x & 3u, i = blockIdx.y, tid = threadIdx.x;
+    const float *mi = gathered + (size_t)i * 2 * part, *qi = mi + part;
+    const unsigned int c2 = cnt.n2[i], per = (c2 + 3u) / 4u, lo = quarter * per, hi = lo + per < c2 ? lo + per : c2;
+    double sd = 0.0, sq = 0.0, ws = 0.0;
+    for (unsigned int c = lo + tid; c < hi; c += 256u) {
+        const double mu = (double)mi[(size_t)c * D + d];
+        sd += mu;
+        sq += mu * mu;
+        ws += (double)(qi[(size_t)c * D + d] / nf); /* biased per-chain variance (quirk Q8) */
+    }
+    red[0][tid] = sd;
+    red[1][tid] = sq;
+    red[2][tid] = ws;
+    __syncthreads();
+    for (unsigned int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            red[0][tid] += red[0][tid + st];
+            red[1][tid] += red[1][tid + st];
+            red[2][tid] += red[2][tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid < 3)
+        out[(((size_t)i * D + d) * 4 + quarter) * 3 + tid] = red[tid][0];
+}
+
 /* one host thread per device for the life of the group: calls into the per-device ABI block only their own thread,
  * and per-thread state of that ABI (the statistics' work buffers) stays with its device */
 class Worker {
@@ -486,7 +525,8 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
         return MMCMC_ERR_SHAPE;
     const size_t part = 2 * g->cmax * D;             /* per-device means (or ssq), padded to the largest shard */
     const size_t own = 2 * part + m * D;             /* means | ssq | acov */
-    const size_t total = own + N * 2 * part + m * D; /* + gathered [N][means | ssq] + reduced acov */
+    const size_t n_cs = N * D * 4 * 3;               /* partial cross-chain sums (f64) of mm_group_cross_sums_kernel */
+    const size_t total = own + N * 2 * part + m * D + 2 * n_cs + 2; /* + gathered [N][means | ssq] + reduced acov + the partial sums */
     if (used_rccl)
         *used_rccl = g->exchange_status;
     std::vector<float> h_own(g->use_rccl ? 0 : N * own);
@@ -531,6 +571,16 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
                 return (int)hipErrorUnknown;
             if (rccl().AllReduce(acov, acov_all, m * D, kNcclFloat32, kNcclSum, s.comm, s.stream) != 0)
                 return (int)hipErrorUnknown;
+            if (i == 0 && N <= 64) { /* the cross-chain sums of ALL ranks' half-chains, from shard 0's copy of the gathered statistics */
+                GroupCounts cnt;
+                for (size_t r = 0; r < N; ++r)
+                    cnt.n2[r] = (unsigned int)(2 * g->sh[r].n);
+                double *cs = reinterpret_cast<double *>(s.d_stats + ((own + N * 2 * part + m * D + 1) / 2) * 2);
+                hipLaunchKernelGGL(mm_group_cross_sums_kernel, dim3((unsigned int)D * 4u, (unsigned int)N), dim3(256), 0, s.stream, gathered,
+                                   part, (unsigned int)D, (float)m, cnt, cs);
+                if ((e = hipGetLastError()) != hipSuccess)
+                    return (int)e;
+            }
         } else {
             if ((e = hipMemcpyAsync(h_own.data() + (size_t)i * own, s.d_stats, own * sizeof(float), hipMemcpyDeviceToHost, s.stream)) != hipSuccess)
                 return (int)e;
@@ -540,8 +590,42 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
     });
     if (st != MMCMC_OK)
         return st;
-    /* host finish on the global statistics in splitcat order: first halves of all chains, then second halves */
-    std::vector<float> g_all(N * 2 * part), acov(m * D, 0.f);
+    /* RCCL path: the finish needs the gathered statistics only through their cross-chain sums, which shard 0 has reduced on
+     * the device.  Host-exchange path (a device listed twice, no RCCL): the host walks the statistics in splitcat order (first
+     * halves of all chains, then second halves) */
+    std::vector<float> acov;
+    if (g->use_rccl && N <= 64) {
+        /* a few KB come back: the reduced lag sums and the N x 4 partial cross-chain sums per parameter */
+        Shard &s0 = g->sh[0];
+        (void)hipSetDevice(s0.device);
+        const float *acov_all = s0.d_stats + own + N * 2 * part;
+        const double *cs = reinterpret_cast<const double *>(s0.d_stats + ((own + N * 2 * part + m * D + 1) / 2) * 2);
+        std::vector<double> h_cs(n_cs);
+        acov.resize(m * D);
+        hipError_t e = hipMemcpy(acov.data(), acov_all, acov.size() * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(h_cs.data(), cs, n_cs * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return (int)e;
+        const double c2 = 2.0 * (double)g->n_chains;
+        std::vector<double> dsum(D), wsum(D);
+        for (size_t d = 0; d < D; ++d) {
+            double sd = 0.0, sq = 0.0, ws = 0.0;
+            for (size_t r = 0; r < N; ++r)
+                for (size_t qtr = 0; qtr < 4; ++qtr) {
+                    const double *q3 = h_cs.data() + ((r * D + d) * 4 + qtr) * 3;
+                    sd += q3[0];
+                    sq += q3[1];
+                    ws += q3[2];
+                }
+            const double ds = sq - sd * sd / c2; /* sum of (mean - overall mean)^2 */
+            dsum[d] = ds > 0.0 ? ds : 0.0;
+            wsum[d] = ws;
+        }
+        return mmcmc_stats_finish_sums(dsum.data(), wsum.data(), acov.data(), 2 * g->n_chains, m, D, rhat, ess);
+    }
+    std::vector<float> g_all(N * 2 * part);
+    acov.assign(m * D, 0.f);
     if (g->use_rccl) {
         Shard &s0 = g->sh[0];
         (void)hipSetDevice(s0.device);
