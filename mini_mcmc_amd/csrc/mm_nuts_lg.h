@@ -470,8 +470,26 @@ template <int D> __device__ __forceinline__ double *mm_lg_rec_scalar(const mm_nu
     return a.rec + (size_t)mm_lg_cfg<D>::n_vec * D * a.c_pad + (size_t)f * a.c_pad + L.cl;
 }
 
-/* start of a transition (nuts.rs:550-576): momentum, log joint, slice; both edges = (x, p0, grad) */
-template <int D, bool COH = false, int OCC = 1> __device__ __forceinline__ void mm_lg_begin(mm_lg_lane<D> &L, const mm_nuts_lg_args &a)
+/* Both trajectory edges of the wave's chains in REGISTERS (the persistent scheduler, one wave per SIMD: round 5).  With the
+ * edges in the chains' records every doubling starts with a load of the edge it extends and ends with a load of the other one
+ * for the whole-trajectory criterion -- two dependent HBM round trips of ~2000 cycles each, which is two thirds of a leaf
+ * iteration per doubling: the doublings 0 .. 3 of a transition (15 leaves) cost 44 000 cycles of leaves and 24 000 of waiting
+ * (tools/nuts_lg_floor_probe.hip by level: 3113 cycles per leaf iteration at level 5, 2930 at level 9).  Here a unit loads both
+ * edges once (a unit that begins a transition: none at all), every doubling of the unit finds them in registers -- the edge
+ * not being extended is not touched by the leaf loop and waits in accumulation registers -- and the unit stores what it changed
+ * when it parks the chains.  `cur` is the edge extended last, per lane (the direction is the chain's own draw): a doubling in
+ * the other direction swaps the two under the lane mask. */
+template <int D> struct mm_lg_edges {
+    static constexpr int NS = D / 4;
+    double cx[NS], cp[NS], cg[NS]; /* the edge extended last: position, momentum, A x */
+    double ox[NS], op[NS], og[NS]; /* the other edge */
+    bool cur_neg;                  /* cur is the minus edge (this lane's chain) */
+};
+
+/* start of a transition (nuts.rs:550-576): momentum, log joint, slice; both edges = (x, p0, grad), written to the chain's
+ * record or (E != nullptr) left in registers */
+template <int D, bool COH, int OCC, bool RES>
+__device__ __forceinline__ void mm_lg_begin(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, mm_lg_edges<D> &E)
 {
     using Cfg = mm_lg_cfg<D, OCC>;
     constexpr int NS = Cfg::NS;
@@ -496,6 +514,16 @@ template <int D, bool COH = false, int OCC = 1> __device__ __forceinline__ void 
     L.alpha = 0.0;
     L.n_alpha = 0;
     L.depth = 0;
+    if constexpr (RES) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            E.cx[s] = E.ox[s] = L.x[s];
+            E.cp[s] = E.op[s] = p0[s];
+            E.cg[s] = E.og[s] = grad[s];
+        }
+        E.cur_neg = false;
+        return;
+    }
     const size_t st = (size_t)a.c_pad * 4;
     double *xm = mm_lg_rec_vec<D>(a, L, Cfg::V_XM), *pm = mm_lg_rec_vec<D>(a, L, Cfg::V_PM),
            *gm = mm_lg_rec_vec<D>(a, L, Cfg::V_GM), *xp = mm_lg_rec_vec<D>(a, L, Cfg::V_XP),
@@ -511,11 +539,17 @@ template <int D, bool COH = false, int OCC = 1> __device__ __forceinline__ void 
     }
 }
 
+template <int D, bool COH = false, int OCC = 1> __device__ __forceinline__ void mm_lg_begin(mm_lg_lane<D> &L, const mm_nuts_lg_args &a)
+{
+    mm_lg_edges<D> none;
+    mm_lg_begin<D, COH, OCC, false>(L, a, none);
+}
+
 /* doubling j of the wave's chains (one iteration of `while s`, nuts.rs:578-671); `alive` in: the chain takes part,
  * out: it wants another doubling */
-template <int D, bool COH = false, int OCC = 1>
+template <int D, bool COH, int OCC, bool RES>
 __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, int j, bool &alive,
-                                               double epsilon, mm_lds_double *lds, double *scr)
+                                               double epsilon, mm_lds_double *lds, double *scr, mm_lg_edges<D> &E)
 {
     using Cfg = mm_lg_cfg<D, OCC>;
     constexpr int NS = Cfg::NS, ES = Cfg::ES;
@@ -569,7 +603,20 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     const bool neg = !(u_run_1 < 0.5); /* v = -1 */
     /* the outer edge in direction v, advanced in place: after the doubling it IS the returned edge */
     double cx[NS], cp[NS], cg[NS];
-    {
+    if constexpr (RES) {
+        /* the edges are in registers (mm_lg_edges): a doubling in the other direction than the last swaps them */
+        const bool sw = neg != E.cur_neg;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cx[s] = sw ? E.ox[s] : E.cx[s];
+            cp[s] = sw ? E.op[s] : E.cp[s];
+            cg[s] = sw ? E.og[s] : E.cg[s];
+            E.ox[s] = sw ? E.cx[s] : E.ox[s];
+            E.op[s] = sw ? E.cp[s] : E.op[s];
+            E.og[s] = sw ? E.cg[s] : E.og[s];
+        }
+        E.cur_neg = neg;
+    } else {
         const double *const ex0 = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_XM : Cfg::V_XP);
         const double *const ep0 = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_PM : Cfg::V_PP);
         const double *const eg0 = mm_lg_rec_vec<D>(a, L, neg ? Cfg::V_GM : Cfg::V_GP);
@@ -1176,28 +1223,40 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
     /* write the advanced edge back; whole-trajectory criterion against the other edge (d = x_cur - x_other).  The
      * record addresses are formed again from an opaque copy of the chain index: kept from the top of the doubling they
      * would hold ten registers across the leaf loop */
-    unsigned long long cl_end = L.cl;
-    asm volatile("" : "+v"(cl_end));
-    auto vec_end = [&](int v) __attribute__((always_inline)) {
-        return a.rec + ((size_t)v * NS * a.c_pad + cl_end) * 4 + L.q;
-    };
-    double *const ex = vec_end(neg ? Cfg::V_XM : Cfg::V_XP);
-    double *const ep = vec_end(neg ? Cfg::V_PM : Cfg::V_PP);
-    double *const eg = vec_end(neg ? Cfg::V_GM : Cfg::V_GP);
-    const double *const ox = vec_end(neg ? Cfg::V_XP : Cfg::V_XM);
-    const double *const op = vec_end(neg ? Cfg::V_PP : Cfg::V_PM);
     double ca = 0.0, cb = 0.0;
+    if constexpr (RES) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const double oxs = mm_lg_ld<COH>(&ox[s * st]), ops = mm_lg_ld<COH>(&op[s * st]);
-        if (alive) {
-            mm_lg_st<COH>(&ex[s * st], cx[s]);
-            mm_lg_st<COH>(&ep[s * st], cp[s]);
-            mm_lg_st<COH>(&eg[s * st], cg[s]);
+        for (int s = 0; s < NS; ++s) {
+            const double d = cx[s] - E.ox[s];
+            ca = fma(d, E.op[s], ca);
+            cb = fma(d, cp[s], cb);
+            E.cx[s] = cx[s];
+            E.cp[s] = cp[s];
+            E.cg[s] = cg[s];
         }
-        const double d = cx[s] - oxs;
-        ca = fma(d, ops, ca);
-        cb = fma(d, cp[s], cb);
+    } else {
+        unsigned long long cl_end = L.cl;
+        asm volatile("" : "+v"(cl_end));
+        auto vec_end = [&](int v) __attribute__((always_inline)) {
+            return a.rec + ((size_t)v * NS * a.c_pad + cl_end) * 4 + L.q;
+        };
+        double *const ex = vec_end(neg ? Cfg::V_XM : Cfg::V_XP);
+        double *const ep = vec_end(neg ? Cfg::V_PM : Cfg::V_PP);
+        double *const eg = vec_end(neg ? Cfg::V_GM : Cfg::V_GP);
+        const double *const ox = vec_end(neg ? Cfg::V_XP : Cfg::V_XM);
+        const double *const op = vec_end(neg ? Cfg::V_PP : Cfg::V_PM);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double oxs = mm_lg_ld<COH>(&ox[s * st]), ops = mm_lg_ld<COH>(&op[s * st]);
+            if (alive) {
+                mm_lg_st<COH>(&ex[s * st], cx[s]);
+                mm_lg_st<COH>(&ep[s * st], cp[s]);
+                mm_lg_st<COH>(&eg[s * st], cg[s]);
+            }
+            const double d = cx[s] - oxs;
+            ca = fma(d, ops, ca);
+            cb = fma(d, cp[s], cb);
+        }
     }
     mm_lg_group_sum2(ca, cb, &ca, &cb);
     const bool crit_all = neg ? (ca <= 0.0 && cb <= 0.0) : (ca >= 0.0 && cb >= 0.0);
@@ -1229,6 +1288,13 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         alive = s_new;
     }
     MM_LG_TICK(L, 4);
+}
+template <int D, bool COH = false, int OCC = 1>
+__device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, int j, bool &alive,
+                                               double epsilon, mm_lds_double *lds, double *scr)
+{
+    mm_lg_edges<D> none;
+    mm_lg_doubling<D, COH, OCC, false>(L, a, j, alive, epsilon, lds, scr, none);
 }
 
 /* Two waves per SIMD (OCC = 2): the doubling as an OUT-OF-LINE call with its state passed and returned by value.
@@ -1679,6 +1745,7 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
         t_prev = _n;                                                                                              \
     } while (0)
 
+    mm_lg_edges<D> E; /* OCC 1: both edges of the unit's chains */
     /* chains this wave keeps from its last unit (they all want doubling keep_level): their columns stay theirs */
     bool keep = false;
     int keep_level = 0;
@@ -1892,7 +1959,10 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
                 L.x[s] = mm_lg_ld<true>(&a.state[L.cl * D + 4 * s + L.q]);
             if (a.write_initial && a.out && valid && m_done == a.m0)
                 mm_lg_write_row<D>(L, a, a.out_t0); /* row 0 = the initial position (nuts.rs:534) */
-            mm_lg_begin<D, true, OCC>(L, a);
+            if constexpr (OCC == 1)
+                mm_lg_begin<D, true, OCC, true>(L, a, E); /* both edges stay in registers until the unit parks its chains */
+            else
+                mm_lg_begin<D, true, OCC>(L, a);
             if (OCC == 2 && valid) {
                 /* two waves per SIMD: the current sample lives in the chain's record from here to the end of the transition */
                 double *xs = mm_lg_rec_vec<D>(a, L, Cfg::V_X);
@@ -1909,6 +1979,22 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     L.x[s] = mm_lg_ld<true>(&xs[s * st]);
+            }
+            if constexpr (OCC == 1) {
+                /* both edges, in the same batch of loads as everything else of the chain: one memory latency per unit */
+                const double *xm = mm_lg_rec_vec<D>(a, L, Cfg::V_XM), *pm = mm_lg_rec_vec<D>(a, L, Cfg::V_PM),
+                             *gm = mm_lg_rec_vec<D>(a, L, Cfg::V_GM), *xp = mm_lg_rec_vec<D>(a, L, Cfg::V_XP),
+                             *pp = mm_lg_rec_vec<D>(a, L, Cfg::V_PP), *gp = mm_lg_rec_vec<D>(a, L, Cfg::V_GP);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    E.cx[s] = mm_lg_ld<true>(&xp[s * st]);
+                    E.cp[s] = mm_lg_ld<true>(&pp[s * st]);
+                    E.cg[s] = mm_lg_ld<true>(&gp[s * st]);
+                    E.ox[s] = mm_lg_ld<true>(&xm[s * st]);
+                    E.op[s] = mm_lg_ld<true>(&pm[s * st]);
+                    E.og[s] = mm_lg_ld<true>(&gm[s * st]);
+                }
+                E.cur_neg = false;
             }
             L.joint = mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT));
             L.logu = mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_LOGU));
@@ -1964,7 +2050,7 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
             alive = io.alive != 0;
         } else {
             for (int j = j_first; j < j_next && __ballot(alive) != 0ull; ++j)
-                mm_lg_doubling<D, true, OCC>(L, a, j, alive, ad.epsilon, lds, scr);
+                mm_lg_doubling<D, true, OCC, true>(L, a, j, alive, ad.epsilon, lds, scr, E);
         }
 
         MM_LGQ_T(2);
@@ -1976,6 +2062,30 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     mm_lg_st<true>(&xs[s * st], L.x[s]);
+            }
+            if constexpr (OCC == 1) {
+                /* the edges the unit changed: the one extended last; both after the several doublings of a unit that began
+                 * the transition (the record holds neither yet) */
+                double *cxr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_XM : Cfg::V_XP),
+                       *cpr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_PM : Cfg::V_PP),
+                       *cgr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_GM : Cfg::V_GP);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    mm_lg_st<true>(&cxr[s * st], E.cx[s]);
+                    mm_lg_st<true>(&cpr[s * st], E.cp[s]);
+                    mm_lg_st<true>(&cgr[s * st], E.cg[s]);
+                }
+                if (qi == 0) {
+                    double *oxr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_XP : Cfg::V_XM),
+                           *opr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_PP : Cfg::V_PM),
+                           *ogr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_GP : Cfg::V_GM);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        mm_lg_st<true>(&oxr[s * st], E.ox[s]);
+                        mm_lg_st<true>(&opr[s * st], E.op[s]);
+                        mm_lg_st<true>(&ogr[s * st], E.og[s]);
+                    }
+                }
             }
             if (L.q == 0) {
                 mm_lg_st<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_JOINT), L.joint);
