@@ -341,6 +341,13 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 g.patience = 8u; /* 65 536 chains: 4 -> 516.5 ms, 16 -> 518.5, 64 -> 520.9, 256 -> 530.3 */
                 if (const char *ev = mm_tuning_env("MMCMC_LGQ_PATIENCE"))
                     g.patience = (unsigned int)atoi(ev);
+                /* a wave stays with the chains it kept only when the queue of their level makes a FULL unit of them; else they
+                 * are queued and the wave takes the deepest full unit there is (config 5 with the edges in registers: 10 ->
+                 * 408.6 ms, 12 -> 390.1, 14 -> 381.2, 16 -> 377.5: 15.27 -> 15.78 chains per unit;
+                 * profiles/r5zzz_lgq_min_unit.log) */
+                g.min_unit = 16u;
+                if (const char *ev = mm_tuning_env("MMCMC_LGQ_MIN_UNIT"))
+                    g.min_unit = (unsigned int)atoi(ev);
                 const unsigned int groups16 = (unsigned int)(c_pad / 16);
                 /* waves per SIMD the scheduler is built for (mm_lg_cfg): 2 wherever two per SIMD can be filled */
                 int occ = lgq_occ;

@@ -136,6 +136,7 @@ struct mm_nuts_lg_args {
     /* persistent kernel only */
     struct mm_lgq_ctrl *ctrl;       /* queue heads / tails, chains left, error flag */
     unsigned int patience;          /* idle polls before a wave settles for a unit of fewer than 16 chains */
+    unsigned int min_unit;          /* a wave stays with the chains it kept when the queue of their level tops them up to this many */
     unsigned int *slots;            /* [MM_LGQ_SHARDS][MM_LGQ_NQ][c_pad] rings of tagged local chain indices */
 #ifdef MM_LG_PROFILE
     unsigned long long *prof;       /* [waves][8] */
@@ -1785,6 +1786,11 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
             return false;
         };
         for (unsigned int polls = 0;;) {
+            if (n_keep == 16u) { /* every chain of the last unit goes on: nothing to ask the queues */
+                qi = keep_q;
+                shard = home;
+                break;
+            }
             /* the state of the own shard's queues in one load: lane i < 16 reads word i */
             unsigned long long w = 0ull;
             if (L.lane < 16)
@@ -1792,10 +1798,10 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
             const bool is_queue = L.lane == 0 || (L.lane > a.j0 && L.lane <= a.max_depth);
             unsigned int avail = is_queue ? (unsigned int)(w >> 32) - (unsigned int)w : 0u;
             if (n_keep > 0u && !give_back) {
-                /* stay with the kept chains if the queue of their level tops them up to 12 or more */
+                /* stay with the kept chains if the queue of their level tops them up to min_unit (16: a full unit) or more */
                 unsigned int want = (unsigned int)__shfl((int)avail, keep_q, 64);
                 want = want < 16u - n_keep ? want : 16u - n_keep;
-                if (n_keep + want >= 12u) {
+                if (n_keep + want >= a.min_unit) {
                     if (want > 0u)
                         (void)claim(home, keep_q, (unsigned long long)__shfl((long long)w, keep_q, 64), want, 1u);
                     qi = keep_q; /* a lost race: the kept chains run alone */

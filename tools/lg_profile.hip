@@ -38,6 +38,7 @@ extern "C" int lgprof_run(const double *mat, double *state, void *adapt, unsigne
     a.row = 0xffffffffu;
     a.ctrl = nullptr;
     a.patience = 64u;
+    a.min_unit = 16u;
     a.slots = nullptr;
     a.prof = prof;
     hipError_t e = mm_launch_nuts_lg<32>(a, nullptr);
