@@ -1956,6 +1956,7 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
          * depend on the index just taken from the queue */
         mm_nuts_adapt<double> ad = mm_lg_ld_adapt<true>(&a.adapt[L.cl]);
         bool alive = valid;
+        bool ran_on = false; /* the unit ran more doublings than it was taken for */
         int j_first, j_next;
         if (qi == 0) {
             const unsigned int m_done = (unsigned int)__double_as_longlong(mm_lg_ld<true>(mm_lg_rec_scalar<D>(a, L, Cfg::F_M)));
@@ -2057,6 +2058,13 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
         } else {
             for (int j = j_first; j < j_next && __ballot(alive) != 0ull; ++j)
                 mm_lg_doubling<D, true, OCC, true>(L, a, j, alive, ad.epsilon, lds, scr, E);
+            /* a full unit whose 16 chains ALL go on is the next unit as it stands: it runs on here, without parking the chains,
+             * asking the queues and loading them again (some 25 000 cycles of memory round trips per unit) */
+            while (j_next < a.max_depth && __ballot(alive) == ~0ull) {
+                mm_lg_doubling<D, true, OCC, true>(L, a, j_next, alive, ad.epsilon, lds, scr, E);
+                ++j_next;
+                ran_on = true;
+            }
         }
 
         MM_LGQ_T(2);
@@ -2071,7 +2079,7 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
             }
             if constexpr (OCC == 1) {
                 /* the edges the unit changed: the one extended last; both after the several doublings of a unit that began
-                 * the transition (the record holds neither yet) */
+                 * the transition (the record holds neither yet) or ran on */
                 double *cxr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_XM : Cfg::V_XP),
                        *cpr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_PM : Cfg::V_PP),
                        *cgr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_GM : Cfg::V_GP);
@@ -2081,7 +2089,7 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
                     mm_lg_st<true>(&cpr[s * st], E.cp[s]);
                     mm_lg_st<true>(&cgr[s * st], E.cg[s]);
                 }
-                if (qi == 0) {
+                if (qi == 0 || ran_on) {
                     double *oxr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_XP : Cfg::V_XM),
                            *opr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_PP : Cfg::V_PM),
                            *ogr = mm_lg_rec_vec<D>(a, L, E.cur_neg ? Cfg::V_GP : Cfg::V_GM);

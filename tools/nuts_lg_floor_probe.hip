@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #include "mm_nuts_lg.h"
@@ -220,6 +221,92 @@ template <int D> __global__ __launch_bounds__(64) void product_doubling_kernel(c
     out[(size_t)blockIdx.x * 64 + L.lane] = sum + (alive ? 1.0 : 0.0);
 }
 
+// A unit that BEGINS a transition, as the persistent scheduler runs it (edges in registers: mm_lg_edges), without the scheduler:
+// mm_lg_begin + doublings 0 .. j0 - 1, `reps` times.  Against the per-level numbers above this is what the momentum draw, the
+// seven prologues / epilogues and the short doublings (0: one leaf in the guarded code; 1, 2: one and two pairs) cost.
+template <int D> __global__ __launch_bounds__(64) void product_begin_unit_kernel(const mm_nuts_lg_args a, int j0, unsigned int reps, double eps, double *out)
+{
+    using Cfg = mm_lg_cfg<D>;
+    constexpr int NS = Cfg::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw3[];
+    mm_lg_lane<D> L;
+    L.lane = threadIdx.x & 63;
+    L.q = L.lane >> 4;
+    L.cl = (unsigned long long)blockIdx.x * 16 + (L.lane & 15);
+    L.active = true;
+    L.chain = L.cl;
+    L.n_lf = 0;
+    L.n_leaf_iters = 0;
+    L.m = 1;
+    mm_lds_double *const lds = (mm_lds_double *)mm_lds_raw3 + L.lane;
+    double *const scr = a.scratch + (size_t)blockIdx.x * Cfg::scratch_doubles_per_wave + L.lane;
+    mm_lg_load_A<D>(L, a.mat);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        L.x[s] = 1e-3 * (double)((L.lane * 7 + s * 13) % 17 - 8);
+    mm_lg_edges<D> E;
+    bool alive = true;
+    for (unsigned int r = 0; r < reps; ++r) {
+        L.m = 1 + r;
+        mm_lg_begin<D, true, 1, true>(L, a, E);
+        L.logu = L.joint - 50.0; /* every leaf inside the slice */
+        alive = true;
+        for (int j = 0; j < j0 && __ballot(alive) != 0ull; ++j)
+            mm_lg_doubling<D, true, 1, true>(L, a, j, alive, eps, lds, scr, E);
+    }
+    double sum = L.alpha + (double)L.n + (double)L.n_lf + E.cx[0] + E.ox[1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        sum += L.x[s];
+    out[(size_t)blockIdx.x * 64 + L.lane] = sum + (alive ? 1.0 : 0.0);
+}
+
+static void run_begin_unit(const double *dA, double *dout, int j0, unsigned int reps)
+{
+    constexpr int D = 32;
+    using Cfg = mm_lg_cfg<D>;
+    const int grid = 1024;
+    mm_nuts_lg_args a{};
+    a.mat = dA;
+    a.n_chains = (unsigned long long)grid * 16;
+    a.c_pad = a.n_chains;
+    a.seed = 42;
+    a.max_depth = 12;
+    a.target_accept_p = 0.8;
+    (void)hipMalloc((void **)&a.rec, Cfg::rec_doubles(a.c_pad) * sizeof(double));
+    (void)hipMalloc((void **)&a.scratch, Cfg::scratch_doubles_per_wave * grid * sizeof(double));
+    (void)hipMemset(a.rec, 0, Cfg::rec_doubles(a.c_pad) * sizeof(double));
+    (void)hipMemset(a.scratch, 0, Cfg::scratch_doubles_per_wave * grid * sizeof(double));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(product_begin_unit_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((product_begin_unit_kernel<D>), dim3(grid), dim3(64), Cfg::lds_bytes, 0, a, j0, reps, 1e-7, dout);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best)
+            best = ms;
+    }
+    std::vector<double> ho(1024 * 64);
+    (void)hipMemcpy(ho.data(), dout, ho.size() * 8, hipMemcpyDeviceToHost);
+    double cs = 0;
+    for (double v : ho)
+        cs += v;
+    const double iters = (double)reps * (double)((1u << j0) - 1u);
+    const double ms_per_iter = best / iters;
+    printf("{\"variant\": \"a unit that begins a transition (mm_lg_begin + doublings 0..%d, edges in registers) x %u, all 16 chains live and valid, no scheduler\", \"ms\": %.3f, "
+           "\"leaf_iterations_per_wave\": %.0f, \"ns_per_leaf_iteration\": %.2f, \"cycles_per_leaf_iteration_at_2.4GHz\": %.0f, "
+           "\"cycles_per_unit_at_2.4GHz\": %.0f, \"checksum\": %.6e}\n",
+           j0 - 1, reps, best, iters, ms_per_iter * 1e6, ms_per_iter * 1e-3 * 2.4e9, best / reps * 1e-3 * 2.4e9, cs);
+    (void)hipFree(a.rec);
+    (void)hipFree(a.scratch);
+}
+
 static void run_product(const double *dA, double *dout, int j, unsigned int reps)
 {
     constexpr int D = 32;
@@ -299,8 +386,9 @@ template <int VARIANT> static void run(const char *what, const double *dA, doubl
            what, best, iters, ms_per_iter_all_simds * 1e6, ms_per_iter_all_simds * 1e-3 * 2.4e9, ms_per_iter_all_simds * cfg5_iters_per_simd, cs);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool units_only = argc > 1 && std::string(argv[1]) == "units";
     constexpr int D = 32;
     std::vector<double> hA(D * D, 0.0);
     for (int i = 0; i < D; ++i)
@@ -313,6 +401,11 @@ int main()
     (void)hipMalloc(&dout, 1024 * 64 * 8);
     (void)hipMalloc(&dcyc, 1024 * 8);
     const unsigned int n_pairs = 20000; /* 40 000 leaf iterations per wave: ~60 ms */
+    run_begin_unit(dA, dout, 7, 300);
+    run_begin_unit(dA, dout, 4, 2400);
+    run_begin_unit(dA, dout, 2, 9600);
+    if (units_only)
+        return 0;
     run<0>("leaf + paired acceptance statistic + level-0 merge", dA, dout, dcyc, n_pairs);
     run<1>("... + one merge per pair with records from LDS", dA, dout, dcyc, n_pairs);
     run<2>("... + one push per pair and a first-leaf record every second pair, into LDS", dA, dout, dcyc, n_pairs);
