@@ -414,9 +414,13 @@ template <class TT, class ST> struct Nuts : NutsBase {
                         return e;
                     if (level >= 0)
                         auto_level = level;
-                    const unsigned int pilot = 16;
+                    unsigned int pilot = 16;
+                    if (const char *ev = mm_tuning_env("MMCMC_LGQ_PILOT"))
+                        pilot = (unsigned int)atoi(ev);
                     if (level < 0 && total >= 4 * pilot) {
                         mm_nuts_lg_args g1 = g, g2 = g;
+                        if (const char *ev = mm_tuning_env("MMCMC_LGQ_PILOT_LEVEL"))
+                            g1.j0 = atoi(ev);
                         g1.n_pre = a.n_pre < pilot ? a.n_pre : pilot;
                         g1.n_rec = pilot - g1.n_pre;
                         if ((e = launch(g1)) != hipSuccess)

@@ -2056,14 +2056,17 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
             L.aux_blk = io.aux_blk;
             alive = io.alive != 0;
         } else {
-            for (int j = j_first; j < j_next && __ballot(alive) != 0ull; ++j)
+            /* the doublings the unit was taken for -- and on: a full unit whose 16 chains ALL go on is the next unit as it
+             * stands, it runs without parking the chains, asking the queues and loading them again (some 25 000 cycles of
+             * memory round trips; rare where trees differ in depth, the rule where they do not) */
+            int j = j_first;
+            while (__ballot(alive) != 0ull && (j < j_next || (j < a.max_depth && __ballot(alive) == ~0ull))) {
                 mm_lg_doubling<D, true, OCC, true>(L, a, j, alive, ad.epsilon, lds, scr, E);
-            /* a full unit whose 16 chains ALL go on is the next unit as it stands: it runs on here, without parking the chains,
-             * asking the queues and loading them again (some 25 000 cycles of memory round trips per unit) */
-            while (j_next < a.max_depth && __ballot(alive) == ~0ull) {
-                mm_lg_doubling<D, true, OCC, true>(L, a, j_next, alive, ad.epsilon, lds, scr, E);
-                ++j_next;
+                ++j;
+            }
+            if (j > j_next) {
                 ran_on = true;
+                j_next = j;
             }
         }
 
