@@ -404,8 +404,11 @@ int main(int argc, char **argv)
     run_begin_unit(dA, dout, 7, 300);
     run_begin_unit(dA, dout, 4, 2400);
     run_begin_unit(dA, dout, 2, 9600);
-    if (units_only)
+    if (units_only) {
+        run_product(dA, dout, 7, 300);
+        run_product(dA, dout, 9, 75);
         return 0;
+    }
     run<0>("leaf + paired acceptance statistic + level-0 merge", dA, dout, dcyc, n_pairs);
     run<1>("... + one merge per pair with records from LDS", dA, dout, dcyc, n_pairs);
     run<2>("... + one push per pair and a first-leaf record every second pair, into LDS", dA, dout, dcyc, n_pairs);
