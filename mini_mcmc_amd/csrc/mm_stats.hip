@@ -1139,7 +1139,20 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
     const unsigned int lane = threadIdx.x;
     float *const S = lds_raw;                                        /* [N] */
     mm_cx *const lds = reinterpret_cast<mm_cx *>(lds_raw + N);       /* the transform's exchange block */
-    const unsigned int d = blockIdx.x % D, wg = blockIdx.x / D;
+    /* Workgroups go to the eight XCDs in turn (blockIdx.x mod 8) and every XCD has its own L2: with d = blockIdx.x mod D the D
+     * workgroups that read the SAME chains (one parameter each, interleaved in the same cache lines) sat on D different XCDs and
+     * every line came from HBM D times.  Here the D workgroups of a chain group are neighbours on ONE XCD: one fetch, D - 1 hits
+     * in that L2 (round 5: [65536, 4000, 3] 3.3 -> see DESIGN 5.2).  The launcher gives a multiple of 8 chain groups whenever
+     * there are that many chains. */
+    unsigned int d, wg;
+    if (n_wg % 8u == 0u) {
+        const unsigned int xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        d = i % D;
+        wg = (i / D) * 8u + xcd;
+    } else {
+        d = blockIdx.x % D;
+        wg = blockIdx.x / D;
+    }
     for (unsigned int i = lane; i < N; i += 64u)
         S[i] = 0.f;
     MM_WAVE_LDS_SYNC();
@@ -1555,7 +1568,7 @@ struct StatsLongPlan {
     bool use = false;
     unsigned int N1 = 0, N = 0, n_wg = 0;
 };
-static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, int sel_in = -1)
+static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int sel_in = -1)
 {
     StatsLongPlan p;
     const size_t m = n / 2;
@@ -1567,8 +1580,15 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, int sel_in = -1)
     while ((size_t)p.N1 * 2048 < 2 * m)
         p.N1 *= 2;
     p.N = 2048u * p.N1;
-    /* device-independent (the workgroup count fixes the f32 summation grouping): 512 waves' worth, fewer for few chains */
-    p.n_wg = (unsigned int)std::min<size_t>(512, n_chains);
+    /* device-independent (the workgroup count fixes the f32 summation grouping): at most 512 chain groups, and no more than fit
+     * the one-wave workgroups an MI355X holds at once with this kernel's LDS (1024 at N1 = 2: a launch of 1536 ran a second,
+     * half-empty round), a multiple of 8 (the kernel's XCD mapping); fewer for few chains */
+    const size_t lds = ((size_t)p.N + 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
+    const size_t resident = 256 * std::max<size_t>(1, (160u << 10) / lds); /* MI355X: 256 CUs x workgroups per CU by their LDS */
+    size_t g = 512;
+    if (dim > 0 && g * dim > resident)
+        g = std::max<size_t>(8, resident / dim / 8 * 8);
+    p.n_wg = (unsigned int)std::min<size_t>(g, n_chains);
     return p;
 }
 
@@ -1711,7 +1731,7 @@ static size_t stats_ws_floats(size_t n_chains, size_t n, size_t dim, unsigned in
     const StatsFftPlan p = stats_fft_plan(n_chains, n, dim, device, MMCMC_STATS_KERNEL_FFT); /* whichever kernel runs */
     if (p.use)
         need = std::max(need, ((size_t)p.n_wg + n_parts) * dim * p.N);
-    const StatsLongPlan lp = stats_long_plan(n_chains, n, MMCMC_STATS_KERNEL_FFT);
+    const StatsLongPlan lp = stats_long_plan(n_chains, n, dim, MMCMC_STATS_KERNEL_FFT);
     if (lp.use) /* slabs | partial totals | their f64 sum */
         need = std::max(need, ((size_t)lp.n_wg + n_parts + 2) * dim * lp.N);
     return need;
@@ -1770,7 +1790,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
             *parts_out = final_out ? 0 : 1;
         return MMCMC_OK;
     }
-    const StatsLongPlan lp = stats_long_plan(n_chains, n);
+    const StatsLongPlan lp = stats_long_plan(n_chains, n, dim);
     if (lp.use) {
         const mm_cx *tw = stats_fft_twiddles(device, 32), *wN = stats_long_tables(device, lp.N1);
         if (!tw || !wN)
