@@ -498,13 +498,45 @@ __device__ __forceinline__ void mm_lg_begin(mm_lg_lane<D> &L, const mm_nuts_lg_a
     L.aux_have = 0xffffffffu;
     L.aux_blk.w[0] = L.aux_blk.w[1] = L.aux_blk.w[2] = L.aux_blk.w[3] = 0u;
     double p0[NS], grad[NS];
+    if constexpr (NS % 2 == 0) {
+        /* Coordinate d = 4 s + q is a half of Philox block d >> 1 = 2 s + (q >> 1): the lanes q and q ^ 1 of a chain need the
+         * SAME NS blocks, one the cosine and one the sine half of each Box-Muller pair.  Each evaluates half of the blocks in
+         * full (even rows s < NS / 2, odd rows the rest) and the two trade the halves they do not use themselves -- rows q and
+         * q ^ 1 are what v_permlane16_swap exchanges -- instead of both evaluating all NS (a Philox block, a logarithm, a square
+         * root and a sine / cosine pair in f64 each: 6600 of the 29 500 cycles a unit that begins a transition spends outside its
+         * leaves, tools/nuts_lg_floor_probe.hip).  Same functions of the same arguments: same bits. */
+        constexpr int H = NS / 2;
+        const bool odd = (L.q & 1) != 0;
+        double mine[H], give[H];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int d = 4 * s + L.q;
-        mm_u32x4 blk = mm_block(a.seed, L.chain, L.m, (uint32_t)(d >> 1));
-        double z0, z1;
-        mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
-        p0[s] = (d & 1) ? z1 : z0;
+        for (int i = 0; i < H; ++i) {
+            const int s = odd ? H + i : i;
+            mm_u32x4 blk = mm_block(a.seed, L.chain, L.m, (uint32_t)(2 * s + (L.q >> 1)));
+            double z0, z1;
+            mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
+            mine[i] = odd ? z1 : z0;
+            give[i] = odd ? z0 : z1;
+        }
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            const unsigned int glo = (unsigned int)__double2loint(give[i]), ghi = (unsigned int)__double2hiint(give[i]);
+            /* first result: even rows keep their own, odd rows get the even partner's; second: even rows get the odd partner's */
+            const u2 l2 = __builtin_amdgcn_permlane16_swap(glo, glo, false, false);
+            const u2 h2 = __builtin_amdgcn_permlane16_swap(ghi, ghi, false, false);
+            const double got = odd ? __hiloint2double((int)h2[0], (int)l2[0]) : __hiloint2double((int)h2[1], (int)l2[1]);
+            p0[i] = odd ? got : mine[i];
+            p0[H + i] = odd ? mine[i] : got;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int d = 4 * s + L.q;
+            mm_u32x4 blk = mm_block(a.seed, L.chain, L.m, (uint32_t)(d >> 1));
+            double z0, z1;
+            mm_box_muller_f64(mm_u53(blk.w[0], blk.w[1]), mm_u53(blk.w[2], blk.w[3]), &z0, &z1);
+            p0[s] = (d & 1) ? z1 : z0;
+        }
     }
     const double ulogp = mm_lg_logp_ax<D, OCC == 2>(L, L.x, grad); /* grad holds A x = -gradient (see mm_lg_logp_ax) */
     L.joint = ulogp - mm_lg_dot<NS>(p0, p0) * 0.5;
