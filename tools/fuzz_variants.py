@@ -4,10 +4,11 @@
   - Gibbs mixture: likewise;
   - tracker: whole blocks (one wave per parameter, tiles of 16 rows) against step-by-step feeding (the plain kernel);
   - NUTS: asynchronous-lane pair kernel against the lanes in step, compiled and run-time compiled dimensions;
+  - lane-group NUTS (D = 16, 32, f64): the persistent scheduler against the single launch;
   - MH / HMC at the compiled dimensions up to 8: the four-waves-per-SIMD kernel (5) against the one-wave kernels (0, 2), any
     chain count, run length, iterations per launch, f32 and f64;
   - diagnostics: the power-spectrum kernel against the direct sums (R-hat / ESS to 1e-4 / 2e-3).
-usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n h s, default dgtnhsm]"""
+usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n l h s, default dgtnlhsm]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,7 +19,7 @@ from mini_mcmc_amd.distributions import IsotropicGaussian, RosenbrockND, Standar
 from mini_mcmc_amd.nuts import NUTS
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
-fam = sys.argv[2] if len(sys.argv) > 2 else "dgtnhsm"
+fam = sys.argv[2] if len(sys.argv) > 2 else "dgtnlhsm"
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 print("seed", rng.bit_generator.state["state"]["state"] & 0xffff)
 
@@ -101,6 +102,32 @@ while "n" in fam and time.time() - t0 < budget:
     assert all(np.array_equal(sa[k], sb[k]) for k in sa), (type(tgt).__name__, tgt.dim, mode)
     n += 1
 print(f"NUTS: {n} random cases, default kernel == lanes in step / run-time-dimension kernel")
+
+from mini_mcmc_amd.distributions import GaussianND
+t0, n = time.time(), 0
+while "l" in fam and time.time() - t0 < budget:
+    # lane-group NUTS (dense Gaussian, f64, matrix cores): the persistent scheduler (3: queues, units, chains handed from wave to
+    # wave, edges in registers) against the single launch in which every wave keeps its chains (1) -- random chain counts, depth
+    # caps, first compaction levels, step-size targets, and a continued run
+    d = int(rng.choice([16, 32]))
+    tgt = GaussianND.ill_conditioned(d, float(10 ** rng.uniform(0, 4)), int(rng.integers(100)))
+    C = int(rng.integers(2048, 5000))
+    init = init_with_seed(C, d, int(rng.integers(1000))) * float(rng.uniform(0.05, 1.0))
+    seed, p_acc, md = int(rng.integers(1 << 30)), float(rng.uniform(0.6, 0.95)), int(rng.integers(3, 9))
+    a = NUTS(tgt, init, p_acc, mode=2).set_seed(seed).set_max_depth(md).set_kernel_variant(3)
+    if rng.random() < 0.5:
+        a.set_compaction(int(rng.integers(1, md + 1)))
+    b = NUTS(tgt, init, p_acc, mode=2).set_seed(seed).set_max_depth(md).set_kernel_variant(1)
+    for _ in range(2):
+        nc, nd = int(rng.integers(1, 40)), int(rng.integers(0, 40))
+        oa, ob = a._run(nc, nd, False, "numpy"), b._run(nc, nd, False, "numpy")
+        assert np.array_equal(oa, ob), ("lane groups", d, C, seed, p_acc, md, nc, nd)
+        assert np.array_equal(a.leapfrog_counts(), b.leapfrog_counts()) and np.array_equal(a.depth_histogram(), b.depth_histogram())
+        sa, sb = a.adapt_state(), b.adapt_state()
+        assert all(np.array_equal(sa[k], sb[k]) for k in sa), ("lane groups: adaptation state", d, C, seed)
+    n += 1
+if "l" in fam:
+    print(f"lane-group NUTS: {n} random cases, persistent scheduler == single launch")
 
 from mini_mcmc_amd.distributions import Gaussian2D, Rosenbrock2D
 from mini_mcmc_amd.hmc import HMC
