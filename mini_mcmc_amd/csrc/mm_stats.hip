@@ -1344,6 +1344,18 @@ __global__ __launch_bounds__(256) void mm_fft_finish_kernel(const float *__restr
     for (unsigned int f = tid; f < N; f += 256) {
         double t0 = 0.0, t1 = 0.0;
         unsigned int p = 0;
+        /* eight loads in flight, added in the order of the plain loop (even parts into t0, odd into t1) */
+        for (; p + 7 < n_parts; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = parts[(size_t)(p + u) * total + (size_t)f * D + d];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                t0 += (double)v[u];
+                t1 += (double)v[u + 1];
+            }
+        }
         for (; p + 1 < n_parts; p += 2) {
             t0 += (double)parts[(size_t)p * total + (size_t)f * D + d];
             t1 += (double)parts[(size_t)(p + 1) * total + (size_t)f * D + d];
@@ -1405,12 +1417,36 @@ __global__ __launch_bounds__(256) void mm_stats_tail_kernel(const float *__restr
         const float shift = means[d];
         const unsigned long long per = (c2 + MM_WB_CHUNKS - 1) / MM_WB_CHUNKS;
         const unsigned long long lo = ch * per, hi = lo + per < c2 ? lo + per : c2;
+        /* four strands per thread, their loads in flight together (one dependent pair of loads per trip made these blocks the
+         * longest of the launch: 16 trips of a memory latency each at 131 072 half-chains), combined in a fixed order */
         double sd = 0.0, sq = 0.0, ws = 0.0;
-        for (unsigned long long c = lo + tid; c < hi; c += 256) {
-            const double df = (double)(means[c * D + d] - shift);
-            sd += df;
-            sq += df * df;
-            ws += (double)(ssq[c * D + d] / nf); /* biased per-chain variance (quirk Q8) */
+        {
+            double sd4[4] = {0.0, 0.0, 0.0, 0.0}, sq4[4] = {0.0, 0.0, 0.0, 0.0}, ws4[4] = {0.0, 0.0, 0.0, 0.0};
+            unsigned long long c = lo + tid;
+            for (; c + 768 < hi; c += 1024) {
+                float mu[4], qq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mu[u] = means[(c + 256ull * u) * D + d];
+                    qq[u] = ssq[(c + 256ull * u) * D + d];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double df = (double)(mu[u] - shift);
+                    sd4[u] += df;
+                    sq4[u] += df * df;
+                    ws4[u] += (double)(qq[u] / nf); /* biased per-chain variance (quirk Q8) */
+                }
+            }
+            for (; c < hi; c += 256) {
+                const double df = (double)(means[c * D + d] - shift);
+                sd4[0] += df;
+                sq4[0] += df * df;
+                ws4[0] += (double)(ssq[c * D + d] / nf);
+            }
+            sd = (sd4[0] + sd4[1]) + (sd4[2] + sd4[3]);
+            sq = (sq4[0] + sq4[1]) + (sq4[2] + sq4[3]);
+            ws = (ws4[0] + ws4[1]) + (ws4[2] + ws4[3]);
         }
         red[0][tid] = sd;
         red[1][tid] = sq;
