@@ -1122,8 +1122,8 @@ void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, uns
  * The chain is read N1 + 1 times (once for the means), from L2 after the first: this path is for samples whose direct
  * lag sums would cost m^2 (a [65536, 4000, 3] sample: 406 ms through the direct kernel, and no kernel at all beyond
  * m = 6800 at D = 3, where its LDS layout ends).  N <= 32768: m <= 16384. */
-template <class T, int N1>
-__global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n,
+template <class T, int N1, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n,
                                                                unsigned int D, unsigned int m, unsigned int n_wg,
                                                                const mm_cx *__restrict__ tw, const mm_cx *__restrict__ wN,
                                                                float *__restrict__ means, float *__restrict__ ssq,
@@ -1136,9 +1136,16 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
     constexpr int AC = HALF >= 8 ? 4 : 8;
     using pl = mm_fft_plan<R1>;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    const unsigned int lane = threadIdx.x;
+    /* WAVES > 1 (round 5, N1 = 4 and 8): the residues k1 of a chain are dealt to the waves of the workgroup (k1 = wave, wave +
+     * WAVES, ...), which share ONE spectrum S[N] -- the bins k1 + N1 k2 of different residues are different words, so no two waves
+     * ever meet and S needs no synchronisation between the first and the last barrier of the launch -- and each have their own
+     * exchange block.  With one wave per workgroup the 64 KB spectrum of N1 = 8 left one wave per CU (S is what fills the LDS);
+     * four waves beside one S are four per CU, and each reads the chain N1 / WAVES + 1 / WAVES times instead of N1 + 1. */
+    static_assert(WAVES == 1 || N1 % WAVES == 0, "residues are dealt evenly");
+    __shared__ float msum[2][WAVES][2]; /* the waves' shares of the two half-chains' sums, by chain parity */
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float *const S = lds_raw;                                        /* [N] */
-    mm_cx *const lds = reinterpret_cast<mm_cx *>(lds_raw + N);       /* the transform's exchange block */
+    mm_cx *const lds = reinterpret_cast<mm_cx *>(lds_raw + N) + (size_t)wave * pl::LDS_CX; /* the wave's exchange block */
     /* Workgroups go to the eight XCDs in turn (blockIdx.x mod 8) and every XCD has its own L2: with d = blockIdx.x mod D the D
      * workgroups that read the SAME chains (one parameter each, interleaved in the same cache lines) sat on D different XCDs and
      * every line came from HBM D times.  Here the D workgroups of a chain group are neighbours on ONE XCD: one fetch, D - 1 hits
@@ -1153,9 +1160,12 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
         d = blockIdx.x % D;
         wg = blockIdx.x / D;
     }
-    for (unsigned int i = lane; i < N; i += 64u)
+    for (unsigned int i = threadIdx.x; i < N; i += 64u * WAVES)
         S[i] = 0.f;
-    MM_WAVE_LDS_SYNC();
+    if constexpr (WAVES > 1)
+        __syncthreads();
+    else
+        MM_WAVE_LDS_SYNC();
     auto tw1_of = [&](int b) -> mm_cx { return tw[b * 64 + lane]; };
     auto tw2_of = [&](int g) -> mm_cx { return tw[R1 * 64 + g * 8 + (lane & 7u)]; };
     const size_t second = (size_t)(n - m) * D; /* the second half-chain: rows [n - m, n) */
@@ -1165,7 +1175,8 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
      * [65536, 4000, 3] 4.0 -> 3.3 ms).  At N1 = 4 the 128 cached values per lane made the kernel SLOWER ([65536, 8000, 3]
      * 13.4 -> 19.4 ms): kept to N1 = 2 */
     constexpr bool CACHE = HALF == 1;
-    for (unsigned long long c = wg; c < C; c += n_wg) {
+    unsigned int parity = 0;
+    for (unsigned long long c = wg; c < C; c += n_wg, parity ^= 1u) {
         const T *const base = sample + (size_t)c * n * D + d;
         float s0 = 0.f, s1 = 0.f;
         float c0[CACHE ? R1 : 1][CACHE ? HALF : 1], c1[CACHE ? R1 : 1][CACHE ? HALF : 1];
@@ -1188,7 +1199,7 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
                     s1 += in ? c1[a][n1] : 0.f;
                 }
         } else
-        for (unsigned int t0 = lane; t0 < m; t0 += 64u * 8u) {
+        for (unsigned int t0 = lane + 64u * 8u * wave; t0 < m; t0 += 64u * 8u * WAVES) {
             float u0[8], u1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1203,13 +1214,41 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
                 s1 += in ? u1[u] : 0.f;
             }
         }
-        const float mu0 = wave_sum_dpp_bcast(s0) * inv_m, mu1 = wave_sum_dpp_bcast(s1) * inv_m;
+        float t0s = wave_sum_dpp_bcast(s0), t1s = wave_sum_dpp_bcast(s1);
+        if constexpr (WAVES > 1) {
+            /* every wave summed its share of the time steps: the shares meet in LDS and are added in wave order.  One barrier
+             * per chain (the buffer alternates with the chain's parity: a wave two chains ahead cannot exist, it would have had
+             * to pass the barrier in between) */
+            if (lane == 0u) {
+                msum[parity][wave][0] = t0s;
+                msum[parity][wave][1] = t1s;
+            }
+            __syncthreads();
+            t0s = msum[parity][0][0];
+            t1s = msum[parity][0][1];
+#pragma unroll
+            for (int w2 = 1; w2 < WAVES; ++w2) {
+                t0s += msum[parity][w2][0];
+                t1s += msum[parity][w2][1];
+            }
+        }
+        const float mu0 = t0s * inv_m, mu1 = t1s * inv_m;
         float q0 = 0.f, q1 = 0.f;
-        for (unsigned int k1 = 0; k1 < (unsigned int)N1; ++k1) {
+        for (unsigned int k1 = wave; k1 < (unsigned int)N1; k1 += (unsigned int)WAVES) {
+            /* The offsets of a lane's R1 x HALF points (and their in-range masks, and the twiddle indices) depend on neither the
+             * chain nor the residue, and the compiler, left to itself, computes them all ONCE before the chain loop and keeps
+             * them: hundreds of 64-bit values it has no registers for (N1 = 8: 2.4 KB of scratch per lane, 245 spill stores
+             * ahead of the loop and a scratch reload in front of every load of the sample -- a residue pass took eleven times
+             * what it takes at N1 = 2; 4.9 KB at N1 = 16).  An opaque copy of the lane index per residue makes them cheap
+             * arithmetic again, done where it is used. */
+            unsigned int lane_k = lane;
+            if constexpr (N1 == 4 || N1 == 8) /* N1 = 16 is faster with the spilled table than with the arithmetic (307 vs 381 ms) */
+                asm volatile("" : "+v"(lane_k));
+            const mm_cx *wNk = wN;
             mm_cx w1[HALF]; /* w_N1^(n1 k1) */
 #pragma unroll
             for (int n1 = 0; n1 < HALF; ++n1)
-                w1[n1] = wN[(((unsigned int)n1 * k1) & (unsigned int)(N1 - 1)) * 2048u];
+                w1[n1] = wNk[(((unsigned int)n1 * k1) & (unsigned int)(N1 - 1)) * 2048u];
             mm_cx y[R1];
 #pragma unroll
             for (int a0 = 0; a0 < R1; a0 += AC) {
@@ -1217,8 +1256,8 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
                 mm_cx wt[AC];
 #pragma unroll
                 for (int aa = 0; aa < AC; ++aa) {
-                    const unsigned int n2 = 64u * (a0 + aa) + lane;
-                    wt[aa] = wN[(n2 * k1) & (N - 1u)]; /* w_N^(n2 k1) */
+                    const unsigned int n2 = 64u * (a0 + aa) + lane_k;
+                    wt[aa] = wNk[(n2 * k1) & (N - 1u)]; /* w_N^(n2 k1) */
 #pragma unroll
                     for (int n1 = 0; n1 < HALF; ++n1) {
                         if constexpr (CACHE) {
@@ -1233,7 +1272,7 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
                 }
 #pragma unroll
                 for (int aa = 0; aa < AC; ++aa) {
-                    const unsigned int n2 = 64u * (a0 + aa) + lane;
+                    const unsigned int n2 = 64u * (a0 + aa) + lane_k;
                     mm_cx acc = mm_cx{0.f, 0.f};
 #pragma unroll
                     for (int n1 = 0; n1 < HALF; ++n1) {
@@ -1273,16 +1312,19 @@ __global__ __launch_bounds__(64) void mm_chain_fft_long_kernel(const T *__restri
         }
         q0 = wave_sum_dpp_bcast(q0);
         q1 = wave_sum_dpp_bcast(q1);
-        if (lane == 0u) {
+        if (lane == 0u && wave == 0u) { /* residue 0, where the squares are taken, is wave 0's */
             means[(size_t)c * D + d] = mu0;
             means[((size_t)c + (size_t)C) * D + d] = mu1;
             ssq[(size_t)c * D + d] = q0;
             ssq[((size_t)c + (size_t)C) * D + d] = q1;
         }
     }
-    MM_WAVE_LDS_SYNC();
+    if constexpr (WAVES > 1)
+        __syncthreads();
+    else
+        MM_WAVE_LDS_SYNC();
     float *const out = slabs + ((size_t)wg * D + d) * N;
-    for (unsigned int i = lane; i < N; i += 64u)
+    for (unsigned int i = threadIdx.x; i < N; i += 64u * WAVES)
         out[i] = S[i];
 }
 
@@ -1602,7 +1644,7 @@ static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int de
 /* the long-chain path (mm_chain_fft_long_kernel): half-chains of 1025 .. 16384 draws */
 struct StatsLongPlan {
     bool use = false;
-    unsigned int N1 = 0, N = 0, n_wg = 0;
+    unsigned int N1 = 0, N = 0, n_wg = 0, waves = 1;
 };
 static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int sel_in = -1)
 {
@@ -1619,7 +1661,12 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
     /* device-independent (the workgroup count fixes the f32 summation grouping): at most 512 chain groups, and no more than fit
      * the one-wave workgroups an MI355X holds at once with this kernel's LDS (1024 at N1 = 2: a launch of 1536 ran a second,
      * half-empty round), a multiple of 8 (the kernel's XCD mapping); fewer for few chains */
-    const size_t lds = ((size_t)p.N + 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
+    /* waves per workgroup: one where the chain is cached in registers (N1 = 2) and where a second exchange block no longer
+     * fits beside the spectrum (N1 = 16: 128 KB); four at N1 = 8 ([16384, 16000, 3]: 32.8 -> 9.4 ms, with the kernel's spills
+     * gone), two at N1 = 4 (where the L2 is the limit: every residue pass pulls the chain's lines again, all D parameters of
+     * them -- one / two / four waves 15.8 / 13.0 / 14.7 ms at [65536, 8000, 3]) */
+    p.waves = p.N1 == 8 ? 4u : (p.N1 == 4 ? 2u : 1u);
+    const size_t lds = ((size_t)p.N + (size_t)p.waves * 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
     const size_t resident = 256 * std::max<size_t>(1, (160u << 10) / lds); /* MI355X: 256 CUs x workgroups per CU by their LDS */
     size_t g = 512;
     if (dim > 0 && g * dim > resident)
@@ -1838,26 +1885,26 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
             MM_HIP(hipMallocAsync((void **)&ws, (slab_floats + part_floats + p_floats) * sizeof(float), stream));
         float *bins = ws + slab_floats;
         double *P = reinterpret_cast<double *>(ws + ((slab_floats + part_floats + 1) / 2) * 2);
-        const size_t lds = ((size_t)lp.N + 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
+        const size_t lds = ((size_t)lp.N + (size_t)lp.waves * 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
         const unsigned int grid = lp.n_wg * (unsigned int)dim;
         hipError_t le = hipSuccess;
-#define MM_LONG_LAUNCH(TT, NN)                                                                                      \
+#define MM_LONG_LAUNCH(TT, NN, WW)                                                                                  \
     do {                                                                                                            \
         if (lds > 64 * 1024)                                                                                        \
-            le = hipFuncSetAttribute((const void *)mm_chain_fft_long_kernel<TT, NN>,                                \
+            le = hipFuncSetAttribute((const void *)mm_chain_fft_long_kernel<TT, NN, WW>,                            \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
         if (le == hipSuccess)                                                                                       \
-            hipLaunchKernelGGL((mm_chain_fft_long_kernel<TT, NN>), dim3(grid), dim3(64), lds, stream, (const TT *)sample, \
-                               (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, lp.n_wg, tw, \
-                               wN, means, ssq, ws);                                                                 \
+            hipLaunchKernelGGL((mm_chain_fft_long_kernel<TT, NN, WW>), dim3(grid), dim3(64 * WW), lds, stream,      \
+                               (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, \
+                               (unsigned int)m, lp.n_wg, tw, wN, means, ssq, ws);                                   \
     } while (0)
 #define MM_LONG_PICK(TT)                                                                                            \
     do {                                                                                                            \
         switch (lp.N1) {                                                                                            \
-        case 2: MM_LONG_LAUNCH(TT, 2); break;                                                                       \
-        case 4: MM_LONG_LAUNCH(TT, 4); break;                                                                       \
-        case 8: MM_LONG_LAUNCH(TT, 8); break;                                                                       \
-        default: MM_LONG_LAUNCH(TT, 16); break;                                                                     \
+        case 2: MM_LONG_LAUNCH(TT, 2, 1); break;                                                                    \
+        case 4: MM_LONG_LAUNCH(TT, 4, 2); break;                                                                    \
+        case 8: MM_LONG_LAUNCH(TT, 8, 4); break;                                                                    \
+        default: MM_LONG_LAUNCH(TT, 16, 1); break;                                                                  \
         }                                                                                                           \
     } while (0)
         if (dtype == MMCMC_F32)

@@ -917,7 +917,7 @@ def test_nuts_posterior_and_run_progress_stats(M, O):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2), (5, 2050, 2),
-                                   (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2), (64, 33000, 2), (400, 2100, 3)])
+                                   (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2), (64, 33000, 2), (400, 2100, 3), (9, 7000, 3), (70, 5001, 2), (33, 12000, 1)])
 def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
     """Half-chains beyond 1024 draws (mm_chain_fft_long_kernel: the transform cut into N1 residues of 2048-point wave-level
     transforms) and beyond 16 384 (mm_lag_sums_any_kernel: any length, straight from global memory): R-hat / ESS against
