@@ -1142,6 +1142,7 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
      * exchange block.  With one wave per workgroup the 64 KB spectrum of N1 = 8 left one wave per CU (S is what fills the LDS);
      * four waves beside one S are four per CU, and each reads the chain N1 / WAVES + 1 / WAVES times instead of N1 + 1. */
     static_assert(WAVES == 1 || N1 % WAVES == 0, "residues are dealt evenly");
+    static_assert(N1 != 4 || WAVES > 1, "the staged column becomes visible at the barrier of the means");
     __shared__ float msum[2][WAVES][2]; /* the waves' shares of the two half-chains' sums, by chain parity */
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float *const S = lds_raw;                                        /* [N] */
@@ -1175,6 +1176,12 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
      * [65536, 4000, 3] 4.0 -> 3.3 ms).  At N1 = 4 the 128 cached values per lane made the kernel SLOWER ([65536, 8000, 3]
      * 13.4 -> 19.4 ms): kept to N1 = 2 */
     constexpr bool CACHE = HALF == 1;
+    /* N1 = 4 (half-chains of 2049 .. 4096 draws): the parameter's column of both half-chains is STAGED in LDS once per chain
+     * (32 KB beside the 32 KB spectrum), by the pass that sums it for the means, and the four residue passes read it from there:
+     * from the L2 every pass pulled the chain's lines again -- all D parameters of them, 75 GB at [65536, 8000, 3] -- and the
+     * kernel sat at the L2's bandwidth whatever its occupancy. */
+    constexpr bool STAGE = N1 == 4;
+    float *const st0 = lds_raw + N + (size_t)WAVES * 2 * pl::LDS_CX, *const st1 = st0 + N / 2;
     unsigned int parity = 0;
     for (unsigned long long c = wg; c < C; c += n_wg, parity ^= 1u) {
         const T *const base = sample + (size_t)c * n * D + d;
@@ -1198,7 +1205,9 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
                     s0 += in ? c0[a][n1] : 0.f;
                     s1 += in ? c1[a][n1] : 0.f;
                 }
-        } else
+        } else {
+        if constexpr (STAGE)
+            __syncthreads(); /* the last chain's residue passes have read the staged column */
         for (unsigned int t0 = lane + 64u * 8u * wave; t0 < m; t0 += 64u * 8u * WAVES) {
             float u0[8], u1[8];
 #pragma unroll
@@ -1212,7 +1221,14 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
                 const bool in = t0 + 64u * u < m;
                 s0 += in ? u0[u] : 0.f;
                 s1 += in ? u1[u] : 0.f;
+                if constexpr (STAGE) {
+                    if (in) {
+                        st0[t0 + 64u * u] = u0[u];
+                        st1[t0 + 64u * u] = u1[u];
+                    }
+                }
             }
+        }
         }
         float t0s = wave_sum_dpp_bcast(s0), t1s = wave_sum_dpp_bcast(s1);
         if constexpr (WAVES > 1) {
@@ -1263,6 +1279,9 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
                         if constexpr (CACHE) {
                             r0[aa][n1] = c0[a0 + aa][n1];
                             r1[aa][n1] = c1[a0 + aa][n1];
+                        } else if constexpr (STAGE) {
+                            r0[aa][n1] = st0[n2 + 2048u * n1]; /* t < N / 2: inside the block; beyond m masked below */
+                            r1[aa][n1] = st1[n2 + 2048u * n1];
                         } else {
                             const unsigned int t = n2 + 2048u * n1, tc = t < m ? t : m - 1u;
                             r0[aa][n1] = (float)base[(size_t)tc * D];
@@ -1646,6 +1665,11 @@ struct StatsLongPlan {
     bool use = false;
     unsigned int N1 = 0, N = 0, n_wg = 0, waves = 1;
 };
+/* LDS of a workgroup of the long-chain kernel: the spectrum, an exchange block per wave, at N1 = 4 the staged column */
+static size_t stats_long_lds(unsigned int N, unsigned int waves, unsigned int N1)
+{
+    return ((size_t)N + (size_t)waves * 2 * (size_t)mm_fft_plan<32>::LDS_CX + (N1 == 4 ? (size_t)N : 0)) * sizeof(float);
+}
 static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int sel_in = -1)
 {
     StatsLongPlan p;
@@ -1663,10 +1687,10 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
      * half-empty round), a multiple of 8 (the kernel's XCD mapping); fewer for few chains */
     /* waves per workgroup: one where the chain is cached in registers (N1 = 2) and where a second exchange block no longer
      * fits beside the spectrum (N1 = 16: 128 KB); four at N1 = 8 ([16384, 16000, 3]: 32.8 -> 9.4 ms, with the kernel's spills
-     * gone), two at N1 = 4 (where the L2 is the limit: every residue pass pulls the chain's lines again, all D parameters of
-     * them -- one / two / four waves 15.8 / 13.0 / 14.7 ms at [65536, 8000, 3]) */
-    p.waves = p.N1 == 8 ? 4u : (p.N1 == 4 ? 2u : 1u);
-    const size_t lds = ((size_t)p.N + (size_t)p.waves * 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
+     * gone) and at N1 = 4 (with the column staged in LDS: [65536, 8000, 3] 13.0 -> 12.1 ms; without it one / two / four waves
+     * 15.8 / 13.0 / 14.7 ms) */
+    p.waves = (p.N1 == 8 || p.N1 == 4) ? 4u : 1u;
+    const size_t lds = stats_long_lds(p.N, p.waves, p.N1);
     const size_t resident = 256 * std::max<size_t>(1, (160u << 10) / lds); /* MI355X: 256 CUs x workgroups per CU by their LDS */
     size_t g = 512;
     if (dim > 0 && g * dim > resident)
@@ -1885,7 +1909,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
             MM_HIP(hipMallocAsync((void **)&ws, (slab_floats + part_floats + p_floats) * sizeof(float), stream));
         float *bins = ws + slab_floats;
         double *P = reinterpret_cast<double *>(ws + ((slab_floats + part_floats + 1) / 2) * 2);
-        const size_t lds = ((size_t)lp.N + (size_t)lp.waves * 2 * (size_t)mm_fft_plan<32>::LDS_CX) * sizeof(float);
+        const size_t lds = stats_long_lds(lp.N, lp.waves, lp.N1);
         const unsigned int grid = lp.n_wg * (unsigned int)dim;
         hipError_t le = hipSuccess;
 #define MM_LONG_LAUNCH(TT, NN, WW)                                                                                  \
@@ -1902,7 +1926,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
     do {                                                                                                            \
         switch (lp.N1) {                                                                                            \
         case 2: MM_LONG_LAUNCH(TT, 2, 1); break;                                                                    \
-        case 4: MM_LONG_LAUNCH(TT, 4, 2); break;                                                                    \
+        case 4: MM_LONG_LAUNCH(TT, 4, 4); break;                                                                    \
         case 8: MM_LONG_LAUNCH(TT, 8, 4); break;                                                                    \
         default: MM_LONG_LAUNCH(TT, 16, 1); break;                                                                  \
         }                                                                                                           \
