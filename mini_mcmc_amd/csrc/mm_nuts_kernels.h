@@ -472,14 +472,18 @@ __device__ __forceinline__ void mm_nuts_pair_body(const mm_nuts_args<TT, ST> &a)
             const double d1 = ring[64 * ((k0 + 1u) & (MM_NUTS_RING - 1u))];
             const double d2 = ring[64 * ((k0 + 2u) & (MM_NUTS_RING - 1u))];
             unsigned int used = 0;
-            auto draw = [&]() -> double {
-                const double r = used == 0u ? d0 : (used == 1u ? d1 : d2);
-                ++used;
-                return r;
+            /* The next of the tick's (at most three) draws, selected among VALUES.  As a closure with d0, d1, d2 and `used`
+             * captured by reference -- handed to hand_up_with, which calls it inside its merge branch -- the compiler selected
+             * among their ADDRESSES and loaded through the one it picked: the three draws and a table of three pointers lived in
+             * private memory, five stores and a dependent scratch load in every tick of every chain (round 5,
+             * tools/scratch_scan.py: 64 - 72 bytes of scratch in every instance of this kernel). */
+            auto next_draw = [](unsigned int k, double a0, double a1, double a2) -> double {
+                return k == 0u ? a0 : (k == 1u ? a1 : a2);
             };
             MM_NP_LANES(7, phase == 1); /* doublings begun */
             if (phase == 1) {
-                T.double_begin_with(ad.epsilon, draw());
+                T.double_begin_with(ad.epsilon, next_draw(used, d0, d1, d2));
+                ++used;
                 phase = 2;
             }
             int r = Tree::HAND_MORE; /* phase 4: a subtree on its way up */
@@ -493,11 +497,17 @@ __device__ __forceinline__ void mm_nuts_pair_body(const mm_nuts_args<TT, ST> &a)
             MM_NP_LANES(9, second);     /* second leaves */
             if (second) {
                 T.leaf(a.P);
-                r = T.pair_second(draw());
+                r = T.pair_second(next_draw(used, d0, d1, d2));
+                ++used;
             }
             MM_NP_LANES(10, r == Tree::HAND_MORE && T.sibling_waits(stk)); /* merges at level >= 1 */
-            if (r == Tree::HAND_MORE && T.sibling_waits(stk))
-                r = T.hand_up_with(stk, draw);
+            if (r == Tree::HAND_MORE && T.sibling_waits(stk)) {
+                /* a waiting sibling is merged -- and the draw taken -- unless S has reached the doubling's own level */
+                const double u3 = next_draw(used, d0, d1, d2);
+                const bool draws = T.S_level != (uint32_t)T.j;
+                r = T.hand_up_with(stk, [u3]() -> double { return u3; });
+                used += draws ? 1u : 0u;
+            }
             while (__ballot(r == Tree::HAND_MORE && !T.sibling_waits(stk)) != 0ull) {
                 MM_NP_ADD(11, 1);       /* trips of the free-step loop */
                 MM_NP_LANES(12, r == Tree::HAND_MORE && !T.sibling_waits(stk));
@@ -507,7 +517,8 @@ __device__ __forceinline__ void mm_nuts_pair_body(const mm_nuts_args<TT, ST> &a)
             phase = r == Tree::HAND_MORE ? 4 : 2;
             MM_NP_LANES(13, r == Tree::HAND_DONE); /* doublings ended */
             if (r == Tree::HAND_DONE) {
-                T.double_end_with(x, a.max_depth, draw());
+                T.double_end_with(x, a.max_depth, next_draw(used, d0, d1, d2));
+                ++used;
                 phase = 1;
                 if (!T.s) {
                     phase = 0;
