@@ -73,10 +73,12 @@ while "t" in fam and time.time() - t0 < budget:
         k = min(int(rng.integers(1, 16)), steps - t)
         tb.step(dev, t0=t, k=k)
         t += k
-    assert np.array_equal(ta.rhat(), tb.rhat()) and ta.p_accept == tb.p_accept, (chains, steps, params, x.dtype)
+    # NaN == NaN here: two chains that never moved in a parameter have no variance at all, and both feeding orders say so
+    same = lambda u, v: np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True)
+    assert same(ta.rhat(), tb.rhat()) and same(ta.p_accept, tb.p_accept), (chains, steps, params, x.dtype, ta.rhat(), tb.rhat())
     ra, mxa, pa = ta.chain_stats()
     rb, mxb, pb = tb.chain_stats()
-    assert np.array_equal(ra, rb) and mxa == mxb and pa == pb, (chains, steps, params)
+    assert same(ra, rb) and same(mxa, mxb) and same(pa, pb), (chains, steps, params)
     n += 1
 print(f"tracker: {n} random cases, whole blocks == step by step")
 
