@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
         }
         }
         float t0s = wave_sum_dpp_bcast(s0), t1s = wave_sum_dpp_bcast(s1);
-        if constexpr (WAVES > 1) {
+        if constexpr (WAVES > 1 && !CACHE) { /* (a wave that caches the chain has summed all of it itself) */
             /* every wave summed its share of the time steps: the shares meet in LDS and are added in wave order.  One barrier
              * per chain (the buffer alternates with the chain's parity: a wave two chains ahead cannot exist, it would have had
              * to pass the barrier in between) */
