@@ -16,15 +16,11 @@ for co in isa_mix.code_objects(so):
         f.write(co)
         f.flush()
         notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True).stdout
-    name = None
-    for ln in notes.splitlines():
-        m = re.search(r"\.name:\s+(\S+)", ln)
-        if m and not ln.strip().startswith(".name:           ") is None:
-            name = m.group(1)
+    cur_sz = 0
+    for ln in notes.splitlines():  # per kernel the metadata lists .private_segment_fixed_size before .symbol
         m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", ln)
         if m:
-            sz = int(m.group(1))
-            cur_sz = sz
+            cur_sz = int(m.group(1))
         m = re.search(r"\.symbol:\s+(\S+)\.kd", ln)
         if m:
             rows.append((cur_sz, m.group(1)))
