@@ -20,6 +20,7 @@ SO = os.path.join(ROOT, "mini_mcmc_amd", "libmmcmc.so")
 HMC = "mm_run_split_kernelIf9mm_targetIfLi4ELi3EELi1ELi10E"  # <float, RosenbrockND<3>, HMC, L = 10, ...>
 MH = "mm_run_split_kernelIf9mm_targetIfLi0ELi2EELi0ELi0E"    # <float, Gaussian2D, MH, ...>
 LGQ = "mm_nuts_lgq_kernelILi32ELi1E"                          # config 5's persistent scheduler, one wave per SIMD
+PAIR = "mm_nuts_pair_kernelIfd9mm_targetIfLi4ELi3EELb1E"      # small-D NUTS (RosenbrockND(3), mode 0): the tick's draws once lived in scratch
 
 
 def _text(want):
@@ -32,7 +33,7 @@ def _text(want):
     return [ln.split("//")[0].strip() for ln in lines]
 
 
-@pytest.mark.parametrize("want", [HMC, MH, LGQ])
+@pytest.mark.parametrize("want", [HMC, MH, LGQ, PAIR])
 def test_hot_kernels_keep_their_state_in_registers(want):
     text = _text(want)
     spills = [ln for ln in text if ln.startswith("scratch_") or ln.startswith("buffer_load_dword v") and "offen" in ln]
