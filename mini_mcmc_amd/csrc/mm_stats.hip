@@ -1122,6 +1122,9 @@ void mm_chain_fft_kernel(const T *__restrict__ sample, unsigned long long C, uns
  * The chain is read N1 + 1 times (once for the means), from L2 after the first: this path is for samples whose direct
  * lag sums would cost m^2 (a [65536, 4000, 3] sample: 406 ms through the direct kernel, and no kernel at all beyond
  * m = 6800 at D = 3, where its LDS layout ends).  N <= 32768: m <= 16384. */
+#ifndef MM_STATS_LONG_PREFETCH
+#define MM_STATS_LONG_PREFETCH 1
+#endif
 template <class T, int N1, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n,
                                                                unsigned int D, unsigned int m, unsigned int n_wg,
@@ -1183,11 +1186,40 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
     constexpr bool STAGE = N1 == 4;
     float *const st0 = lds_raw + N + (size_t)WAVES * 2 * pl::LDS_CX, *const st1 = st0 + N / 2;
     unsigned int parity = 0;
+    /* N1 = 2: the NEXT chain's points are requested before this chain's two transforms and arrive behind them (one wave per
+     * SIMD has nobody to hide a memory latency behind; the second set of 64 registers is there) */
+    float nx0[CACHE ? R1 : 1][CACHE ? HALF : 1], nx1[CACHE ? R1 : 1][CACHE ? HALF : 1];
+    auto fetch = [&](unsigned long long cc, float (&f0)[CACHE ? R1 : 1][CACHE ? HALF : 1], float (&f1)[CACHE ? R1 : 1][CACHE ? HALF : 1])
+                     __attribute__((always_inline)) {
+        const T *const b = sample + (size_t)cc * n * D + d;
+#pragma unroll
+        for (int a = 0; a < (CACHE ? R1 : 1); ++a)
+#pragma unroll
+            for (int n1 = 0; n1 < (CACHE ? HALF : 1); ++n1) {
+                const unsigned int t = 64u * a + lane + 2048u * n1, tc = t < m ? t : m - 1u;
+                f0[a][n1] = (float)b[(size_t)tc * D];
+                f1[a][n1] = (float)b[second + (size_t)tc * D];
+            }
+    };
+    if constexpr (CACHE && MM_STATS_LONG_PREFETCH)
+        if (wg < C)
+            fetch(wg, nx0, nx1);
     for (unsigned long long c = wg; c < C; c += n_wg, parity ^= 1u) {
         const T *const base = sample + (size_t)c * n * D + d;
         float s0 = 0.f, s1 = 0.f;
         float c0[CACHE ? R1 : 1][CACHE ? HALF : 1], c1[CACHE ? R1 : 1][CACHE ? HALF : 1];
         if constexpr (CACHE) {
+            if constexpr (MM_STATS_LONG_PREFETCH) {
+#pragma unroll
+                for (int a = 0; a < R1; ++a)
+#pragma unroll
+                    for (int n1 = 0; n1 < HALF; ++n1) {
+                        c0[a][n1] = nx0[a][n1];
+                        c1[a][n1] = nx1[a][n1];
+                    }
+                if (c + n_wg < C)
+                    fetch(c + n_wg, nx0, nx1);
+            } else
 #pragma unroll
             for (int a = 0; a < R1; ++a)
 #pragma unroll
