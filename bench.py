@@ -228,12 +228,17 @@ def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
             ms.append(mh.timing()["kernel_ms"])
         ke = float(np.median(ms))
         mh_bytes = C_PER_GPU * 2 * 4 * (1000 + 2)
-        out["config2_mh"] = {"kernel_ms": kb, "kernel_ms_how": f"HIP events on the launch stream around {n_b2b} back-to-back launches / {n_b2b} (as roofline.kernel_ms of the headline)",
-                             "kernel_ms_one_launch_at_a_time": ke, "ms_per_run_back_to_back": k,
+        # `kernel_ms` / `hbm_frac` are again what they were up to BENCH_r04 -- the median of launches timed one at a
+        # time (comparable across rounds) -- and the throughput figure of launches queued back to back (the method of the
+        # headline's roofline.kernel_ms, where one launch's tail overlaps the next one's head) has keys of its own
+        out["config2_mh"] = {"kernel_ms": ke, "kernel_ms_how": "median of 10 launches timed one at a time by HIP events on the launch stream (the definition of BENCH_r01..r04; BENCH_r05 quoted the back-to-back figure under this key)",
+                             "kernel_ms_back_to_back": kb,
+                             "kernel_ms_back_to_back_how": f"HIP events on the launch stream around {n_b2b} back-to-back launches / {n_b2b} (as roofline.kernel_ms of the headline; what rocprofv3's average over the run agrees with)",
+                             "ms_per_run_back_to_back": k,
                              "samples_per_s": C_PER_GPU * 1000 / (k * 1e-3),
                              "algorithmic_bytes_per_launch": mh_bytes,
-                             "hbm_frac": mh_bytes / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "hbm_frac_one_launch_at_a_time": mh_bytes / (ke * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "hbm_frac": mh_bytes / (ke * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "hbm_frac_back_to_back": mh_bytes / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "stream": "the MH sampler's paired f32 stream at D <= 2 (csrc/mm_rng.h, round 5: one Philox block per two transitions)"}
         del mh, mh_out
         # config 3, long run: 1000 collected after 200; ESS / R-hat of that sample
@@ -345,6 +350,34 @@ def side_configs(dev, cpu_seconds: float = 0.0) -> dict:
     return out
 
 
+EXCHANGE_TEXT = {1: "rccl (ncclAllGather + ncclAllReduce inside libmmcmc.so)", 0: "host (a device is listed twice)",
+                 -1: "host FALLBACK: no RCCL library could be loaded", -2: "host FALLBACK: ncclCommInitAll failed"}
+
+
+def group_verdict(devices, pci_bus_ids, exchange_status: int, rccl_ranks: int):
+    """(data, exit_code, problems) of a device-group line.  A run over N DISTINCT devices is a scaling measurement: its
+    diagnostics must have travelled over RCCL with N ranks, and the N devices must be N different GPUs by PCI
+    bus id -- otherwise the line is still printed, `data` says in capitals what happened, and the process exits non-zero
+    so that no harness can take the line for a measurement.  A device listed twice (the one-GPU rehearsal,
+    MMCMC_BENCH_GROUP_DEVICES=0,0) goes through the host by design: exit 0, and `data` says it is a rehearsal."""
+    n = len(devices)
+    distinct = len(set(devices)) == n
+    problems = []
+    if distinct:
+        if exchange_status != 1:
+            problems.append("DIAGNOSTICS FELL BACK TO THE HOST (" + EXCHANGE_TEXT.get(exchange_status, f"status {exchange_status}") + ")")
+        if rccl_ranks != n:
+            problems.append(f"RCCL COMMUNICATOR HAS {rccl_ranks} RANKS FOR {n} DEVICES")
+        if len(set(pci_bus_ids)) != n:
+            problems.append("TWO DEVICE ORDINALS SHARE A PCI BUS ID: " + ",".join(pci_bus_ids))
+    data = "synthetic"
+    if not distinct:
+        data += "; REHEARSAL: a device is listed twice, its shards share one GPU and the statistics travel through the host by design -- not a scaling measurement"
+    if problems:
+        data += "; " + "; ".join(problems) + " -- NOT A VALID SCALING MEASUREMENT"
+    return data, (3 if problems else 0), problems
+
+
 def main_group(args) -> None:
     """--group: the same headline through the in-library device group -- one process, N devices (MMCMC_BENCH_GROUP_DEVICES =
     comma-separated device list overrides 0..N-1, e.g. "0,0" rehearses two shards on one GPU through the host exchange).
@@ -371,7 +404,7 @@ def main_group(args) -> None:
     def step():
         # nothing goes back to the host: every shard's launch is ENQUEUED on that shard's stream and the call returns
         # (include/mmcmc.h) -- the same back-to-back queueing as the N = 1 line's mmcmc_hmc_run on torch's stream
-        g.run(N_COLLECT, N_DISCARD, to_host=False, accept_counts=False)
+        g.run_async(N_COLLECT, N_DISCARD)
 
     t_pre, pre = time.perf_counter(), 0
     while time.perf_counter() - t_pre < args.preroll_seconds:
@@ -391,9 +424,14 @@ def main_group(args) -> None:
     dt = time.perf_counter() - t0
     g.split_rhat_mean_ess()
     ts = time.perf_counter()
+    phases = {"local_partials_ms": 0.0, "exchange_ms": 0.0, "finish_ms": 0.0}
     for _ in range(5):
         rhat, ess = g.split_rhat_mean_ess()
+        for k, v in g.stats_phases().items():  # where the call's time goes: every shard's local statistics | the
+            phases[k] += v / 5                 # collectives (+ cross-chain sums on shard 0) | the finish
     stats_s = (time.perf_counter() - ts) / 5
+    pci = g.pci_bus_ids()
+    data, exit_code, problems = group_verdict(devices, pci, g.exchange_status, rccl_ranks)
     samples = float(args.steps) * C_PER_GPU * n * N_COLLECT
     ms = dt / args.steps * 1e3
     alg_bytes = C_PER_GPU * DIM * 4 * (N_COLLECT + 2)
@@ -403,20 +441,20 @@ def main_group(args) -> None:
     res = {
         "metric": "samples/sec (all chains), 3D Rosenbrock HMC", "value": samples / dt, "unit": "samples/s", "n_gpus": n,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": data,
         "config": {"workload": "BASELINE.json configs[2] per device (configs[3] at 8): RosenbrockND D=3 HMC, 65536 chains/GPU, "
                                "eps=0.032, L=10, f32, run(400, 50) per step", "chains_per_gpu": C_PER_GPU, "dim": DIM,
                    "n_leapfrog": N_LEAPFROG, "n_collect": N_COLLECT, "n_discard": N_DISCARD, "devices": devices,
                    "parallelism": f"in-library device group x{n}: one process, one stream per device, launches enqueued back to back, no data-path collective"},
         "leapfrog_steps_per_s": float(args.steps) * C_PER_GPU * n * (N_COLLECT + N_DISCARD) * N_LEAPFROG / dt,
         "ess_min": float(ess.min()), "split_rhat_max_conventional": rhat_max,
-        "stats_ms": stats_s * 1e3,
-        "diagnostics_exchange": {1: "rccl (ncclAllGather + ncclAllReduce inside libmmcmc.so)", 0: "host (a device is listed twice)",
-                                 -1: "host FALLBACK: no RCCL library could be loaded", -2: "host FALLBACK: ncclCommInitAll failed"}[g.exchange_status],
+        "stats_ms": stats_s * 1e3, "stats_phases_ms": phases,
+        "diagnostics_exchange": EXCHANGE_TEXT[g.exchange_status],
         "diagnostics_exchange_decided_at_create": exch_status,
         "preroll": {"seconds": args.preroll_seconds, "steps": pre},
-        "rccl_ranks": rccl_ranks,
+        "rccl_ranks": rccl_ranks, "pci_bus_ids": pci, "problems": problems,
         "kernel_ms_per_device": [float(x) for x in kernel_ms_per_device],
+        "kernel_ms_spread_max_over_min": float(max(kernel_ms_per_device) / max(min(kernel_ms_per_device), 1e-9)),
         # the kernel's launch duration per device: HIP events on each shard's own stream around the timed region / steps (with a
         # device listed twice its two streams share the device, so each stream's figure covers both shards' launches)
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -429,7 +467,12 @@ def main_group(args) -> None:
     }
     conv = rhat_max <= 1.05
     res["ess_per_s" if conv else "ess_per_s_unconverged"] = float(ess.min()) * args.steps / (dt + stats_s * args.steps)
-    print(json.dumps(res))
+    print(json.dumps(res), flush=True)
+    if exit_code:
+        # printed first (the line is evidence of WHAT went wrong), then a non-zero exit: a scaling run cannot take the
+        # host path, a short communicator or one GPU under two ordinals and still look like a measurement
+        g.close()
+        sys.exit(exit_code)
 
 
 def main() -> None:
@@ -554,6 +597,15 @@ def main() -> None:
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    # every rank's own kernel time and the PCI bus id of the GPU it really ran on: rank 0 prints both, and refuses (non-zero
+    # exit after printing) a launcher run in which two ranks shared a GPU or the process group is not RCCL
+    pci_buf = C.create_string_buffer(32)
+    L.check(lib.mmcmc_device_pci_bus_id(local_rank, pci_buf, 32), "mmcmc_device_pci_bus_id")
+    mine = {"rank": rank, "device": local_rank, "pci_bus_id": pci_buf.value.decode(), "kernel_ms": float(kernel_ms_timed_region)}
+    per_rank = [mine]
+    if distributed:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # diagnostics on the last sample (outside the timed region): RCCL all-gather / all-reduce of sufficient statistics
     def diagnostics():
@@ -601,7 +653,17 @@ def main() -> None:
                 pipe_ms = (time.perf_counter() - tp) / n_pipe * 1e3
         sampler.enable_timing(True)
 
+    exit_code = 0
     if rank == 0:
+        backend = dist.get_backend() if distributed else None
+        if distributed:
+            data, exit_code, problems = group_verdict([0] * world if dryrun else [r["device"] for r in per_rank],
+                                                      [r["pci_bus_id"] for r in per_rank], 1 if backend == "nccl" else 0,
+                                                      dist.get_world_size() if backend == "nccl" else 0)
+            if dryrun:
+                data = "synthetic; DRY RUN: all ranks on one device over gloo, not a measurement"
+        else:
+            data, problems = "synthetic", []
         samples = float(args.steps) * C_PER_GPU * world * N_COLLECT
         ms_per_step = dt_max / args.steps * 1e3
         k_ms = float(kernel_ms_timed_region)
@@ -653,7 +715,7 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if not dryrun else "synthetic; DRY RUN: all ranks on one device over gloo, not a measurement",
+            "data": data,
             "config": {
                 "workload": "BASELINE.json configs[2]: RosenbrockND D=3 HMC, 65536 chains/GPU, eps=0.032, L=10, f32, "
                             "run(n_collect=400, n_discard=50) per step, init_with_seed(C,3,42), seed 42",
@@ -669,6 +731,11 @@ def main() -> None:
                         "not converged (nor has the reference's example in 450 transitions) and the figure is named "
                         "ess_per_s_unconverged: it is not an efficiency; side.config3_converged measures ESS/s on a converged run",
             "stats_ms": stats_s * 1e3,
+            "diagnostics_exchange": (f"torch.distributed backend {backend}: two all-reduces of cross-chain sums "
+                                     "(stats.split_rhat_mean_ess_distributed)" if distributed else "single device"),
+            "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0) if distributed else None,
+            "per_rank": per_rank, "problems": problems,
+            "kernel_ms_spread_max_over_min": max(r["kernel_ms"] for r in per_rank) / max(min(r["kernel_ms"] for r in per_rank), 1e-9),
             "pipelined_ms_per_step": pipe_ms,
             "ess_per_s_pipelined_unconverged": (float(ess.min()) / (pipe_ms * 1e-3)) if pipe_ms else None,
             "preroll": {"seconds": args.preroll_seconds, "steps": preroll_steps,
@@ -702,9 +769,11 @@ def main() -> None:
             res["side"] = side_configs(dev, 0.0 if args.no_cpu_baseline else max(3.0, args.cpu_seconds / 3))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)  # after the line: a launcher run that shared GPUs or left RCCL cannot pass for a measurement
 
 
 if __name__ == "__main__":

@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define MMCMC_VERSION 100 /* 0.1.0 */
+/* 101 (round 6): + mmcmc_{mh,hmc}_group_run_async, mmcmc_*_group_stats_phases, mmcmc_device_pci_bus_id,
+ *   MMCMC_ERR_GROUP_BROKEN; mmcmc_*_group_run blocks again whatever its arguments (100 inferred "asynchronous" from
+ *   out_host == NULL && accept_counts == NULL); mmcmc_nuts_set_repacking (100, measured slower, removed) stays removed.
+ * A binding checks mmcmc_version() >= the version it was generated from (rust/mini-mcmc-hip: assert_abi, in every constructor). */
+#define MMCMC_VERSION 101 /* 0.1.1 */
 
 /* ---- status ---- */
 #define MMCMC_OK 0
@@ -39,6 +43,7 @@ extern "C" {
 #define MMCMC_ERR_SHAPE (-3)        /* the analogue of ndarray::ShapeError from core.rs:184       */
 #define MMCMC_ERR_NO_DEVICE (-4)    /* no HIP device: the engine never falls back to the CPU      */
 #define MMCMC_ERR_STATE (-5)        /* call made in the wrong state (e.g. timing before any run)  */
+#define MMCMC_ERR_GROUP_BROKEN (-6) /* a device group whose shards stand at different iterations (a run failed on some) */
 
 /* ---- element types ---- */
 #define MMCMC_F32 0
@@ -103,6 +108,9 @@ typedef struct mmcmc_timing {
 int mmcmc_version(void);
 const char *mmcmc_status_string(int status);
 int mmcmc_device_count(int *count);
+/* hipDeviceGetPCIBusId of `device` as "dddd:bb:dd.f" into buf (len >= 16): a scaling run prints it per shard so that two
+ * "devices" that are one GPU cannot pass for two */
+int mmcmc_device_pci_bus_id(int device, char *buf, size_t len);
 
 /* ---- core.rs:394-435  init_with_seed / init_det (seed 42): n*d StandardNormal draws of the reference's own
  *      stream (rand 0.9 SmallRng = xoshiro256++, rand_distr 0.5 ziggurat), row-major, as double. Host only. */
@@ -309,18 +317,26 @@ int mmcmc_proposal_register_source(const char *name, int target_kind, int dim, c
  * the global index, so the sample does not depend on the number of devices), runs the shards with no data-path
  * collective, and reduces split-R-hat / ESS (stats.rs:416-546) over all chains: per-device
  * sufficient statistics, RCCL ncclAllGather of the per-half-chain means / sums of squares + ncclAllReduce of the lag
- * sums over xGMI, host finish in the single-GPU summation order.  (RCCL is bound at run time; if it is missing, or a
+ * sums over xGMI; the cross-chain sums of withinvar are then reduced on shard 0 (f64 partial sums of the means relative
+ * to the mean of the first half of global chain 0 -- the shift the single-GPU kernel uses -- grouped per rank, so equal to
+ * the single-GPU result to rounding, not bit for bit) and the finish is the single-GPU one.  (RCCL is bound at run time; if it is missing, or a
  * device is listed twice -- several shards on one GPU --, the statistics travel through the host; *used_rccl says which:
  * 1 = RCCL; 0 = the host by design (a device listed twice); -1 = the host as a FALLBACK because no RCCL library could be
  * loaded; -2 = the host because ncclCommInitAll failed -- check it in a scaling run.)
  *   init: host [n_chains, dim] of dtype.  run: the sample stays on the devices (mmcmc_hmc_group_shard gives each shard's
  *   device pointer [n_i, n_collect, dim]); out_host, if not NULL, also receives [n_chains, n_collect, dim];
  *   accept_counts: host [n_chains] or NULL.  A second run continues the chains.
- *   ASYNCHRONOUS when nothing goes back to the host: an MH / HMC group_run with out_host == NULL and accept_counts == NULL
- *   enqueues every shard's launch on that shard's stream and returns (as mmcmc_hmc_run does on a caller's stream), so runs
- *   issued back to back keep all devices busy; mmcmc_*_group_sync waits for them.  _state, _split_rhat_mean_ess and a later
- *   run are ordered behind the queued work by the streams; read a shard's device pointer only after _sync.  With a host
- *   destination or accept counts (and for NUTS) the call returns when the results are there.
+ *   _run BLOCKS: it returns when every shard's results are there, also with out_host == NULL and accept_counts == NULL
+ *   (the shards' device pointers may then be read from any stream).
+ *   _run_async (MH / HMC; version 101 -- version 100 inferred this from two NULL arguments of _run) enqueues every shard's
+ *   launch on that shard's stream and returns (as mmcmc_hmc_run does on a caller's stream), so runs issued back to back keep
+ *   all devices busy; mmcmc_*_group_sync waits for them and reports their errors.  _state, _split_rhat_mean_ess and a later
+ *   run are ordered behind the queued work by the streams; read a shard's device pointer only after _sync.
+ *   A run (either spelling) that fails after SOME shards have advanced leaves them at different iterations: what was queued
+ *   is waited for, the failing status returned, and every later run / diagnostics call of the group returns
+ *   MMCMC_ERR_GROUP_BROKEN (_state, _shard, _destroy still work).
+ *   _stats_phases: host wall-clock milliseconds of the last _split_rhat_mean_ess, ms3 = {every shard's local statistics,
+ *   the exchange (collectives + cross-chain sums, or the host copies), the finish}.
  *   _stream_timer(g, 0, NULL) records a start event on every shard's stream, _stream_timer(g, 1, ms) the end events, waits
  *   and writes each shard's elapsed device milliseconds into ms [n_devices].
  *   _exchange: how the diagnostics' statistics will travel -- decided in _create, where the RCCL communicators are made
@@ -331,6 +347,8 @@ int mmcmc_hmc_group_create(mmcmc_hmc_group **out, const mmcmc_target_desc *targe
 int mmcmc_hmc_group_seed(mmcmc_hmc_group *g, uint64_t seed);
 int mmcmc_hmc_group_set_chain_offset(mmcmc_hmc_group *g, uint64_t first_global_chain);
 int mmcmc_hmc_group_run(mmcmc_hmc_group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts);
+int mmcmc_hmc_group_run_async(mmcmc_hmc_group *g, size_t n_collect, size_t n_discard);
+int mmcmc_hmc_group_stats_phases(mmcmc_hmc_group *g, double *ms3);
 int mmcmc_hmc_group_state(mmcmc_hmc_group *g, void *out); /* host [n_chains, dim] */
 int mmcmc_hmc_group_split_rhat_mean_ess(mmcmc_hmc_group *g, float *rhat, float *ess, int *used_rccl); /* of the last run */
 int mmcmc_hmc_group_shard(mmcmc_hmc_group *g, int i, int *device, size_t *first_chain, size_t *n_chains, void **sample_dev);
@@ -344,6 +362,8 @@ int mmcmc_mh_group_create(mmcmc_mh_group **out, const mmcmc_target_desc *target,
 int mmcmc_mh_group_seed(mmcmc_mh_group *g, uint64_t seed);
 int mmcmc_mh_group_set_chain_offset(mmcmc_mh_group *g, uint64_t first_global_chain);
 int mmcmc_mh_group_run(mmcmc_mh_group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts);
+int mmcmc_mh_group_run_async(mmcmc_mh_group *g, size_t n_collect, size_t n_discard);
+int mmcmc_mh_group_stats_phases(mmcmc_mh_group *g, double *ms3);
 int mmcmc_mh_group_state(mmcmc_mh_group *g, void *out);
 int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *g, float *rhat, float *ess, int *used_rccl);
 int mmcmc_mh_group_sync(mmcmc_mh_group *g);
@@ -360,6 +380,7 @@ int mmcmc_nuts_group_seed(mmcmc_nuts_group *g, uint64_t seed);
 int mmcmc_nuts_group_set_chain_offset(mmcmc_nuts_group *g, uint64_t first_global_chain);
 int mmcmc_nuts_group_set_max_depth(mmcmc_nuts_group *g, int max_depth);
 int mmcmc_nuts_group_run(mmcmc_nuts_group *g, size_t n_collect, size_t n_discard, void *out_host, int progress);
+int mmcmc_nuts_group_stats_phases(mmcmc_nuts_group *g, double *ms3);
 int mmcmc_nuts_group_state(mmcmc_nuts_group *g, void *out); /* host [n_chains, dim] of the tensor type */
 int mmcmc_nuts_group_leapfrog_counts(mmcmc_nuts_group *g, uint64_t *out); /* host [n_chains] */
 int mmcmc_nuts_group_split_rhat_mean_ess(mmcmc_nuts_group *g, float *rhat, float *ess, int *used_rccl);

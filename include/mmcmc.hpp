@@ -373,7 +373,7 @@ template <class T> class HMCGroup {
      * row keep every device busy); sync() waits, split_rhat_mean_ess() orders itself behind them */
     void run_on_devices(size_t n_collect, size_t n_discard)
     {
-        check(mmcmc_hmc_group_run(g_, n_collect, n_discard, nullptr, nullptr), "mmcmc_hmc_group_run");
+        check(mmcmc_hmc_group_run_async(g_, n_collect, n_discard), "mmcmc_hmc_group_run_async");
     }
     void sync() { check(mmcmc_hmc_group_sync(g_), "mmcmc_hmc_group_sync"); }
     /* how the diagnostics will travel (1 RCCL, 0 host by design, < 0 host as a fallback), known from construction on */

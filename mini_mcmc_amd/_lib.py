@@ -17,7 +17,7 @@ F32, F64 = 0, 1
 GAUSSIAN2D, DIFFABLE_GAUSSIAN2D, ISOTROPIC_GAUSSIAN, ROSENBROCK2D, ROSENBROCK_ND, STANDARD_NORMAL, GAUSSIAN_ND = range(7)
 
 OK = 0
-ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_SHAPE, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4, -5
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_SHAPE, ERR_NO_DEVICE, ERR_STATE, ERR_GROUP_BROKEN = -1, -2, -3, -4, -5, -6
 
 
 class TargetDesc(C.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "mmcmc_version": (C.c_int, []),
     "mmcmc_status_string": (C.c_char_p, [C.c_int]),
     "mmcmc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mmcmc_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "mmcmc_init_with_seed": (C.c_int, [C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_double)]),
     "mmcmc_mh_create": (C.c_int, [C.POINTER(_vp), _TP, _PP, _vp, C.c_size_t, C.c_int, C.c_int]),
     "mmcmc_mh_seed": (C.c_int, [_vp, C.c_uint64]),
@@ -170,6 +171,8 @@ SIGNATURES = {
     "mmcmc_hmc_group_seed": (C.c_int, [_vp, C.c_uint64]),
     "mmcmc_hmc_group_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
     "mmcmc_hmc_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint64)]),
+    "mmcmc_hmc_group_run_async": (C.c_int, [_vp, C.c_size_t, C.c_size_t]),
+    "mmcmc_hmc_group_stats_phases": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "mmcmc_hmc_group_state": (C.c_int, [_vp, _vp]),
     "mmcmc_hmc_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mmcmc_hmc_group_shard": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
@@ -181,6 +184,8 @@ SIGNATURES = {
     "mmcmc_mh_group_seed": (C.c_int, [_vp, C.c_uint64]),
     "mmcmc_mh_group_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
     "mmcmc_mh_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_uint64)]),
+    "mmcmc_mh_group_run_async": (C.c_int, [_vp, C.c_size_t, C.c_size_t]),
+    "mmcmc_mh_group_stats_phases": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "mmcmc_mh_group_state": (C.c_int, [_vp, _vp]),
     "mmcmc_mh_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mmcmc_mh_group_sync": (C.c_int, [_vp]),
@@ -192,6 +197,7 @@ SIGNATURES = {
     "mmcmc_nuts_group_set_chain_offset": (C.c_int, [_vp, C.c_uint64]),
     "mmcmc_nuts_group_set_max_depth": (C.c_int, [_vp, C.c_int]),
     "mmcmc_nuts_group_run": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp, C.c_int]),
+    "mmcmc_nuts_group_stats_phases": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "mmcmc_nuts_group_state": (C.c_int, [_vp, _vp]),
     "mmcmc_nuts_group_leapfrog_counts": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "mmcmc_nuts_group_split_rhat_mean_ess": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -843,9 +843,25 @@ const char *mmcmc_status_string(int status)
         return "no HIP device (the engine has no CPU fallback)";
     case MMCMC_ERR_STATE:
         return "handle in the wrong state";
+    case MMCMC_ERR_GROUP_BROKEN:
+        return "device group broken: a run failed after some shards had advanced";
     default:
         return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
     }
+}
+
+int mmcmc_device_pci_bus_id(int device, char *buf, size_t len)
+{
+    if (!buf || len < 16)
+        return MMCMC_ERR_INVALID_ARG;
+    buf[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return MMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= n)
+        return MMCMC_ERR_INVALID_ARG;
+    const hipError_t e = hipDeviceGetPCIBusId(buf, (int)len, device);
+    return e == hipSuccess ? MMCMC_OK : (int)e;
 }
 
 int mmcmc_device_count(int *count)

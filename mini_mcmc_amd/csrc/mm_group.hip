@@ -5,12 +5,13 @@
  * with one sampler handle per device the caller of the C ABI would have to write the sharding and the exchange of the
  * diagnostics itself.  A group owns one handle per device -- device i holds the contiguous block of global chains
  * [first_i, first_i + n_i), keyed into the random stream by their GLOBAL index, so the samples do not depend on the
- * number of devices.  A `run` that hands nothing back to the host (no host sample, no accept counts; MH / HMC) is
- * ENQUEUED on every shard's stream by the calling thread and returns at once -- like the single-device call on a
- * caller's stream, so back-to-back runs keep every device busy without a host round trip per run (mmcmc_*_group_sync
- * waits; everything that reads results is ordered behind the queued work by the shard's stream).  Calls that block
- * (host output, accept counts, NUTS with its adaptation hand-offs, the diagnostics) run from one host thread per
- * device, each blocking only its own thread.  Chains never talk to each other while sampling: no data-path collective.  The one exchange is
+ * number of devices.  `mmcmc_*_group_run` BLOCKS (whatever its arguments).  The asynchronous spelling is its own entry
+ * point, `mmcmc_{mh,hmc}_group_run_async`: the launches are ENQUEUED on every shard's stream by the calling thread and
+ * the call returns at once -- like the single-device call on a caller's stream, so back-to-back runs keep every device
+ * busy without a host round trip per run (mmcmc_*_group_sync waits; everything that reads results is ordered behind the
+ * queued work by the shard's stream).  Calls that block (group_run, NUTS with its adaptation hand-offs, the
+ * diagnostics) run from one host thread per device, each blocking only its own thread.  A run that fails after some
+ * shards have advanced and others have not marks the group broken (MMCMC_ERR_GROUP_BROKEN from then on).  Chains never talk to each other while sampling: no data-path collective.  The one exchange is
  * the split-R-hat / ESS reduction (stats.rs:416-546): every device reduces its own sample to the per-half-chain
  * statistics (mmcmc_stats_partials), RCCL all-gathers means / sums of squares over xGMI (ncclAllGather) and
  * all-reduces the lag sums (ncclAllReduce), and the host finish (mmcmc_stats_finish) runs on the gathered statistics
@@ -24,6 +25,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -84,9 +86,13 @@ __global__ __launch_bounds__(256) void mm_group_cross_sums_kernel(const float *_
     const unsigned int d = blockIdx.x >> 2, quarter = blockIdx.x & 3u, i = blockIdx.y, tid = threadIdx.x;
     const float *mi = gathered + (size_t)i * 2 * part, *qi = mi + part;
     const unsigned int c2 = cnt.n2[i], per = (c2 + 3u) / 4u, lo = quarter * per, hi = lo + per < c2 ? lo + per : c2;
+    /* the means are taken relative to the mean of the FIRST half of global chain 0 -- rank 0's first entry, the very shift
+     * mm_stats_tail_kernel uses on one device (means[d] of the splitcat order) -- and subtracted in f32 as there, so that
+     * sum((mean - overall)^2) = Sq - Sd^2 / c2 loses no digits on a target far from the origin */
+    const float shift = gathered[d];
     double sd = 0.0, sq = 0.0, ws = 0.0;
     for (unsigned int c = lo + tid; c < hi; c += 256u) {
-        const double mu = (double)mi[(size_t)c * D + d];
+        const double mu = (double)(mi[(size_t)c * D + d] - shift);
         sd += mu;
         sq += mu * mu;
         ws += (double)(qi[(size_t)c * D + d] / nf); /* biased per-chain variance (quirk Q8) */
@@ -195,6 +201,10 @@ struct Group {
      * twice: RCCL refuses two ranks on one GPU); -1 the host as a FALLBACK: libnccl / librccl not found; -2: ncclCommInitAll
      * failed (e.g. no peer access) -- a scaling run must not take the host path silently */
     int exchange_status = 0;
+    /* an asynchronous run whose enqueue loop failed half way leaves the shards at different iterations: the group refuses
+     * every later run / diagnostics call with MMCMC_ERR_GROUP_BROKEN instead of continuing on an inconsistent state */
+    bool broken = false;
+    double phase_ms[3] = {0.0, 0.0, 0.0}; /* last group_split_rhat_ess: local partials | exchange | finish (host wall clock) */
     uint64_t user_offset = 0;
     std::vector<Shard> sh;
     size_t esize() const { return dtype == MMCMC_F32 ? 4 : 8; }
@@ -383,17 +393,24 @@ static int shard_reserve_sample(Shard &s, size_t bytes)
 }
 
 /* run(n_collect, n_discard) of every chain; the sample stays on the devices (one shard each) and, when out_host is
- * given, is also copied into the caller's [n_chains, n_collect, dim] array; accept_counts [n_chains] or NULL.
- * MH / HMC with neither: enqueued on every shard's stream from this thread, returns without waiting (group_sync). */
-int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts)
+ * given, is also copied into the caller's [n_chains, n_collect, dim] array; accept_counts [n_chains] or NULL.  BLOCKING:
+ * returns when every shard's results are there (also with out_host == NULL and accept_counts == NULL: a caller may read
+ * mmcmc_*_group_shard's device pointer from any stream afterwards).  async (mmcmc_{mh,hmc}_group_run_async only):
+ * enqueued on every shard's stream from this thread, returns without waiting (group_sync). */
+int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts, bool async)
 {
     if (!g)
         return MMCMC_ERR_INVALID_ARG;
+    if (g->broken)
+        return MMCMC_ERR_GROUP_BROKEN;
     const size_t esz = g->esize(), row = n_collect * (size_t)g->dim * esz;
-    if (g->sampler != 2 && !out_host && !accept_counts) {
+    if (async) {
+        if (g->sampler == 2)
+            return MMCMC_ERR_UNSUPPORTED; /* NUTS hands adaptation state over between its launches: blocking only */
         int prev = -1;
         (void)hipGetDevice(&prev);
         int st = MMCMC_OK;
+        /* every allocation first: a failure here has advanced no shard */
         for (Shard &s : g->sh) {
             if (hipSetDevice(s.device) != hipSuccess) {
                 st = MMCMC_ERR_NO_DEVICE;
@@ -401,11 +418,27 @@ int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint
             }
             if ((st = shard_reserve_sample(s, s.n * row)) != MMCMC_OK)
                 break;
-            void *d_out = n_collect ? s.d_sample : nullptr;
-            st = g->sampler ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, nullptr, s.stream)
-                            : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, nullptr, s.stream);
-            if (st != MMCMC_OK)
-                break;
+        }
+        size_t enqueued = 0;
+        if (st == MMCMC_OK)
+            for (Shard &s : g->sh) {
+                if (hipSetDevice(s.device) != hipSuccess) {
+                    st = MMCMC_ERR_NO_DEVICE;
+                    break;
+                }
+                void *d_out = n_collect ? s.d_sample : nullptr;
+                st = g->sampler ? mmcmc_hmc_run(s.hmc, n_collect, n_discard, d_out, 1, nullptr, s.stream)
+                                : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, nullptr, s.stream);
+                if (st != MMCMC_OK)
+                    break;
+                ++enqueued;
+            }
+        if (st != MMCMC_OK && enqueued > 0) {
+            /* shards 0 .. enqueued - 1 have advanced, the rest have not: wait for what was queued and refuse further use */
+            for (size_t i = 0; i < enqueued; ++i)
+                if (hipSetDevice(g->sh[i].device) == hipSuccess)
+                    (void)hipStreamSynchronize(g->sh[i].stream);
+            g->broken = true;
         }
         if (prev >= 0)
             (void)hipSetDevice(prev);
@@ -413,7 +446,8 @@ int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint
             g->last_collect = n_collect;
         return st;
     }
-    const int st = for_each_shard(g, [&](Shard &s, int) -> int {
+    std::vector<char> advanced(g->sh.size(), 0); /* which shards' samplers have run (each written by its own worker) */
+    const int st = for_each_shard(g, [&](Shard &s, int i) -> int {
         if (hipSetDevice(s.device) != hipSuccess)
             return MMCMC_ERR_NO_DEVICE;
         const size_t bytes = s.n * row;
@@ -427,6 +461,7 @@ int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint
                              : mmcmc_mh_run(s.mh, n_collect, n_discard, d_out, 1, acc, s.stream);
         if (rc != MMCMC_OK)
             return rc;
+        advanced[(size_t)i] = 1;
         hipError_t e = hipSuccess;
         if (out_host && n_collect) /* through the device's own pinned bounce ring: every shard over its own link, side by side */
             e = mm_copy_to_host((char *)out_host + s.first * row, s.d_sample, bytes, s.device, s.stream);
@@ -436,6 +471,13 @@ int group_run(Group *g, size_t n_collect, size_t n_discard, void *out_host, uint
     });
     if (st == MMCMC_OK)
         g->last_collect = n_collect;
+    else {
+        size_t n_adv = 0;
+        for (char a : advanced)
+            n_adv += a ? 1 : 0;
+        if (n_adv > 0 && n_adv < g->sh.size())
+            g->broken = true; /* some shards have run and others not: same rule as the asynchronous path */
+    }
     return st;
 }
 
@@ -508,6 +550,7 @@ int group_state(Group *g, void *out)
 {
     if (!g || !out)
         return MMCMC_ERR_INVALID_ARG;
+    /* a broken group's shards stand at different iterations; their states are still what each shard holds -- readable */
     const size_t esz = g->esize();
     return for_each_shard(g, [&](Shard &s, int) -> int {
         void *p = (char *)out + s.first * (size_t)g->dim * esz;
@@ -520,9 +563,21 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
 {
     if (!g || !rhat || !ess)
         return MMCMC_ERR_INVALID_ARG;
+    if (g->broken)
+        return MMCMC_ERR_GROUP_BROKEN;
     const size_t n = g->last_collect, m = n / 2, D = (size_t)g->dim, N = g->sh.size();
     if (m < 1)
         return MMCMC_ERR_SHAPE;
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_begin = clk::now();
+    clk::time_point t_local = t_begin, t_exch = t_begin;
+    auto phases = [&](int rc) { /* local partials | exchange (collectives + cross sums / host copies) | finish */
+        const clk::time_point t_end = clk::now();
+        g->phase_ms[0] = std::chrono::duration<double, std::milli>(t_local - t_begin).count();
+        g->phase_ms[1] = std::chrono::duration<double, std::milli>(t_exch - t_local).count();
+        g->phase_ms[2] = std::chrono::duration<double, std::milli>(t_end - t_exch).count();
+        return rc;
+    };
     const size_t part = 2 * g->cmax * D;             /* per-device means (or ssq), padded to the largest shard */
     const size_t own = 2 * part + m * D;             /* means | ssq | acov */
     const size_t n_cs = N * D * 4 * 3;               /* partial cross-chain sums (f64) of mm_group_cross_sums_kernel */
@@ -558,6 +613,7 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
     });
     if (st != MMCMC_OK)
         return st;
+    t_local = t_exch = clk::now();
     /* phase 2: the exchange */
     st = for_each_shard(g, [&](Shard &s, int i) -> int {
         if (hipSetDevice(s.device) != hipSuccess)
@@ -590,6 +646,7 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
     });
     if (st != MMCMC_OK)
         return st;
+    t_exch = clk::now();
     /* RCCL path: the finish needs the gathered statistics only through their cross-chain sums, which shard 0 has reduced on
      * the device.  Host-exchange path (a device listed twice, no RCCL): the host walks the statistics in splitcat order (first
      * halves of all chains, then second halves) */
@@ -622,7 +679,7 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
             dsum[d] = ds > 0.0 ? ds : 0.0;
             wsum[d] = ws;
         }
-        return mmcmc_stats_finish_sums(dsum.data(), wsum.data(), acov.data(), 2 * g->n_chains, m, D, rhat, ess);
+        return phases(mmcmc_stats_finish_sums(dsum.data(), wsum.data(), acov.data(), 2 * g->n_chains, m, D, rhat, ess));
     }
     std::vector<float> g_all(N * 2 * part);
     acov.assign(m * D, 0.f);
@@ -653,7 +710,16 @@ int group_split_rhat_ess(Group *g, float *rhat, float *ess, int *used_rccl)
             std::memcpy(ssq.data() + ((size_t)half * C + s.first) * D, qi + (size_t)half * s.n * D, s.n * D * sizeof(float));
         }
     }
-    return mmcmc_stats_finish(means.data(), ssq.data(), acov.data(), 2 * C, m, D, rhat, ess);
+    return phases(mmcmc_stats_finish(means.data(), ssq.data(), acov.data(), 2 * C, m, D, rhat, ess));
+}
+
+int group_stats_phases(Group *g, double *ms3)
+{
+    if (!g || !ms3)
+        return MMCMC_ERR_INVALID_ARG;
+    for (int i = 0; i < 3; ++i)
+        ms3[i] = g->phase_ms[i];
+    return MMCMC_OK;
 }
 
 } // namespace
@@ -691,8 +757,13 @@ int mmcmc_hmc_group_seed(mmcmc_hmc_group *h, uint64_t seed) { return h ? group_s
 int mmcmc_hmc_group_set_chain_offset(mmcmc_hmc_group *h, uint64_t off) { return h ? group_set_chain_offset(h->g, off) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_hmc_group_run(mmcmc_hmc_group *h, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts)
 {
-    return h ? group_run(h->g, n_collect, n_discard, out_host, accept_counts) : MMCMC_ERR_INVALID_ARG;
+    return h ? group_run(h->g, n_collect, n_discard, out_host, accept_counts, false) : MMCMC_ERR_INVALID_ARG;
 }
+int mmcmc_hmc_group_run_async(mmcmc_hmc_group *h, size_t n_collect, size_t n_discard)
+{
+    return h ? group_run(h->g, n_collect, n_discard, nullptr, nullptr, true) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_hmc_group_stats_phases(mmcmc_hmc_group *h, double *ms3) { return h ? group_stats_phases(h->g, ms3) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_hmc_group_state(mmcmc_hmc_group *h, void *out) { return h ? group_state(h->g, out) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_hmc_group_split_rhat_mean_ess(mmcmc_hmc_group *h, float *rhat, float *ess, int *used_rccl)
 {
@@ -752,8 +823,13 @@ int mmcmc_mh_group_seed(mmcmc_mh_group *h, uint64_t seed) { return h ? group_see
 int mmcmc_mh_group_set_chain_offset(mmcmc_mh_group *h, uint64_t off) { return h ? group_set_chain_offset(h->g, off) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_mh_group_run(mmcmc_mh_group *h, size_t n_collect, size_t n_discard, void *out_host, uint64_t *accept_counts)
 {
-    return h ? group_run(h->g, n_collect, n_discard, out_host, accept_counts) : MMCMC_ERR_INVALID_ARG;
+    return h ? group_run(h->g, n_collect, n_discard, out_host, accept_counts, false) : MMCMC_ERR_INVALID_ARG;
 }
+int mmcmc_mh_group_run_async(mmcmc_mh_group *h, size_t n_collect, size_t n_discard)
+{
+    return h ? group_run(h->g, n_collect, n_discard, nullptr, nullptr, true) : MMCMC_ERR_INVALID_ARG;
+}
+int mmcmc_mh_group_stats_phases(mmcmc_mh_group *h, double *ms3) { return h ? group_stats_phases(h->g, ms3) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_mh_group_state(mmcmc_mh_group *h, void *out) { return h ? group_state(h->g, out) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_mh_group_split_rhat_mean_ess(mmcmc_mh_group *h, float *rhat, float *ess, int *used_rccl)
 {
@@ -815,8 +891,9 @@ int mmcmc_nuts_group_run(mmcmc_nuts_group *h, size_t n_collect, size_t n_discard
     if (!h)
         return MMCMC_ERR_INVALID_ARG;
     h->g->progress = progress ? 1 : 0;
-    return group_run(h->g, n_collect, n_discard, out_host, nullptr);
+    return group_run(h->g, n_collect, n_discard, out_host, nullptr, false);
 }
+int mmcmc_nuts_group_stats_phases(mmcmc_nuts_group *h, double *ms3) { return h ? group_stats_phases(h->g, ms3) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_nuts_group_state(mmcmc_nuts_group *h, void *out) { return h ? group_state(h->g, out) : MMCMC_ERR_INVALID_ARG; }
 int mmcmc_nuts_group_leapfrog_counts(mmcmc_nuts_group *h, uint64_t *out)
 {

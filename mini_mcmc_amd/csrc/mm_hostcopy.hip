@@ -9,7 +9,10 @@
  * own slice of every chunk, so the destination's page faults and the DRAM traffic are spread over cores).  A destination
  * that IS pinned (hipHostMalloc / hipHostRegister / torch's pin_memory) gets the one direct copy as before.
  *
- * One stager per device (its own buffers and lock: shards of a device group copy side by side over their own links).
+ * One stager per device (its own buffers and lock: shards of a device group copy side by side over their own links; they
+ * share the copy-thread budget, and waiting threads yield the CPU after a short spin).  The 32 MB pinned ring of a device
+ * that has staged once stays with the process (freeing pinned memory from a static destructor races the runtime's own
+ * teardown); hosts with a single usable CPU get the plain copy.
  */
 #include "mm_hostcopy.h"
 
@@ -41,7 +44,7 @@ Stager &stager(int device)
     return s[device & 63];
 }
 
-int copy_threads()
+int usable_cpus()
 {
     cpu_set_t set;
     int n = 0;
@@ -49,9 +52,20 @@ int copy_threads()
         n = CPU_COUNT(&set);
     if (n <= 0)
         n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    return n < 1 ? 1 : n;
+}
+
+/* staged copies in flight in this process (the shards of a device group copy side by side): they SHARE the copy-thread
+ * budget -- eight shards no longer start 8 x (8 + 1) spinning threads on a 16-CPU affinity mask */
+std::atomic<int> g_active{0};
+
+int copy_threads(int cpus, int active)
+{
     /* DRAM, not cores, is the limit from a handful of threads on; leave half the usable CPUs to the caller */
-    n = n / 2;
-    return n < 1 ? 1 : (n > 8 ? 8 : n);
+    int n = cpus / 2;
+    n = n < 1 ? 1 : (n > 8 ? 8 : n);
+    n = n / (active < 1 ? 1 : active);
+    return n < 1 ? 1 : n;
 }
 
 bool is_pinned_host(const void *p)
@@ -64,12 +78,27 @@ bool is_pinned_host(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
-inline void relax()
-{
+/* waiting: `pause` for the first few hundred polls (a chunk is 0.15 ms of DMA), then give the CPU away between polls */
+struct Backoff {
+    unsigned int spins = 0;
+    void wait()
+    {
+        if (++spins < 256) {
 #if defined(__x86_64__)
-    __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
-}
+        } else {
+            sched_yield();
+        }
+    }
+    void reset() { spins = 0; }
+};
+
+struct ActiveGuard {
+    int n;
+    ActiveGuard() : n(g_active.fetch_add(1, std::memory_order_relaxed) + 1) {}
+    ~ActiveGuard() { g_active.fetch_sub(1, std::memory_order_relaxed); }
+};
 
 } // namespace
 
@@ -78,11 +107,14 @@ hipError_t mm_copy_to_host(void *dst, const void *d_src, size_t bytes, int devic
     if (bytes == 0)
         return hipSuccess;
     hipError_t e;
-    if (bytes < kDirectBelow || is_pinned_host(dst)) {
+    const int cpus = usable_cpus();
+    /* with one usable CPU a copy thread and the DMA driver would only take turns: the plain copy */
+    if (bytes < kDirectBelow || cpus < 2 || is_pinned_host(dst)) {
         if ((e = hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream)) != hipSuccess)
             return e;
         return hipStreamSynchronize(stream);
     }
+    ActiveGuard active;
     Stager &st = stager(device);
     std::lock_guard<std::mutex> lock(st.mu);
     if (!st.ready) {
@@ -95,7 +127,7 @@ hipError_t mm_copy_to_host(void *dst, const void *d_src, size_t bytes, int devic
         st.ready = true;
     }
     const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
-    const int T = copy_threads();
+    const int T = copy_threads(cpus, active.n);
     /* published: chunks whose DMA has finished (the workers may read them); consumed[i % kRing]: workers done with chunk i */
     std::atomic<size_t> published{0};
     std::atomic<unsigned int> consumed[kRing];
@@ -103,11 +135,13 @@ hipError_t mm_copy_to_host(void *dst, const void *d_src, size_t bytes, int devic
     for (auto &c : consumed)
         c.store(0, std::memory_order_relaxed);
     auto worker = [&](int t) {
+        Backoff bo;
         for (size_t i = 0; i < n_chunks; ++i) {
+            bo.reset();
             while (published.load(std::memory_order_acquire) <= i) {
                 if (failed.load(std::memory_order_relaxed))
                     return;
-                relax();
+                bo.wait();
             }
             const size_t off = i * kChunk, len = (off + kChunk <= bytes) ? kChunk : bytes - off;
             /* slices on 4 KB boundaries: every destination page is faulted in and written by one thread */
@@ -135,6 +169,7 @@ hipError_t mm_copy_to_host(void *dst, const void *d_src, size_t bytes, int devic
     }
     size_t issued = 0, pub = 0;
     e = hipSuccess;
+    Backoff bo;
     while (pub < n_chunks) {
         bool progressed = false;
         if (issued < n_chunks) {
@@ -161,8 +196,10 @@ hipError_t mm_copy_to_host(void *dst, const void *d_src, size_t bytes, int devic
                 break;
             }
         }
-        if (!progressed)
-            relax();
+        if (progressed)
+            bo.reset();
+        else
+            bo.wait();
     }
     if (e != hipSuccess) {
         failed.store(true, std::memory_order_relaxed);

@@ -25,10 +25,31 @@ class _Group:
         L.check(self._fn("set_chain_offset")(self._h, int(first_global_chain)), "group_set_chain_offset")
         return self
 
+    def run_async(self, n_collect: int, n_discard: int = 0):
+        """mmcmc_{mh,hmc}_group_run_async: the launches are only ENQUEUED on the shards' streams and the call returns at
+        once; the sample stays on the devices (`shards`), `sync()` waits, the diagnostics and `state()` order themselves
+        behind the queued work."""
+        L.check(self._fn("run_async")(self._h, n_collect, n_discard), f"mmcmc_{self._prefix}_group_run_async")
+        self.accept_counts = None
+
+    def stats_phases(self) -> dict:
+        """host wall-clock milliseconds of the last `split_rhat_mean_ess`, by phase"""
+        ms = (C.c_double * 3)()
+        L.check(self._fn("stats_phases")(self._h, ms), "group_stats_phases")
+        return {"local_partials_ms": ms[0], "exchange_ms": ms[1], "finish_ms": ms[2]}
+
+    def pci_bus_ids(self):
+        """hipDeviceGetPCIBusId of every shard's device"""
+        out = []
+        for d in self.devices:
+            buf = C.create_string_buffer(32)
+            L.check(L.lib().mmcmc_device_pci_bus_id(int(d), buf, 32), "mmcmc_device_pci_bus_id")
+            out.append(buf.value.decode())
+        return out
+
     def run(self, n_collect: int, n_discard: int = 0, to_host: bool = True, accept_counts: bool = True):
         """sample [n_chains, n_collect, dim] on the host (to_host=False: it stays on the devices, see `shards`).
-        to_host=False and accept_counts=False: the launches are only ENQUEUED on the shards' streams and the call
-        returns at once (include/mmcmc.h); `sync()` waits, the diagnostics and `state()` order themselves behind them."""
+        Blocks until every shard's results are there, whatever is handed back (`run_async` is the queued spelling)."""
         out = np.empty((self.n_chains, n_collect, self.dim), dtype=self.dtype) if to_host else None
         acc = np.zeros(self.n_chains, dtype=np.uint64) if accept_counts else None
         st = self._fn("run")(self._h, n_collect, n_discard, out.ctypes.data if to_host else None,

@@ -43,6 +43,16 @@ fn check(status: c_int) -> Result<(), MmcmcError> {
     Err(MmcmcError { status, message })
 }
 
+/// The loaded `libmmcmc.so` must be at least the version the `-sys` crate was generated from (`MMCMC_VERSION` of
+/// include/mmcmc.h: entry points are only ever added between versions, removals bump it).  Every constructor calls this.
+pub fn assert_abi() -> Result<(), MmcmcError> {
+    let have = unsafe { sys::mmcmc_version() };
+    if have >= sys::MMCMC_VERSION {
+        return Ok(());
+    }
+    Err(MmcmcError { status: sys::MMCMC_ERR_UNSUPPORTED, message: format!("libmmcmc.so is version {have}, this crate was generated for {}", sys::MMCMC_VERSION) })
+}
+
 /// `ChainRunner::run` can only fail with a `ShapeError` (core.rs:184); the engine's MMCMC_ERR_SHAPE maps onto it, and so
 /// does anything else `run` reports (the trait's signature has no other channel).
 fn shape_error(status: c_int) -> ShapeError {
@@ -139,6 +149,7 @@ impl<T: GpuFloat> GpuMetropolisHastings<T> {
     /// `MetropolisHastings::new(target, proposal, initial_states)` (metropolis_hastings.rs:149-159);
     /// `proposal_std` = `IsotropicGaussian::new(std)`.
     pub fn new(target: GpuTarget, proposal_std: f64, initial_states: Vec<Vec<T>>) -> Result<Self, MmcmcError> {
+        assert_abi()?;
         let (flat, n, d) = flatten(&initial_states);
         let desc = target.desc(d);
         let prop = sys::mmcmc_proposal_desc { kind: sys::MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN, reserved: 0, std: proposal_std };
@@ -184,6 +195,7 @@ unsafe impl<T: GpuFloat> Send for GpuHmc<T> {}
 impl<T: GpuFloat> GpuHmc<T> {
     /// `HMC::new(target, initial_positions, step_size, n_leapfrog)` (hmc.rs:87-109)
     pub fn new(target: GpuTarget, initial_positions: Vec<Vec<T>>, step_size: f64, n_leapfrog: usize) -> Result<Self, MmcmcError> {
+        assert_abi()?;
         let (flat, n, d) = flatten(&initial_positions);
         let desc = target.desc(d);
         let mut h = null_mut();
@@ -232,6 +244,7 @@ unsafe impl Send for GpuNuts {}
 impl GpuNuts {
     /// `NUTS::new(target, initial_positions, target_accept_p)` (nuts.rs:123-129); `scalars_f64` picks the reference's `T`.
     pub fn new(target: GpuTarget, initial_positions: Vec<Vec<f64>>, target_accept_p: f64, scalars_f64: bool) -> Result<Self, MmcmcError> {
+        assert_abi()?;
         let (flat, n, d) = flatten(&initial_positions);
         let desc = target.desc(d);
         let mut h = null_mut();
@@ -269,6 +282,7 @@ pub struct GpuNutsGroup {
 unsafe impl Send for GpuNutsGroup {}
 impl GpuNutsGroup {
     pub fn new_on(devices: &[i32], target: GpuTarget, initial_positions: Vec<Vec<f64>>, target_accept_p: f64, scalars_f64: bool) -> Result<Self, MmcmcError> {
+        assert_abi()?;
         let (flat, n, d) = flatten(&initial_positions);
         let desc = target.desc(d);
         let mut g = null_mut();
@@ -376,6 +390,7 @@ unsafe impl Send for GpuTracker {}
 impl GpuTracker {
     /// `MultiChainTracker::new(n_chains, n_params)` (stats.rs:207-226)
     pub fn new(n_chains: usize, n_params: usize) -> Result<Self, MmcmcError> {
+        assert_abi()?;
         let mut h = null_mut();
         check(unsafe { sys::mmcmc_tracker_create(&mut h, n_chains, n_params, 0) })?;
         Ok(Self { h, dim: n_params, n_chains })
@@ -429,6 +444,7 @@ pub struct GpuHmcGroup<T: GpuFloat> {
 unsafe impl<T: GpuFloat> Send for GpuHmcGroup<T> {}
 impl<T: GpuFloat> GpuHmcGroup<T> {
     pub fn new_on(devices: &[i32], target: GpuTarget, initial_positions: Vec<Vec<T>>, step_size: f64, n_leapfrog: usize) -> Result<Self, MmcmcError> {
+        assert_abi()?;
         let (flat, n, d) = flatten(&initial_positions);
         let desc = target.desc(d);
         let mut g = null_mut();
@@ -450,7 +466,7 @@ impl<T: GpuFloat> GpuHmcGroup<T> {
     /// The same run with the sample left on the devices: only enqueued on the shards' streams (returns at once; several in
     /// a row keep every device busy).  `sync` waits; `split_rhat_mean_ess` orders itself behind the queued runs.
     pub fn run_on_devices(&mut self, n_collect: usize, n_discard: usize) -> Result<(), MmcmcError> {
-        check(unsafe { sys::mmcmc_hmc_group_run(self.g, n_collect, n_discard, null_mut(), null_mut()) })
+        check(unsafe { sys::mmcmc_hmc_group_run_async(self.g, n_collect, n_discard) })
     }
     pub fn sync(&mut self) -> Result<(), MmcmcError> {
         check(unsafe { sys::mmcmc_hmc_group_sync(self.g) })
@@ -486,6 +502,7 @@ pub struct GpuMhGroup<T: GpuFloat> {
 unsafe impl<T: GpuFloat> Send for GpuMhGroup<T> {}
 impl<T: GpuFloat> GpuMhGroup<T> {
     pub fn new_on(devices: &[i32], target: GpuTarget, proposal_std: f64, initial_states: Vec<Vec<T>>) -> Result<Self, MmcmcError> {
+        assert_abi()?;
         let (flat, n, d) = flatten(&initial_states);
         let desc = target.desc(d);
         let prop = sys::mmcmc_proposal_desc { kind: sys::MMCMC_PROPOSAL_ISOTROPIC_GAUSSIAN, reserved: 0, std: proposal_std };

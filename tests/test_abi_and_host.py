@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/mmcmc.h but not exported by libmmcmc.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.mmcmc_version() == 100
+    assert lib.mmcmc_version() == 101
 
 
 def test_header_is_plain_c(tmp_path):

@@ -37,6 +37,99 @@ def test_bench_decides_group_before_touching_a_gpu():
         assert "torch.distributed.run" not in out.stderr
 
 
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_a_scaling_line_that_fell_back_cannot_exit_zero():
+    """over N DISTINCT devices the diagnostics must have travelled over RCCL with N ranks and the ordinals
+    must be N different GPUs; otherwise the line says so in capitals and the process exits non-zero AFTER printing it.
+    Fed here with the statuses a box without RCCL (-1), with a failing ncclCommInitAll (-2), a short communicator and a
+    GPU listed under two ordinals would produce -- no GPU needed."""
+    B = _bench_module()
+    ids8 = [f"0000:{b:02x}:00.0" for b in range(8)]
+    data, code, problems = B.group_verdict(list(range(8)), ids8, 1, 8)
+    assert (data, code, problems) == ("synthetic", 0, [])
+    for status in (-1, -2, 0):
+        data, code, problems = B.group_verdict(list(range(8)), ids8, status, 0)
+        assert code != 0 and "DIAGNOSTICS FELL BACK TO THE HOST" in data and "NOT A VALID SCALING MEASUREMENT" in data
+        assert len(problems) == 2  # the fallback and the missing ranks
+    data, code, _ = B.group_verdict(list(range(8)), ids8, 1, 4)
+    assert code != 0 and "RCCL COMMUNICATOR HAS 4 RANKS FOR 8 DEVICES" in data
+    data, code, _ = B.group_verdict([0, 1], ["0000:05:00.0", "0000:05:00.0"], 1, 2)
+    assert code != 0 and "SHARE A PCI BUS ID" in data
+    # the one-GPU rehearsal (a device listed twice) goes through the host BY DESIGN: exit 0, and the line says what it is
+    data, code, problems = B.group_verdict([0, 0], ["0000:05:00.0"] * 2, 0, 0)
+    assert code == 0 and problems == [] and "REHEARSAL" in data
+    assert B.group_verdict([0], ["0000:05:00.0"], 1, 1) == ("synthetic", 0, [])
+
+
+def test_a_group_line_with_a_problem_is_printed_and_then_exits_non_zero(monkeypatch, capsys):
+    """main_group end to end with the device group replaced by a stand-in whose exchange status is the -1 / -2 fallback:
+    the JSON line IS printed (it is the evidence) and SystemExit carries a non-zero code."""
+    import types
+
+    import numpy as np
+
+    B = _bench_module()
+    for status in (-1, -2):
+        class FakeGroup:
+            def __init__(self, target, init, eps, L, devices):
+                self.devices, self.exchange_status = list(devices), status
+
+            def set_seed(self, seed):
+                return self
+
+            def exchange(self):
+                return status, 0
+
+            def run_async(self, nc, nd):
+                pass
+
+            def sync(self):
+                pass
+
+            def timer_start(self):
+                pass
+
+            def timer_stop(self):
+                return np.array([0.19, 0.20], dtype=np.float32) * 2
+
+            def split_rhat_mean_ess(self):
+                return np.full(3, 0.6, np.float32), np.full(3, 1e4, np.float32)
+
+            def stats_phases(self):
+                return {"local_partials_ms": 0.1, "exchange_ms": 2.0, "finish_ms": 0.01}
+
+            def pci_bus_ids(self):
+                return ["0000:05:00.0", "0000:15:00.0"]
+
+            def close(self):
+                pass
+
+        import mini_mcmc_amd.group as G
+        import torch
+
+        monkeypatch.setattr(G, "HMCGroup", FakeGroup)
+        monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+        monkeypatch.delenv("MMCMC_BENCH_GROUP_DEVICES", raising=False)
+        args = types.SimpleNamespace(gpus=2, steps=2, warmup=1, preroll_seconds=0.0)
+        with pytest.raises(SystemExit) as e:
+            B.main_group(args)
+        assert e.value.code not in (0, None)
+        line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+        assert len(line) == 1
+        j = json.loads(line[0])
+        assert "DIAGNOSTICS FELL BACK TO THE HOST" in j["data"] and j["rccl_ranks"] == 0 and len(j["problems"]) == 2
+        assert j["pci_bus_ids"] == ["0000:05:00.0", "0000:15:00.0"] and j["kernel_ms_spread_max_over_min"] == pytest.approx(0.20 / 0.19, rel=1e-5)
+        assert j["stats_phases_ms"]["exchange_ms"] == pytest.approx(2.0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [["--gpus", "2", "--group"], ["--gpus", "2"]])
 def test_bench_group_path_on_one_device(args):
@@ -45,6 +138,8 @@ def test_bench_group_path_on_one_device(args):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["unit"] == "samples/s"
     assert j["value"] > 1e9 and j["config"]["devices"] == [0, 0]
     assert j["diagnostics_exchange"].startswith("host (a device is listed twice)") and j["rccl_ranks"] == 0
+    assert "REHEARSAL" in j["data"] and j["problems"] == [] and len(j["pci_bus_ids"]) == 2 and j["pci_bus_ids"][0] == j["pci_bus_ids"][1]
+    assert j["kernel_ms_spread_max_over_min"] >= 1.0 and set(j["stats_phases_ms"]) == {"local_partials_ms", "exchange_ms", "finish_ms"}
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] < 1
 

@@ -21,8 +21,13 @@ def test_group_symbols_exported_and_no_device_without_gpu():
     from mini_mcmc_amd import _lib as L
 
     lib = mini_mcmc_amd.lib()
-    for sym in ("create", "seed", "set_chain_offset", "run", "state", "split_rhat_mean_ess", "sync", "stream_timer", "exchange", "destroy"):
+    for sym in ("create", "seed", "set_chain_offset", "run", "state", "split_rhat_mean_ess", "sync", "stream_timer", "exchange",
+                "stats_phases", "destroy"):
         assert hasattr(lib, "mmcmc_hmc_group_" + sym) and hasattr(lib, "mmcmc_mh_group_" + sym) and hasattr(lib, "mmcmc_nuts_group_" + sym)
+    assert hasattr(lib, "mmcmc_hmc_group_run_async") and hasattr(lib, "mmcmc_mh_group_run_async") and hasattr(lib, "mmcmc_device_pci_bus_id")
+    assert not hasattr(lib, "mmcmc_nuts_group_run_async")  # NUTS hands adaptation state over between launches: blocking only
+    assert lib.mmcmc_version() >= 101  # the version that made "asynchronous" an entry point of its own
+    assert b"broken" in lib.mmcmc_status_string(L.ERR_GROUP_BROKEN)
     if not torch.cuda.is_available():
         from mini_mcmc_amd.distributions import RosenbrockND
 
@@ -198,7 +203,7 @@ def test_group_async_runs_equal_the_blocking_ones(devices):
     assert (status, ranks) == ((1, 1) if len(devices) == 1 else (0, 0))
     a.timer_start()
     for k in range(5):
-        assert a.run(nc, nd if k == 0 else 0, to_host=False, accept_counts=False) is None  # enqueued only
+        assert a.run_async(nc, nd if k == 0 else 0) is None  # enqueued only
     ms = a.timer_stop()
     assert ms.shape == (len(devices),) and (ms > 0).all()
     for k in range(5):
@@ -208,8 +213,8 @@ def test_group_async_runs_equal_the_blocking_ones(devices):
     assert np.array_equal(ra, rb) and np.array_equal(ea, eb) and a.exchange_status == status
     assert np.array_equal(a.state(), b.state()) and np.array_equal(a.state(), ref[:, -1, :])
     # a growing sample buffer while launches are still queued on the old one, then a blocking run behind the queue
-    a.run(nc, 0, to_host=False, accept_counts=False)
-    a.run(2 * nc, 0, to_host=False, accept_counts=False)
+    a.run_async(nc, 0)
+    a.run_async(2 * nc, 0)
     b.run(nc, 0, to_host=False)
     b.run(2 * nc, 0, to_host=False)
     assert np.array_equal(a.run(7, 0), b.run(7, 0)) and np.array_equal(a.accept_counts, b.accept_counts)
@@ -217,3 +222,71 @@ def test_group_async_runs_equal_the_blocking_ones(devices):
     one = HMC(RosenbrockND(3), init, 0.032, 10).set_seed(42)
     one.run(5 * nc + 3 * nc + 7, nd)
     assert np.array_equal(a.state(), one.state())
+
+
+@pytest.mark.gpu
+def test_group_run_with_nothing_handed_back_blocks_and_async_is_its_own_entry_point():
+    """version 100 inferred "asynchronous" from out_host == NULL && accept_counts == NULL, so a C caller who
+    passed NULL / NULL and then read the shard's device pointer on its own stream raced the queued kernels.  Now
+    mmcmc_*_group_run blocks whatever its arguments -- checked by reading the shard's device memory on ANOTHER stream with no
+    synchronisation of ours right after the call returns -- and the queued spelling is mmcmc_*_group_run_async."""
+    import torch
+
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import RosenbrockND
+    from mini_mcmc_amd.group import HMCGroup
+    from mini_mcmc_amd.hmc import HMC
+
+    C_, nc, nd = 65536, 400, 50  # the headline launch: long enough (0.19 ms) that an unsynchronised read would see old bytes
+    init = init_with_seed(C_, 3, 42, np.float32)
+    g = HMCGroup(RosenbrockND(3), init, 0.032, 10, devices=[0]).set_seed(42)
+    one = HMC(RosenbrockND(3), init, 0.032, 10).set_seed(42)
+    ref = one.run(nc, nd)
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        assert g.run(nc, nd if rep == 0 else 0, to_host=False, accept_counts=False) is None  # NULL / NULL: must BLOCK
+        (dev, first, n, ptr), = g.shards()
+        host = np.empty((C_, nc, 3), dtype=np.float32)
+        from mini_mcmc_amd import _lib as L
+
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        assert hip.hipMemcpyAsync(host.ctypes.data, ptr, host.nbytes, 2, C.c_void_p(side.cuda_stream)) == 0
+        side.synchronize()
+        if rep == 0:
+            assert np.array_equal(host, ref)
+        else:
+            assert np.array_equal(host, one.run(nc, 0))
+    assert g.pci_bus_ids()[0].count(":") == 2
+    r, e = g.split_rhat_mean_ess()
+    ph = g.stats_phases()
+    assert set(ph) == {"local_partials_ms", "exchange_ms", "finish_ms"} and all(v > 0 for v in ph.values()) and sum(ph.values()) < 50
+
+
+@pytest.mark.gpu
+def test_group_cross_chain_sums_keep_their_digits_on_an_offset_target(O):
+    """the RCCL finish forms B from sum(mean^2) - sum(mean)^2 / 2C over f32 means; unshifted, a parameter far from
+    the origin gives digits away to cancellation (f64 partial sums: ~1e-7 relative at this offset, more further out, where
+    an f32 sampler no longer resolves its target anyway).  The device reduction now subtracts the shift the single-device
+    tail kernel uses (the mean of the first half of global chain 0) before squaring.  Gaussian2D centred at (3000, -2000)
+    with unit covariance: the group over RCCL (one rank: the path with the device reduction) must give the single-device
+    R-hat / ESS and the oracle's."""
+    from mini_mcmc_amd import stats as S
+    from mini_mcmc_amd.core import init_with_seed
+    from mini_mcmc_amd.distributions import Gaussian2D, IsotropicGaussian
+    from mini_mcmc_amd.group import MetropolisHastingsGroup
+
+    C_, nc, nd = 8192, 400, 100
+    mean = np.array([3000.0, -2000.0])
+    init = (init_with_seed(C_, 2, 42, np.float32).astype(np.float64) + mean).astype(np.float32)
+    g = MetropolisHastingsGroup(Gaussian2D(mean.tolist(), [[1.0, 0.0], [0.0, 1.0]]), IsotropicGaussian(1.0), init, devices=[0]).seed(42)
+    out = g.run(nc, nd)
+    r1, e1 = g.split_rhat_mean_ess()
+    assert g.exchange_status == 1  # RCCL with one rank: mm_group_cross_sums_kernel
+    r0, e0 = S.split_rhat_mean_ess(out)
+    np.testing.assert_allclose(r1, r0, rtol=1e-5)
+    np.testing.assert_allclose(e1, e0, rtol=1e-4)
+    ro, eo = O.split_rhat_mean_ess(out)
+    np.testing.assert_allclose(r1, ro, rtol=1e-4)
+    np.testing.assert_allclose(e1, eo, rtol=5e-3)
+    assert np.all(np.abs(r1 - 1.0) < 0.05)  # a converged unit Gaussian: with the digits lost this is far off or NaN

@@ -106,16 +106,18 @@ def test_hmc_config3_f64_vs_reference_order(M, O):
 
 def test_hmc_config3_f32_full_size_vs_reference_order(M, O):
     """BASELINE config 3 at full size (65 536 chains, f32, 400 + 50): in f32 single trajectories of a chaotic target
-    drift apart, so the bar is north_star's: accept counts agree for > 90 % of the chains (98.5 % expected) and the
-    pooled posterior mean / covariance are within 1 % of the CPU reference order's."""
+    drift apart, so the bar is north_star's: accept counts agree for 98.5 % of the chains (measured on the CPU, host build
+    of the engine's headers against oracle/mh_hmc.c: 0.98495; the GPU equals that host build bit for bit, so the
+    assertion is the measured figure minus a 0.5 % margin) and the pooled posterior mean / covariance are within 1 % of
+    the CPU reference order's."""
     C, nc, nd = 65536, 400, 50
     init = M.core.init_with_seed(C, 3, 42, np.float32)
     h = M.hmc.HMC(M.dist.RosenbrockND(3), init, 0.032, 10).set_seed(42)
     g = h.run(nc, nd)
     o = O.HMC(O.rosenbrock_nd(3), init, 0.032, 10, np.float32).use_engine_stream(42)
     ref = o.run(nc, nd)
-    assert np.mean(h.accept_counts == o.accept_counts) > 0.9
-    assert abs(h.accept_counts.mean() - o.accept_counts.mean()) < 0.5
+    assert np.mean(h.accept_counts == o.accept_counts) > 0.98  # measured 0.98495
+    assert abs(h.accept_counts.mean() - o.accept_counts.mean()) < 0.1  # measured 0.021 of 450 transitions
     fg, fo = g.reshape(-1, 3).astype(np.float64), ref.reshape(-1, 3).astype(np.float64)
     co = np.cov(fo.T)
     sd = np.sqrt(np.diag(co))
@@ -127,11 +129,52 @@ def test_hmc_config3_f32_full_size_vs_reference_order(M, O):
     o8 = O.HMC(O.rosenbrock_nd(3), init, 0.032, 10, np.float32).use_engine_stream(42)
     r8 = o8.run(8, 0)
     same = h8.accept_counts == o8.accept_counts
-    assert same.mean() > 0.995
+    assert same.mean() > 0.999  # measured 0.99960
     err = (np.abs(g8[same][:, 0] - r8[same][:, 0]) / np.maximum(1.0, np.abs(r8[same][:, 0]))).max(axis=1)
     # CPU measurement of the same comparison: median 1.2e-7, 99.9 % quantile 8e-5, worst of 65 536 chains 4e-3 (starting
     # points far out in the tails, where one transition already amplifies an f32 ulp)
     assert np.median(err) < 1e-6 and np.quantile(err, 0.999) < 1e-3 and err.max() < 5e-2
+
+
+@pytest.mark.parametrize("params", [[0.0, 0.0, 1.0, 0.0, 0.0, 1.0], GAUSS], ids=["config2", "correlated"])
+def test_mh_config2_f32_full_size_vs_reference_order(M, O, params):
+    """BASELINE config 2 at full size and in its own dtype (Gaussian2D, IsotropicGaussian(1) proposal, 65 536 chains,
+    f32, run(1000, 100)) through the C ABI against oracle/mh_hmc.c (metropolis_hastings.rs:303-315 op for op: logp of
+    the current point recomputed, q-terms kept, strict >) on the engine stream -- no host build of the product's headers
+    in between.  Measured on the CPU first (host build of the engine's headers, which the GPU equals bit for bit,
+    against the same oracle; both targets): 65 532 of 65 536 chains give the oracle's sample in EVERY one of the 1000
+    collected draws (0.99994; a decision flips only where the cached f32 ratio and the recomputed one straddle ln u),
+    accept counts differ by at most 13 on the four others, pooled mean / covariance agree to 2e-6 of a standard
+    deviation, the first 8 transitions are bit-identical for all chains.  Asserted: those figures with a margin."""
+    C, nc, nd = 65536, 1000, 100
+    init = M.core.init_with_seed(C, 2, 42, np.float32)
+    tgt = M.dist.Gaussian2D(params[:2], [params[2:4], params[4:6]])
+    s = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(1.0), init).seed(42)
+    g = s.run(nc, nd)
+    o = O.MetropolisHastings(O.gaussian2d(params[:2], [params[2:4], params[4:6]]), 1.0, init, np.float32).use_engine_stream(42)
+    ref = o.run(nc, nd)
+    same = s.accept_counts == o.accept_counts
+    assert same.mean() >= 0.9998  # measured 0.99994 (4 chains of 65 536)
+    assert np.abs(s.accept_counts.astype(np.int64) - o.accept_counts.astype(np.int64)).max() <= 40  # measured 13 / 8
+    identical = (g == ref).all(axis=(1, 2))
+    assert identical.mean() >= 0.9998  # whole 1000-draw samples, bit for bit
+    fg, fo = g.reshape(-1, 2).astype(np.float64), ref.reshape(-1, 2).astype(np.float64)
+    co = np.cov(fo.T)
+    sd = np.sqrt(np.diag(co))
+    assert np.all(np.abs(fg.mean(axis=0) - fo.mean(axis=0)) < 1e-4 * sd)          # north_star: 1 %; measured 2e-6
+    assert np.all(np.abs(np.cov(fg.T) - co) < 1e-4 * np.outer(sd, sd))            # measured 1e-6
+    # and against the exact posterior (north_star: moments within 1 % at 65 536 chains)
+    mean, cov = np.array(params[:2]), np.array([params[2:4], params[4:6]])
+    sde = np.sqrt(np.diag(cov))
+    assert np.all(np.abs(fg.mean(axis=0) - mean) < 0.01 * sde)
+    assert np.all(np.abs(np.cov(fg.T) - cov) < 0.01 * np.outer(sde, sde))
+    # the first 8 transitions: every decision and every bit
+    s8 = M.mh.MetropolisHastings(tgt, M.dist.IsotropicGaussian(1.0), init).seed(42)
+    g8 = s8.run(8, 0)
+    o8 = O.MetropolisHastings(O.gaussian2d(params[:2], [params[2:4], params[4:6]]), 1.0, init, np.float32).use_engine_stream(42)
+    r8 = o8.run(8, 0)
+    assert np.array_equal(s8.accept_counts, o8.accept_counts)
+    assert np.array_equal(g8, r8)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

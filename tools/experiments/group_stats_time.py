@@ -6,7 +6,7 @@ from mini_mcmc_amd.group import HMCGroup
 for devs in ([0], [0, 0]):
     n = 65536 * len(devs)
     g = HMCGroup(RosenbrockND(3), init_with_seed(n, 3, 42, np.float32), 0.032, 10, devices=devs).set_seed(42)
-    g.run(400, 50, to_host=False, accept_counts=False)
+    g.run_async(400, 50)
     g.sync()
     for _ in range(3):
         g.split_rhat_mean_ess()
