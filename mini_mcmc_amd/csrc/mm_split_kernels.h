@@ -49,7 +49,10 @@
 #define MM_SPLIT_HMC_PFLUSH 0
 #endif
 #define MM_SPLIT_NTILE(MH) (((MH) || MM_SPLIT_HMC_PFLUSH) ? 2 : 1)
-template <class T, int D, int RB, int WANT, int NTILE> struct mm_split_try {
+/* PW: wave pairs (64 chains each) per workgroup -- 4 (one workgroup per CU, its barrier joins 4 (1 + NN) waves) or 1
+ * (round 6: workgroup = ONE pair, 1 + NN waves, four workgroups per CU each with a quarter of the LDS and its own copy of
+ * the table; the barrier joins 1 + NN waves and a pair never waits for another pair's transition wave) */
+template <class T, int D, int RB, int WANT, int NTILE, int PW = 4> struct mm_split_try {
     static constexpr int epl = 16 / (int)sizeof(T);
     static constexpr int nw = (D + 1 + epl - 1) / epl * epl; /* noise row of one chain: z[D], ln u, padded to 16 bytes */
     static constexpr size_t row_bytes = (size_t)64 * nw * sizeof(T); /* one transition of one wave pair */
@@ -59,35 +62,36 @@ template <class T, int D, int RB, int WANT, int NTILE> struct mm_split_try {
     using Tile = mm_tile_t<T, D, (tile_t > 0 ? tile_t : RB)>;
     static constexpr size_t tile_bytes = (Tile::lds_bytes_per_wave + 15) / 16 * 16;
     static constexpr size_t table_bytes = (Tile::lds_bytes_table + 15) / 16 * 16;
-    static constexpr size_t lds_bytes = table_bytes + 4 * NTILE * tile_bytes + 4 * ring_bytes;
-    static constexpr int ntile = NTILE;
-    static constexpr bool ok = tile_t >= RB && lds_bytes <= 160 * 1024;
+    static constexpr size_t lds_bytes = table_bytes + PW * NTILE * tile_bytes + PW * ring_bytes;
+    static constexpr int ntile = NTILE, pw = PW;
+    static constexpr size_t lds_budget = (size_t)160 * 1024 * PW / 4; /* 4 / PW workgroups share a CU's 160 KB */
+    static constexpr bool ok = tile_t >= RB && lds_bytes <= lds_budget;
 };
-template <class T, int D, bool MH, int NT, int I = 0> struct mm_split_pick {
+template <class T, int D, bool MH, int NT, int I = 0, int PW = 4> struct mm_split_pick {
     static constexpr int rb_hmc[12] = {8, 4, 8, 4, 2, 8, 4, 2, 2, 8, 4, 2}, want_hmc[12] = {48, 48, 32, 32, 48, 24, 24, 32, 24, 16, 16, 16};
     static constexpr int rb_mh[12] = {8, 8, 8, 4, 4, 4, 8, 2, 2, 2, 4, 2}, want_mh[12] = {48, 32, 24, 48, 32, 24, 16, 48, 32, 24, 16, 16};
     static constexpr int rb = MH ? rb_mh[I] : rb_hmc[I], want = MH ? want_mh[I] : want_hmc[I];
-    using Try = mm_split_try<T, D, rb, want, NT>;
-    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick<T, D, MH, NT, I + 1>::type>::type;
+    using Try = mm_split_try<T, D, rb, want, NT, PW>;
+    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick<T, D, MH, NT, I + 1, PW>::type>::type;
 };
-template <class T, int D, bool MH, int NT> struct mm_split_pick<T, D, MH, NT, 12> {
-    using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, NT>; /* RB = TILE_T = 2: always fits up to dim 8 */
+template <class T, int D, bool MH, int NT, int PW> struct mm_split_pick<T, D, MH, NT, 12, PW> {
+    using type = mm_split_try<T, D, 2, 2 * (int)(sizeof(T) / 4) * D, NT, PW>; /* RB = TILE_T = 2: always fits up to dim 8 */
 };
 /* RBF != 0: a ring half of exactly RBF transitions (several noise waves per pair want a batch their pairs divide), the
  * largest tile that fits beside it */
-template <class T, int D, bool MH, int RBF, int NT, int I = 0> struct mm_split_pick_rb {
+template <class T, int D, bool MH, int RBF, int NT, int I = 0, int PW = 4> struct mm_split_pick_rb {
     static constexpr int want[6] = {48, 40, 32, 24, 16, 8};
-    using Try = mm_split_try<T, D, RBF, want[I], NT>;
-    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick_rb<T, D, MH, RBF, NT, I + 1>::type>::type;
+    using Try = mm_split_try<T, D, RBF, want[I], NT, PW>;
+    using type = typename mm_cond<Try::ok, Try, typename mm_split_pick_rb<T, D, MH, RBF, NT, I + 1, PW>::type>::type;
 };
-template <class T, int D, bool MH, int RBF, int NT> struct mm_split_pick_rb<T, D, MH, RBF, NT, 6> {
-    using type = mm_split_try<T, D, RBF, RBF * (int)(sizeof(T) / 4) * D, NT>;
+template <class T, int D, bool MH, int RBF, int NT, int PW> struct mm_split_pick_rb<T, D, MH, RBF, NT, 6, PW> {
+    using type = mm_split_try<T, D, RBF, RBF * (int)(sizeof(T) / 4) * D, NT, PW>;
 };
-template <class T, int D, bool MH, int RBF = 0, int NT = MM_SPLIT_NTILE(MH)>
-struct mm_split_plan : mm_cond<RBF == 0, typename mm_split_pick<T, D, MH, NT>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2), NT>::type>::type {
-    using Base = typename mm_cond<RBF == 0, typename mm_split_pick<T, D, MH, NT>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2), NT>::type>::type;
+template <class T, int D, bool MH, int RBF = 0, int NT = MM_SPLIT_NTILE(MH), int PW = 4>
+struct mm_split_plan : mm_cond<RBF == 0, typename mm_split_pick<T, D, MH, NT, 0, PW>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2), NT, 0, PW>::type>::type {
+    using Base = typename mm_cond<RBF == 0, typename mm_split_pick<T, D, MH, NT, 0, PW>::type, typename mm_split_pick_rb<T, D, MH, (RBF ? RBF : 2), NT, 0, PW>::type>::type;
     static constexpr int rb = (int)(Base::ring_bytes / 2 / Base::row_bytes);
-    static_assert(Base::tile_t >= rb && Base::lds_bytes <= 160 * 1024, "LDS plan of the split kernel");
+    static_assert(Base::tile_t >= rb && Base::lds_bytes <= Base::lds_budget, "LDS plan of the split kernel");
 };
 /* HMC with the tiles written out by the least-loaded noise wave: where two tiles and a ring half of 8 transitions fit the
  * 160 KB (f32 up to D = 3).  Config 3 in tools/split_probe.hip (tools/experiments/split_hmc_pflush.sh, three rounds):
@@ -161,11 +165,12 @@ __device__ unsigned long long mm_split_prof[2][3]; /* [role][barrier wait / tota
  * other's LDS and issue latencies where the step is short (MH).  RBF: ring half (0 = the plan's choice). */
 /* the kernel proper is a device function so that a run-time compiled translation unit (user targets, csrc/mm_rtc.hip) can
  * wrap it in an extern "C" kernel of its own, like mm_run_kernel_body */
-template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0, int NT = MM_SPLIT_NTILE(SAMPLER == MM_SAMPLER_MH)>
+template <class T, class Tgt, int SAMPLER, int LCT = 0, int QP = 0, int NN = 1, int RBF = 0, int NT = MM_SPLIT_NTILE(SAMPLER == MM_SAMPLER_MH), int PW = 4>
 __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
 {
     constexpr int D = Tgt::dim;
-    using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH, RBF, NT>;
+    static_assert(PW == 4 || PW == 2 || PW == 1, "wave pairs per workgroup");
+    using Plan = mm_split_plan<T, D, SAMPLER == MM_SAMPLER_MH, RBF, NT, PW>;
     using Tile = typename Plan::Tile;
     constexpr int TILE_T = Tile::tile_t, STRIDE = Tile::stride, NW = Plan::nw, RB = Plan::rb, EPL = Plan::epl;
     constexpr int QN = 2 * QP; /* transitions per batch whose noise the transition wave draws itself */
@@ -185,14 +190,19 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds_raw[];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6; /* 0..3 transition waves, 4.. noise waves (NN per pair) */
-    const int pair = wave & 3;
-    const bool noise_wave = wave >= 4;
-    const int noise_rank = (wave >> 2) - 1; /* which of the pair's NN noise waves */
+    const int wave = threadIdx.x >> 6;
+    /* the workgroup's waves in groups of PW: group `tw` holds the transition waves, the NN others the noise waves.  PW = 4:
+     * tw = 0 (a group is one wave per SIMD).  PW < 4: a group covers PW of the four SIMDs, and tw rotates with the workgroup
+     * index so that the 4 / PW workgroups of a CU put their transition waves on different SIMDs */
+    const int group = wave / PW;
+    const int tw = PW == 4 ? 0 : (int)(blockIdx.x % (unsigned int)(4 / PW)) % (1 + NN);
+    const int pair = wave % PW;
+    const bool noise_wave = group != tw;
+    const int noise_rank = (group - tw - 1 + (1 + NN)) % (1 + NN); /* which of the pair's NN noise waves */
     T *const tiles = reinterpret_cast<T *>(mm_lds_raw + Plan::table_bytes + (size_t)pair * Plan::ntile * Plan::tile_bytes);
     constexpr size_t TILE_ELEMS = Plan::tile_bytes / sizeof(T);
-    T *const ring = reinterpret_cast<T *>(mm_lds_raw + Plan::table_bytes + 4 * Plan::ntile * Plan::tile_bytes + (size_t)pair * Plan::ring_bytes);
-    const unsigned long long c = (unsigned long long)blockIdx.x * 256ull + (unsigned long long)(pair * 64 + lane);
+    T *const ring = reinterpret_cast<T *>(mm_lds_raw + Plan::table_bytes + PW * Plan::ntile * Plan::tile_bytes + (size_t)pair * Plan::ring_bytes);
+    const unsigned long long c = (unsigned long long)blockIdx.x * (64ull * PW) + (unsigned long long)(pair * 64 + lane);
     const unsigned long long wave_c0 = c - lane;
     const unsigned long long chain = a.chain_offset + c;
     const unsigned int n_silent = a.n_discard + (a.out ? 0u : a.n_collect);
@@ -203,7 +213,7 @@ __device__ __forceinline__ void mm_run_split_body(const mm_run_args<T> &a)
     using Tab = typename mm_cond<sizeof(T) == 4, mm_icdf_lds, mm_icdf_global>::type;
     Tab tab;
     if constexpr (sizeof(T) == 4) {
-        mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, 256u * (1u + NN));
+        mm_icdf_lds_fill(reinterpret_cast<float *>(mm_lds_raw), threadIdx.x, 64u * PW * (1u + NN));
         mm_icdf_lds_check(mm_lds_raw);
         tab.tab = mm_icdf_lds_at0();
     }
@@ -510,6 +520,12 @@ __global__ __launch_bounds__(256 * (1 + NN)) void mm_run_split_kernel(const mm_r
 {
     mm_run_split_body<T, Tgt, SAMPLER, LCT, QP, NN, RBF, NT>(a);
 }
+/* workgroup = PW pairs (PW = 1, 2): 64 PW (1 + NN) threads, 1 + NN waves per SIMD as before (4 / PW workgroups per CU) */
+template <class T, class Tgt, int SAMPLER, int PW, int LCT = 0, int QP = 0, int NN = 3, int RBF = 0, int NT = MM_SPLIT_NTILE(SAMPLER == MM_SAMPLER_MH)>
+__global__ __launch_bounds__(64 * PW * (1 + NN)) __attribute__((amdgpu_waves_per_eu(1 + NN, 1 + NN))) void mm_run_splitw_kernel(const mm_run_args<T> a)
+{
+    mm_run_split_body<T, Tgt, SAMPLER, LCT, QP, NN, RBF, NT, PW>(a);
+}
 
 #if !defined(__HIPCC_RTC__)
 #include <atomic>
@@ -531,6 +547,26 @@ hipError_t mm_launch_run_split(const mm_run_args<T> &a, hipStream_t stream)
     }
     const unsigned int grid = (unsigned int)((a.n_chains + 255ull) / 256ull);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * (1 + NN)), Plan::lds_bytes, stream, a);
+    return hipGetLastError();
+}
+template <class T, class Tgt, int SAMPLER, int PW, int LCT = 0, int QP = 0, int NN = 3, int RBF = 0, int NT = MM_SPLIT_NTILE(SAMPLER == MM_SAMPLER_MH)>
+hipError_t mm_launch_run_splitw(const mm_run_args<T> &a, hipStream_t stream)
+{
+    using Plan = mm_split_plan<T, Tgt::dim, SAMPLER == MM_SAMPLER_MH, RBF, NT, PW>;
+    static std::atomic<unsigned long long> attr_set{0};
+    auto kern = mm_run_splitw_kernel<T, Tgt, SAMPLER, PW, LCT, QP, NN, RBF, NT>;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (Plan::lds_bytes > 64 * 1024 && (dev >= 64 || !((attr_set >> dev) & 1ull))) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)Plan::lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        if (dev < 64)
+            attr_set |= 1ull << dev;
+    }
+    const unsigned int grid = (unsigned int)((a.n_chains + 64ull * PW - 1ull) / (64ull * PW));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * PW * (1 + NN)), Plan::lds_bytes, stream, a);
     return hipGetLastError();
 }
 #endif /* !__HIPCC_RTC__ */

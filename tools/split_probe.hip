@@ -54,6 +54,15 @@ template <class Tgt, int SAMPLER, int LCT> static void bench(const char *name, i
                 (void)hipEventRecord(e0);
                 if (kern == 0)
                     (void)mm_launch_run<float, Tgt, SAMPLER, 2, LCT>(a, 1024, 64, 0);
+#ifdef MM_PROBE_PW /* round 6: workgroup = PW (1 or 2) pairs of 64 chains, 4 / PW workgroups per CU; -DMM_PROBE_PW_HMC: HMC too */
+#ifndef MM_PROBE_PW_HMC
+#define MM_PROBE_PW_HMC 0
+#endif
+                else if (SAMPLER == MM_SAMPLER_MH || MM_PROBE_PW_HMC)
+                    (void)mm_launch_run_splitw<float, Tgt, SAMPLER, MM_PROBE_PW, LCT, (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_QP : MM_PROBE_HMC_QP),
+                                               (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_NN : MM_PROBE_HMC_NN),
+                                               (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_RB : MM_PROBE_HMC_RB)>(a, 0);
+#endif
                 else
                     (void)mm_launch_run_split<float, Tgt, SAMPLER, LCT, (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_QP : MM_PROBE_HMC_QP),
                                               (SAMPLER == MM_SAMPLER_MH ? MM_PROBE_MH_NN : MM_PROBE_HMC_NN),
