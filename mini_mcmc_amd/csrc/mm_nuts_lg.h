@@ -156,6 +156,9 @@ struct mm_nuts_lg_args {
 #ifndef MM_LG_LEAN
 #define MM_LG_LEAN 1 /* round 5: the leaf loop without lane guards (mm_lg_doubling: "lean pair loop"); 0 = the guarded loop only */
 #endif
+#ifndef MM_LG_F_RECENT
+#define MM_LG_F_RECENT 1 /* round 6: the last LDS first-leaf slot keeps the most recent leaf with c >= LF + 1 (load_rec); 0 = slot per c only */
+#endif
 #ifndef MM_LG_WALK_UNROLL
 #define MM_LG_WALK_UNROLL 3 /* config 5: 0 510 ms, 1 496, 2 473, 3 469, 4 470 */
 #endif
@@ -580,10 +583,24 @@ template <int D, bool COH = false, int OCC = 1> __device__ __forceinline__ void 
 
 /* doubling j of the wave's chains (one iteration of `while s`, nuts.rs:578-671); `alive` in: the chain takes part,
  * out: it wants another doubling */
+#ifndef MM_LG_UNIFORM_J
+#define MM_LG_UNIFORM_J 1 /* round 6: the doubling's level as an SGPR (below); 0 = as the caller hands it over */
+#endif
 template <int D, bool COH, int OCC, bool RES>
-__device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, int j, bool &alive,
+__device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_lg_args &a, int j_in, bool &alive,
                                                double epsilon, mm_lds_double *lds, double *scr, mm_lg_edges<D> &E)
 {
+    /* Round 6: the level of the doubling is the same in all 64 lanes BY CONSTRUCTION (a unit is taken from ONE queue), but the
+     * persistent scheduler derives it from queue words its lanes loaded, so the compiler had to treat it -- and with it the
+     * number of leaves, the pair loop's exit, `k >= j` of every walk level and the level of the push -- as a per-lane value:
+     * the pair loop was compiled as a DIVERGENT loop (exit mask accumulated in SGPR pairs, s_and_saveexec around every walk
+     * level, phi copies of the edge at the back edge, a full s_waitcnt at the join).  One v_readfirstlane makes all of it
+     * scalar control flow. */
+#if MM_LG_UNIFORM_J
+    const int j = __builtin_amdgcn_readfirstlane(j_in);
+#else
+    const int j = j_in;
+#endif
     using Cfg = mm_lg_cfg<D, OCC>;
     constexpr int NS = Cfg::NS, ES = Cfg::ES;
     const size_t st = (size_t)a.c_pad * 4;
@@ -614,14 +631,21 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 r.fp[s] = f[(NS + s) * 64];
             }
         };
+        /* Round 6 -- which first-leaf record a merge reads: the sibling's first leaf i0 (the leaf index with its k + 1 low
+         * bits cleared) is filed under c = ctz(i0) >= k + 1.  For a merge at a level k <= LF either c <= LF (its own LDS
+         * slot) or i0 is THE most recent multiple of 2^(LF + 1) -- so the last LDS slot keeps "the most recent leaf with
+         * c >= LF + 1" whatever its c (a leaf with c >= LF + 2 is filed there AND under its c in HBM, for the merges at
+         * levels > LF) and every merge at a level <= LF finds its first-leaf record in LDS.  Before, a quarter of all pairs
+         * (1/4 of those with one trailing one in the pair index, 1/2 with two, all with three) waited for an HBM round
+         * trip here, now 1/16 (the merges at levels > LE, whose entries are in HBM anyway). */
         if (k > Cfg::LE)
             take((const double *)(scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64),
                  (const double *)(scr + (size_t)(Cfg::hbm_E + (k - 1 - Cfg::LE) * ES) * 64));
-        else if (cc > 1 + Cfg::LF)
+        else if (MM_LG_F_RECENT ? k > Cfg::LF : cc > 1 + Cfg::LF)
             take((const double *)(scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64),
                  (const mm_lds_double *)(lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64));
         else
-            take((const mm_lds_double *)(lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64),
+            take((const mm_lds_double *)(lds + (size_t)(Cfg::lds_F + ((cc > Cfg::LF + 1 ? Cfg::LF + 1 : cc) - 2) * Cfg::FS) * 64),
                  (const mm_lds_double *)(lds + (size_t)(Cfg::lds_E + (k - 1) * ES) * 64));
     };
     /* where the first leaf of the sibling at level k of `leaf` is filed */
@@ -725,14 +749,15 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
 #ifdef MM_LG_EXPERIMENT_NO_HBM
                 cc = cc > 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM ? 1 + Cfg::LF + MM_LG_EXPERIMENT_NO_HBM : cc;
 #endif
-                if (cc <= 1 + Cfg::LF) {
-                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
+                if (MM_LG_F_RECENT || cc <= 1 + Cfg::LF) { /* always in LDS: under c, or in the last slot ("the most recent leaf with c >= LF + 1", load_rec) */
+                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + ((cc > Cfg::LF + 1 ? Cfg::LF + 1 : cc) - 2) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         f[s * 64] = cx[s];
                         f[(NS + s) * 64] = cp[s];
                     }
-                } else {
+                }
+                if (cc > 1 + Cfg::LF) { /* and under c in HBM for the merges at levels > LF */
                     double *f = scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
@@ -967,14 +992,15 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if (j > 1 && (leaf & 3u) == 0u) {
 #endif
                 const int cc = leaf ? (__ffs((int)leaf) - 1) : MM_NUTS_JMAX;
-                if (cc <= 1 + Cfg::LF) {
-                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + (cc - 2) * Cfg::FS) * 64;
+                if (MM_LG_F_RECENT || cc <= 1 + Cfg::LF) { /* always in LDS: under c, or in the last slot ("the most recent leaf with c >= LF + 1", load_rec) */
+                    mm_lds_double *f = lds + (size_t)(Cfg::lds_F + ((cc > Cfg::LF + 1 ? Cfg::LF + 1 : cc) - 2) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         f[s * 64] = cx[s];
                         f[(NS + s) * 64] = cp[s];
                     }
-                } else {
+                }
+                if (cc > 1 + Cfg::LF) { /* and under c in HBM for the merges at levels > LF */
                     double *f = scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
