@@ -159,6 +159,9 @@ struct mm_nuts_lg_args {
 #ifndef MM_LG_F_RECENT
 #define MM_LG_F_RECENT 1 /* round 6: the last LDS first-leaf slot keeps the most recent leaf with c >= LF + 1 (load_rec); 0 = slot per c only */
 #endif
+#ifndef MM_LG_CHECK_FORM
+#define MM_LG_CHECK_FORM 3 /* round 6 (profiles/r6i_, r6j_nuts_check_form*_probe.log; best case 2873 cycles per leaf iteration): 0 = the check and its rare case inside the pair loop (round 5); 1 = its branch marked unlikely (2879); 2 = the three conditions as 64-bit lane masks on the scalar unit (2833); 3 = 2 + the rare case handled OUTSIDE the fast loop, which is left and entered again (2789; without any check: 2725) */
+#endif
 #ifndef MM_LG_WALK_UNROLL
 #define MM_LG_WALK_UNROLL 3 /* config 5: 0 510 ms, 1 496, 2 473, 3 469, 4 470 */
 #endif
@@ -951,12 +954,17 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             ka += 1u;
             return 0.25 + 1e-9 * (double)ka;
 #endif
-            const unsigned int b = ka >> 1, g = b >> 2;
+#if MM_LG_UNIFORM_J
+            const unsigned int kau = (unsigned int)__builtin_amdgcn_readfirstlane((int)ka); /* lock-step draws: one index for the wave */
+#else
+            const unsigned int kau = ka;
+#endif
+            const unsigned int b = kau >> 1, g = b >> 2;
             if (g != have_s) {
                 L.aux_blk = mm_block(a.seed, L.chain, L.m, MM_AUX_BLOCK + 4u * g + (unsigned int)L.q);
                 have_s = g;
             }
-            const bool odd = (ka & 1u) != 0u;
+            const bool odd = (kau & 1u) != 0u;
             const int src = lane15x4 + 64 * (int)(b & 3u);
             const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? L.aux_blk.w[2] : L.aux_blk.w[0]));
             const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? L.aux_blk.w[3] : L.aux_blk.w[1]));
@@ -1074,9 +1082,28 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             }
         };
         constexpr int WU = MM_LG_WALK_UNROLL;
+        /* what the pair hands to the validity check (and, MM_LG_CHECK_FORM 3, out of the fast loop) */
+        unsigned int P_n = 0, P_nalpha = 0, lf1 = 0;
+        double P_alpha = 0.0;
+        bool first_ok = true;
+        int k_stop = 0;
+#if MM_LG_CHECK_FORM == 3
+        /* Round 6: the validity check LEAVES the pair loop instead of handling its case inside it.  The fast loop then changes
+         * none of dead / live01 / died / F_* (they are invariant in it), carries no join behind a rare block, and its only
+         * vector-dependent branch is one scalar test of three lane masks; the slow path (a chain retires: at most once per chain
+         * and transition) runs between two entries of the fast loop. */
+        unsigned int leaf = 0;
+        for (;;) {
+            if (__ballot(!dead) == 0ull)
+                break;
+            unsigned long long m_inv1 = 0ull, m_inv2 = 0ull;
+            bool slow = false;
+            for (; leaf < n_leaves; leaf += 2) {
+#else
         for (unsigned int leaf = 0; leaf < n_leaves; leaf += 2) {
             if (__ballot(!dead) == 0ull)
                 break;
+#endif
             /* ---- the first leaf of the pair: its one-leaf subtree waits for the sibling in registers */
             leaf_l(leaf);
             const double d_first = d_last;
@@ -1086,15 +1113,15 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 pfx[s] = cx[s];
                 pfp[s] = cp[s];
             }
-            const unsigned int P_n = S_n, P_nalpha = S_nalpha;
+            P_n = S_n;
+            P_nalpha = S_nalpha;
             /* a first leaf that is not valid is handed up as it is and its sibling never built (nuts.rs:858-899): here the lane
              * runs on regardless and is set right at the end of the pair (ONE check per pair: a branch on a freshly computed
              * lane mask drains the wave's pipeline) */
-            const bool first_ok = S_s;
+            first_ok = S_s;
             /* ---- its sibling, both acceptance statistics in one pass (even rows the first leaf's d, odd rows the second's),
              *      the merge at level 0 */
             leaf_l(leaf | 1u);
-            double P_alpha;
             {
                 const double e = mm_lg_accept_prob((L.q & 1) ? d_last : d_first);
                 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
@@ -1106,8 +1133,8 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             }
             merge_l(pfx, pfp, pfx, mm_true_t(), P_alpha, P_n, P_nalpha);
             /* ---- the pair is handed up: merges at the levels of the trailing ones of the pair index, then a push */
-            const unsigned int lf1 = leaf | 1u;
-            int k_stop = 0; /* the level of the push; j: the doubling is complete */
+            lf1 = leaf | 1u;
+            k_stop = 0; /* the level of the push; j: the doubling is complete */
             auto level = [&](int k) __attribute__((always_inline)) {
                 if (k >= j) {
                     k_stop = j;
@@ -1159,11 +1186,56 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             for (int k = WU + 1; k_stop == 0; ++k)
                 level(k);
 #endif
+#if MM_LG_CHECK_FORM == 3
+                {
+                    const unsigned long long m_dead = __ballot(dead), m_first = __ballot(first_ok), m_ok = __ballot(S_s);
+                    m_inv1 = ~m_dead & ~m_first;
+                    m_inv2 = ~m_dead & m_first & ~m_ok;
+                    if (__builtin_expect((m_inv1 | m_inv2) != 0ull, 0)) {
+                        slow = true;
+                        break;
+                    }
+                }
+                if (k_stop >= j)
+                    break; /* reached the doubling's own level: complete */
+            }
+            if (!slow)
+                break; /* complete, or cut short by the scheduler's leaf count */
+            {
+                const bool inv1 = ((m_inv1 >> L.lane) & 1ull) != 0ull, inv2 = ((m_inv2 >> L.lane) & 1ull) != 0ull;
+                if (inv1) {
+                    S_n = P_n;
+                    S_nalpha = P_nalpha;
+                    S_alpha = P_alpha; /* min(1, exp(d)) of the first leaf */
+                    lf -= 1u;          /* the sibling's leapfrog step was not the chain's */
+                }
+                retire(leaf, 1, inv1);
+                retire(lf1, k_stop + 1, inv2);
+            }
+            if (k_stop >= j)
+                break;
+            leaf += 2;
+            if (leaf >= n_leaves)
+                break;
+        }
+#else
 #ifndef MM_LG_EXP_NO_RETIRE
+#if MM_LG_CHECK_FORM == 2
+            {
+                const unsigned long long m_dead = __ballot(dead), m_first = __ballot(first_ok), m_ok = __ballot(S_s);
+                const unsigned long long m_inv1 = ~m_dead & ~m_first, m_inv2 = ~m_dead & m_first & ~m_ok;
+                if (__builtin_expect((m_inv1 | m_inv2) != 0ull, 0)) {
+                    const bool inv1 = ((m_inv1 >> L.lane) & 1ull) != 0ull, inv2 = ((m_inv2 >> L.lane) & 1ull) != 0ull;
+#else
             {
                 const bool inv1 = !dead && !first_ok;       /* the first leaf was not valid: what the sibling added is undone */
                 const bool inv2 = !dead && first_ok && !S_s; /* the pair's subtree turned: it does not wait, it returns */
+#if MM_LG_CHECK_FORM == 1
+                if (__builtin_expect(__ballot(inv1 || inv2) != 0ull, 0)) {
+#else
                 if (__ballot(inv1 || inv2) != 0ull) {
+#endif
+#endif
                     if (inv1) {
                         S_n = P_n;
                         S_nalpha = P_nalpha;
@@ -1178,6 +1250,7 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             if (k_stop >= j)
                 break; /* reached the doubling's own level: complete */
         }
+#endif
         MM_LG_TICK(L, 2); /* tools/lg_profile.py: the whole lean loop lands in section 2 */
         if (died) {
             S_n = F_n;
@@ -1972,6 +2045,12 @@ __global__ __launch_bounds__(OCC == 2 ? 512 : 64, OCC == 2 ? 2 : 1) void mm_nuts
             keep = false;
         }
         MM_LGQ_T(0);
+#if MM_LG_UNIFORM_J
+        /* the queue (= the level of the unit) is the same in all 64 lanes by construction: say so, and everything derived from it
+         * -- the kind of unit, the doublings it runs, the hand-over's queue -- is scalar control flow (mm_lg_doubling, round 6) */
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        shard = __builtin_amdgcn_readfirstlane(shard);
+#endif
         if (quit || qi < 0)
             break;
         const bool use_keep = n_keep > 0u && !give_back; /* wave-uniform; then qi == keep_q in the own shard */
