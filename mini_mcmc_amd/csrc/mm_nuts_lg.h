@@ -162,6 +162,9 @@ struct mm_nuts_lg_args {
 #ifndef MM_LG_CHECK_FORM
 #define MM_LG_CHECK_FORM 3 /* round 6 (profiles/r6i_, r6j_nuts_check_form*_probe.log; best case 2873 cycles per leaf iteration): 0 = the check and its rare case inside the pair loop (round 5); 1 = its branch marked unlikely (2879); 2 = the three conditions as 64-bit lane masks on the scalar unit (2833); 3 = 2 + the rare case handled OUTSIDE the fast loop, which is left and entered again (2789; without any check: 2725) */
 #endif
+#ifndef MM_LG_PINGPONG
+#define MM_LG_PINGPONG 1 /* round 6: the pair's two leaves write (x, p) alternately into the first-leaf copy and back (no register copies); 0 = in place + copy */
+#endif
 #ifndef MM_LG_WALK_UNROLL
 #define MM_LG_WALK_UNROLL 3 /* config 5: 0 510 ms, 1 496, 2 473, 3 469, 4 470 */
 #endif
@@ -193,6 +196,15 @@ template <int D, int OCC = 1> struct mm_lg_cfg {
 };
 
 typedef double mm_d4 __attribute__((ext_vector_type(4)));
+/* fma(a, b, c) as the THREE-address v_fma_f64 with a destination of its own.  The compiler prefers the two-address
+ * v_fmac_f64 (dst = dst + a b) and, where the old value of c must survive or lives elsewhere, puts a v_mov_b64 in front of
+ * it: the lean pair loop of mm_lg_doubling carried 29 such copies per pair (round 6).  Same operation, same bits. */
+__device__ __forceinline__ double mm_fma3(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 struct mm_true_t { static constexpr bool value = true; };
 struct mm_false_t { static constexpr bool value = false; };
 /* LDS is addressed through an explicitly address-space-3 pointer: where an accessor picks LDS or HBM by a uniform
@@ -971,21 +983,33 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             ka += 1u;
             return mm_u53(hi, lo);
         };
-        auto leaf_l = [&](unsigned int leaf) __attribute__((always_inline)) {
+        /* (xi, pi) -> (xo, po): the pair's first leaf reads the edge and writes the first-leaf copy, the second reads that
+         * and writes the edge (MM_LG_PINGPONG); in place when xo == xi */
+        auto leaf_io = [&](unsigned int leaf, const double *xi, const double *pi, double *xo, double *po) __attribute__((always_inline)) {
             MM_LG_COUNT(L, 6);
             leaf_iters += 1u;
+            double ph[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                cp[s] = fma(nh, cg[s], cp[s]);
-                cx[s] = fma(epsv, cp[s], cx[s]);
+#if MM_LG_PINGPONG
+                ph[s] = mm_fma3(nh, cg[s], pi[s]);
+                xo[s] = mm_fma3(epsv, ph[s], xi[s]);
+#else
+                ph[s] = fma(nh, cg[s], pi[s]);
+                xo[s] = fma(epsv, ph[s], xi[s]);
+#endif
             }
-            mm_lg_ax<D, false>(L, cx, cg);
+            mm_lg_ax<D, false>(L, xo, cg);
             double xy = 0.0, pp = 0.0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                cp[s] = fma(nh, cg[s], cp[s]);
-                xy = fma(cx[s], cg[s], xy);
-                pp = fma(cp[s], cp[s], pp);
+#if MM_LG_PINGPONG
+                po[s] = mm_fma3(nh, cg[s], ph[s]);
+#else
+                po[s] = fma(nh, cg[s], ph[s]);
+#endif
+                xy = fma(xo[s], cg[s], xy);
+                pp = fma(po[s], po[s], pp);
             }
             mm_lg_group_sum2(xy, pp, &xy, &pp);
             const double lp = -0.5 * xy;
@@ -1004,16 +1028,16 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                     mm_lds_double *f = lds + (size_t)(Cfg::lds_F + ((cc > Cfg::LF + 1 ? Cfg::LF + 1 : cc) - 2) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        f[s * 64] = cx[s];
-                        f[(NS + s) * 64] = cp[s];
+                        f[s * 64] = xo[s];
+                        f[(NS + s) * 64] = po[s];
                     }
                 }
                 if (cc > 1 + Cfg::LF) { /* and under c in HBM for the merges at levels > LF */
                     double *f = scr + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        f[s * 64] = cx[s];
-                        f[(NS + s) * 64] = cp[s];
+                        f[s * 64] = xo[s];
+                        f[(NS + s) * 64] = po[s];
                     }
                 }
             }
@@ -1105,14 +1129,18 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 break;
 #endif
             /* ---- the first leaf of the pair: its one-leaf subtree waits for the sibling in registers */
-            leaf_l(leaf);
-            const double d_first = d_last;
             double pfx[NS], pfp[NS];
+#if MM_LG_PINGPONG
+            leaf_io(leaf, cx, cp, pfx, pfp);
+#else
+            leaf_io(leaf, cx, cp, cx, cp);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 pfx[s] = cx[s];
                 pfp[s] = cp[s];
             }
+#endif
+            const double d_first = d_last;
             P_n = S_n;
             P_nalpha = S_nalpha;
             /* a first leaf that is not valid is handed up as it is and its sibling never built (nuts.rs:858-899): here the lane
@@ -1121,7 +1149,11 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
             first_ok = S_s;
             /* ---- its sibling, both acceptance statistics in one pass (even rows the first leaf's d, odd rows the second's),
              *      the merge at level 0 */
-            leaf_l(leaf | 1u);
+#if MM_LG_PINGPONG
+            leaf_io(leaf | 1u, pfx, pfp, cx, cp);
+#else
+            leaf_io(leaf | 1u, cx, cp, cx, cp);
+#endif
             {
                 const double e = mm_lg_accept_prob((L.q & 1) ? d_last : d_first);
                 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
