@@ -415,13 +415,14 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
  *   AUTO    what the reference does (stats.rs:549): direct sums for half-chains up to 100 draws (register tiles on the
  *           vector ALU), the power spectrum above (one wave-level FFT per chain and parameter, one inverse for all);
  *   FFT / TILE1 / TILE / MFMA / DIRECT   that kernel wherever its shape limits allow, AUTO's choice elsewhere
- *           (FFT: 2 <= n/2 <= 16384 -- one wave-level transform up to 1024, N1 residues of 2048-point transforms beyond;
- *           TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).  Half-chains longer than
- *           16384 draws -- and, under DIRECT, any the staging kernels cannot hold in a workgroup's LDS -- are reduced
+ *           (FFT: 2 <= n/2 <= 131072 -- one wave-level transform up to 1024, N1 = 2 .. 128 residues of 2048-point
+ *           transforms beyond, one residue and parameter per wave with its spectrum in registers (version 101; 100 ended
+ *           at 16384); TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).  Half-chains longer
+ *           than 131072 draws -- and, under DIRECT, any the staging kernels cannot hold in a workgroup's LDS -- are reduced
  *           straight from global memory (O(chains x dim x n^2), meant for a few very long chains): any n < 2^31 with
- *           dim x n/2 < 2^32 and 2 x chains x dim < 2^31 (MMCMC_ERR_SHAPE beyond), and chains x dim x (n/2)^2 <= 2^46 --
- *           about ten seconds of device time -- (MMCMC_ERR_UNSUPPORTED beyond: e.g. [65536, 40000, 3]; split such a
- *           sample by parameter or thin it).
+ *           dim x n/2 < 2^32 and 2 x chains x dim < 2^31 (MMCMC_ERR_SHAPE beyond), and chains x dim x (n/2)^2 within the
+ *           direct-work limit (default 2^46, about ten seconds of device time; MMCMC_ERR_UNSUPPORTED beyond;
+ *           mmcmc_stats_set_direct_work_limit(0) removes the limit).
  * For measurements and for the agreement test; results never depend on it beyond rounding.  Process-wide and meant to
  * be set once: a call that races with it picks one kernel or the other (its work buffer fits both).  Under one selection
  * R-hat / ESS are bit-reproducible across devices too: no kernel's summation grouping depends on the device. */
@@ -432,6 +433,9 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
 #define MMCMC_STATS_KERNEL_MFMA 4
 #define MMCMC_STATS_KERNEL_DIRECT 5
 int mmcmc_stats_set_kernel(int kind);
+/* lag products the O(n^2) from-global-memory path may be asked for before it returns MMCMC_ERR_UNSUPPORTED (process-wide;
+ * default 2^46; 0 = no limit: the call then runs however long it takes) */
+int mmcmc_stats_set_direct_work_limit(uint64_t max_lag_products);
 /* basic_stats stats.rs:310-336 (host) and RunStats::from stats.rs:360-371 */
 int mmcmc_basic_stats_from(const float *data, size_t len, mmcmc_basic_stats *out);
 int mmcmc_run_stats_from(const void *sample, int sample_is_device, int dtype, size_t n_chains, size_t n, size_t dim,

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mmcmc_split_rhat_mean_ess": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                             C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, _vp]),
     "mmcmc_stats_set_kernel": (C.c_int, [C.c_int]),
+    "mmcmc_stats_set_direct_work_limit": (C.c_int, [C.c_uint64]),
     "mmcmc_stats_partials": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, C.c_int, _vp]),
     "mmcmc_stats_finish": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
                                      C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -1379,6 +1379,187 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
         out[i] = S[i];
 }
 
+/* ---- half-chains beyond 2048 draws, round 6: one (residue, parameter) per WAVE, the spectrum in REGISTERS -------------------
+ * The cut is the one above (N = N1 x 2048, t = n2 + 2048 n1, f = k1 + N1 k2), but a wave keeps ONE residue k1 of ONE
+ * parameter for all the chains it walks: the 2048 bins k1 + N1 k2 of its |Z|^2 are 32 registers per lane that pass 3
+ * accumulates into directly, exactly as the short path does (mm_chain_fft_kernel) -- no spectrum in LDS (round 5's
+ * mm_chain_fft_long_kernel kept S[N] there: one wave per SIMD at N1 = 4 and 8, one per CU at N1 = 16, a read-modify-write of
+ * 2048 LDS words per residue and chain; a 2048-point residue transform took 38 000 cycles against ~6000).  N1 is a run-time value (any power of two: half-chains up to 131 072 draws), the sum over
+ * the N1 / 2 data blocks of a point a run-time loop.
+ * The half-chain means come from a streaming pass of their own (mm_half_chain_means_kernel: the sample once, flat and
+ * coalesced); the sums of squares are taken by the residue-0 waves, which see every point once.
+ * Workgroup = one wave; blockIdx -> (XCD, chain group, (k1, d)) so that the N1 D waves reading the same chains sit on ONE
+ * XCD (one fetch from HBM, N1 D - 1 hits in its L2) and run at the same time; slabs [n_grp][D][N] as everywhere. */
+template <class T>
+__global__ __launch_bounds__(1024) void mm_half_chain_means_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n,
+                                                                   unsigned int D, unsigned int m, float *__restrict__ means)
+{
+    /* block = 64 D threads over ONE half-chain taken as a flat array of m D numbers: thread i sees parameter i mod D only
+     * (the stride 64 D is a multiple of D), reads are unit-stride over the block; its sum meets the 63 others of its
+     * parameter in LDS, added in a fixed order */
+    __shared__ float part[1024];
+    const unsigned long long hc = blockIdx.x;
+    const unsigned long long chain = hc < C ? hc : hc - C;
+    const unsigned int row0 = hc < C ? 0u : n - m;
+    const T *src = sample + (chain * n + row0) * D;
+    const unsigned int W = 64u * D, tid = threadIdx.x, total = m * D;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    unsigned int e = tid;
+    for (; e + 3u * W < total; e += 4u * W) {
+        const float a = (float)src[e], b = (float)src[e + W], c = (float)src[e + 2u * W], d = (float)src[e + 3u * W];
+        s0 += a;
+        s1 += b;
+        s2 += c;
+        s3 += d;
+    }
+    for (; e < total; e += W)
+        s0 += (float)src[e];
+    part[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (tid < D) {
+        float s = 0.f;
+        for (unsigned int k = 0; k < 64u; ++k)
+            s += part[tid + k * D];
+        means[hc * D + tid] = s / (float)m;
+    }
+}
+
+template <class T, int HP = 2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n, unsigned int D, unsigned int m,
+                             unsigned int N1, unsigned int n_grp, const mm_cx *__restrict__ tw, const mm_cx *__restrict__ wN,
+                             const float *__restrict__ means, float *__restrict__ ssq, float *__restrict__ slabs)
+{
+    /* ONE wave per SIMD with the 512-register budget, and nothing but the sample's loads in the vector-memory queue: the
+     * transform's twiddles and the residue's w_N^(n2 k1) sit in registers for the life of the wave, the wave-uniform
+     * w_N1^(n1 k1) come through the scalar cache.  A lane's 32 points of HP data blocks of both half-chains (64 HP
+     * registers) are REQUESTED for the next step -- the next group of data blocks of this chain, or the first group of the
+     * next chain -- as soon as the pre-sum has consumed the current ones, so the long step, the 2048-point transform, runs
+     * with the next chain's loads in flight (first version of this kernel, two waves per SIMD, loads in batches of 16 with
+     * their use right behind: [65536, 8000, 3] 12.9 ms = eight exposed memory latencies per chain and residue). */
+    constexpr int R1 = 32;
+    using pl = mm_fft_plan<R1>;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    mm_cx *const lds = reinterpret_cast<mm_cx *>(lds_raw);
+    const unsigned int lane = threadIdx.x;
+    const unsigned int N = 2048u * N1, HALF = N1 / 2u, per = D * N1, G = HALF / (unsigned int)HP;
+    unsigned int kd, grp;
+    if (n_grp % 8u == 0u) {
+        const unsigned int xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        kd = i % per;
+        grp = (i / per) * 8u + xcd;
+    } else {
+        kd = blockIdx.x % per;
+        grp = blockIdx.x / per;
+    }
+    /* d fastest: the D waves that read the very same cache lines (interleaved parameters) are neighbours */
+    const unsigned int d = kd % D, k1 = __builtin_amdgcn_readfirstlane(kd / D);
+    mm_cx tw1[R1], tw2[8], wt[R1];
+#pragma unroll
+    for (int b = 1; b < R1; ++b)
+        tw1[b] = tw[b * 64 + lane];
+    tw1[0] = mm_cx{1.f, 0.f};
+#pragma unroll
+    for (int g = 1; g < 8; ++g)
+        tw2[g] = tw[R1 * 64 + g * 8 + (lane & 7u)];
+    tw2[0] = mm_cx{1.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < R1; ++a)
+        wt[a] = wN[((64u * (unsigned int)a + lane) * k1) & (N - 1u)]; /* w_N^(n2 k1), n2 = 64 a + lane */
+    auto tw1_of = [&](int b) -> mm_cx { return tw1[b]; };
+    auto tw2_of = [&](int g) -> mm_cx { return tw2[g]; };
+    float S[pl::J][8];
+#pragma unroll
+    for (int j = 0; j < pl::J; ++j)
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            S[j][h] = 0.f;
+    const size_t second = (size_t)(n - m) * D; /* the second half-chain: rows [n - m, n) */
+    float pf0[R1][HP], pf1[R1][HP];
+    auto request = [&](unsigned long long cc, unsigned int g) __attribute__((always_inline)) {
+        const T *const b = sample + (size_t)cc * n * D + d;
+        /* the 128 offsets depend on the lane only: computed once ahead of the chain loop they would take 256 registers (and did:
+         * 1.5 KB of scratch); an opaque copy of the lane index per request keeps them arithmetic beside their loads */
+        unsigned int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
+#pragma unroll
+        for (int a = 0; a < R1; ++a)
+#pragma unroll
+            for (int h = 0; h < HP; ++h) {
+                const unsigned int t = 64u * (unsigned int)a + lane_k + 2048u * (g * (unsigned int)HP + (unsigned int)h), tc = t < m ? t : m - 1u;
+                pf0[a][h] = (float)b[(size_t)tc * D];
+                pf1[a][h] = (float)b[second + (size_t)tc * D];
+            }
+    };
+    unsigned long long c = grp;
+    float mu0 = 0.f, mu1 = 0.f;
+    if (c < C) {
+        mu0 = means[(size_t)c * D + d];
+        mu1 = means[((size_t)c + (size_t)C) * D + d];
+        request(c, 0u);
+    }
+    for (; c < C; c += n_grp) {
+        float q0 = 0.f, q1 = 0.f;
+        const float m0 = mu0, m1 = mu1;
+        mm_cx y[R1];
+#pragma unroll
+        for (int a = 0; a < R1; ++a)
+            y[a] = mm_cx{0.f, 0.f};
+        for (unsigned int g = 0; g < G; ++g) {
+            mm_cx w1[HP]; /* w_N1^(n1 k1): one value for the wave, through the scalar cache */
+#pragma unroll
+            for (int h = 0; h < HP; ++h)
+                w1[h] = wN[(((g * (unsigned int)HP + (unsigned int)h) * k1) & (N1 - 1u)) * 2048u];
+#pragma unroll
+            for (int a = 0; a < R1; ++a)
+#pragma unroll
+                for (int h = 0; h < HP; ++h) {
+                    const bool in = 64u * (unsigned int)a + lane + 2048u * (g * (unsigned int)HP + (unsigned int)h) < m;
+                    const mm_cx v = mm_cx{in ? pf0[a][h] - m0 : 0.f, in ? pf1[a][h] - m1 : 0.f};
+                    if (k1 == 0u) { /* every point of the chain passes here exactly once */
+                        q0 = fmaf(v.re, v.re, q0);
+                        q1 = fmaf(v.im, v.im, q1);
+                    }
+                    y[a] = mm_cx_add(y[a], mm_cx_mul(v, w1[h].re, w1[h].im));
+                }
+            /* the registers are free again: the next step's points, in flight behind whatever comes next */
+            if (g + 1u < G) {
+                request(c, g + 1u);
+            } else if (c + n_grp < C) {
+                mu0 = means[((size_t)c + n_grp) * D + d];
+                mu1 = means[((size_t)c + n_grp + (size_t)C) * D + d];
+                request(c + n_grp, 0u);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < R1; ++a)
+            y[a] = mm_cx_mul(y[a], wt[a].re, wt[a].im);
+        mm_fft_pass1_full<R1>(y, tw1_of, lds, (int)lane);
+        MM_WAVE_LDS_SYNC();
+        mm_cx v2[pl::J][8];
+        mm_fft_pass2_load<R1>(v2, lds, (int)lane);
+        MM_WAVE_LDS_SYNC();
+        mm_fft_pass2_store<R1>(v2, tw2_of, lds, (int)lane);
+        MM_WAVE_LDS_SYNC();
+        mm_fft_pass3<R1>(lds, (int)lane, S); /* |Z|^2 of this chain's 2048 bins onto the wave's running spectrum */
+        MM_WAVE_LDS_SYNC();
+        if (k1 == 0u) {
+            q0 = wave_sum_dpp_bcast(q0);
+            q1 = wave_sum_dpp_bcast(q1);
+            if (lane == 0u) {
+                ssq[(size_t)c * D + d] = q0;
+                ssq[((size_t)c + (size_t)C) * D + d] = q1;
+            }
+        }
+    }
+    float *const out = slabs + ((size_t)grp * D + d) * N;
+#pragma unroll
+    for (int j = 0; j < pl::J; ++j)
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            out[k1 + N1 * (unsigned int)mm_fft_bin<R1>((int)lane, j, h)] = S[j][h];
+}
+
 /* P[f D + d] = the sum of the tail kernel's partial totals, in f64 (fixed order) */
 __global__ __launch_bounds__(256) void mm_fft_psum_kernel(const float *__restrict__ parts, unsigned int n_parts, size_t total,
                                                           double *__restrict__ P)
@@ -1644,6 +1825,8 @@ static unsigned int stats_n_slabs(size_t n_chains)
 
 /* ---- which kernel reduces a sample: mmcmc_stats_set_kernel (include/mmcmc.h) ---- */
 static std::atomic<int> g_stats_kernel{MMCMC_STATS_KERNEL_AUTO};
+/* lag products (chains x dim x (n / 2)^2) the O(m^2) from-global-memory path may be asked for; 0 = no limit */
+static std::atomic<uint64_t> g_stats_direct_work_limit{1ull << 46};
 
 /* the power-spectrum path (mm_chain_fft_kernel): half-chains longer than 100 draws, as stats.rs:549 switches */
 struct StatsFftPlan {
@@ -1695,8 +1878,10 @@ static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int de
 /* the long-chain path (mm_chain_fft_long_kernel): half-chains of 1025 .. 16384 draws */
 struct StatsLongPlan {
     bool use = false;
+    bool res = false; /* round 6: one (residue, parameter) per wave, spectrum in registers (mm_chain_fft_res_kernel): N1 >= 4 */
     unsigned int N1 = 0, N = 0, n_wg = 0, waves = 1;
 };
+constexpr size_t kStatsLongMaxM = 131072; /* N = 2^18: the inverse (mm_fft_finish_long_kernel) is O(m N) per parameter */
 /* LDS of a workgroup of the long-chain kernel: the spectrum, an exchange block per wave, at N1 = 4 the staged column */
 static size_t stats_long_lds(unsigned int N, unsigned int waves, unsigned int N1)
 {
@@ -1707,13 +1892,29 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
     StatsLongPlan p;
     const size_t m = n / 2;
     const int sel = sel_in >= 0 ? sel_in : g_stats_kernel.load(std::memory_order_relaxed);
-    if ((sel != MMCMC_STATS_KERNEL_AUTO && sel != MMCMC_STATS_KERNEL_FFT) || m <= 1024 || m > 16384)
+    if ((sel != MMCMC_STATS_KERNEL_AUTO && sel != MMCMC_STATS_KERNEL_FFT) || m <= 1024 || m > kStatsLongMaxM)
         return p;
     p.use = true;
     p.N1 = 2;
     while ((size_t)p.N1 * 2048 < 2 * m)
         p.N1 *= 2;
     p.N = 2048u * p.N1;
+#ifdef MMCMC_TUNING
+    const bool old_kernels = mm_tuning_env("MMCMC_STATS_LONG_OLD") != nullptr && p.N1 <= 16; /* A / B against round 5's kernels */
+#else
+    const bool old_kernels = false;
+#endif
+    if (p.N1 >= 4 && !old_kernels) {
+        /* chain groups: as many as keep ONE resident round of one-wave workgroups busy -- one per SIMD by their registers, 1024
+         * on an MI355X; the figure is a constant, not a device query, because the group count fixes the f32 summation grouping
+         * -- in multiples of 8 (the kernel's XCD mapping), at most 512 */
+        p.res = true;
+        const size_t per = dim * p.N1;
+        size_t g = per > 0 ? 1024 / per : 8;
+        g = std::min<size_t>(512, std::max<size_t>(8, g / 8 * 8));
+        p.n_wg = (unsigned int)std::min<size_t>(g, n_chains);
+        return p;
+    }
     /* device-independent (the workgroup count fixes the f32 summation grouping): at most 512 chain groups, and no more than fit
      * the one-wave workgroups an MI355X holds at once with this kernel's LDS (1024 at N1 = 2: a launch of 1536 ran a second,
      * half-empty round), a multiple of 8 (the kernel's XCD mapping); fewer for few chains */
@@ -1944,6 +2145,35 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         const size_t lds = stats_long_lds(lp.N, lp.waves, lp.N1);
         const unsigned int grid = lp.n_wg * (unsigned int)dim;
         hipError_t le = hipSuccess;
+        if (lp.res) {
+            /* means by a streaming pass (dim <= 16: 64 dim threads per half-chain; wider samples through the any-length moments
+             * kernel), then one wave per (chain group, residue, parameter) */
+            if ((uint64_t)2 * n_chains >= (1ull << 31) || (uint64_t)lp.n_wg * dim * lp.N1 >= (1ull << 31))
+                return MMCMC_ERR_SHAPE;
+            const unsigned int g_mean = (unsigned int)(2 * n_chains), g_res = lp.n_wg * (unsigned int)dim * lp.N1;
+            const size_t lds_res = (size_t)mm_fft_plan<32>::LDS_CX * sizeof(mm_cx);
+#define MM_RES_LAUNCH(TT)                                                                                           \
+    do {                                                                                                            \
+        if (dim <= 16)                                                                                              \
+            hipLaunchKernelGGL(mm_half_chain_means_kernel<TT>, dim3(g_mean), dim3(64u * (unsigned int)dim), 0, stream, \
+                               (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, \
+                               (unsigned int)m, means);                                                             \
+        else                                                                                                        \
+            hipLaunchKernelGGL(mm_half_chain_moments_any_kernel<TT>, dim3(g_mean * (unsigned int)dim), dim3(64), 0, stream, \
+                               (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, \
+                               (unsigned int)m, means, ssq);                                                        \
+        hipLaunchKernelGGL(mm_chain_fft_res_kernel<TT>, dim3(g_res), dim3(64), lds_res, stream, (const TT *)sample, \
+                           (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, lp.N1, \
+                           lp.n_wg, tw, wN, means, ssq, ws);                                                        \
+    } while (0)
+            if (dim > 16 && (uint64_t)2 * n_chains * dim >= (1ull << 31))
+                return MMCMC_ERR_SHAPE;
+            if (dtype == MMCMC_F32)
+                MM_RES_LAUNCH(float);
+            else
+                MM_RES_LAUNCH(double);
+#undef MM_RES_LAUNCH
+        } else {
 #define MM_LONG_LAUNCH(TT, NN, WW)                                                                                  \
     do {                                                                                                            \
         if (lds > 64 * 1024)                                                                                        \
@@ -1954,6 +2184,7 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
                                (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, \
                                (unsigned int)m, lp.n_wg, tw, wN, means, ssq, ws);                                   \
     } while (0)
+#ifdef MMCMC_TUNING /* round 5's kernels for N1 = 4, 8, 16: measurement builds only (MMCMC_STATS_LONG_OLD) */
 #define MM_LONG_PICK(TT)                                                                                            \
     do {                                                                                                            \
         switch (lp.N1) {                                                                                            \
@@ -1963,12 +2194,16 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         default: MM_LONG_LAUNCH(TT, 16, 1); break;                                                                  \
         }                                                                                                           \
     } while (0)
+#else
+#define MM_LONG_PICK(TT) MM_LONG_LAUNCH(TT, 2, 1)
+#endif
         if (dtype == MMCMC_F32)
             MM_LONG_PICK(float);
         else
             MM_LONG_PICK(double);
 #undef MM_LONG_PICK
 #undef MM_LONG_LAUNCH
+        }
         MM_HIP(le);
         MM_HIP(hipGetLastError());
         const unsigned int total_b = (unsigned int)(dim * lp.N);
@@ -2096,12 +2331,17 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
              * moments and lag sums straight from global memory, any length */
             /* 32-bit quantities of this path: the moments kernel's grid (2 C D workgroups) and dim * m (the tail kernel's
              * element count); and a WORK bound -- the lag sums here cost C * D * m^2 products like the reference's
-             * brute-force branch (stats.rs:622-654), ~6e12 per second on this device: past 2^46 (about ten seconds; e.g.
-             * [65536, 40000, 3]) the call is refused instead of occupying the device for minutes (include/mmcmc.h) */
+             * brute-force branch (stats.rs:622-654), ~6e12 per second on this device: past the limit (default 2^46, about ten
+             * seconds; mmcmc_stats_set_direct_work_limit moves or removes it) the call is refused instead of occupying the device
+             * for minutes.  Round 6: under AUTO / FFT this path is reached only beyond 131 072 draws per half-chain -- up to
+             * there the power spectrum is taken residue by residue (mm_chain_fft_res_kernel), e.g. [65536, 40000, 3] */
             if ((uint64_t)dim * m >= (1ull << 32) || (uint64_t)2 * n_chains * dim >= (1ull << 31))
                 return MMCMC_ERR_SHAPE;
-            if ((long double)n_chains * (long double)dim * (long double)m * (long double)m > 70368744177664.0L /* 2^46 */)
-                return MMCMC_ERR_UNSUPPORTED;
+            {
+                const uint64_t limit = g_stats_direct_work_limit.load(std::memory_order_relaxed); /* mmcmc_stats_set_direct_work_limit */
+                if (limit != 0 && (long double)n_chains * (long double)dim * (long double)m * (long double)m > (long double)limit)
+                    return MMCMC_ERR_UNSUPPORTED;
+            }
             n_slabs = std::min(n_slabs, 16u);
             if (!slabs)
                 MM_HIP(hipMallocAsync((void **)&slabs, (size_t)n_slabs * dim * m * sizeof(float), stream));
@@ -2213,6 +2453,12 @@ static float *stats_pinned(size_t n_floats)
 }
 
 extern "C" {
+
+int mmcmc_stats_set_direct_work_limit(uint64_t max_lag_products)
+{
+    g_stats_direct_work_limit.store(max_lag_products, std::memory_order_relaxed);
+    return MMCMC_OK;
+}
 
 int mmcmc_stats_set_kernel(int kind)
 {

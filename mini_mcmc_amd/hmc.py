@@ -59,3 +59,40 @@ class HMC(_Sampler):
     def positions(self) -> np.ndarray:
         """hmc.rs:49 `positions` [n_chains, D]."""
         return self.state()
+
+
+def run_chain_of_handles(target: Target, initial_positions, eps_range, leapfrog_range, n_per_launch: int, burn_launches: int,
+                         keep_launches: int, seed: int = 42, schedule_seed: int = 7, device: int = 0):
+    """A converged sample from the REFERENCE's sampler on a target where one fixed (step_size, n_leapfrog) does not mix
+    (RosenbrockND(3): profiles/r5b_, r6m_converged_probe.jsonl).  `HMC` has no jitter (hmc.rs:87-121, 304-431), but its
+    constructor takes any initial positions: launch k is `HMC::new(target, positions of launch k - 1, eps_k, L_k)` followed
+    by `run(n_per_launch, 0)` (hmc.rs:137-158), with eps_k ~ U(eps_range), L_k ~ U{leapfrog_range} drawn on the host from
+    numpy's PCG64(schedule_seed) -- every launch IS the reference's sampler, each leaves the target invariant, so does their
+    sequence.  Handle k is seeded `seed + k` (a handle's stream starts at iteration 0).  The first `burn_launches` launches are
+    discarded.  Returns (sample [n_chains, keep_launches * n_per_launch, dim] as a torch tensor on the device, info)."""
+    import torch
+
+    rng = np.random.default_rng(schedule_seed)
+    state = np.ascontiguousarray(initial_positions)
+    n_chains, dim = state.shape
+    keep = torch.empty((n_chains, keep_launches * n_per_launch, dim), dtype=torch.float32 if state.dtype == np.float32 else torch.float64,
+                       device=torch.device("cuda", device))
+    kernel_ms, accepts, leapfrogs, schedule = 0.0, 0.0, 0.0, []
+    for k in range(burn_launches + keep_launches):
+        eps = float(rng.uniform(eps_range[0], eps_range[1]))
+        n_leap = int(rng.integers(leapfrog_range[0], leapfrog_range[1] + 1))
+        h = HMC(target, state, eps, n_leap, device=device).set_seed(seed + k)
+        t = h.run(n_per_launch, 0, to="torch")
+        torch.cuda.synchronize(device)
+        kernel_ms += float(h.timing()["kernel_ms"])
+        leapfrogs += float(n_chains) * n_per_launch * n_leap
+        if k >= burn_launches:
+            keep[:, (k - burn_launches) * n_per_launch:(k - burn_launches + 1) * n_per_launch] = t
+            accepts += float(h.accept_counts.mean())
+        schedule.append((eps, n_leap))
+        state = h.state()
+        h.close()
+        del t
+    info = {"kernel_ms": kernel_ms, "launches": burn_launches + keep_launches, "leapfrogs": leapfrogs,
+            "accept_rate": accepts / (keep_launches * n_per_launch), "schedule_head": schedule[:4]}
+    return keep, info

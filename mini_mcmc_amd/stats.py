@@ -82,6 +82,12 @@ def set_kernel(kind: str = "auto") -> None:
     L.check(L.lib().mmcmc_stats_set_kernel(STATS_KERNELS[kind]), "mmcmc_stats_set_kernel")
 
 
+def set_direct_work_limit(max_lag_products: int = 1 << 46) -> None:
+    """mmcmc_stats_set_direct_work_limit: chains x params x (n / 2)^2 the O(n^2) from-global-memory path (half-chains beyond
+    131 072 draws, or under set_kernel("direct")) accepts before it refuses; 0 = no limit."""
+    L.check(L.lib().mmcmc_stats_set_direct_work_limit(int(max_lag_products)), "mmcmc_stats_set_direct_work_limit")
+
+
 def split_rhat_mean_ess(sample, device: int | None = None):
     """stats.rs:416-423: sample [chains, n, params] (numpy, or a torch tensor in HBM) -> (rhat[params], ess[params]).
     `rhat` is the reference's sqrt(W / var+) (quirk Q7)."""

@@ -917,10 +917,13 @@ def test_nuts_posterior_and_run_progress_stats(M, O):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2), (5, 2050, 2),
-                                   (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2), (64, 33000, 2), (400, 2100, 3), (9, 7000, 3), (70, 5001, 2), (33, 12000, 1)])
+                                   (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2), (64, 33000, 2), (400, 2100, 3), (9, 7000, 3), (70, 5001, 2), (33, 12000, 1),
+                                   (64, 20000, 2), (3, 250000, 2), (1, 300000, 1), (16, 16384, 17), (700, 4100, 3)])
 def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
-    """Half-chains beyond 1024 draws (mm_chain_fft_long_kernel: the transform cut into N1 residues of 2048-point wave-level
-    transforms) and beyond 16 384 (mm_lag_sums_any_kernel: any length, straight from global memory): R-hat / ESS against
+    """Half-chains beyond 1024 draws (the transform cut into N1 residues of 2048-point wave-level transforms: N1 = 2
+    mm_chain_fft_long_kernel, N1 = 4 .. 128 mm_chain_fft_res_kernel -- round 6: one residue and parameter per wave, spectrum in
+    registers, half-chains up to 131 072 draws) and beyond (mm_lag_sums_any_kernel: any length, straight from global memory;
+    (1, 300000, 1)); more than 16 parameters (the means through the any-length moments kernel): R-hat / ESS against
     oracle/stats.c's FFT branch (stats.rs:576-620), odd n (the middle draw dropped), few chains, the first and the last length
     of each path, one chain of 10^5 draws; equal to the direct sums where those still exist; reproducible bit for bit;
     the partial statistics the multi-GPU path exchanges agree with the one-call path."""
@@ -949,7 +952,9 @@ def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
     means, ssq, acov = S.stats_partials(t)
     r4, e4 = S.stats_finish(means.cpu().numpy(), ssq.cpu().numpy(), acov.cpu().numpy())
     np.testing.assert_allclose(r4, r1, rtol=1e-6)
-    np.testing.assert_allclose(e4, e1, rtol=1e-5)
+    # the two entry points cut the slabs' totals into different numbers of f32 partial sums: measured 2.4e-5 at (2, 32770, 1)
+    # through the 32-residue power spectrum (1e-5 held while that shape went through the O(n^2) sums with f64 totals)
+    np.testing.assert_allclose(e4, e1, rtol=1e-4)
 
 
 @pytest.mark.gpu
@@ -970,8 +975,14 @@ def test_split_rhat_mean_ess_refuses_shapes_beyond_its_stated_limits(M):
     def call(c, n, d):
         return lib.mmcmc_split_rhat_mean_ess(C.c_void_p(buf.data_ptr()), 1, L.F32, c, n, d, rhat, ess, 0, None)
 
-    assert call(65536, 40000, 3) == L.ERR_UNSUPPORTED      # 65536 * 3 * 20000^2 = 7.9e13 > 2^46
-    assert call(64, 33000, 2) == L.OK                       # the same path inside its limits (values: the parity test above)
+    # (round 6: [65536, 40000, 3], refused until then, is inside the power-spectrum path now -- half-chains up to 131 072 draws)
+    assert call(4096, 300000, 3) == L.ERR_UNSUPPORTED      # n / 2 > 131072 -> O(n^2) path: 4096 * 3 * 150000^2 = 2.8e14 > 2^46
+    try:  # the limit is a setter now (advisor r5): 64 * 2 * 150000^2 = 2.9e12 is inside 2^46 and outside 2^40
+        assert lib.mmcmc_stats_set_direct_work_limit(1 << 40) == L.OK
+        assert call(64, 300000, 2) == L.ERR_UNSUPPORTED
+    finally:
+        lib.mmcmc_stats_set_direct_work_limit(1 << 46)
+    assert call(64, 33000, 2) == L.OK                       # inside the limits (N1 = 32 residues; values: the parity test above)
     torch.cuda.synchronize()
 
 
