@@ -64,7 +64,7 @@ class HMC(_Sampler):
 def run_chain_of_handles(target: Target, initial_positions, eps_range, leapfrog_range, n_per_launch: int, burn_launches: int,
                          keep_launches: int, seed: int = 42, schedule_seed: int = 7, device: int = 0):
     """A converged sample from the REFERENCE's sampler on a target where one fixed (step_size, n_leapfrog) does not mix
-    (RosenbrockND(3): profiles/r5b_, r6m_converged_probe.jsonl).  `HMC` has no jitter (hmc.rs:87-121, 304-431), but its
+    (RosenbrockND(3): profiles/r5b_, r6m_converged_probe.jsonl, r6s_converged_hmc_robustness.jsonl).  `HMC` has no jitter (hmc.rs:87-121, 304-431), but its
     constructor takes any initial positions: launch k is `HMC::new(target, positions of launch k - 1, eps_k, L_k)` followed
     by `run(n_per_launch, 0)` (hmc.rs:137-158), with eps_k ~ U(eps_range), L_k ~ U{leapfrog_range} drawn on the host from
     numpy's PCG64(schedule_seed) -- every launch IS the reference's sampler, each leaves the target invariant, so does their

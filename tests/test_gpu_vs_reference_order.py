@@ -429,9 +429,11 @@ def test_rosenbrock3_converged_posterior_equals_the_exact_moments(M):
 def test_rosenbrock3_hmc_converges_as_a_chain_of_handles(M):
     """BASELINE's metric names HMC on RosenbrockND(3): ONE fixed (eps, L) -- all the reference's HMC has, hmc.rs:87-121 -- leaves
     var(x2) at 1.2-1.9x the exact value with split R-hat 1.06-1.75 (profiles/r6m_converged_probe.jsonl).  A sequence of handles,
-    each `HMC::new(target, last positions, eps_k, L_k)` + `run(100, 0)` with eps_k ~ U(0.01, 0.03), L_k ~ U{50..200}
+    each `HMC::new(target, last positions, eps_k, L_k)` + `run(100, 0)` with eps_k ~ U(0.004, 0.016), L_k ~ U{100..400}
     (hmc.run_chain_of_handles: 20 launches discarded, 40 kept), must give the exact moments (quadrature, as in the NUTS test
-    above) within north_star's 1 % and a conventional split R-hat <= 1.05 over the 131 072 half-chains."""
+    above) within north_star's 1 % and a conventional split R-hat <= 1.05 over the 131 072 half-chains.  The band is the one
+    that held over four noise / schedule seeds (profiles/r6s_converged_hmc_robustness.jsonl: R-hat <= 1.003, moments within
+    0.04 %, ESS 2.1e7-4.8e7); eps up to 0.03 met the 1 % with one seed of four."""
     from mini_mcmc_amd import stats as S
     from mini_mcmc_amd.hmc import run_chain_of_handles
 
@@ -444,15 +446,15 @@ def test_rosenbrock3_hmc_converges_as_a_chain_of_handles(M):
     e14 = (w * (mu1 ** 4 + 6 * mu1 ** 2 * s1 + 3 * s1 ** 2)).sum()
     mean = np.array([m0, m1, e1sq])
     var = np.array([(w * (x0 - m0) ** 2).sum(), e1sq - m1 ** 2, e14 + 1.0 / 200.0 - e1sq ** 2])
-    t, info = run_chain_of_handles(M.dist.RosenbrockND(3), M.core.init_with_seed(65536, 3, 42, np.float32), (0.01, 0.03), (50, 200),
+    t, info = run_chain_of_handles(M.dist.RosenbrockND(3), M.core.init_with_seed(65536, 3, 42, np.float32), (0.004, 0.016), (100, 400),
                                    100, 20, 40, seed=42)
-    assert t.shape == (65536, 4000, 3) and info["launches"] == 60 and 0.85 < info["accept_rate"] < 0.99
+    assert t.shape == (65536, 4000, 3) and info["launches"] == 60 and 0.85 < info["accept_rate"] < 0.999
     rhat, ess = S.split_rhat_mean_ess(t)
-    assert float((1.0 / rhat).max()) <= 1.05, rhat  # measured 1.004
-    assert float(ess.min()) > 5e6, ess               # measured 1.4e7 of 2.6e8 draws
+    assert float((1.0 / rhat).max()) <= 1.05, rhat  # measured 1.0012
+    assert float(ess.min()) > 5e6, ess               # measured 4.5e7 of 2.6e8 draws
     x = t.double().reshape(-1, 3)
-    np.testing.assert_allclose(x.mean(dim=0).cpu().numpy(), mean, rtol=0.01)  # measured: 1e-4 of a standard deviation
-    np.testing.assert_allclose(x.var(dim=0).cpu().numpy(), var, rtol=0.01)    # measured: 1e-3
+    np.testing.assert_allclose(x.mean(dim=0).cpu().numpy(), mean, rtol=0.01)  # measured: 2e-4
+    np.testing.assert_allclose(x.var(dim=0).cpu().numpy(), var, rtol=0.01)    # measured: 2e-4
 
 
 def test_nuts_depth_cap_matches_oracle_cap(M, O):
