@@ -162,6 +162,9 @@ struct mm_nuts_lg_args {
 #ifndef MM_LG_CHECK_FORM
 #define MM_LG_CHECK_FORM 3 /* round 6 (profiles/r6i_, r6j_nuts_check_form*_probe.log; best case 2873 cycles per leaf iteration): 0 = the check and its rare case inside the pair loop (round 5); 1 = its branch marked unlikely (2879); 2 = the three conditions as 64-bit lane masks on the scalar unit (2833); 3 = 2 + the rare case handled OUTSIDE the fast loop, which is left and entered again (2789; without any check: 2725) */
 #endif
+#ifndef MM_LG_TOUCH
+#define MM_LG_TOUCH 0 /* round 6 experiment: touch the HBM records of a pair's level-(LE + 1) merge two leaves ahead */
+#endif
 #ifndef MM_LG_PINGPONG
 #define MM_LG_PINGPONG 1 /* round 6: the pair's two leaves write (x, p) alternately into the first-leaf copy and back (no register copies); 0 = in place + copy */
 #endif
@@ -1127,6 +1130,25 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
         for (unsigned int leaf = 0; leaf < n_leaves; leaf += 2) {
             if (__ballot(!dead) == 0ull)
                 break;
+#endif
+#if MM_LG_TOUCH
+            /* Round 6: a pair whose index ends in >= LE ones will merge at level LE + 1 with records that live in HBM (1/16 of
+             * the pairs at LE = 3; ~2000 cycles of exposed latency each: one wave per SIMD has nobody to hide it behind).  Their
+             * cache lines are TOUCHED here, two leaves ahead -- one 4-byte load per 128-byte line into a register nobody reads,
+             * two loads per lane -- so that the merge's own loads find them in the L1 / L2. */
+            if ((((leaf >> 1) + 1u) & ((1u << (Cfg::LE + 1)) - 1u)) == 0u && (int)Cfg::LE + 1 < j) {
+                const unsigned int lfp = leaf | 1u;
+                const unsigned int i0 = lfp & ~((2u << (Cfg::LE + 1)) - 1u);
+                const int cc = i0 ? (__ffs((int)i0) - 1) : MM_NUTS_JMAX;
+                const double *const scr0 = scr - L.lane; /* `scr` is the lane's own column of the wave's lane-interleaved slots */
+                const float *e = reinterpret_cast<const float *>(scr0 + (size_t)(Cfg::hbm_E + 0 * ES) * 64);
+                const float *f = reinterpret_cast<const float *>(scr0 + (size_t)(Cfg::hbm_F + (cc - 2 - Cfg::LF) * Cfg::FS) * 64);
+                float t0 = 0.f, t1 = 0.f;
+                if (L.lane * 32 < ES * 128)
+                    t0 = __builtin_nontemporal_load(e + L.lane * 32);
+                t1 = __builtin_nontemporal_load(f + L.lane * 32);
+                asm volatile("" ::"v"(t0), "v"(t1));
+            }
 #endif
             /* ---- the first leaf of the pair: its one-leaf subtree waits for the sibling in registers */
             double pfx[NS], pfp[NS];
