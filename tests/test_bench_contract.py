@@ -178,7 +178,7 @@ def test_bench_line_contract_and_roofline_is_the_hbm_fraction():
     # counter-derived fields are either quoted with their provenance or absent -- never literals
     if r["issue"] is not None:
         c = r["issue"]["counters"]
-        assert c["round"].startswith("r5") and "mm_run_split_kernel" in c["kernel"] and len(c["sources_sha256"]) == 64
+        assert c["round"].startswith("r6") and "mm_run_split_kernel" in c["kernel"] and len(c["sources_sha256"]) == 64
     if r["traffic"] is not None:
         assert 0.9 < r["traffic"] / alg < 1.5 and "profiles/hmc_kernel_traffic.json" in r["traffic_source"]
     cb = j["cpu_baseline"]
