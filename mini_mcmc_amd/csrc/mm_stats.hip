@@ -1424,8 +1424,8 @@ __global__ __launch_bounds__(1024) void mm_half_chain_means_kernel(const T *__re
     }
 }
 
-template <class T, int HP = 2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <class T, int R1, int HP, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C, unsigned int n, unsigned int D, unsigned int m,
                              unsigned int N1, unsigned int n_grp, const mm_cx *__restrict__ tw, const mm_cx *__restrict__ wN,
                              const float *__restrict__ means, float *__restrict__ ssq, float *__restrict__ slabs)
@@ -1437,12 +1437,14 @@ void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C,
      * next chain -- as soon as the pre-sum has consumed the current ones, so the long step, the 2048-point transform, runs
      * with the next chain's loads in flight (first version of this kernel, two waves per SIMD, loads in batches of 16 with
      * their use right behind: [65536, 8000, 3] 12.9 ms = eight exposed memory latencies per chain and residue). */
-    constexpr int R1 = 32;
+    /* R1 = 32: data blocks and inner transforms of 2048 points, one wave per SIMD (the form described above); R1 = 16: of 1024
+     * points -- twice the residues, half the registers: two waves per SIMD (N1 counts blocks of 64 R1 points) */
+    constexpr unsigned int BLK = 64u * R1;
     using pl = mm_fft_plan<R1>;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     mm_cx *const lds = reinterpret_cast<mm_cx *>(lds_raw);
     const unsigned int lane = threadIdx.x;
-    const unsigned int N = 2048u * N1, HALF = N1 / 2u, per = D * N1, G = HALF / (unsigned int)HP;
+    const unsigned int N = BLK * N1, HALF = N1 / 2u, per = D * N1, G = HALF / (unsigned int)HP;
     unsigned int kd, grp;
     if (n_grp % 8u == 0u) {
         const unsigned int xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
@@ -1486,7 +1488,7 @@ void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C,
         for (int a = 0; a < R1; ++a)
 #pragma unroll
             for (int h = 0; h < HP; ++h) {
-                const unsigned int t = 64u * (unsigned int)a + lane_k + 2048u * (g * (unsigned int)HP + (unsigned int)h), tc = t < m ? t : m - 1u;
+                const unsigned int t = 64u * (unsigned int)a + lane_k + BLK * (g * (unsigned int)HP + (unsigned int)h), tc = t < m ? t : m - 1u;
                 pf0[a][h] = (float)b[(size_t)tc * D];
                 pf1[a][h] = (float)b[second + (size_t)tc * D];
             }
@@ -1509,12 +1511,12 @@ void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C,
             mm_cx w1[HP]; /* w_N1^(n1 k1): one value for the wave, through the scalar cache */
 #pragma unroll
             for (int h = 0; h < HP; ++h)
-                w1[h] = wN[(((g * (unsigned int)HP + (unsigned int)h) * k1) & (N1 - 1u)) * 2048u];
+                w1[h] = wN[(((g * (unsigned int)HP + (unsigned int)h) * k1) & (N1 - 1u)) * BLK];
 #pragma unroll
             for (int a = 0; a < R1; ++a)
 #pragma unroll
                 for (int h = 0; h < HP; ++h) {
-                    const bool in = 64u * (unsigned int)a + lane + 2048u * (g * (unsigned int)HP + (unsigned int)h) < m;
+                    const bool in = 64u * (unsigned int)a + lane + BLK * (g * (unsigned int)HP + (unsigned int)h) < m;
                     const mm_cx v = mm_cx{in ? pf0[a][h] - m0 : 0.f, in ? pf1[a][h] - m1 : 0.f};
                     if (k1 == 0u) { /* every point of the chain passes here exactly once */
                         q0 = fmaf(v.re, v.re, q0);
@@ -1893,6 +1895,7 @@ static StatsFftPlan stats_fft_plan(size_t n_chains, size_t n, size_t dim, int de
 struct StatsLongPlan {
     bool use = false;
     bool res = false; /* round 6: one (residue, parameter) per wave, spectrum in registers (mm_chain_fft_res_kernel): N1 >= 4 */
+    unsigned int res_r1 = 32; /* its inner transform: 64 res_r1 points */
     unsigned int N1 = 0, N = 0, n_wg = 0, waves = 1;
 };
 constexpr size_t kStatsLongMaxM = 131072; /* N = 2^18: the inverse (mm_fft_finish_long_kernel) is O(m N) per parameter */
@@ -1923,8 +1926,15 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
          * on an MI355X; the figure is a constant, not a device query, because the group count fixes the f32 summation grouping
          * -- in multiples of 8 (the kernel's XCD mapping), at most 512 */
         p.res = true;
-        const size_t per = dim * p.N1;
-        size_t g = per > 0 ? 1024 / per : 8;
+        /* inner transforms of 1024 points, two waves per SIMD (round 6, second version): twice the residues */
+        p.res_r1 = 16;
+#ifdef MMCMC_TUNING
+        if (mm_tuning_env("MMCMC_STATS_RES_R1_32"))
+            p.res_r1 = 32;
+#endif
+        const size_t n1r = (size_t)p.N / (64 * p.res_r1);
+        const size_t per = dim * n1r;
+        size_t g = per > 0 ? (p.res_r1 == 16 ? 2048 : 1024) / per : 8;
         g = std::min<size_t>(512, std::max<size_t>(8, g / 8 * 8));
         p.n_wg = (unsigned int)std::min<size_t>(g, n_chains);
         return p;
@@ -2162,10 +2172,14 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
         if (lp.res) {
             /* means by a streaming pass (dim <= 16: 64 dim threads per half-chain; wider samples through the any-length moments
              * kernel), then one wave per (chain group, residue, parameter) */
-            if ((uint64_t)2 * n_chains >= (1ull << 31) || (uint64_t)lp.n_wg * dim * lp.N1 >= (1ull << 31))
+            const unsigned int n1r = lp.N / (64u * lp.res_r1);
+            if ((uint64_t)2 * n_chains >= (1ull << 31) || (uint64_t)lp.n_wg * dim * n1r >= (1ull << 31))
                 return MMCMC_ERR_SHAPE;
-            const unsigned int g_mean = (unsigned int)(2 * n_chains), g_res = lp.n_wg * (unsigned int)dim * lp.N1;
-            const size_t lds_res = (size_t)mm_fft_plan<32>::LDS_CX * sizeof(mm_cx);
+            const unsigned int g_mean = (unsigned int)(2 * n_chains), g_res = lp.n_wg * (unsigned int)dim * n1r;
+            const size_t lds_res = (size_t)(lp.res_r1 == 16 ? mm_fft_plan<16>::LDS_CX : mm_fft_plan<32>::LDS_CX) * sizeof(mm_cx);
+            const mm_cx *tw_res = lp.res_r1 == 16 ? stats_fft_twiddles(device, 16) : tw;
+            if (!tw_res)
+                return (int)hipErrorOutOfMemory;
 #define MM_RES_LAUNCH(TT)                                                                                           \
     do {                                                                                                            \
         if (dim <= 16)                                                                                              \
@@ -2176,9 +2190,14 @@ static int stats_partials_impl(const void *sample, int dtype, size_t n_chains, s
             hipLaunchKernelGGL(mm_half_chain_moments_any_kernel<TT>, dim3(g_mean * (unsigned int)dim), dim3(64), 0, stream, \
                                (const TT *)sample, (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, \
                                (unsigned int)m, means, ssq);                                                        \
-        hipLaunchKernelGGL(mm_chain_fft_res_kernel<TT>, dim3(g_res), dim3(64), lds_res, stream, (const TT *)sample, \
-                           (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, lp.N1, \
-                           lp.n_wg, tw, wN, means, ssq, ws);                                                        \
+        if (lp.res_r1 == 16)                                                                                        \
+            hipLaunchKernelGGL((mm_chain_fft_res_kernel<TT, 16, 2, 2>), dim3(g_res), dim3(64), lds_res, stream, (const TT *)sample, \
+                               (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, n1r, \
+                               lp.n_wg, tw_res, wN, means, ssq, ws);                                                \
+        else                                                                                                        \
+            hipLaunchKernelGGL((mm_chain_fft_res_kernel<TT, 32, 2, 1>), dim3(g_res), dim3(64), lds_res, stream, (const TT *)sample, \
+                               (unsigned long long)n_chains, (unsigned int)n, (unsigned int)dim, (unsigned int)m, n1r, \
+                               lp.n_wg, tw_res, wN, means, ssq, ws);                                                \
     } while (0)
             if (dim > 16 && (uint64_t)2 * n_chains * dim >= (1ull << 31))
                 return MMCMC_ERR_SHAPE;
