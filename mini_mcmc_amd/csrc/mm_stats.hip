@@ -1926,11 +1926,13 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
          * on an MI355X; the figure is a constant, not a device query, because the group count fixes the f32 summation grouping
          * -- in multiples of 8 (the kernel's XCD mapping), at most 512 */
         p.res = true;
-        /* inner transforms of 1024 points, two waves per SIMD (round 6, second version): twice the residues */
-        p.res_r1 = 16;
+        /* inner transforms of 2048 points, one wave per SIMD.  (1024 points and two waves per SIMD -- twice the residues, half
+         * the registers; MMCMC_STATS_RES_R1_16 in measurement builds -- is slower throughout: [65536, 8000, 3] 16.8 against 7.7 ms,
+         * [16384, 20000, 3] 31.3 against 20.7: every residue reads the chain again, profiles/r6za_stats_long_timing_r1_16.log) */
+        p.res_r1 = 32;
 #ifdef MMCMC_TUNING
-        if (mm_tuning_env("MMCMC_STATS_RES_R1_32"))
-            p.res_r1 = 32;
+        if (mm_tuning_env("MMCMC_STATS_RES_R1_16"))
+            p.res_r1 = 16;
 #endif
         const size_t n1r = (size_t)p.N / (64 * p.res_r1);
         const size_t per = dim * n1r;
