@@ -162,6 +162,9 @@ struct mm_nuts_lg_args {
 #ifndef MM_LG_CHECK_FORM
 #define MM_LG_CHECK_FORM 3 /* round 6 (profiles/r6i_, r6j_nuts_check_form*_probe.log; best case 2873 cycles per leaf iteration): 0 = the check and its rare case inside the pair loop (round 5); 1 = its branch marked unlikely (2879); 2 = the three conditions as 64-bit lane masks on the scalar unit (2833); 3 = 2 + the rare case handled OUTSIDE the fast loop, which is left and entered again (2789; without any check: 2725) */
 #endif
+#ifndef MM_LG_DEEP_EARLY
+#define MM_LG_DEEP_EARLY 0 /* round 6 experiment: the level-(WU + 1) merge's HBM records requested ahead of the LDS-level merges */
+#endif
 #ifndef MM_LG_TOUCH
 #define MM_LG_TOUCH 0 /* round 6 experiment: touch the HBM records of a pair's level-(LE + 1) merge two leaves ahead */
 #endif
@@ -1233,12 +1236,37 @@ __device__ __forceinline__ void mm_lg_doubling(mm_lg_lane<D> &L, const mm_nuts_l
                 k_stop = (lf1 + 1u >= n_leaves) ? j : 1;
             }
 #else
+#if MM_LG_DEEP_EARLY
+            /* Round 6 experiment: a pair whose index ends in WU + 1 ones merges at level WU + 1 with records from HBM.  Their
+             * loads depend on nothing the LDS-level merges compute, so they are issued BEFORE those (~1800 cycles of merges at
+             * levels 1 .. WU under the latency) instead of after them. */
+            constexpr int KD = WU + 1;
+            const bool deep = KD < j && (lf1 & ((2u << KD) - 1u)) == ((2u << KD) - 1u);
+            rec rdeep;
+            if (deep)
+                load_rec(KD, first_slot(lf1, KD), rdeep);
+#pragma unroll
+            for (int k = 1; k <= WU; ++k)
+                if (k_stop == 0)
+                    level(k);
+            if (k_stop == 0) {
+                if (deep) {
+                    const unsigned long long cnt = (unsigned long long)__double_as_longlong(rdeep.cnt);
+                    merge_l(rdeep.fx, rdeep.fp, rdeep.prime, mm_false_t(), rdeep.alpha, (unsigned int)cnt, (unsigned int)(cnt >> 32));
+                } else {
+                    level(KD);
+                }
+            }
+            for (int k = KD + 1; k_stop == 0; ++k)
+                level(k);
+#else
 #pragma unroll
             for (int k = 1; k <= WU; ++k)
                 if (k_stop == 0)
                     level(k);
             for (int k = WU + 1; k_stop == 0; ++k)
                 level(k);
+#endif
 #endif
 #if MM_LG_CHECK_FORM == 3
                 {
