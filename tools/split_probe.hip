@@ -107,5 +107,9 @@ int main()
     const double g[6] = {0.0, 0.0, 1.0, 0.0, 0.0, 1.0};
     mm_fill_params<float>(MM_GAUSSIAN2D, g, &P);
     bench<mm_target<float, MM_GAUSSIAN2D, 2>, MM_SAMPLER_MH, 0>("mh cfg2", 2, 1000, 100, 1.0f, P);
+#ifdef MM_PROBE_MH_ALIGNED /* round 6: does the alignment of a chain's output row matter?  1008 x 8 B = 63 whole 128-byte lines per chain */
+    bench<mm_target<float, MM_GAUSSIAN2D, 2>, MM_SAMPLER_MH, 0>("mh 1008", 2, 1008, 92, 1.0f, P);
+    bench<mm_target<float, MM_GAUSSIAN2D, 2>, MM_SAMPLER_MH, 0>("mh 1024", 2, 1024, 76, 1.0f, P);
+#endif
     return 0;
 }
