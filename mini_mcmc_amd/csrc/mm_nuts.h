@@ -51,6 +51,27 @@ MM_HD float mm_sqrtT(float x) { return sqrtf(x); }
 MM_HD double mm_sqrtT(double x) { return sqrt(x); }
 MM_HD float mm_minT(float a, float b) { return fminf(a, b); }
 MM_HD double mm_minT(double a, double b) { return fmin(a, b); }
+
+/* min(1, exp(d)), the acceptance statistic of a NUTS leaf (nuts.rs:823-826), without the exponential where it cannot matter:
+ * for d >= 0 (and for a NaN, which fmin drops) the minimum is 1 whatever exp returns, for d < 0 exp(d) <= 1 is the minimum
+ * itself -- the same bits as mm_minT(1, mm_exp_hotT(d)) for every d.  Written as a branch so that a wave none of whose
+ * working lanes has d < 0 skips the exponential altogether (round 6: the tail of a one-chain-per-lane NUTS launch is ONE
+ * live lane, half of whose leaves have d >= 0; in mode 0 the f64 exponential is ~30 two-slot instructions of its ~470 per leaf). */
+#ifndef MM_NUTS_ACCEPT_BRANCH
+#define MM_NUTS_ACCEPT_BRANCH 1
+#endif
+template <class ST> MM_HD ST mm_accept_stat(ST d)
+{
+#if MM_NUTS_ACCEPT_BRANCH
+    ST a = ST(1);
+    if (d < ST(0))
+        a = mm_exp_hotT(d);
+    return a;
+#else
+    return mm_minT(ST(1), mm_exp_hotT(d));
+#endif
+}
+
 MM_HD bool mm_is_real(float x) { return x == x && x != MM_INFINITY_F && x != -MM_INFINITY_F; }
 MM_HD bool mm_is_real(double x) { return x == x && x != (double)MM_INFINITY_F && x != -(double)MM_INFINITY_F; }
 
@@ -296,7 +317,7 @@ template <class TT, class ST, class Tgt, class Red = mm_red_seq<TT, Tgt::dim>> s
         S_level = 0;
         S_n = (logu < jointp) ? 1u : 0u;
         S_s = (logu - ST(1000)) < jointp;
-        S_alpha = mm_minT(ST(1), mm_exp_hotT(jointp - joint));
+        S_alpha = mm_accept_stat<ST>(jointp - joint);
         S_nalpha = 1;
         MM_UNROLL
         for (int i = 0; i < D; ++i) {

@@ -202,7 +202,7 @@ MM_HD mm_nuts_info mm_gen_nuts_step(int kind, const mm_tparams<TT> &P, const S &
             S_level = 0;
             S_n = (logu < jointp) ? 1u : 0u;
             S_s = (logu - ST(1000)) < jointp;
-            S_alpha = mm_minT(ST(1), mm_exp_hotT(jointp - joint));
+            S_alpha = mm_accept_stat<ST>(jointp - joint);
             S_nalpha = 1;
             mm_gen_copy(s, MM_NV_SFX, MM_NV_CX);
             mm_gen_copy(s, MM_NV_SFP, MM_NV_CP);
