@@ -399,6 +399,24 @@ int eh_lnu_f32(const float *u, size_t n, float *out)
     return 0;
 }
 
+/* the NUTS leaf's acceptance statistic as the product evaluates it (mm_nuts.h: mm_accept_stat, a branch that skips the
+ * exponential for d >= 0) beside the form it replaced, min(1, exp(d)): out_new, out_old [n] (tests/test_step_parity.py) */
+int eh_accept_stat(int dtype, const void *d, size_t n, void *out_new, void *out_old)
+{
+    for (size_t i = 0; i < n; ++i) {
+        if (dtype == 0) {
+            const float x = ((const float *)d)[i];
+            ((float *)out_new)[i] = mm_accept_stat<float>(x);
+            ((float *)out_old)[i] = mm_minT(1.0f, mm_exp_hotT(x));
+        } else {
+            const double x = ((const double *)d)[i];
+            ((double *)out_new)[i] = mm_accept_stat<double>(x);
+            ((double *)out_old)[i] = mm_minT(1.0, mm_exp_hotT(x));
+        }
+    }
+    return 0;
+}
+
 /* noise of (chain, iteration) as the engine draws it: z [n, dim], u [n] */
 int eh_noise(int dtype, uint64_t seed, uint64_t chain_offset, uint32_t iteration, size_t n, int dim, void *z, void *u)
 {

@@ -740,6 +740,19 @@ def engine_host_ratio_filter_disagreements(ratio, u):
     return int(engine_host_lib().eh_ratio_filter_disagreements(_d(r), _d(uu), r.size))
 
 
+def engine_host_accept_stat(d):
+    """(new, old): the product's NUTS acceptance statistic (mm_nuts.h: mm_accept_stat) and the form it replaced, min(1, exp(d)),
+    both from the host build of the engine's headers, value by value."""
+    x = np.ascontiguousarray(d)
+    assert x.dtype in (np.float32, np.float64)
+    a, b = np.empty_like(x), np.empty_like(x)
+    E = engine_host_lib()
+    E.eh_accept_stat.restype = C.c_int
+    E.eh_accept_stat.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    E.eh_accept_stat(0 if x.dtype == np.float32 else 1, x.ctypes.data, x.size, a.ctypes.data, b.ctypes.data)
+    return a, b
+
+
 def engine_host_lnu_f32(u):
     """The PRODUCT's ln u of the f32 accept uniform (mm_rng.h: mm_lnu_f32) compiled for the host."""
     x = np.ascontiguousarray(u, dtype=np.float32)

@@ -106,3 +106,21 @@ def test_engine_hmc_ess_band(O, kats):
     m = ess.mean(axis=0)
     assert k["ess1_band"][0] <= m[0] <= k["ess1_band"][1], m
     assert k["ess2_band"][0] <= m[1] <= k["ess2_band"][1], m
+
+
+def test_nuts_accept_statistic_branch_form_gives_the_bits_of_min_1_exp(O):
+    """mm_accept_stat (csrc/mm_nuts.h, round 6) evaluates the leaf's acceptance statistic min(1, exp(d)) (nuts.rs:823-826) as
+    `a = 1; if (d < 0) a = exp(d)` so that a wave with no d < 0 among its working lanes skips the exponential.  The claim is
+    bit-identity for EVERY d: checked here on the host build of the same header over a million draws of both signs and
+    scales, the neighbourhood of zero, signed zeros, infinities, NaN and the exponential's under- / overflow thresholds."""
+    rng = np.random.default_rng(5)
+    for dt in (np.float64, np.float32):
+        d = np.concatenate([
+            rng.standard_normal(400_000) * 3.0, rng.standard_normal(200_000) * 1e-6, rng.standard_normal(200_000) * 300.0,
+            -np.abs(rng.standard_normal(200_000)) * 1e-12,
+            np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -745.2, -745.0, 709.8, 710.0, -103.98, -103.9, 88.73, -1e-300, 1e-300,
+                      -5e-324, 5e-324, np.nextafter(0.0, -1.0), np.nextafter(0.0, 1.0)]),
+        ]).astype(dt)
+        new, old = O.engine_host_accept_stat(d)
+        assert np.array_equal(new.view(np.uint64 if dt == np.float64 else np.uint32), old.view(np.uint64 if dt == np.float64 else np.uint32))
+        assert np.all(new[~np.isnan(d)] <= 1.0) and np.all(new[d >= 0] == 1.0) and new[np.isnan(d)].tolist() == [1.0]
