@@ -338,7 +338,10 @@ template <class TT, class ST> struct Nuts : NutsBase {
                 /* persistent scheduler: one resident wave per SIMD (fewer if there are fewer groups of 16 chains) */
                 g.ctrl = d_lg_ctrl;
                 g.slots = d_lg_lists;
-                g.patience = 8u; /* 65 536 chains: 4 -> 516.5 ms, 16 -> 518.5, 64 -> 520.9, 256 -> 530.3 */
+                /* idle polls before a wave settles for less than a full unit.  Round 2 (65 536 chains): 4 -> 516.5 ms, 16 -> 518.5,
+                 * 64 -> 520.9, 256 -> 530.3; round 6, with the leaf loop 25 % faster: 0 / 1 / 2 / 4 / 8 -> 347.9 / 348.0 / 348.5 /
+                 * 349.3 / 349.7 ms at 15.75-15.77 chains per unit (profiles/r6zh_lgq_patience.log): waiting buys no fuller units */
+                g.patience = 1u;
                 if (const char *ev = mm_tuning_env("MMCMC_LGQ_PATIENCE"))
                     g.patience = (unsigned int)atoi(ev);
                 /* a wave stays with the chains it kept only when the queue of their level makes a FULL unit of them; else they
