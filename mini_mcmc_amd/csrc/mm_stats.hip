@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(64 * WAVES) void mm_chain_fft_long_kernel(const T *
  * parameter for all the chains it walks: the 2048 bins k1 + N1 k2 of its |Z|^2 are 32 registers per lane that pass 3
  * accumulates into directly, exactly as the short path does (mm_chain_fft_kernel) -- no spectrum in LDS (round 5's
  * mm_chain_fft_long_kernel kept S[N] there: one wave per SIMD at N1 = 4 and 8, one per CU at N1 = 16, a read-modify-write of
- * 2048 LDS words per residue and chain; a 2048-point residue transform took 38 000 cycles against ~6000).  N1 is a run-time value (any power of two: half-chains up to 131 072 draws), the sum over
+ * 2048 LDS words per residue and chain; a 2048-point residue transform took 38 000 cycles against ~6000).  N1 is a run-time value (any count >= 3 with 2048 N1 >= 2 m: half-chains up to 131 072 draws), the sum over
  * the N1 / 2 data blocks of a point a run-time loop.
  * The half-chain means come from a streaming pass of their own (mm_half_chain_means_kernel: the sample once, flat and
  * coalesced); the sums of squares are taken by the residue-0 waves, which see every point once.
@@ -1444,7 +1444,9 @@ void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C,
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     mm_cx *const lds = reinterpret_cast<mm_cx *>(lds_raw);
     const unsigned int lane = threadIdx.x;
-    const unsigned int N = BLK * N1, HALF = N1 / 2u, per = D * N1, G = HALF / (unsigned int)HP;
+    /* N1 is ANY count of blocks with N = BLK N1 >= 2 m (the outer step is a plain sum over the data blocks: nothing in it wants
+     * a power of two); only the NB = ceil(m / BLK) blocks that hold draws are walked, in G steps of HP */
+    const unsigned int N = BLK * N1, NB = (m + BLK - 1u) / BLK, per = D * N1, G = (NB + (unsigned int)HP - 1u) / (unsigned int)HP;
     unsigned int kd, grp;
     if (n_grp % 8u == 0u) {
         const unsigned int xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
@@ -1467,7 +1469,7 @@ void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C,
     tw2[0] = mm_cx{1.f, 0.f};
 #pragma unroll
     for (int a = 0; a < R1; ++a)
-        wt[a] = wN[((64u * (unsigned int)a + lane) * k1) & (N - 1u)]; /* w_N^(n2 k1), n2 = 64 a + lane */
+        wt[a] = wN[((64u * (unsigned int)a + lane) * k1) % N]; /* w_N^(n2 k1), n2 = 64 a + lane */
     auto tw1_of = [&](int b) -> mm_cx { return tw1[b]; };
     auto tw2_of = [&](int g) -> mm_cx { return tw2[g]; };
     float S[pl::J][8];
@@ -1507,11 +1509,15 @@ void mm_chain_fft_res_kernel(const T *__restrict__ sample, unsigned long long C,
 #pragma unroll
         for (int a = 0; a < R1; ++a)
             y[a] = mm_cx{0.f, 0.f};
+        unsigned int r1k = 0u; /* n1 k1 mod N1, stepped */
         for (unsigned int g = 0; g < G; ++g) {
             mm_cx w1[HP]; /* w_N1^(n1 k1): one value for the wave, through the scalar cache */
 #pragma unroll
-            for (int h = 0; h < HP; ++h)
-                w1[h] = wN[(((g * (unsigned int)HP + (unsigned int)h) * k1) & (N1 - 1u)) * BLK];
+            for (int h = 0; h < HP; ++h) {
+                w1[h] = wN[r1k * BLK];
+                r1k += k1;
+                r1k = r1k >= N1 ? r1k - N1 : r1k;
+            }
 #pragma unroll
             for (int a = 0; a < R1; ++a)
 #pragma unroll
@@ -1595,9 +1601,16 @@ __global__ __launch_bounds__(256) void mm_fft_finish_long_kernel(const double *_
      * error stays at 32^2 ulps of a double, far below the f32 result).  An arc is N / 8 >= 512 terms: whole runs of 32. */
     double a0 = 0.0, a1 = 0.0;
     const unsigned int f_lo = q * (N / 8), f_hi = f_lo + N / 8;
-    const double k2 = 2.0 * cos_tab[lag & (N - 1u)];
+    /* N = 2048 N1 with any N1: the table index f lag mod N is stepped, not masked (lag < m <= N / 2; 32 lag < 2^32) */
+    const double k2 = 2.0 * cos_tab[lag];
+    const unsigned int step = (32u * lag) % N;
+    unsigned int i0 = (unsigned int)(((unsigned long long)f_lo * lag) % N);
     for (unsigned int f = f_lo; f < f_hi; f += 32) {
-        double c0 = cos_tab[(f * lag) & (N - 1u)], c1 = cos_tab[((f + 1u) * lag) & (N - 1u)];
+        unsigned int i1 = i0 + lag;
+        i1 = i1 >= N ? i1 - N : i1;
+        double c0 = cos_tab[i0], c1 = cos_tab[i1];
+        i0 += step;
+        i0 = i0 >= N ? i0 - N : i0;
         a0 = fma(P[(size_t)f * D + d], c0, a0);
         a1 = fma(P[(size_t)(f + 1u) * D + d], c1, a1);
 #pragma unroll
@@ -1912,16 +1925,24 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
     if ((sel != MMCMC_STATS_KERNEL_AUTO && sel != MMCMC_STATS_KERNEL_FFT) || m <= 1024 || m > kStatsLongMaxM)
         return p;
     p.use = true;
-    p.N1 = 2;
-    while ((size_t)p.N1 * 2048 < 2 * m)
-        p.N1 *= 2;
-    p.N = 2048u * p.N1;
+    /* N = 2048 N1 >= 2 m, N1 the SMALLEST such count (round 6, late: it was the next power of two -- but a residue wave reads
+     * the whole chain, so time goes as N1 x the data: m = 10 000 took N1 = 16 where 10 do, [16384, 20000, 3] 20.7 -> 9.0 ms, [16384, 40000, 3] 73 -> 31.7) */
+    p.N1 = (unsigned int)std::max<size_t>(2, (m + 1023) / 1024);
 #ifdef MMCMC_TUNING
-    const bool old_kernels = mm_tuning_env("MMCMC_STATS_LONG_OLD") != nullptr && p.N1 <= 16; /* A / B against round 5's kernels */
+    bool old_kernels = false, pow2 = mm_tuning_env("MMCMC_STATS_LONG_POW2") != nullptr; /* A / B against the power-of-two cut */
+    if (mm_tuning_env("MMCMC_STATS_LONG_OLD") != nullptr && m <= 16384) /* ... and against round 5's kernels */
+        old_kernels = pow2 = true;
+    if (pow2) {
+        unsigned int q = 2;
+        while (q < p.N1)
+            q *= 2;
+        p.N1 = q;
+    }
 #else
     const bool old_kernels = false;
 #endif
-    if (p.N1 >= 4 && !old_kernels) {
+    p.N = 2048u * p.N1;
+    if (p.N1 >= 3 && !old_kernels) {
         /* chain groups: as many as keep ONE resident round of one-wave workgroups busy -- one per SIMD by their registers, 1024
          * on an MI355X; the figure is a constant, not a device query, because the group count fixes the f32 summation grouping
          * -- in multiples of 8 (the kernel's XCD mapping), at most 512 */
@@ -1961,11 +1982,9 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
 /* w_N^j = exp(-2 pi i j / N), j < N, as f32 pairs, then cos(2 pi j / N) as f64: one table per device and N1, never freed */
 static const mm_cx *stats_long_tables(int device, unsigned int N1)
 {
-    static std::atomic<const mm_cx *> tab[64][8];
-    int k = 0;
-    while ((2u << k) < N1)
-        ++k; /* N1 = 2 -> 0, 4 -> 1, 8 -> 2, 16 -> 3 */
-    const mm_cx *t = tab[device & 63][k & 7].load(std::memory_order_acquire);
+    static std::atomic<const mm_cx *> tab[64][129]; /* N1 <= kStatsLongMaxM / 1024 = 128 */
+    const unsigned int k = N1 <= 128u ? N1 : 0u;
+    const mm_cx *t = tab[device & 63][k].load(std::memory_order_acquire);
     if (t)
         return t;
     const unsigned int N = 2048u * N1;
@@ -1985,7 +2004,7 @@ static const mm_cx *stats_long_tables(int device, unsigned int N1)
         return nullptr;
     }
     const mm_cx *expected = nullptr;
-    if (!tab[device & 63][k & 7].compare_exchange_strong(expected, d, std::memory_order_acq_rel)) {
+    if (!tab[device & 63][k].compare_exchange_strong(expected, d, std::memory_order_acq_rel)) {
         (void)hipFree(d);
         return expected;
     }

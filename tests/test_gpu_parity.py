@@ -918,11 +918,12 @@ def test_nuts_posterior_and_run_progress_stats(M, O):
 @pytest.mark.gpu
 @pytest.mark.parametrize("c,n,p", [(40, 2600, 3), (6, 9000, 2), (3, 20001, 1), (130, 4096, 4), (2, 32768, 2), (5, 2050, 2),
                                    (2, 32770, 1), (2, 40000, 2), (1, 100001, 3), (12, 36000, 2), (64, 33000, 2), (400, 2100, 3), (9, 7000, 3), (70, 5001, 2), (33, 12000, 1),
-                                   (64, 20000, 2), (3, 250000, 2), (1, 300000, 1), (16, 16384, 17), (700, 4100, 3)])
+                                   (64, 20000, 2), (3, 250000, 2), (1, 300000, 1), (16, 16384, 17), (700, 4100, 3), (4, 6144, 2), (2, 262144, 1), (24, 10240, 3)])
 def test_split_rhat_mean_ess_long_chains_vs_oracle(M, O, c, n, p):
     """Half-chains beyond 1024 draws (the transform cut into N1 residues of 2048-point wave-level transforms: N1 = 2
-    mm_chain_fft_long_kernel, N1 = 4 .. 128 mm_chain_fft_res_kernel -- round 6: one residue and parameter per wave, spectrum in
-    registers, half-chains up to 131 072 draws) and beyond (mm_lag_sums_any_kernel: any length, straight from global memory;
+    mm_chain_fft_long_kernel, N1 = 3 .. 128 mm_chain_fft_res_kernel -- round 6: one residue and parameter per wave, spectrum in
+    registers, half-chains up to 131 072 draws; N1 = ceil(m / 1024), ANY count, not the next power of two: the shapes here take
+    3, 4, 5, 6, 8, 10, 16, 17, 18, 20, 49, 123, 128, with m = 1024 N1 exactly at (4, 6144, 2) and (24, 10240, 3)) and beyond (mm_lag_sums_any_kernel: any length, straight from global memory;
     (1, 300000, 1)); more than 16 parameters (the means through the any-length moments kernel): R-hat / ESS against
     oracle/stats.c's FFT branch (stats.rs:576-620), odd n (the middle draw dropped), few chains, the first and the last length
     of each path, one chain of 10^5 draws; equal to the direct sums where those still exist; reproducible bit for bit;

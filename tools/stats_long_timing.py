@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mini_mcmc_amd import stats as S
-for c, n, d in ((65536, 4000, 3), (65536, 8000, 3), (16384, 16000, 3), (16384, 20000, 3), (65536, 4000, 2), (65536, 4000, 1), (16384, 40000, 3), (4096, 200000, 3), (64, 20000, 2)):
+for c, n, d in ((65536, 4000, 3), (65536, 8000, 3), (16384, 16000, 3), (16384, 20000, 3), (65536, 4000, 2), (65536, 4000, 1), (16384, 40000, 3), (4096, 200000, 3), (64, 20000, 2), (16384, 5000, 3), (16384, 12000, 3), (16384, 32768, 3)):
     x = torch.randn(c, n, d, device="cuda")
     for _ in range(2):
         r, e = S.split_rhat_mean_ess(x)
