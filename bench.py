@@ -551,6 +551,9 @@ def main() -> None:
     dryrun = distributed and os.environ.get("MMCMC_BENCH_DRYRUN_ONE_DEVICE") == "1"
     if dryrun:
         local_rank = 0
+    # a launcher that shows every rank ONE device (HIP_VISIBLE_DEVICES per rank) leaves ordinal 0 only: take the ordinal modulo
+    # what this process sees -- whether the ranks really sit on different GPUs is decided below from the PCI bus ids
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -690,7 +693,9 @@ def main() -> None:
     if rank == 0:
         backend = dist.get_backend() if distributed else None
         if distributed:
-            data, exit_code, problems = group_verdict([0] * world if dryrun else [r["device"] for r in per_rank],
+            # one rank per GPU is the contract of this path, whatever ordinal each process calls its GPU: N ranks must show N
+            # different PCI bus ids
+            data, exit_code, problems = group_verdict([0] * world if dryrun else list(range(world)),
                                                       [r["pci_bus_id"] for r in per_rank], 1 if backend == "nccl" else 0,
                                                       dist.get_world_size() if backend == "nccl" else 0)
             if dryrun:
