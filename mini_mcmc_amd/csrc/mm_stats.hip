@@ -1979,7 +1979,8 @@ static StatsLongPlan stats_long_plan(size_t n_chains, size_t n, size_t dim, int 
     return p;
 }
 
-/* w_N^j = exp(-2 pi i j / N), j < N, as f32 pairs, then cos(2 pi j / N) as f64: one table per device and N1, never freed */
+/* w_N^j = exp(-2 pi i j / N), j < N, as f32 pairs, then cos(2 pi j / N) as f64: one table per device and N1, never freed
+ * (32 KB x N1; a process that used every N1 = 2 .. 128 once holds 260 MB of them per device) */
 static const mm_cx *stats_long_tables(int device, unsigned int N1)
 {
     static std::atomic<const mm_cx *> tab[64][129]; /* N1 <= kStatsLongMaxM / 1024 = 128 */
