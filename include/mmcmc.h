@@ -415,8 +415,8 @@ int mmcmc_stats_finish_sums(const double *dsum, const double *wsum, const float 
  *   AUTO    what the reference does (stats.rs:549): direct sums for half-chains up to 100 draws (register tiles on the
  *           vector ALU), the power spectrum above (one wave-level FFT per chain and parameter, one inverse for all);
  *   FFT / TILE1 / TILE / MFMA / DIRECT   that kernel wherever its shape limits allow, AUTO's choice elsewhere
- *           (FFT: 2 <= n/2 <= 131072 -- one wave-level transform up to 1024, N1 = 2 .. 128 residues of 2048-point
- *           transforms beyond, one residue and parameter per wave with its spectrum in registers (version 101; 100 ended
+ *           (FFT: 2 <= n/2 <= 131072 -- one wave-level transform up to 1024, N1 = ceil(n/2 / 1024) = 2 .. 128 residues of
+ *           2048-point transforms beyond (any count, not a power of two), one residue and parameter per wave with its spectrum in registers (version 101; 100 ended
  *           at 16384); TILE1: n/2 <= 512; TILE: up to 8 tiles per lane; MFMA: LDS layout up to 64 KB).  Half-chains longer
  *           than 131072 draws -- and, under DIRECT, any the staging kernels cannot hold in a workgroup's LDS -- are reduced
  *           straight from global memory (O(chains x dim x n^2), meant for a few very long chains): any n < 2^31 with
