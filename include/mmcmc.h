@@ -33,8 +33,9 @@ extern "C" {
 /* 101 (round 6): + mmcmc_{mh,hmc}_group_run_async, mmcmc_*_group_stats_phases, mmcmc_device_pci_bus_id,
  *   MMCMC_ERR_GROUP_BROKEN; mmcmc_*_group_run blocks again whatever its arguments (100 inferred "asynchronous" from
  *   out_host == NULL && accept_counts == NULL); mmcmc_nuts_set_repacking (100, measured slower, removed) stays removed.
+ * 102 (round 6): + mmcmc_rtc_compiler_info; long-chain diagnostics take N1 = ceil(n/2 / 1024) residues (any count).
  * A binding checks mmcmc_version() >= the version it was generated from (rust/mini-mcmc-hip: assert_abi, in every constructor). */
-#define MMCMC_VERSION 101 /* 0.1.1 */
+#define MMCMC_VERSION 102 /* 0.1.2 */
 
 /* ---- status ---- */
 #define MMCMC_OK 0
@@ -280,8 +281,10 @@ int mmcmc_hmc_kernel_variant(mmcmc_hmc *h); /* the variant in use (>= 0) or a ne
 int mmcmc_target_register_source(const char *name, int dim, const char *hip_source, int *kind_out, char *log, size_t log_len);
 
 /* Which compiler builds run-time compiled units (process-wide; default AUTO).  AUTO: `hipcc --genco` in a child process
- * wherever hipcc is found (PATH, then /opt/rocm/bin), hipRTC (libhiprtc.so, bound at run time) otherwise.  hipRTC was
- * caught miscompiling one kernel of these units that hipcc compiles correctly, hence the order.
+ * wherever hipcc is found (PATH, then /opt/rocm/bin), hipRTC (libhiprtc.so, bound at run time) otherwise.  A hipRTC was
+ * caught miscompiling one kernel of these units that hipcc compiles correctly, hence the order; it was the copy PyTorch
+ * bundles (ROCm 7.0.2's compiler, which a Python process that imported torch resolves libhiprtc.so.7 to), not the system's
+ * 7.2, which emits hipcc's code (csrc/mm_rtc.hip at g_compiler).
  * HIPCC / HIPRTC pin one of them (registration then returns MMCMC_ERR_UNSUPPORTED where it is missing). */
 #define MMCMC_RTC_COMPILER_AUTO 0
 #define MMCMC_RTC_COMPILER_HIPCC 1
@@ -290,6 +293,13 @@ int mmcmc_rtc_set_compiler(int which);
 /* which compiler built the unit behind a kind handed out by a mmcmc_*_register_source call: MMCMC_RTC_COMPILER_HIPCC or
  * MMCMC_RTC_COMPILER_HIPRTC (MMCMC_ERR_INVALID_ARG: no such kind) */
 int mmcmc_rtc_unit_compiler(int kind);
+/* (version 102) which copy of hipRTC this process would compile with -- the file the dynamic loader resolved, e.g.
+ * .../torch/lib/libhiprtc.so once PyTorch is imported --, the HIP version (major * 10^7 + minor * 10^5 + patch) of the
+ * runtime the process bound (hipRTC and its compiler library come from the same bundle) and of the compiler the library was
+ * built with (what a `hipcc --genco` child normally is).  Any pointer may be NULL.  MMCMC_ERR_UNSUPPORTED (empty path): no
+ * usable libhiprtc.  Needs no GPU.  A unit built by the hipRTC of an older runtime than the library's compiler says so in the
+ * `log` of its register call. */
+int mmcmc_rtc_compiler_info(char *hiprtc_path, size_t path_len, int *process_hip_version, int *built_hip_version);
 
 /* ---- user-defined proposals (csrc/mm_rtc.hip) --------------------------------------------------------------------
  * `Proposal` is an open trait too (distributions.rs:92-101), and the reference keeps BOTH q-terms in the acceptance

@@ -128,6 +128,7 @@ SIGNATURES = {
     "mmcmc_tracker_n": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "mmcmc_rtc_set_compiler": (C.c_int, [C.c_int]),
     "mmcmc_rtc_unit_compiler": (C.c_int, [C.c_int]),
+    "mmcmc_rtc_compiler_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmcmc_tracker_shape": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "mmcmc_tracker_within_var": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "mmcmc_ess_from_chainstats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_float),

@@ -659,12 +659,18 @@ template <class TT, class ST> struct Nuts : NutsBase {
              * ring of uniforms, stack in the scratch area).  The unit's lanes-in-step kernel (mm_nuts_run_body) is NOT
              * launched: it gave wrong, run-to-run different samples at RosenbrockND(19) / (23) in f64 and a memory fault at
              * StandardNormal(25) in f32, while the same template compiled into the library by hipcc is correct at those
-             * dimensions (tools/experiments/repro_nuts_dims.py).  Bisected: not the hipRTC version (PyTorch's in-process
-             * 7.0.2 and the build's own 7.2 in a separate link namespace fail alike), not the target id, not the module
-             * launch (the unit's source compiled offline by hipcc --genco and injected is correct): hipRTC's compilation
-             * of that kernel, cause not found.  The pair kernel passed every such comparison, and every unit is
-             * checked against the run-time-dimension kernel before its first use (rtc_unit_verified) */
-            e = rtc_run_kernel == 2
+             * dimensions (tools/experiments/repro_nuts_dims.py).  Round 6 (mm_rtc.hip, at g_compiler): it was the hipRTC the
+             * process had loaded -- PyTorch's bundled one, whose comgr is the 7.0.2 compiler; the system's 7.2 hipRTC emits
+             * hipcc's code and is correct, and today's sources compile correctly under both.  The policy stays: the pair
+             * kernel passed every comparison under every compiler, and every unit is checked against a second kernel before
+             * its first use (rtc_unit_verified) */
+            int run_kernel = rtc_run_kernel;
+            /* measurement builds: launch the unit's lanes-in-step kernel from an ordinary handle (never inside the unit's
+             * check) -- tools/experiments/rtc_lanes_in_step.py asks whether hipRTC still gets that kernel wrong */
+            if (const char *rk = mm_tuning_env("MMCMC_RTC_RUN_KERNEL"))
+                if (g_rtc_create_mode == 0)
+                    run_kernel = atoi(rk) == 0 ? 0 : 2;
+            e = run_kernel == 2
                     ? mm_rtc_launch_nuts(user, type_mode, 2, &a, sizeof(a), grid64, (size_t)MM_NUTS_RING * 64 * sizeof(double), st)
                     : mm_rtc_launch_nuts(user, type_mode, 0, &a, sizeof(a), grid64, user_lds, st); /* dynamic LDS = its output tile */
         } else if (use_generic) {

@@ -178,6 +178,18 @@ def set_rtc_compiler(which: str = "auto") -> None:
     L.check(L.lib().mmcmc_rtc_set_compiler(RTC_COMPILERS[which]), "mmcmc_rtc_set_compiler")
 
 
+def rtc_compiler_info() -> dict:
+    """mmcmc_rtc_compiler_info: {"hiprtc_path": str or None, "process_hip": (major, minor, patch), "built_with": (major, minor,
+    patch)} -- which copy of hipRTC this process would compile units with (the one PyTorch bundles once torch is imported: its
+    7.0.2 compiler miscompiled a NUTS kernel in rounds 3-4), the HIP runtime the process bound, and the compiler the library
+    was built with.  Needs no GPU."""
+    buf = C.create_string_buffer(512)
+    pv, bv = C.c_int(0), C.c_int(0)
+    st = L.lib().mmcmc_rtc_compiler_info(buf, 512, C.byref(pv), C.byref(bv))
+    split = lambda v: (v // 10000000, v // 100000 % 100, v % 100000)
+    return {"hiprtc_path": buf.value.decode() if st == L.OK else None, "process_hip": split(pv.value), "built_with": split(bv.value)}
+
+
 class UserProposal:
     """A proposal of the user's own: the GPU analogue of `impl Proposal for MyProposal` (distributions.rs:92-101).
 

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/mmcmc.h but not exported by libmmcmc.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.mmcmc_version() == 101
+    assert lib.mmcmc_version() == 102
 
 
 def test_header_is_plain_c(tmp_path):
@@ -149,3 +149,18 @@ def test_basic_stats_matches_oracle(lib, O, kats):
         assert a.mean == pytest.approx(b["mean"], rel=1e-6) and a.std == pytest.approx(b["std"], rel=1e-5)
     s = basic_stats("ESS", np.array([3.0, 1.0, 2.0, 5.0], dtype=np.float32))
     assert str(s) == "ESS in [1.00, 5.00], median: 2.00, mean: 2.75 ± 1.71"
+
+
+def test_rtc_compiler_info_needs_no_gpu():
+    """mmcmc_rtc_compiler_info (ABI 102): which copy of hipRTC the process would compile units with, the HIP runtime it bound
+    and the compiler the library was built with -- answered without a device (round 6: the NUTS kernel that "hipRTC"
+    miscompiled in rounds 3-4 was miscompiled by the 7.0.2 compiler PyTorch bundles, not by the system's 7.2)."""
+    from mini_mcmc_amd import _lib as L
+    from mini_mcmc_amd.distributions import rtc_compiler_info
+
+    v = rtc_compiler_info()
+    assert v["built_with"][0] >= 6
+    assert v["hiprtc_path"] is None or "hiprtc" in v["hiprtc_path"]
+    assert v["process_hip"][0] in (0, 6, 7, 8)
+    lib = L.lib()
+    assert lib.mmcmc_rtc_compiler_info(None, 0, None, None) in (0, -2)  # every pointer may be NULL

@@ -223,6 +223,15 @@ def test_units_are_built_by_hipcc_in_a_child_process_and_hiprtc_agrees_where_it_
         set_rtc_compiler("hiprtc")
         b = UserTarget("ros3_rtc", 3, ROSENBROCK3)
         assert b.compiler == "hiprtc"
+        # round 6: WHICH hipRTC -- the copy this process bound (PyTorch's once torch is imported: the 7.0.2 compiler that
+        # miscompiled a NUTS kernel in rounds 3-4); a unit built by the hipRTC of an older runtime than the library's
+        # compiler says so in its log
+        from mini_mcmc_amd.distributions import rtc_compiler_info
+
+        info = rtc_compiler_info()
+        assert info["hiprtc_path"] and "hiprtc" in info["hiprtc_path"]
+        older = info["process_hip"][:2] < info["built_with"][:2]
+        assert ("older than" in b.compile_log) == older, (info, b.compile_log)
         set_rtc_compiler("hipcc")
         c = UserTarget("ros3_cc", 3, ROSENBROCK3)
         assert c.compiler == "hipcc"
