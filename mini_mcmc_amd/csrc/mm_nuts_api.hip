@@ -797,12 +797,18 @@ static bool rtc_unit_verified(const void *unit, const mmcmc_target_desc *target,
     bool ok = one(-1, 2, a) && one(-1, 2, a2) && a == a2;
     /* the second opinion of a USER unit is the unit's lanes-in-step kernel -- the very kernel hipRTC was caught miscompiling
      * (wrong samples at RosenbrockND(19) / (23) f64, a device memory fault at StandardNormal(25) f32): it is launched only
-     * from units hipcc built.  A hipRTC-built user unit (no hipcc on the machine, or mmcmc_rtc_set_compiler(HIPRTC)) keeps
+     * from units hipcc built -- and (round 6, when the compiler was identified: the hipRTC PyTorch bundles, ROCm 7.0.2's;
+     * the system's 7.2 emits hipcc's code) from units built by the hipRTC of a runtime at least as new as the compiler this
+     * library was built with.  A user unit built by an OLDER hipRTC (no hipcc on the machine, torch imported first) keeps
      * the run-twice check alone: refusing a correct pair kernel on the word of a broken referee, or faulting the process
      * inside the check, would be worse than the exposure it closes (advisor r4). */
+    int process_hip = 0, built_hip = 0;
+    (void)mmcmc_rtc_compiler_info(nullptr, 0, &process_hip, &built_hip);
+    const bool referee_trusted = mm_rtc_compiler((const mm_user_target *)unit) == MMCMC_RTC_COMPILER_HIPCC ||
+                                 (process_hip > 0 && process_hip / 100000 >= built_hip / 100000);
     if (ok && target->kind < MM_USER_KIND_BASE)
         ok = one(6, 2, g) && a == g;
-    else if (ok && mm_rtc_compiler((const mm_user_target *)unit) == MMCMC_RTC_COMPILER_HIPCC)
+    else if (ok && referee_trusted)
         ok = one(-1, 0, g) && a == g;
     g_rtc_create_mode = 0;
     if (!errored) {

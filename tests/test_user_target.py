@@ -280,10 +280,11 @@ def test_user_source_nuts_at_the_dimensions_where_hiprtc_failed(O):
 
 @pytest.mark.gpu
 def test_user_source_nuts_built_by_hiprtc_at_the_dimensions_where_it_failed(O):
-    """The same user sources with the compiler pinned to hipRTC (a machine without hipcc): the unit's lanes-in-step kernel --
-    the one hipRTC was caught miscompiling, a device memory fault at StandardNormal(25) f32 -- must NOT be launched as the
-    referee (advisor r4): the handle is created on the run-twice check alone, and the pair kernel it launches equals the
-    library's own run-time-D kernel bit for bit."""
+    """The same user sources with the compiler pinned to hipRTC (a machine without hipcc) in THIS process, which has imported
+    torch and therefore binds PyTorch's bundled hipRTC (ROCm 7.0.2's compiler, older than the library's): the unit's
+    lanes-in-step kernel -- the one that compiler was caught miscompiling, a device memory fault at StandardNormal(25) f32 --
+    must NOT be launched as the referee (advisor r4): the handle is created on the run-twice check alone, and the pair kernel
+    it launches equals the library's own run-time-D kernel bit for bit."""
     from mini_mcmc_amd.core import init_with_seed
     from mini_mcmc_amd.distributions import RosenbrockND, StandardNormal, UserTarget, set_rtc_compiler
     from mini_mcmc_amd.nuts import NUTS
@@ -304,6 +305,54 @@ def test_user_source_nuts_built_by_hiprtc_at_the_dimensions_where_it_failed(O):
             assert np.array_equal(ou, ob) and np.array_equal(su.leapfrog_counts(), sb.leapfrog_counts()), (what, dim, mode)
     finally:
         set_rtc_compiler("auto")
+
+
+_SYSTEM_HIPRTC_CHILD = r'''
+import json, sys
+sys.modules["torch"] = None  # `import torch` now raises ImportError: the engine binds the system's ROCm libraries
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from mini_mcmc_amd.core import init_with_seed
+from mini_mcmc_amd.distributions import RosenbrockND, UserTarget, rtc_compiler_info, set_rtc_compiler
+from mini_mcmc_amd.nuts import NUTS
+dim, mode = 23, 2
+src = open(sys.argv[2]).read()
+set_rtc_compiler("hiprtc")
+user = UserTarget("ros23_system_hiprtc", dim, src)
+init = init_with_seed(77, dim, 31) * 0.5
+su = NUTS(user, init, 0.8, mode=mode).set_seed(5)  # created => its pair kernel agreed with its lanes-in-step kernel
+ou = su._run(4, 7, False, "numpy")
+ob = NUTS(RosenbrockND(dim), init, 0.8, mode=mode).set_seed(5).set_kernel_variant(6)._run(4, 7, False, "numpy")
+print("RESULT " + json.dumps({"compiler": user.compiler, "info": rtc_compiler_info(), "variant": su.kernel_variant,
+                              "equal": bool(np.array_equal(ou, ob)), "log": user.compile_log[:200]}))
+'''
+
+
+@pytest.mark.gpu
+def test_user_source_nuts_built_by_the_systems_hiprtc_is_refereed_and_right(O, tmp_path):
+    """Round 6 found which hipRTC miscompiled the lanes-in-step kernel in rounds 3-4: the copy PyTorch bundles (ROCm 7.0.2's
+    compiler); the system's 7.2 emits hipcc's code.  A process that never imports torch binds the system's: there a
+    hipRTC-built user unit IS checked against its lanes-in-step kernel (mm_nuts_api.hip: rtc_unit_verified -- the referee is
+    trusted when hipRTC's runtime is at least as new as the library's compiler), is accepted at the dimension that failed
+    (RosenbrockND(23), f64), and equals the library's run-time-dimension kernel.  One child process (this one has torch)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if not os.path.exists("/opt/rocm/lib/libhiprtc.so"):
+        pytest.skip("no system hipRTC")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "ros23.hip"
+    src.write_text(_rosenbrock_source(23))
+    r = subprocess.run([sys.executable, "-c", _SYSTEM_HIPRTC_CHILD, root, str(src)], capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, (r.returncode, r.stderr[-800:])
+    res = json.loads(line[0][7:])
+    assert res["compiler"] == "hiprtc" and res["variant"] == 7 and res["equal"], res
+    assert "/torch/" not in res["info"]["hiprtc_path"], res
+    if res["info"]["process_hip"][:2] >= res["info"]["built_with"][:2]:
+        assert "older than" not in res["log"], res
 
 
 @pytest.mark.gpu
