@@ -7,8 +7,9 @@
   - lane-group NUTS (D = 16, 32, f64): the persistent scheduler against the single launch;
   - MH / HMC at the compiled dimensions up to 8: the four-waves-per-SIMD kernel (5) against the one-wave kernels (0, 2), any
     chain count, run length, iterations per launch, f32 and f64;
-  - diagnostics: the power-spectrum kernel against the direct sums (R-hat / ESS to 1e-4 / 2e-3).
-usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n l h s, default dgtnlhsm]"""
+  - diagnostics: the power-spectrum kernel against the direct sums (R-hat / ESS to 1e-4 / 2e-3); x: long half-chains
+    (N1 residues, any N1) against the direct sums.
+usage: python tools/fuzz_variants.py [seconds per family, default 40] [families: any of d g t n l h s x m, default dgtnlhsm]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -188,6 +189,31 @@ while "s" in fam and time.time() - t0 < budget:
     assert np.allclose(res["fft"][0], res["direct"][0], rtol=1e-4) and np.allclose(res["fft"][1], res["direct"][1], rtol=2e-3), (c, m2, p, phi)
     n += 1
 print(f"diagnostics: {n} random cases, power spectrum == direct sums (1e-4 / 2e-3)")
+
+t0, n = time.time(), 0
+while "x" in fam and time.time() - t0 < budget:
+    # long half-chains: N1 = ceil(m / 1024) residues of 2048-point transforms, ANY N1 (round 6), against the direct sums
+    c, m2, p = int(rng.integers(1, 24)), int(rng.integers(2050, 60000)), int(rng.integers(1, 5))
+    if rng.random() < 0.3:
+        m2 = 2048 * int(rng.integers(1, 24)) + int(rng.integers(-2, 3))  # at the edges of a residue count
+    x = np.zeros((c, m2, p), dtype=np.float32)
+    e = rng.standard_normal((c, m2, p)).astype(np.float32)
+    phi = float(rng.uniform(0, 0.95))
+    for t in range(1, m2):
+        x[:, t] = phi * x[:, t - 1] + e[:, t]
+    x += rng.uniform(-50, 50, size=(1, 1, p)).astype(np.float32)
+    tt = torch.from_numpy(x).cuda()
+    res = {}
+    try:
+        for k in ("auto", "direct"):
+            S.set_kernel(k)
+            res[k] = S.split_rhat_mean_ess(tt)
+    finally:
+        S.set_kernel("auto")
+    assert np.allclose(res["auto"][0], res["direct"][0], rtol=1e-4) and np.allclose(res["auto"][1], res["direct"][1], rtol=5e-3), (c, m2, p, phi, res)
+    n += 1
+if "x" in fam:
+    print(f"long diagnostics: {n} random cases, power spectrum (N1 residues) == direct sums (1e-4 / 5e-3)")
 
 t0, n = time.time(), 0
 while "m" in fam and time.time() - t0 < budget:
